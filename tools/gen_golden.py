@@ -1,0 +1,277 @@
+#!/usr/bin/env python3
+"""Generate the golden fixtures under tests/golden/ from the REFERENCE itself.
+
+Runs only in the build container, where /root/reference exists: imports
+caption_src/SAModel.py on CPU (three harness-side shims),
+fills it with the procedural weights of oracle/paramgen.py and records small
+.npz fixtures (inputs are regenerated from seeds, never stored).  This script
+contains no reference code; it only references the path.  Nothing here runs on
+the GPU box.
+
+    python tools/gen_golden.py            # writes tests/golden/*.npz
+"""
+from __future__ import annotations
+
+import argparse
+import contextlib
+import io
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import paramgen as pg  # noqa: E402
+
+REF = "/root/reference/caption_src"
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+# dims of the fixtures ------------------------------------------------------------
+CFG = {
+    # BASELINE.json configs[0]: batch 8, 26 frames, hidden 512, seq_len 20
+    "c1": dict(B=8, K=26, R=512, A=1536, E=468, V=20000, C=14, L=20, F1=1536, F2=1024, H=128),
+    # deliberately awkward sizes: nothing a multiple of 32, E not a multiple of 4
+    "tiny": dict(B=5, K=7, R=24, A=40, E=18, V=61, C=5, L=6, F1=20, F2=12, H=128),
+    # BASELINE.json configs[4] shape at small batch (fp32 golden, 1e-2 tol for bf16)
+    "c5": dict(B=4, K=40, R=1024, A=1536, E=468, V=20000, C=14, L=6, F1=1536, F2=1024, H=128),
+}
+WEIGHT_CLASS = 0.5
+
+
+def import_reference():
+    sys.modules["h5py"] = types.ModuleType("h5py")
+    torch.Tensor.cuda = lambda self, *a, **k: self
+    torch.nn.Module.cuda = lambda self, *a, **k: self
+    torch.cuda.manual_seed = lambda s: None
+    _narrow = torch.Tensor.narrow
+
+    def narrow(self, *a, **k):
+        if "dimension" in k:
+            k["dim"] = k.pop("dimension")
+        return _narrow(self, *a, **k)
+
+    torch.Tensor.narrow = narrow
+    sys.path.insert(0, REF)
+    sys.argv = ["x"]
+    import SAModel as ref  # noqa
+    return ref
+
+
+def build_ref(ref, d, P, p_drop=0.0):
+    opt = argparse.Namespace(seed=1024, vocab_size=d.V, category_size=d.C,
+                             input_encoding_size=d.E, rnn_size=d.R, num_layers=1,
+                             drop_prob_lm=p_drop, seq_length=d.L, feat_size=d.F1,
+                             feat_size2=d.F2, att_size=d.A, fusion_activity="ReLU")
+    model = ref.SAModel(opt)
+    sd = {k: torch.from_numpy(v.copy()) for k, v in P.items()}
+    missing = model.load_state_dict(sd, strict=False)
+    assert not missing.unexpected_keys, missing
+    assert all("running" in k or "num_batches" in k for k in missing.missing_keys), missing
+    return model
+
+
+def tt(x):
+    return {k: torch.from_numpy(v) for k, v in x.items()}
+
+
+def sample_idx(name, shape, n=16):
+    tot = int(np.prod(shape))
+    return (pg.hash_u32(7, zlib_crc(name), 3, n).astype(np.int64) % tot)
+
+
+def zlib_crc(s):
+    import zlib
+    return zlib.crc32(s.encode()) & 0xFFFFFFFF
+
+
+def grads_summary(model, full=False):
+    out = {}
+    for name, prm in model.named_parameters():
+        g = prm.grad
+        if g is None:
+            g = torch.zeros_like(prm)
+        g = g.detach().numpy()
+        out["gnorm/" + name] = np.float64(np.sqrt((g.astype(np.float64) ** 2).sum()))
+        out["gsamp/" + name] = g.reshape(-1)[sample_idx(name, g.shape)].copy()
+        if full:
+            out["gfull/" + name] = g.copy()
+    return out
+
+
+def quiet():
+    return contextlib.redirect_stdout(io.StringIO())
+
+
+def gen_xe(ref, tag, ragged, full):
+    d = pg.make_dims(**CFG[tag])
+    P = pg.make_params(d)
+    x = tt(pg.make_inputs(d, seed=0, ragged=ragged))
+    model = build_ref(ref, d, P)
+    model.train()
+    steps = []
+    hook = model.lstmcore.register_forward_hook(
+        lambda m, i, o: steps.append([o[1][0][0][0].detach().numpy().copy(), o[1][0][1][0].detach().numpy().copy(),
+                                      o[1][1][0][0].detach().numpy().copy(), o[1][1][1][0].detach().numpy().copy()]))
+    enc_out = []
+    h2 = model.two_spatial_encoder.register_forward_hook(lambda m, i, o: enc_out.append(o.detach().numpy().copy()))
+    logp, cat = model(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+    hook.remove(); h2.remove()
+    crit, ccrit = ref.LanguageModelCriterion(), ref.ClassiferCriterion()
+    l_xe = crit(logp, x["seq"], x["seq_mask"])
+    l_cls = ccrit(cat, x["cap_classes"], x["seq_mask"], x["class_mask"])
+    loss = l_xe + WEIGHT_CLASS * l_cls
+    model.zero_grad()
+    loss.backward()
+    g = {}
+    g["loss_xe"] = np.float64(l_xe.item()); g["loss_cls"] = np.float64(l_cls.item())
+    g["loss"] = np.float64(loss.item())
+    lp = logp.detach().numpy()
+    ns = lp.shape[2] if full else 32
+    g["logp_slice"] = lp[:, :, :ns].copy()
+    tgt = torch.cat([x["seq"][:, 1:], x["seq"][:, :1]], 1)
+    g["logp_tgt"] = logp.detach().gather(2, tgt.unsqueeze(2)).squeeze(2).numpy()
+    g["cat_logp"] = cat.detach().numpy()
+    st = np.array(steps)                       # (T,4,B,R)
+    nr = st.shape[-1] if full else 16
+    g["state_slice"] = st[:, :, :, :nr].copy()
+    g["V_slice"] = enc_out[0][:, :, :nr].copy()
+    # BN running stats after ONE train-mode forward (momentum 0.1, unbiased var)
+    for mod in ("rgb", "opfl"):
+        bn = getattr(model.two_spatial_encoder, f"visual_emb_{mod}")[1]
+        g[f"bn_{mod}_running_mean"] = bn.running_mean.numpy().copy()
+        g[f"bn_{mod}_running_var"] = bn.running_var.numpy().copy()
+    g.update(grads_summary(model, full))
+    name = f"xe_{tag}{'_ragged' if ragged else ''}.npz"
+    np.savez_compressed(os.path.join(GOLD, name), **g)
+    print("wrote", name, "loss", g["loss"])
+
+
+def gen_greedy(ref, tag, ragged=False):
+    d = pg.make_dims(**CFG[tag])
+    P = pg.make_params(d)
+    x = tt(pg.make_inputs(d, seed=0, ragged=ragged))
+    model = build_ref(ref, d, P)
+    model.eval()          # eval.py:73 / eval_utils.py:25: running stats at their init (0,1)
+    logps = []
+    hook = model.logit.register_forward_hook(lambda m, i, o: logps.append(torch.log_softmax(o, 1).detach().numpy().copy()))
+    with quiet(), torch.no_grad():
+        seq, slp = model.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"sample_max": 1})
+    hook.remove()
+    lp = np.array(logps)                                      # (n+1, B, V)
+    top2 = -np.sort(-lp, axis=2)[:, :, :2]
+    g = dict(seq=seq.numpy(), seqLogprobs=slp.numpy(), margin=(top2[:, :, 0] - top2[:, :, 1]))
+    name = f"greedy_{tag}{'_ragged' if ragged else ''}.npz"
+    np.savez_compressed(os.path.join(GOLD, name), **g)
+    print("wrote", name, "n", seq.shape[1], "min margin", g["margin"][: seq.shape[1]].min())
+
+
+def gen_step(ref):
+    """G5: one LSTMCore_two_layer_gate step from a random state, B=4, c1 sizes."""
+    cfg = dict(CFG["c1"]); cfg["B"] = 4
+    d = pg.make_dims(**cfg)
+    P = pg.make_params(d)
+    model = build_ref(ref, d, P)
+    model.train()
+    B, K, R, E = d.B, d.K, d.R, d.E
+    xt = torch.from_numpy(pg.uniform("step.xt", (B, E), 5, -0.1, 0.1))
+    V = torch.from_numpy(pg.uniform("step.V", (B, K, R), 5, 0.0, 1.0))
+    pos = torch.from_numpy(pg.uniform("step.pos", (B, R), 5, -1.0, 1.0))
+    st = [torch.from_numpy(pg.uniform(f"step.s{i}", (1, B, R), 5, -0.5, 0.5)) for i in range(4)]
+    mk = torch.tensor([[1.0], [1.0], [0.0], [1.0]])
+    alphas = []
+    hk = model.lstmcore.a2w.register_forward_hook(lambda m, i, o: alphas.append(torch.softmax(o, 1).squeeze(-1).detach().numpy().copy()))
+    out, state = model.lstmcore(xt, mk, V, pos, [(st[0], st[1]), (st[2], st[3])])
+    hk.remove()
+    g = dict(out=out.detach().numpy(), h1=state[0][0][0].detach().numpy(), c1=state[0][1][0].detach().numpy(),
+             h2=state[1][0][0].detach().numpy(), c2=state[1][1][0].detach().numpy(), alpha=alphas[0])
+    np.savez_compressed(os.path.join(GOLD, "step_c1.npz"), **g)
+    print("wrote step_c1.npz")
+
+
+def gen_scst(ref, tag):
+    """G6: SCST replay.  The reference samples with torch.multinomial on the CPU
+    generator (SAModel.py:190-194); the sampled tokens are recorded and replayed."""
+    d = pg.make_dims(**CFG[tag])
+    P = pg.make_params(d)
+    x = tt(pg.make_inputs(d, seed=0))
+    model = build_ref(ref, d, P)
+    model.train()                                            # starttrain.py:68 (never toggled)
+    torch.manual_seed(1234)
+    with quiet():
+        seq, slp = model.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"sample_max": 0})
+    reward_b = pg.uniform("reward", (d.B,), 3, -1.0, 1.0)
+    reward = torch.from_numpy(np.repeat(reward_b[:, None], seq.shape[1], 1))   # myutils.py:76
+    loss = ref.RewardCriterion()(slp, seq, reward)
+    model.zero_grad()
+    loss.backward()
+    g = dict(seq=seq.numpy(), seqLogprobs=slp.detach().numpy(), reward=reward.numpy(), loss=np.float64(loss.item()))
+    g.update(grads_summary(model, full=(tag == "tiny")))
+    np.savez_compressed(os.path.join(GOLD, f"scst_{tag}.npz"), **g)
+    print("wrote", f"scst_{tag}.npz", "n", seq.shape[1], "loss", g["loss"])
+
+
+def gen_eval_bn(ref, tag):
+    """G8: eval-mode forward with non-trivial running statistics."""
+    d = pg.make_dims(**CFG[tag])
+    P = pg.make_params(d)
+    x = tt(pg.make_inputs(d, seed=0, ragged=True))
+    model = build_ref(ref, d, P)
+    for mod in ("rgb", "opfl"):
+        bn = getattr(model.two_spatial_encoder, f"visual_emb_{mod}")[1]
+        bn.running_mean.copy_(torch.from_numpy(pg.uniform(f"rm.{mod}", (d.R,), 9, -0.3, 0.3)))
+        bn.running_var.copy_(torch.from_numpy(pg.uniform(f"rv.{mod}", (d.R,), 9, 0.5, 2.0)))
+    model.eval()
+    with torch.no_grad():
+        logp, cat = model(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+        loss = ref.LanguageModelCriterion()(logp, x["seq"], x["seq_mask"])
+    g = dict(loss=np.float64(loss.item()), logp_slice=logp.numpy()[:, :, :32].copy(), cat_logp=cat.numpy())
+    np.savez_compressed(os.path.join(GOLD, f"evalbn_{tag}.npz"), **g)
+    print("wrote", f"evalbn_{tag}.npz", "loss", g["loss"])
+
+
+def gen_beam(ref, tag, beam_size=3):
+    """f-2: beam search (CaptionModel.py:22-128) tokens / logps, eval mode."""
+    cfg = dict(CFG[tag]); cfg["B"] = min(cfg["B"], 3)
+    d = pg.make_dims(**cfg)
+    P = pg.make_params(d)
+    x = tt(pg.make_inputs(d, seed=0))
+    model = build_ref(ref, d, P)
+    model.eval()
+    with quiet(), torch.no_grad():
+        seq, slp = model.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"],
+                                {"beam_size": beam_size})
+    g = dict(seq=seq.numpy(), seqLogprobs=slp.numpy(), beam_size=np.int64(beam_size))
+    np.savez_compressed(os.path.join(GOLD, f"beam_{tag}.npz"), **g)
+    print("wrote", f"beam_{tag}.npz")
+
+
+def main():
+    if not os.path.isdir(REF):
+        print("reference not present; nothing to do")
+        return 0
+    os.makedirs(GOLD, exist_ok=True)
+    torch.set_num_threads(8)
+    ref = import_reference()
+    gen_xe(ref, "tiny", ragged=False, full=True)
+    gen_xe(ref, "tiny", ragged=True, full=True)
+    gen_xe(ref, "c1", ragged=False, full=False)
+    gen_xe(ref, "c1", ragged=True, full=False)
+    gen_xe(ref, "c5", ragged=False, full=False)
+    gen_greedy(ref, "tiny")
+    gen_greedy(ref, "c1")
+    gen_greedy(ref, "c1", ragged=True)
+    gen_step(ref)
+    gen_scst(ref, "tiny")
+    gen_scst(ref, "c1")
+    gen_eval_bn(ref, "tiny")
+    gen_eval_bn(ref, "c1")
+    gen_beam(ref, "tiny")
+    gen_beam(ref, "c1")
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
