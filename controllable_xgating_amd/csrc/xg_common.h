@@ -1,0 +1,83 @@
+// Internal helpers shared by the HIP translation units of libxgate_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/xgate.h"
+
+#define XG_CHECK_LAUNCH()                                  \
+    do {                                                   \
+        if (hipGetLastError() != hipSuccess) return XG_EHIP; \
+    } while (0)
+
+#define XG_TRY(expr)                 \
+    do {                             \
+        int _rc = (expr);            \
+        if (_rc != XG_OK) return _rc; \
+    } while (0)
+
+// ---- dropout hash: must stay bit-identical to oracle/paramgen.py:hash_u32 (test infrastructure) ----
+__host__ __device__ __forceinline__ uint32_t xg_fmix32(uint32_t h) {
+    h ^= h >> 16;
+    h *= 0x85EBCA6Bu;
+    h ^= h >> 13;
+    h *= 0xC2B2AE35u;
+    h ^= h >> 16;
+    return h;
+}
+__host__ __device__ __forceinline__ uint32_t xg_hash(uint32_t seed, uint32_t site, uint32_t step, uint32_t idx) {
+    uint32_t h = xg_fmix32(idx + 0x9E3779B9u * (step + 1u));
+    return xg_fmix32(h ^ (seed ^ (site * 0x632BE5ABu)));
+}
+
+// Dropout descriptor passed by value to kernels.  scale == 1 and thresh == 0 when inactive.
+struct XgDrop {
+    uint32_t seed, site, step, thresh;
+    float scale;
+};
+__host__ __forceinline__ XgDrop xg_make_drop(const XgRun* run, uint32_t site, uint32_t step) {
+    XgDrop d;
+    d.seed = run->seed;
+    d.site = site;
+    d.step = step;
+    if (run->train && run->drop_p > 0.f) {
+        double t = (double)run->drop_p * 4294967296.0;
+        d.thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (uint32_t)t;
+        d.scale = 1.0f / (1.0f - run->drop_p);
+    } else {
+        d.thresh = 0u;
+        d.scale = 1.0f;
+    }
+    return d;
+}
+// multiplier (0 or scale) for flat element index idx
+__device__ __forceinline__ float xg_keep(const XgDrop& d, uint32_t idx) {
+    if (d.thresh == 0u) return 1.0f;
+    return xg_hash(d.seed, d.site, d.step, idx) >= d.thresh ? d.scale : 0.0f;
+}
+
+// dropout sites (oracle/xgate_oracle.py header)
+enum { XG_SITE_EMB_RGB = 0, XG_SITE_EMB_OPFL = 1, XG_SITE_GATE_RGB = 2, XG_SITE_GATE_OPFL = 3, XG_SITE_FUSION = 4,
+       XG_SITE_DGATE = 5, XG_SITE_L1 = 6, XG_SITE_L2 = 7, XG_SITE_CLS = 8 };
+
+__device__ __forceinline__ float xg_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// tanh via exp: accurate to ~1e-7 relative on the value for |x| small because of the 2/(1+e) form
+__device__ __forceinline__ float xg_tanh(float x) {
+    float ax = fabsf(x);
+    float e = __expf(-2.0f * ax);
+    float t = (1.0f - e) / (1.0f + e);
+    return copysignf(t, x);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+static inline int xg_cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int64_t xg_cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

@@ -1,0 +1,334 @@
+// Vocabulary / category heads, criteria and rollout token choice (gfx950).
+// reference: caption_src/SAModel.py:109-110 (log_softmax of logit / classifer), :186-196 (token
+// choice), :200-215 (rollout bookkeeping), :221-267 (criteria).
+// Row kernels: one 1024-thread workgroup per row of V (= 20000) logits; the row is read with
+// coalesced loads, max / sum-exp are reduced with wave64 shuffles + LDS across the 16 waves.
+#include "xg_common.h"
+#include "xg_kernels.h"
+
+namespace {
+
+constexpr int RT = 1024;
+
+__device__ __forceinline__ float block_max(float v, float* red) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < (int)(blockDim.x >> 6); ++i) r = fmaxf(r, red[i]);
+    return r;
+}
+__device__ __forceinline__ float block_sum(float v, float* red) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    float r = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) r += red[i];
+    return r;
+}
+
+__device__ __forceinline__ int out_row(int i, int inner, int outer, int permute) {
+    return permute ? (i % inner) * outer + i / inner : i;
+}
+
+__global__ void __launch_bounds__(RT) log_softmax_kernel(const float* __restrict__ in, int ldin, float* __restrict__ out,
+                                                           int ldout, int V, int inner, int outer, int permute) {
+    __shared__ float red[RT / 64];
+    const int i = blockIdx.x;
+    const float* x = in + (size_t)i * ldin;
+    float* y = out + (size_t)out_row(i, inner, outer, permute) * ldout;
+    float mx = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += RT) mx = fmaxf(mx, x[v]);
+    mx = block_max(mx, red);
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V; v += RT) s += expf(x[v] - mx);
+    s = block_sum(s, red);
+    const float lse = mx + logf(s);
+    for (int v = threadIdx.x; v < V; v += RT) y[v] = x[v] - lse;
+}
+
+__global__ void __launch_bounds__(RT) log_softmax_bwd_kernel(const float* __restrict__ dlogp, const float* __restrict__ logp,
+                                                               int ldp, float* __restrict__ dlogits, int ldd, int V,
+                                                               int inner, int outer, int permute) {
+    __shared__ float red[RT / 64];
+    const int i = blockIdx.x;
+    const size_t ro = (size_t)out_row(i, inner, outer, permute != 0) * ldp;
+    const float* dy = dlogp + ro;
+    const float* y = logp + (permute == 2 ? (size_t)i * ldp : ro);
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V; v += RT) s += dy[v];
+    s = block_sum(s, red);
+    float* dx = dlogits + (size_t)i * ldd;
+    for (int v = threadIdx.x; v < V; v += RT) dx[v] = dy[v] - expf(y[v]) * s;
+}
+
+// ---- criteria on a materialised (B,T,V) log-prob tensor
+__device__ __forceinline__ int64_t tgt_of(const int64_t* target, int b, int t, int T, int roll) {
+    return roll ? target[(size_t)b * T + (t + 1 < T ? t + 1 : 0)] : target[(size_t)b * T + t];   // SAModel.py:228
+}
+__global__ void nll_fwd_kernel(const float* logp, const int64_t* target, const float* mask, const float* mask2,
+                               int B, int T, int V, int roll, float* out2) {
+    __shared__ float red[256 / 64];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    float a = 0.f, m = 0.f;
+    if (i < B * T) {
+        const int b = i / T, t = i % T;
+        m = mask[i] * (mask2 ? mask2[i] : 1.f);
+        const int64_t tg = tgt_of(target, b, t, T, roll);
+        a = -logp[(size_t)i * V + tg] * m;
+    }
+    a = block_sum(a, red);
+    m = block_sum(m, red);
+    if (threadIdx.x == 0) { atomicAdd(out2, a); atomicAdd(out2 + 1, m); }
+}
+__global__ void nll_bwd_kernel(const int64_t* target, const float* mask, const float* mask2, int B, int T, int V,
+                               int roll, const float* sums, float scale, float* dlogp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * T) return;
+    const int b = i / T, t = i % T;
+    const float m = mask[i] * (mask2 ? mask2[i] : 1.f);
+    dlogp[(size_t)i * V + tgt_of(target, b, t, T, roll)] = -scale * m / sums[1];
+}
+
+// ---- fused cross-entropy on time-major logits rows i = t*B + b
+__global__ void __launch_bounds__(RT) xent_fwd_kernel(const float* __restrict__ logits, int ld, const int64_t* seq,
+                                                        const float* mask, const float* mask2, int B, int T, int V,
+                                                        int roll, float* lse_out, float* sums2) {
+    __shared__ float red[RT / 64];
+    const int i = blockIdx.x, t = i / B, b = i % B;
+    const float* x = logits + (size_t)i * ld;
+    float mx = -INFINITY;
+    for (int v = threadIdx.x; v < V; v += RT) mx = fmaxf(mx, x[v]);
+    mx = block_max(mx, red);
+    float s = 0.f;
+    for (int v = threadIdx.x; v < V; v += RT) s += expf(x[v] - mx);
+    s = block_sum(s, red);
+    if (threadIdx.x == 0) {
+        const float lse = mx + logf(s);
+        lse_out[i] = lse;
+        const float m = mask[(size_t)b * T + t] * (mask2 ? mask2[(size_t)b * T + t] : 1.f);
+        const int64_t tg = tgt_of(seq, b, t, T, roll);
+        atomicAdd(sums2, -(x[tg] - lse) * m);
+        atomicAdd(sums2 + 1, m);
+    }
+}
+// dlogits = coef * (softmax - onehot), coef = scale * mask / sum(mask), in place
+__global__ void __launch_bounds__(RT) xent_bwd_kernel(float* __restrict__ logits, int ld, const int64_t* seq,
+                                                        const float* mask, const float* mask2, int B, int T, int V,
+                                                        int roll, const float* lse, const float* sums2,
+                                                        const float* scale_dev, float scale) {
+    const int i = blockIdx.x, t = i / B, b = i % B;
+    float* x = logits + (size_t)i * ld;
+    const float m = mask[(size_t)b * T + t] * (mask2 ? mask2[(size_t)b * T + t] : 1.f);
+    const float coef = (scale_dev ? scale_dev[0] : 1.f) * scale * m / sums2[1];
+    const int64_t tg = tgt_of(seq, b, t, T, roll);
+    const float l = lse[i];
+    for (int v = threadIdx.x; v < V; v += RT) {
+        const float pv = expf(x[v] - l);
+        x[v] = coef * (pv - (v == tg ? 1.f : 0.f));
+    }
+}
+
+// ---- rollout token choice: one workgroup per video
+__global__ void __launch_bounds__(RT) choose_kernel(const float* __restrict__ logp, int V, int mode, const float* uniforms,
+                                                      const int64_t* forced, int64_t fstride, float temperature,
+                                                      int64_t* tok, float* tok_logp) {
+    __shared__ float red[RT / 64];
+    __shared__ int redi[RT / 64];
+    __shared__ float chunk_sum[RT];
+    const int b = blockIdx.x;
+    const float* x = logp + (size_t)b * V;
+    if (mode == XG_ROLLOUT_REPLAY) {
+        if (threadIdx.x == 0) {
+            int64_t t = forced[(size_t)b * fstride];
+            t = t < 0 ? 0 : (t >= V ? V - 1 : t);
+            tok[b] = t;
+            tok_logp[b] = x[t];
+        }
+        return;
+    }
+    if (mode == XG_ROLLOUT_GREEDY) {
+        // argmax, ties -> lowest index (torch.max, SAModel.py:186)
+        float best = -INFINITY; int bi = 0x7fffffff;
+        for (int v = threadIdx.x; v < V; v += RT) {
+            const float f = x[v];
+            if (f > best || (f == best && v < bi)) { best = f; bi = v; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        if (lane == 0) { red[wave] = best; redi[wave] = bi; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int i = 1; i < RT / 64; ++i)
+                if (red[i] > best || (red[i] == best && redi[i] < bi)) { best = red[i]; bi = redi[i]; }
+            tok[b] = bi;
+            tok_logp[b] = best;
+        }
+        return;
+    }
+    // SAMPLE: inverse CDF over w_v = exp(logp_v / temperature) (unnormalised, like torch.multinomial):
+    // each thread owns a contiguous chunk; chunk sums -> serial scan by thread 0 -> owner thread walks its chunk.
+    const int per = (V + RT - 1) / RT;
+    const int v0 = threadIdx.x * per, v1 = min(V, v0 + per);
+    const float invt = 1.0f / temperature;
+    float s = 0.f;
+    for (int v = v0; v < v1; ++v) s += expf(x[v] * invt);
+    chunk_sum[threadIdx.x] = s;
+    __syncthreads();
+    __shared__ float target_s; __shared__ int owner; __shared__ float base_s;
+    if (threadIdx.x == 0) {
+        double tot = 0.0;
+        for (int i = 0; i < RT; ++i) tot += chunk_sum[i];
+        const double target = (double)uniforms[b] * tot;
+        double run = 0.0; int ow = RT - 1; double base = 0.0;
+        for (int i = 0; i < RT; ++i) {
+            if (run + chunk_sum[i] > target) { ow = i; base = run; break; }
+            run += chunk_sum[i];
+            base = run;
+        }
+        owner = ow; base_s = (float)base; target_s = (float)target;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x == owner) {
+        float run = base_s; int pick = min(V, v1) - 1;
+        if (pick < v0) pick = V - 1;
+        for (int v = v0; v < v1; ++v) {
+            run += expf(x[v] * invt);
+            if (run > target_s) { pick = v; break; }
+        }
+        tok[b] = pick;
+        tok_logp[b] = x[pick];
+    }
+}
+
+// SAModel.py:200-215: unfinished &= it>0 ; it *= unfinished ; append ; n = first t with none unfinished
+__global__ void rollout_book_kernel(int t, int B, int Tm1, int replay, const int64_t* tok, const float* tok_logp,
+                                    float* unfinished, int64_t* seq, float* seq_logp, int32_t* n_steps,
+                                    int32_t* alive) {
+    // single workgroup; alive[0] = 1 while the reference's loop would still be running
+    __shared__ int any;
+    if (threadIdx.x == 0) any = 0;
+    __syncthreads();
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        const int64_t it = tok[b];
+        float u = (t == 1) ? (it > 0 ? 1.f : 0.f) : unfinished[b] * (it > 0 ? 1.f : 0.f);
+        unfinished[b] = u;
+        if (u > 0.f) atomicOr(&any, 1);
+    }
+    __syncthreads();
+    const int was_alive = alive[0];
+    const int now_alive = was_alive && (any || replay);
+    for (int b = threadIdx.x; b < B; b += blockDim.x) {
+        if (now_alive) {
+            seq[(size_t)b * Tm1 + (t - 1)] = replay ? tok[b] : (unfinished[b] > 0.f ? tok[b] : 0);
+            seq_logp[(size_t)b * Tm1 + (t - 1)] = tok_logp[b];
+        } else {
+            seq[(size_t)b * Tm1 + (t - 1)] = 0;
+            seq_logp[(size_t)b * Tm1 + (t - 1)] = 0.f;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (was_alive && !now_alive) n_steps[0] = t - 1;      // reference breaks before appending (SAModel.py:206-207)
+        alive[0] = now_alive;
+    }
+}
+
+__global__ void __launch_bounds__(RT) rollout_dlogits_kernel(const float* __restrict__ logp, const int64_t* tok,
+                                                               const float* dslp, int64_t dstride, float* dlogits, int V) {
+    const int b = blockIdx.x;
+    const float d = dslp[(size_t)b * dstride];
+    const int64_t tk = tok[b];
+    const float* y = logp + (size_t)b * V;
+    float* dx = dlogits + (size_t)b * V;
+    for (int v = threadIdx.x; v < V; v += RT) dx[v] = d * ((v == tk ? 1.f : 0.f) - expf(y[v]));
+}
+
+}  // namespace
+
+int xgk_log_softmax(hipStream_t st, const float* in, int ldin, float* out, int ldout, int rows, int V, int inner,
+                    int outer, bool permute) {
+    if (rows <= 0) return XG_OK;
+    hipLaunchKernelGGL(log_softmax_kernel, dim3(rows), dim3(RT), 0, st, in, ldin, out, ldout, V, inner, outer,
+                       permute ? 1 : 0);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_log_softmax_bwd(hipStream_t st, const float* dlogp, const float* logp, int ldp, float* dlogits, int ldd,
+                        int rows, int V, int inner, int outer, int permute) {
+    if (rows <= 0) return XG_OK;
+    hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3(rows), dim3(RT), 0, st, dlogp, logp, ldp, dlogits, ldd, V, inner,
+                       outer, permute);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_nll_fwd(hipStream_t st, const float* logp, const int64_t* target, const float* mask, const float* mask2,
+                int B, int T, int V, int roll, float* out2) {
+    if (hipMemsetAsync(out2, 0, 2 * sizeof(float), st) != hipSuccess) return XG_EHIP;
+    hipLaunchKernelGGL(nll_fwd_kernel, dim3(xg_cdiv(B * T, 256)), dim3(256), 0, st, logp, target, mask, mask2, B, T, V,
+                       roll, out2);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_nll_bwd(hipStream_t st, const int64_t* target, const float* mask, const float* mask2, int B, int T, int V,
+                int roll, const float* sums, float scale, float* dlogp) {
+    if (hipMemsetAsync(dlogp, 0, sizeof(float) * (size_t)B * T * V, st) != hipSuccess) return XG_EHIP;
+    hipLaunchKernelGGL(nll_bwd_kernel, dim3(xg_cdiv(B * T, 256)), dim3(256), 0, st, target, mask, mask2, B, T, V, roll,
+                       sums, scale, dlogp);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_xent_fwd(hipStream_t st, const float* logits, int ld, const int64_t* seq, const float* mask,
+                 const float* mask2, int B, int T, int V, int roll, float* lse, float* sums2) {
+    if (hipMemsetAsync(sums2, 0, 2 * sizeof(float), st) != hipSuccess) return XG_EHIP;
+    hipLaunchKernelGGL(xent_fwd_kernel, dim3(B * T), dim3(RT), 0, st, logits, ld, seq, mask, mask2, B, T, V, roll, lse,
+                       sums2);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_xent_bwd(hipStream_t st, float* logits_inout, int ld, const int64_t* seq, const float* mask,
+                 const float* mask2, int B, int T, int V, int roll, const float* lse, const float* sums2,
+                 const float* scale_dev, float scale) {
+    hipLaunchKernelGGL(xent_bwd_kernel, dim3(B * T), dim3(RT), 0, st, logits_inout, ld, seq, mask, mask2, B, T, V, roll,
+                       lse, sums2, scale_dev, scale);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_choose(hipStream_t st, const float* logp, int B, int V, int mode, const float* uniforms,
+               const int64_t* forced, int64_t forced_stride, float temperature, int64_t* tok, float* tok_logp) {
+    hipLaunchKernelGGL(choose_kernel, dim3(B), dim3(RT), 0, st, logp, V, mode, uniforms, forced, forced_stride,
+                       temperature, tok, tok_logp);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_rollout_book(hipStream_t st, int t, int B, int Tm1, int replay, const int64_t* tok, const float* tok_logp,
+                     float* unfinished, int64_t* seq, float* seq_logp, int32_t* n_steps, int32_t* alive) {
+    hipLaunchKernelGGL(rollout_book_kernel, dim3(1), dim3(256), 0, st, t, B, Tm1, replay, tok, tok_logp, unfinished, seq,
+                       seq_logp, n_steps, alive);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_rollout_dlogits(hipStream_t st, const float* logp, const int64_t* tok, const float* dslp, int64_t dstride,
+                        float* dlogits, int B, int V) {
+    hipLaunchKernelGGL(rollout_dlogits_kernel, dim3(B), dim3(RT), 0, st, logp, tok, dslp, dstride, dlogits, V);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+
+extern "C" int xg_nll_fwd(void* stream, const float* logp, const int64_t* target, const float* mask,
+                          const float* mask2, int B, int T, int V, int roll, float* out) {
+    if (!logp || !target || !mask || !out || B <= 0 || T <= 0 || V <= 0) return XG_EINVAL;
+    return xgk_nll_fwd((hipStream_t)stream, logp, target, mask, mask2, B, T, V, roll, out);
+}
+extern "C" int xg_nll_bwd(void* stream, const int64_t* target, const float* mask, const float* mask2, int B, int T,
+                          int V, int roll, const float* sums, float scale, float* dlogp) {
+    if (!target || !mask || !sums || !dlogp || B <= 0 || T <= 0 || V <= 0) return XG_EINVAL;
+    return xgk_nll_bwd((hipStream_t)stream, target, mask, mask2, B, T, V, roll, sums, scale, dlogp);
+}

@@ -1,0 +1,137 @@
+// Internal launcher prototypes (host side).  Every launcher enqueues on `st` and returns XG_OK / XG_EHIP.
+#pragma once
+#include "xg_common.h"
+
+// ---- xg_gemm.hip
+int xgk_gemm(hipStream_t st, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
+             const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate);
+// Y[M,N] (+)= X[M,K] W[N,K]^T + bias   (nn.Linear forward)
+static inline int xgk_linear(hipStream_t st, int M, int N, int K, const float* X, int ldx, const float* W,
+                             const float* bias, float* Y, int ldy, bool relu = false, bool acc = false) {
+    return xgk_gemm(st, false, true, M, N, K, X, ldx, W, K, Y, ldy, bias, relu, acc);
+}
+
+// ---- xg_pointwise.hip
+enum { XG_ORDER_IFOG = 0 /* decoder two_inputs_lstmcell */, XG_ORDER_IFGO = 1 /* nn.LSTMCell */ };
+enum { XG_MASK_HOLD = 0 /* decoder: keep previous state */, XG_MASK_ZERO = 1 /* encoder: zero state */ };
+
+struct LstmFwdArgs {
+    const float* s;      int lds_;    // (B,4R) pre-activation from the recurrent GEMM (bias included)
+    const float* add;    int ldadd;   // optional second pre-activation term (hoisted input side), may be null
+    const float* c_prev; int ldcp;
+    const float* h_prev; int ldhp;    // only read in HOLD mode
+    const float* mask;   int ldm;     // (B) element b at mask[b*ldm]; null = ones
+    float* gates;        int ldg;     // (B,4R) activated gates, same column order as s; may be null
+    float* c_out;        int ldco;
+    float* h_out;        int ldho;    // post-dropout hidden (stored state AND output)
+    int B, R, order, mask_mode;
+    XgDrop drop;
+};
+int xgk_lstm_fwd(hipStream_t st, const LstmFwdArgs& a);
+
+struct LstmBwdArgs {
+    const float* gates;  int ldg;
+    const float* c_prev; int ldcp;
+    const float* c_out;  int ldco;    // post-mask new cell state
+    const float* mask;   int ldm;
+    const float* dh_out; int lddh;    // grad wrt post-dropout hidden
+    const float* dc_out; int lddc;    // grad wrt new cell state (from the next step); may be null (= 0)
+    float* ds;           int ldds;    // (B,4R) out
+    float* dc_prev;      int lddcp;   // out (overwritten)
+    float* dh_prev;      int lddhp;   // HOLD mode: overwritten with (1-m)*dh' (caller accumulates GEMM terms after)
+    int B, R, order, mask_mode;
+    XgDrop drop;
+};
+int xgk_lstm_bwd(hipStream_t st, const LstmBwdArgs& a);
+
+// y = g*t + t with g = dropout(pre) (pre already ReLU'd by the GEMM epilogue).  g is written back in place of pre.
+// Row r of the (rows,R) operands: dropout step = drop.step + (r / s_div) % s_mod, dropout element index =
+// ((r / b_div) % b_mod) * R + j; target row = r % t_mod when t_mod > 0 (broadcast over steps).  t / y may be null
+// (plain in-place dropout of a ReLU'd activation).
+int xgk_gate_fwd(hipStream_t st, float* pre_g, int ldp, const float* t, int ldt, int t_mod, float* y, int ldy,
+                 int rows, int R, XgDrop drop, int s_div, int s_mod, int b_div, int b_mod);
+// dpre = dy*t*keep*(g>0) ; dt (+)= dy*(g+1)
+int xgk_gate_bwd(hipStream_t st, const float* dy, int lddy, const float* g, int ldg, const float* t, int ldt, int t_mod,
+                 float* dpre, int lddp, float* dt, int lddt, bool dt_accumulate, int rows, int R, XgDrop drop);
+
+// y = dropout(x) (x already ReLU'd) in place ; backward: dx = dy*keep*(y>0) in place
+int xgk_relu_drop_fwd(hipStream_t st, float* x, int64_t n, XgDrop drop);
+int xgk_relu_drop_bwd(hipStream_t st, float* dy, const float* y, int64_t n, XgDrop drop);
+
+// column reductions over rows of X (N,Cn) ld: out[c] += sum_r X[r][c]  (atomic accumulate; caller zeroes)
+int xgk_colsum(hipStream_t st, const float* X, int ld, int N, int Cn, float* out);
+// out1[c] += sum_r X*Y ; (used for BN dgamma and a2w weight grad)
+int xgk_colsum_prod(hipStream_t st, const float* X, int ldx, const float* Y, int ldy, int N, int Cn, float* out);
+
+// BatchNorm1d over rows of Z (N,R): statistics, apply (+ReLU, dropout, row mask), backward
+int xgk_bn_stats(hipStream_t st, const float* Z, int N, int R, float* mean, float* var /*biased*/, float* scratch);
+int xgk_bn_running(hipStream_t st, const float* mean, const float* var, float* rmean, float* rvar, int N, int R,
+                   float momentum);
+// X[r][c] = dropout(relu((Z-mean)*rsqrt(var+eps)*gamma+beta)) * rowmask[r]
+int xgk_bn_apply(hipStream_t st, const float* Z, const float* mean, const float* var, const float* gamma,
+                 const float* beta, const float* rowmask, float* X, int N, int R, float eps, XgDrop drop);
+// dY[r][c] = dX*rowmask*keep*(X>0)  (in place on dX) and sums: sum_dy[c], sum_dyxhat[c] (atomic; caller zeroes)
+int xgk_bn_bwd_reduce(hipStream_t st, float* dX, const float* X, const float* Z, const float* mean, const float* var,
+                      const float* rowmask, int N, int R, float eps, XgDrop drop, float* sum_dy, float* sum_dyxhat);
+// dZ = gamma*invstd*(dY - sum_dy/N - xhat*sum_dyxhat/N) (train) or gamma*invstd*dY (eval), in place on dY
+int xgk_bn_bwd_apply(hipStream_t st, float* dY, const float* Z, const float* mean, const float* var,
+                     const float* gamma, const float* sum_dy, const float* sum_dyxhat, int N, int R, float eps,
+                     bool train);
+
+// row i uses token tok[(i % inner) * s_inner + (i / inner) * s_outer]
+int xgk_embed_gather(hipStream_t st, const float* table, int E, const int64_t* tok, int inner, int64_t s_inner,
+                     int64_t s_outer, int n, int V, float* out, int ldo);
+// dtable[tok(i)] += dX[i]   (atomic)
+int xgk_embed_scatter_add(hipStream_t st, float* dtable, int E, const int64_t* tok, int inner, int64_t s_inner,
+                          int64_t s_outer, int n, int V, const float* dX, int ldx);
+// vbar[b][r] = sum_k V[b][k][r] / sum_k mask[b][k]
+int xgk_masked_mean(hipStream_t st, const float* V, const float* mask, float* out, int B, int K, int R);
+int xgk_axpy(hipStream_t st, float* y, const float* x, float a, int64_t n);          // y += a*x
+int xgk_fill(hipStream_t st, float* y, float v, int64_t n);
+// strided 2-D copy / add: dst[r*ldd + c] (=|+=) src[r*lds + c]
+int xgk_copy2d(hipStream_t st, float* dst, int ldd, const float* src, int lds, int rows, int cols, bool add);
+
+// ---- xg_attn.hip
+// per-sample additive attention: e_k = w . tanh(p + q_k), alpha = softmax_k(e), af = sum_k alpha_k V_k
+int xgk_attn_fwd(hipStream_t st, const float* p, const float* vproj, const float* V, const float* w, float* alpha,
+                 float* af, int B, int K, int R, int A);
+// de[b][k], dp[b][a] from daf[b][r]
+int xgk_attn_bwd(hipStream_t st, const float* daf, int lddaf, const float* p, const float* vproj, const float* V,
+                 const float* w, const float* alpha, float* de, float* dp, int B, int K, int R, int A);
+// after the time loop: dvproj[b][k][a] = w_a sum_t de_t (1-th^2) ; dw[a] += sum de_t th ; dV[b][k][r] (+)= sum_t alpha_t daf_t
+int xgk_attn_bwd_post(hipStream_t st, const float* P /*(T,B,A)*/, const float* vproj, const float* w,
+                      const float* DE /*(T,B,K)*/, float* dvproj, float* dw, int T, int B, int K, int A);
+int xgk_attn_dV(hipStream_t st, const float* ALPHA /*(T,B,K)*/, const float* DAF /*(T,B,ldaf)*/, int lddaf,
+                int64_t daf_tstride, float* dV, int T, int B, int K, int R, bool accumulate);
+
+// ---- xg_heads.hip
+// out[orow(i)] = log_softmax(in[i]) ; orow = (i % inner) * outer + i / inner when permute (time-major -> batch-major)
+int xgk_log_softmax(hipStream_t st, const float* in, int ldin, float* out, int ldout, int rows, int V, int inner,
+                    int outer, bool permute);
+// dlogits[i] = dlogp[drow] - exp(logp[lrow]) * sum_v dlogp[drow]; permute 0: drow = lrow = i; 1: both = orow(i);
+// 2: drow = orow(i), lrow = i (logp kept time-major in the workspace; may alias dlogits)
+int xgk_log_softmax_bwd(hipStream_t st, const float* dlogp, const float* logp, int ldp, float* dlogits, int ldd,
+                        int rows, int V, int inner, int outer, int permute);
+int xgk_nll_fwd(hipStream_t st, const float* logp, const int64_t* target, const float* mask, const float* mask2,
+                int B, int T, int V, int roll, float* out2);
+int xgk_nll_bwd(hipStream_t st, const int64_t* target, const float* mask, const float* mask2, int B, int T, int V,
+                int roll, const float* sums, float scale, float* dlogp);
+// fused: rows are time-major logits (T*B,V): per-row lse, loss accumulation, and dlogits in place
+int xgk_xent_fwd(hipStream_t st, const float* logits, int ld, const int64_t* seq, const float* mask,
+                 const float* mask2, int B, int T, int V, int roll, float* lse, float* sums2);
+int xgk_xent_bwd(hipStream_t st, float* logits_inout, int ld, const int64_t* seq, const float* mask,
+                 const float* mask2, int B, int T, int V, int roll, const float* lse, const float* sums2,
+                 const float* scale_dev, float scale);
+// rollout token choice from a (B,V) log-prob matrix
+int xgk_choose(hipStream_t st, const float* logp, int B, int V, int mode, const float* uniforms,
+               const int64_t* forced, int64_t forced_stride, float temperature, int64_t* tok, float* tok_logp);
+// rollout bookkeeping (SAModel.py:200-215)
+int xgk_rollout_book(hipStream_t st, int t, int B, int Tm1, int replay, const int64_t* tok, const float* tok_logp,
+                     float* unfinished, int64_t* seq, float* seq_logp, int32_t* n_steps, int32_t* alive);
+// dlogits (B,V) row b = d * (onehot(tok) - softmax) for the sampled token (rollout backward)
+int xgk_rollout_dlogits(hipStream_t st, const float* logp, const int64_t* tok, const float* dslp, int64_t dstride,
+                        float* dlogits, int B, int V);
+
+// ---- xg_optim.hip
+int xgk_clip_adam(hipStream_t st, int64_t n, float* p, float* g, float* m, float* v, float lr, float b1, float b2,
+                  float eps, float wd, int step, float clip);

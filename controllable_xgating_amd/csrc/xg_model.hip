@@ -1,0 +1,726 @@
+// Host-side orchestration of the caption decoder hot path on one HIP stream (gfx950).
+// Every function only enqueues kernels; no host synchronisation, no allocation.
+//
+// Reference maths: caption_src/sub_modules.py:118-159 (CG encoder), caption_src/SAModel.py:58-65
+// (init_hidden), caption_src/sub_modules.py:671-687 + :750-770 (decoder step), caption_src/SAModel.py:67-115
+// (teacher-forced forward), :163-219 (rollouts), :221-267 (criteria).
+//
+// Layouts in the workspace (all fp32):
+//   encoder tensors are (B*K, .) rows in (b,k) order, exactly the reference's .view(-1, F);
+//   decoder tensors are time-major (T, B, .) so each step's rows are contiguous and the stacked
+//   (T*B, .) matrices feed the batched head / weight-gradient GEMMs directly.
+#include "xg_common.h"
+#include "xg_kernels.h"
+
+namespace {
+
+struct Ws {
+    // ---- encoder
+    float *Z[2], *X[2], *PRE[2], *Hs[2], *Cs[2], *G[2], *GG[2], *Hprev[2];
+    float *bn_mean[2], *bn_var[2], *bn_s1[2], *bn_s2[2];
+    float *zeroBR, *S, *S2, *Y, *Venc;
+    float *dVw, *dY, *dHs[2], *dGG[2], *dS[2], *dX[2], *dHrec[2], *dCrec[2][2];
+    // ---- decoder
+    float *vbar, *vproj, *Xe, *GP, *POSG, *PRE1, *H1, *C1, *H2, *C2, *G1, *G2, *P, *ALPHA, *AF;
+    float *LOGITS, *HC, *CL, *LSE, *LSEC, *sums;   // sums: 8 floats
+    float *DH2OUT, *DHC, *DCL, *DS1, *DS2, *DP, *DE, *DAF, *dst[2][4], *DVPROJ, *DV, *DPOSG, *DGP, *DXe;
+    float *state_tmp;
+    // ---- rollout
+    int64_t* TOK; float *TOKLP, *UNF; int32_t* alive;
+    size_t bytes;
+};
+
+struct Carver {
+    char* base; size_t off;
+    template <typename T> T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* p = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += n * sizeof(T);
+        return p;
+    }
+};
+
+Ws carve(const XgDims& d, void* base) {
+    Ws w{};
+    Carver c{static_cast<char*>(base), 0};
+    const size_t B = d.B, K = d.K, R = d.R, A = d.A, E = d.E, V = d.V, C = d.C, H = d.H, T = d.T;
+    const size_t N = B * K, TB = T * B;
+    for (int m = 0; m < 2; ++m) {
+        w.Z[m] = c.take<float>(N * R); w.X[m] = c.take<float>(N * R); w.PRE[m] = c.take<float>(N * 4 * R);
+        w.Hs[m] = c.take<float>(N * R); w.Cs[m] = c.take<float>(N * R); w.G[m] = c.take<float>(N * 4 * R);
+        w.GG[m] = c.take<float>(N * R); w.Hprev[m] = c.take<float>(N * R);
+        w.bn_mean[m] = c.take<float>(R); w.bn_var[m] = c.take<float>(R);
+        w.bn_s1[m] = c.take<float>(R); w.bn_s2[m] = c.take<float>(R);
+        w.dHs[m] = c.take<float>(N * R); w.dGG[m] = c.take<float>(N * R); w.dS[m] = c.take<float>(N * 4 * R);
+        w.dX[m] = c.take<float>(N * R); w.dHrec[m] = c.take<float>(B * R);
+        w.dCrec[m][0] = c.take<float>(B * R); w.dCrec[m][1] = c.take<float>(B * R);
+    }
+    w.zeroBR = c.take<float>(B * R); w.S = c.take<float>(B * 4 * R); w.S2 = c.take<float>(B * 4 * R);
+    w.Y = c.take<float>(N * 2 * R); w.Venc = c.take<float>(N * R);
+    w.dVw = c.take<float>(N * R); w.dY = c.take<float>(N * 2 * R);
+    w.vbar = c.take<float>(B * R); w.vproj = c.take<float>(N * A);
+    w.Xe = c.take<float>(TB * E); w.GP = c.take<float>(TB * R); w.POSG = c.take<float>(TB * R);
+    w.PRE1 = c.take<float>(TB * 4 * R);
+    w.H1 = c.take<float>((T + 1) * B * R); w.C1 = c.take<float>((T + 1) * B * R);
+    w.H2 = c.take<float>((T + 1) * B * R); w.C2 = c.take<float>((T + 1) * B * R);
+    w.G1 = c.take<float>(TB * 4 * R); w.G2 = c.take<float>(TB * 4 * R);
+    w.P = c.take<float>(TB * A); w.ALPHA = c.take<float>(TB * K); w.AF = c.take<float>(TB * R);
+    w.LOGITS = c.take<float>(TB * V); w.HC = c.take<float>(TB * H); w.CL = c.take<float>(TB * C);
+    w.LSE = c.take<float>(TB); w.LSEC = c.take<float>(TB); w.sums = c.take<float>(8);
+    w.DH2OUT = c.take<float>(TB * R); w.DHC = c.take<float>(TB * H); w.DCL = c.take<float>(TB * C);
+    w.DS1 = c.take<float>(TB * 4 * R); w.DS2 = c.take<float>(TB * 4 * R); w.DP = c.take<float>(TB * A);
+    w.DE = c.take<float>(TB * K); w.DAF = c.take<float>(TB * R);
+    for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) w.dst[i][j] = c.take<float>(B * R);
+    w.DVPROJ = c.take<float>(N * A); w.DV = c.take<float>(N * R); w.DPOSG = c.take<float>(TB * R);
+    w.DGP = c.take<float>(TB * R); w.DXe = c.take<float>(TB * E);
+    w.state_tmp = c.take<float>(4 * B * R);
+    w.TOK = c.take<int64_t>(TB); w.TOKLP = c.take<float>(TB); w.UNF = c.take<float>(TB);
+    w.alive = c.take<int32_t>(4);
+    w.bytes = (c.off + 255) & ~(size_t)255;
+    return w;
+}
+
+bool dims_ok(const XgDims* d) {
+    return d && d->B > 0 && d->K > 0 && d->R > 0 && d->A > 0 && d->E > 0 && d->V > 1 && d->C > 0 && d->H > 0 &&
+           d->F1 > 0 && d->F2 > 0 && d->T > 0;
+}
+
+#define ZERO(ptr, nfloats) \
+    do { if (hipMemsetAsync((ptr), 0, sizeof(float) * (size_t)(nfloats), st) != hipSuccess) return XG_EHIP; } while (0)
+
+// NN data-gradient GEMM: dX[M,N] (+)= dY[M,Kc] * W[Kc,N]   (W row-major, ldw)
+inline int gemm_nn(hipStream_t st, int M, int N, int Kc, const float* dY, int lddy, const float* W, int ldw,
+                   float* dX, int lddx, bool acc) {
+    return xgk_gemm(st, false, false, M, N, Kc, dY, lddy, W, ldw, dX, lddx, nullptr, false, acc);
+}
+// TN weight-gradient GEMM: dW[N,K] += dY[M,N]^T * X[M,K]
+inline int gemm_tn(hipStream_t st, int Mrows, int N, int K, const float* dY, int lddy, const float* X, int ldx,
+                   float* dW, int lddw) {
+    return xgk_gemm(st, true, false, N, K, Mrows, dY, lddy, X, ldx, dW, lddw, nullptr, false, true);
+}
+
+// ================================================================== encoder
+int encoder_fwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgBnState* bn, const XgBatch& x,
+                const XgRun& run, Ws& w) {
+    const int B = d.B, K = d.K, R = d.R, N = B * K;
+    const float* feats[2] = {x.feats_rgb, x.feats_opfl};
+    const int F[2] = {d.F1, d.F2};
+    const float* emb_w[2] = {p.emb_rgb_w, p.emb_opfl_w};
+    const float* emb_b[2] = {p.emb_rgb_b, p.emb_opfl_b};
+    const float* bn_g[2] = {p.bn_rgb_g, p.bn_opfl_g};
+    const float* bn_b[2] = {p.bn_rgb_b, p.bn_opfl_b};
+    float* rmean[2] = {bn ? bn->rgb_mean : nullptr, bn ? bn->opfl_mean : nullptr};
+    float* rvar[2] = {bn ? bn->rgb_var : nullptr, bn ? bn->opfl_var : nullptr};
+    const float* wih[2] = {p.lstm_rgb_wih, p.lstm_opfl_wih};
+    const float* whh[2] = {p.lstm_rgb_whh, p.lstm_opfl_whh};
+    const float* bih[2] = {p.lstm_rgb_bih, p.lstm_opfl_bih};
+    const float* bhh[2] = {p.lstm_rgb_bhh, p.lstm_opfl_bhh};
+    for (int m = 0; m < 2; ++m) {
+        XG_TRY(xgk_linear(st, N, R, F[m], feats[m], F[m], emb_w[m], emb_b[m], w.Z[m], R));          // sub_modules.py:121,126
+        if (run.train) {
+            XG_TRY(xgk_bn_stats(st, w.Z[m], N, R, w.bn_mean[m], w.bn_var[m], nullptr));
+            if (rmean[m] && rvar[m])
+                XG_TRY(xgk_bn_running(st, w.bn_mean[m], w.bn_var[m], rmean[m], rvar[m], N, R, run.bn_momentum));
+        } else {
+            if (!rmean[m] || !rvar[m]) return XG_EINVAL;
+            if (hipMemcpyAsync(w.bn_mean[m], rmean[m], sizeof(float) * R, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
+            if (hipMemcpyAsync(w.bn_var[m], rvar[m], sizeof(float) * R, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
+        }
+        XG_TRY(xgk_bn_apply(st, w.Z[m], w.bn_mean[m], w.bn_var[m], bn_g[m], bn_b[m], x.feat_mask, w.X[m], N, R,
+                            run.bn_eps, xg_make_drop(&run, m == 0 ? XG_SITE_EMB_RGB : XG_SITE_EMB_OPFL, 0)));
+        XG_TRY(xgk_linear(st, N, 4 * R, R, w.X[m], R, wih[m], bih[m], w.PRE[m], 4 * R));          // hoisted over all K frames
+    }
+    ZERO(w.zeroBR, (size_t)B * R);
+    XgRun nodrop = run; nodrop.drop_p = 0.f;
+    for (int i = 0; i < K; ++i) {                                                                  // sub_modules.py:132-148
+        for (int m = 0; m < 2; ++m) {
+            const float* hp = i == 0 ? w.zeroBR : w.Hs[m] + (size_t)(i - 1) * R;
+            const float* cp = i == 0 ? w.zeroBR : w.Cs[m] + (size_t)(i - 1) * R;
+            const int ldp = i == 0 ? R : K * R;
+            float* S = m == 0 ? w.S : w.S2;
+            XG_TRY(xgk_linear(st, B, 4 * R, R, hp, ldp, whh[m], bhh[m], S, 4 * R));
+            LstmFwdArgs a{};
+            a.s = S; a.lds_ = 4 * R; a.add = w.PRE[m] + (size_t)i * 4 * R; a.ldadd = K * 4 * R;
+            a.c_prev = cp; a.ldcp = ldp; a.h_prev = hp; a.ldhp = ldp;
+            a.mask = x.feat_mask + i; a.ldm = K;
+            a.gates = w.G[m] + (size_t)i * 4 * R; a.ldg = K * 4 * R;
+            a.c_out = w.Cs[m] + (size_t)i * R; a.ldco = K * R;
+            a.h_out = w.Hs[m] + (size_t)i * R; a.ldho = K * R;
+            a.B = B; a.R = R; a.order = XG_ORDER_IFGO; a.mask_mode = XG_MASK_ZERO;
+            a.drop = xg_make_drop(&nodrop, 0, 0);
+            XG_TRY(xgk_lstm_fwd(st, a));
+        }
+    }
+    // cross gates, all frames at once (gated values are not fed back): sub_modules.py:151-152
+    XG_TRY(xgk_linear(st, N, R, R, w.Hs[1], R, p.gate_rgb_w, p.gate_rgb_b, w.GG[0], R, true));
+    XG_TRY(xgk_linear(st, N, R, R, w.Hs[0], R, p.gate_opfl_w, p.gate_opfl_b, w.GG[1], R, true));
+    for (int m = 0; m < 2; ++m) {
+        XgDrop dr = xg_make_drop(&run, m == 0 ? XG_SITE_GATE_RGB : XG_SITE_GATE_OPFL, 0);
+        XG_TRY(xgk_gate_fwd(st, w.GG[m], R, w.Hs[m], R, 0, w.Y + (size_t)m * R, 2 * R, N, R, dr, /*step=row%K*/ 1, K,
+                            /*b=row/K*/ K, 1 << 30));
+    }
+    XG_TRY(xgk_linear(st, N, R, 2 * R, w.Y, 2 * R, p.fusion_w, p.fusion_b, w.Venc, R, true));       // :69-70
+    XG_TRY(xgk_relu_drop_fwd(st, w.Venc, (int64_t)N * R, xg_make_drop(&run, XG_SITE_FUSION, 0)));
+    return XG_OK;
+}
+
+int encoder_bwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgParams& g, const XgBatch& x,
+                const XgRun& run, Ws& w, const float* dV_in) {
+    const int B = d.B, K = d.K, R = d.R, N = B * K;
+    const float* feats[2] = {x.feats_rgb, x.feats_opfl};
+    const int F[2] = {d.F1, d.F2};
+    const float* wih[2] = {p.lstm_rgb_wih, p.lstm_opfl_wih};
+    const float* whh[2] = {p.lstm_rgb_whh, p.lstm_opfl_whh};
+    float* g_wih[2] = {g.lstm_rgb_wih, g.lstm_opfl_wih};
+    float* g_whh[2] = {g.lstm_rgb_whh, g.lstm_opfl_whh};
+    float* g_bih[2] = {g.lstm_rgb_bih, g.lstm_opfl_bih};
+    float* g_bhh[2] = {g.lstm_rgb_bhh, g.lstm_opfl_bhh};
+    const float* gate_w[2] = {p.gate_rgb_w, p.gate_opfl_w};
+    float* g_gate_w[2] = {g.gate_rgb_w, g.gate_opfl_w};
+    float* g_gate_b[2] = {g.gate_rgb_b, g.gate_opfl_b};
+    const float* bn_g[2] = {p.bn_rgb_g, p.bn_opfl_g};
+    float* g_bn_g[2] = {g.bn_rgb_g, g.bn_opfl_g};
+    float* g_bn_b[2] = {g.bn_rgb_b, g.bn_opfl_b};
+    float* g_emb_w[2] = {g.emb_rgb_w, g.emb_opfl_w};
+    float* g_emb_b[2] = {g.emb_rgb_b, g.emb_opfl_b};
+
+    if (hipMemcpyAsync(w.dVw, dV_in, sizeof(float) * (size_t)N * R, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
+    XG_TRY(xgk_relu_drop_bwd(st, w.dVw, w.Venc, (int64_t)N * R, xg_make_drop(&run, XG_SITE_FUSION, 0)));
+    XG_TRY(gemm_tn(st, N, R, 2 * R, w.dVw, R, w.Y, 2 * R, g.fusion_w, 2 * R));
+    XG_TRY(xgk_colsum(st, w.dVw, R, N, R, g.fusion_b));
+    XG_TRY(gemm_nn(st, N, 2 * R, R, w.dVw, R, p.fusion_w, 2 * R, w.dY, 2 * R, false));
+    for (int m = 0; m < 2; ++m) {   // y = g*h + h : dpre -> dGG, dh -> dHs (overwrite)
+        XgDrop dr = xg_make_drop(&run, m == 0 ? XG_SITE_GATE_RGB : XG_SITE_GATE_OPFL, 0);
+        XG_TRY(xgk_gate_bwd(st, w.dY + (size_t)m * R, 2 * R, w.GG[m], R, w.Hs[m], R, 0, w.dGG[m], R, w.dHs[m], R, false,
+                            N, R, dr));
+    }
+    for (int m = 0; m < 2; ++m) {   // gate m takes source = hidden of the OTHER modality
+        const int o = 1 - m;
+        XG_TRY(gemm_tn(st, N, R, R, w.dGG[m], R, w.Hs[o], R, g_gate_w[m], R));
+        XG_TRY(xgk_colsum(st, w.dGG[m], R, N, R, g_gate_b[m]));
+        XG_TRY(gemm_nn(st, N, R, R, w.dGG[m], R, gate_w[m], R, w.dHs[o], R, true));
+    }
+    XgRun nodrop = run; nodrop.drop_p = 0.f;
+    for (int m = 0; m < 2; ++m) {
+        ZERO(w.dHrec[m], (size_t)B * R);
+        ZERO(w.dCrec[m][0], (size_t)B * R);
+        int cur = 0;
+        for (int i = K - 1; i >= 0; --i) {
+            XG_TRY(xgk_copy2d(st, w.dHs[m] + (size_t)i * R, K * R, w.dHrec[m], R, B, R, true));
+            LstmBwdArgs a{};
+            a.gates = w.G[m] + (size_t)i * 4 * R; a.ldg = K * 4 * R;
+            a.c_prev = i == 0 ? w.zeroBR : w.Cs[m] + (size_t)(i - 1) * R; a.ldcp = i == 0 ? R : K * R;
+            a.c_out = w.Cs[m] + (size_t)i * R; a.ldco = K * R;
+            a.mask = x.feat_mask + i; a.ldm = K;
+            a.dh_out = w.dHs[m] + (size_t)i * R; a.lddh = K * R;
+            a.dc_out = w.dCrec[m][cur]; a.lddc = R;
+            a.ds = w.dS[m] + (size_t)i * 4 * R; a.ldds = K * 4 * R;
+            a.dc_prev = w.dCrec[m][cur ^ 1]; a.lddcp = R;
+            a.dh_prev = nullptr; a.lddhp = 0;
+            a.B = B; a.R = R; a.order = XG_ORDER_IFGO; a.mask_mode = XG_MASK_ZERO;
+            a.drop = xg_make_drop(&nodrop, 0, 0);
+            XG_TRY(xgk_lstm_bwd(st, a));
+            cur ^= 1;
+            if (i > 0) XG_TRY(gemm_nn(st, B, R, 4 * R, w.dS[m] + (size_t)i * 4 * R, K * 4 * R, whh[m], R, w.dHrec[m], R, false));
+        }
+        // Hprev[b,k] = H[b,k-1], zero at k = 0 : one clean TN GEMM for dW_hh
+        ZERO(w.Hprev[m], (size_t)N * R);
+        if (K > 1)   // one strided 2-D copy covers all videos: rows = B, cols = (K-1)*R
+            XG_TRY(xgk_copy2d(st, w.Hprev[m] + R, K * R, w.Hs[m], K * R, B, (K - 1) * R, false));
+        XG_TRY(gemm_tn(st, N, 4 * R, R, w.dS[m], 4 * R, w.Hprev[m], R, g_whh[m], R));
+        XG_TRY(gemm_tn(st, N, 4 * R, R, w.dS[m], 4 * R, w.X[m], R, g_wih[m], R));
+        XG_TRY(xgk_colsum(st, w.dS[m], 4 * R, N, 4 * R, g_bih[m]));
+        XG_TRY(xgk_colsum(st, w.dS[m], 4 * R, N, 4 * R, g_bhh[m]));
+        XG_TRY(gemm_nn(st, N, R, 4 * R, w.dS[m], 4 * R, wih[m], R, w.dX[m], R, false));
+        // BatchNorm + ReLU + dropout + mask backward (sub_modules.py:121-123)
+        ZERO(w.bn_s1[m], R); ZERO(w.bn_s2[m], R);
+        XG_TRY(xgk_bn_bwd_reduce(st, w.dX[m], w.X[m], w.Z[m], w.bn_mean[m], w.bn_var[m], x.feat_mask, N, R, run.bn_eps,
+                                 xg_make_drop(&run, m == 0 ? XG_SITE_EMB_RGB : XG_SITE_EMB_OPFL, 0), w.bn_s1[m], w.bn_s2[m]));
+        XG_TRY(xgk_axpy(st, g_bn_b[m], w.bn_s1[m], 1.f, R));
+        XG_TRY(xgk_axpy(st, g_bn_g[m], w.bn_s2[m], 1.f, R));
+        XG_TRY(xgk_bn_bwd_apply(st, w.dX[m], w.Z[m], w.bn_mean[m], w.bn_var[m], bn_g[m], w.bn_s1[m], w.bn_s2[m], N, R,
+                                run.bn_eps, run.train != 0));
+        XG_TRY(gemm_tn(st, N, R, F[m], w.dX[m], R, feats[m], F[m], g_emb_w[m], F[m]));
+        XG_TRY(xgk_colsum(st, w.dX[m], R, N, R, g_emb_b[m]));
+    }
+    return XG_OK;
+}
+
+// ================================================================== decoder pieces
+int init_hidden(hipStream_t st, const XgDims& d, const XgParams& p, const float* V, const float* feat_mask, Ws& w,
+                float* h1, float* c1, float* h2, float* c2) {
+    const int B = d.B, R = d.R;
+    XG_TRY(xgk_masked_mean(st, V, feat_mask, w.vbar, B, d.K, R));
+    XG_TRY(xgk_linear(st, B, R, R, w.vbar, R, p.ih1_w, p.ih1_b, h1, R));
+    XG_TRY(xgk_linear(st, B, R, R, w.vbar, R, p.ic1_w, p.ic1_b, c1, R));
+    XG_TRY(xgk_linear(st, B, R, R, w.vbar, R, p.ih2_w, p.ih2_b, h2, R));
+    XG_TRY(xgk_linear(st, B, R, R, w.vbar, R, p.ic2_w, p.ic2_b, c2, R));
+    return XG_OK;
+}
+
+struct StepIO {
+    const float* xt;      // (B,E)
+    const float* posg;    // (B,R) gated POS feature
+    const float* pre1;    // (B,4R) hoisted xt/pos' contribution of cell 1, or null (computed here)
+    const float* mask; int ldm;
+    const float *h1, *c1, *h2, *c2;   // previous state (B,R) contiguous
+    float *h1o, *c1o, *h2o, *c2o;     // new state
+    float *P, *alpha, *af, *g1, *g2;  // saved per-step tensors (alpha / gates may be scratch)
+    int t;
+};
+
+// attention + the two cells for one step (sub_modules.py:677-684)
+int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& run, Ws& w, const float* V,
+              const float* vproj, const StepIO& s) {
+    const int B = d.B, R = d.R, A = d.A, E = d.E;
+    XG_TRY(xgk_gemm(st, false, true, B, A, R, s.h1, R, p.h2a_w, 2 * R, s.P, A, p.h2a_b, false, false));
+    XG_TRY(xgk_gemm(st, false, true, B, A, R, s.h2, R, p.h2a_w + R, 2 * R, s.P, A, nullptr, false, true));
+    XG_TRY(xgk_attn_fwd(st, s.P, vproj, V, p.a2w_w, s.alpha, s.af, B, d.K, R, A));
+    // cell 1: lstm_1(xt, pos', h1)
+    XG_TRY(xgk_linear(st, B, 4 * R, R, s.h1, R, p.l1_h2h_w, p.l1_h2h_b, w.S, 4 * R));
+    if (!s.pre1) {
+        XG_TRY(xgk_linear(st, B, 4 * R, E, s.xt, E, p.l1_i2h_w, p.l1_i2h_b, w.S, 4 * R, false, true));
+        XG_TRY(xgk_linear(st, B, 4 * R, R, s.posg, R, p.l1_a2h_w, p.l1_a2h_b, w.S, 4 * R, false, true));
+    }
+    LstmFwdArgs a{};
+    a.s = w.S; a.lds_ = 4 * R; a.add = s.pre1; a.ldadd = 4 * R;
+    a.c_prev = s.c1; a.ldcp = R; a.h_prev = s.h1; a.ldhp = R; a.mask = s.mask; a.ldm = s.ldm;
+    a.gates = s.g1; a.ldg = 4 * R; a.c_out = s.c1o; a.ldco = R; a.h_out = s.h1o; a.ldho = R;
+    a.B = B; a.R = R; a.order = XG_ORDER_IFOG; a.mask_mode = XG_MASK_HOLD;
+    a.drop = xg_make_drop(&run, XG_SITE_L1, s.t);
+    XG_TRY(xgk_lstm_fwd(st, a));
+    // cell 2: lstm_2(h1', af, h2)
+    XG_TRY(xgk_linear(st, B, 4 * R, R, s.h1o, R, p.l2_i2h_w, p.l2_i2h_b, w.S2, 4 * R));
+    XG_TRY(xgk_linear(st, B, 4 * R, R, s.af, R, p.l2_a2h_w, p.l2_a2h_b, w.S2, 4 * R, false, true));
+    XG_TRY(xgk_linear(st, B, 4 * R, R, s.h2, R, p.l2_h2h_w, p.l2_h2h_b, w.S2, 4 * R, false, true));
+    LstmFwdArgs c{};
+    c.s = w.S2; c.lds_ = 4 * R; c.add = nullptr; c.ldadd = 0;
+    c.c_prev = s.c2; c.ldcp = R; c.h_prev = s.h2; c.ldhp = R; c.mask = s.mask; c.ldm = s.ldm;
+    c.gates = s.g2; c.ldg = 4 * R; c.c_out = s.c2o; c.ldco = R; c.h_out = s.h2o; c.ldho = R;
+    c.B = B; c.R = R; c.order = XG_ORDER_IFOG; c.mask_mode = XG_MASK_HOLD;
+    c.drop = xg_make_drop(&run, XG_SITE_L2, s.t);
+    XG_TRY(xgk_lstm_fwd(st, c));
+    return XG_OK;
+}
+
+// teacher-forced decoder, states into w.H1/C1/H2/C2 (SAModel.py:85-112)
+int decoder_fwd_xe(hipStream_t st, const XgDims& d, const XgParams& p, const XgBatch& x, const XgRun& run, Ws& w) {
+    const int B = d.B, R = d.R, A = d.A, E = d.E, T = d.T, TB = T * B, N = B * d.K;
+    const size_t BR = (size_t)B * R;
+    XG_TRY(init_hidden(st, d, p, w.Venc, x.feat_mask, w, w.H1, w.C1, w.H2, w.C2));
+    XG_TRY(xgk_linear(st, N, A, R, w.Venc, R, p.v2a_w, p.v2a_b, w.vproj, A));                       // hoisted v2a(V), :677
+    XG_TRY(xgk_embed_gather(st, p.embed_w, E, x.seq, /*inner=*/B, /*s_inner=*/T, /*s_outer=*/1, TB, d.V, w.Xe, E));
+    XG_TRY(xgk_linear(st, TB, R, E, w.Xe, E, p.dgate_w, p.dgate_b, w.GP, R, true));                 // :682 gate, all steps
+    XG_TRY(xgk_gate_fwd(st, w.GP, R, x.pos_feats, R, B, w.POSG, R, TB, R, xg_make_drop(&run, XG_SITE_DGATE, 0),
+                        /*step=row/B*/ B, 1 << 30, /*b=row%B*/ 1, B));
+    XG_TRY(xgk_linear(st, TB, 4 * R, E, w.Xe, E, p.l1_i2h_w, p.l1_i2h_b, w.PRE1, 4 * R));
+    XG_TRY(xgk_linear(st, TB, 4 * R, R, w.POSG, R, p.l1_a2h_w, p.l1_a2h_b, w.PRE1, 4 * R, false, true));
+    for (int t = 0; t < T; ++t) {
+        StepIO s{};
+        s.xt = w.Xe + (size_t)t * B * E; s.posg = w.POSG + t * BR; s.pre1 = w.PRE1 + (size_t)t * B * 4 * R;
+        s.mask = x.seq_mask + t; s.ldm = T;
+        s.h1 = w.H1 + t * BR; s.c1 = w.C1 + t * BR; s.h2 = w.H2 + t * BR; s.c2 = w.C2 + t * BR;
+        s.h1o = w.H1 + (t + 1) * BR; s.c1o = w.C1 + (t + 1) * BR; s.h2o = w.H2 + (t + 1) * BR; s.c2o = w.C2 + (t + 1) * BR;
+        s.P = w.P + (size_t)t * B * A; s.alpha = w.ALPHA + (size_t)t * B * d.K; s.af = w.AF + t * BR;
+        s.g1 = w.G1 + (size_t)t * B * 4 * R; s.g2 = w.G2 + (size_t)t * B * 4 * R; s.t = t;
+        XG_TRY(core_step(st, d, p, run, w, w.Venc, w.vproj, s));
+    }
+    return XG_OK;
+}
+
+// classifier hidden + logits for the stacked outputs H2[1..T] (SAModel.py:109-110)
+int heads_fwd_logits(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& run, Ws& w, int rows) {
+    const int B = d.B, R = d.R;
+    const float* Hout = w.H2 + (size_t)B * R;
+    XG_TRY(xgk_linear(st, rows, d.V, R, Hout, R, p.logit_w, p.logit_b, w.LOGITS, d.V));
+    XG_TRY(xgk_linear(st, rows, d.H, R, Hout, R, p.cls0_w, p.cls0_b, w.HC, d.H, true));
+    XG_TRY(xgk_gate_fwd(st, w.HC, d.H, nullptr, 0, 0, nullptr, 0, rows, d.H, xg_make_drop(&run, XG_SITE_CLS, 0), B, 1 << 30,
+                        1, B));
+    XG_TRY(xgk_linear(st, rows, d.C, d.H, w.HC, d.H, p.cls3_w, p.cls3_b, w.CL, d.C));
+    return XG_OK;
+}
+
+// Shared reverse-time pass.  On entry: DH2OUT (TB,R) holds d(loss)/d(h2'_t) from the heads.
+// mask: element (b,t) at mask[b*ldm + t*tstride].  tokens likewise for the embedding scatter.
+int decoder_bwd_core(hipStream_t st, const XgDims& d, const XgParams& p, const XgParams& g, const XgBatch& x,
+                     const XgRun& run, Ws& w, const float* mask, int ldm, int mask_tstride, const int64_t* tok,
+                     int tok_bstride, int tok_tstride) {
+    const int B = d.B, K = d.K, R = d.R, A = d.A, E = d.E, T = d.T, TB = T * B, N = B * K;
+    const size_t BR = (size_t)B * R;
+    int cur = 0;
+    for (int j = 0; j < 4; ++j) ZERO(w.dst[0][j], BR);
+    for (int t = T - 1; t >= 0; --t) {
+        float *dh1n = w.dst[cur][0], *dc1n = w.dst[cur][1], *dh2n = w.dst[cur][2], *dc2n = w.dst[cur][3];
+        float *dh1p = w.dst[cur ^ 1][0], *dc1p = w.dst[cur ^ 1][1], *dh2p = w.dst[cur ^ 1][2], *dc2p = w.dst[cur ^ 1][3];
+        float* ds1 = w.DS1 + (size_t)t * B * 4 * R;
+        float* ds2 = w.DS2 + (size_t)t * B * 4 * R;
+        float* dp = w.DP + (size_t)t * B * A;
+        float* daf = w.DAF + t * BR;
+        const float* mk = mask + (size_t)t * mask_tstride;
+        XG_TRY(xgk_axpy(st, dh2n, w.DH2OUT + t * BR, 1.f, BR));
+        LstmBwdArgs a{};
+        a.gates = w.G2 + (size_t)t * B * 4 * R; a.ldg = 4 * R;
+        a.c_prev = w.C2 + t * BR; a.ldcp = R; a.c_out = w.C2 + (t + 1) * BR; a.ldco = R;
+        a.mask = mk; a.ldm = ldm; a.dh_out = dh2n; a.lddh = R; a.dc_out = dc2n; a.lddc = R;
+        a.ds = ds2; a.ldds = 4 * R; a.dc_prev = dc2p; a.lddcp = R; a.dh_prev = dh2p; a.lddhp = R;
+        a.B = B; a.R = R; a.order = XG_ORDER_IFOG; a.mask_mode = XG_MASK_HOLD;
+        a.drop = xg_make_drop(&run, XG_SITE_L2, t);
+        XG_TRY(xgk_lstm_bwd(st, a));
+        XG_TRY(gemm_nn(st, B, R, 4 * R, ds2, 4 * R, p.l2_i2h_w, R, dh1n, R, true));     // d h1'_t
+        XG_TRY(gemm_nn(st, B, R, 4 * R, ds2, 4 * R, p.l2_a2h_w, R, daf, R, false));     // d af_t
+        XG_TRY(gemm_nn(st, B, R, 4 * R, ds2, 4 * R, p.l2_h2h_w, R, dh2p, R, true));     // d h2_{t-1}
+        XG_TRY(xgk_attn_bwd(st, daf, R, w.P + (size_t)t * B * A, w.vproj, w.Venc, p.a2w_w, w.ALPHA + (size_t)t * B * K,
+                            w.DE + (size_t)t * B * K, dp, B, K, R, A));
+        LstmBwdArgs c{};
+        c.gates = w.G1 + (size_t)t * B * 4 * R; c.ldg = 4 * R;
+        c.c_prev = w.C1 + t * BR; c.ldcp = R; c.c_out = w.C1 + (t + 1) * BR; c.ldco = R;
+        c.mask = mk; c.ldm = ldm; c.dh_out = dh1n; c.lddh = R; c.dc_out = dc1n; c.lddc = R;
+        c.ds = ds1; c.ldds = 4 * R; c.dc_prev = dc1p; c.lddcp = R; c.dh_prev = dh1p; c.lddhp = R;
+        c.B = B; c.R = R; c.order = XG_ORDER_IFOG; c.mask_mode = XG_MASK_HOLD;
+        c.drop = xg_make_drop(&run, XG_SITE_L1, t);
+        XG_TRY(xgk_lstm_bwd(st, c));
+        XG_TRY(gemm_nn(st, B, R, 4 * R, ds1, 4 * R, p.l1_h2h_w, R, dh1p, R, true));
+        XG_TRY(gemm_nn(st, B, R, A, dp, A, p.h2a_w, 2 * R, dh1p, R, true));             // p_t = h2a([h1;h2])
+        XG_TRY(gemm_nn(st, B, R, A, dp, A, p.h2a_w + R, 2 * R, dh2p, R, true));
+        cur ^= 1;
+    }
+    // gradients wrt the initial state -> img_embed_* (init_hidden; vbar is detached: SAModel.py:59-62)
+    {
+        float* gst[4] = {w.dst[cur][0], w.dst[cur][1], w.dst[cur][2], w.dst[cur][3]};
+        float* gw[4] = {g.ih1_w, g.ic1_w, g.ih2_w, g.ic2_w};
+        float* gb[4] = {g.ih1_b, g.ic1_b, g.ih2_b, g.ic2_b};
+        for (int j = 0; j < 4; ++j) {
+            XG_TRY(gemm_tn(st, B, R, R, gst[j], R, w.vbar, R, gw[j], R));
+            XG_TRY(xgk_colsum(st, gst[j], R, B, R, gb[j]));
+        }
+    }
+    // batched weight gradients over all T steps
+    XG_TRY(gemm_tn(st, TB, 4 * R, R, w.DS2, 4 * R, w.H1 + BR, R, g.l2_i2h_w, R));
+    XG_TRY(gemm_tn(st, TB, 4 * R, R, w.DS2, 4 * R, w.AF, R, g.l2_a2h_w, R));
+    XG_TRY(gemm_tn(st, TB, 4 * R, R, w.DS2, 4 * R, w.H2, R, g.l2_h2h_w, R));
+    XG_TRY(xgk_colsum(st, w.DS2, 4 * R, TB, 4 * R, g.l2_i2h_b));
+    XG_TRY(xgk_colsum(st, w.DS2, 4 * R, TB, 4 * R, g.l2_a2h_b));
+    XG_TRY(xgk_colsum(st, w.DS2, 4 * R, TB, 4 * R, g.l2_h2h_b));
+    XG_TRY(gemm_tn(st, TB, 4 * R, R, w.DS1, 4 * R, w.H1, R, g.l1_h2h_w, R));
+    XG_TRY(gemm_tn(st, TB, 4 * R, E, w.DS1, 4 * R, w.Xe, E, g.l1_i2h_w, E));
+    XG_TRY(gemm_tn(st, TB, 4 * R, R, w.DS1, 4 * R, w.POSG, R, g.l1_a2h_w, R));
+    XG_TRY(xgk_colsum(st, w.DS1, 4 * R, TB, 4 * R, g.l1_i2h_b));
+    XG_TRY(xgk_colsum(st, w.DS1, 4 * R, TB, 4 * R, g.l1_a2h_b));
+    XG_TRY(xgk_colsum(st, w.DS1, 4 * R, TB, 4 * R, g.l1_h2h_b));
+    XG_TRY(gemm_tn(st, TB, A, R, w.DP, A, w.H1, R, g.h2a_w, 2 * R));
+    XG_TRY(gemm_tn(st, TB, A, R, w.DP, A, w.H2, R, g.h2a_w + R, 2 * R));
+    XG_TRY(xgk_colsum(st, w.DP, A, TB, A, g.h2a_b));
+    // input side of cell 1: pos' gate, embedding
+    XG_TRY(gemm_nn(st, TB, R, 4 * R, w.DS1, 4 * R, p.l1_a2h_w, R, w.DPOSG, R, false));
+    XG_TRY(gemm_nn(st, TB, E, 4 * R, w.DS1, 4 * R, p.l1_i2h_w, E, w.DXe, E, false));
+    XG_TRY(xgk_gate_bwd(st, w.DPOSG, R, w.GP, R, x.pos_feats, R, B, w.DGP, R, nullptr, 0, false, TB, R,
+                        xg_make_drop(&run, XG_SITE_DGATE, 0)));
+    XG_TRY(gemm_tn(st, TB, R, E, w.DGP, R, w.Xe, E, g.dgate_w, E));
+    XG_TRY(xgk_colsum(st, w.DGP, R, TB, R, g.dgate_b));
+    XG_TRY(gemm_nn(st, TB, E, R, w.DGP, R, p.dgate_w, E, w.DXe, E, true));
+    XG_TRY(xgk_embed_scatter_add(st, g.embed_w, E, tok, B, tok_bstride, tok_tstride, TB, d.V, w.DXe, E));
+    // attention: dq in one pass, then the hoisted projection's gradients
+    XG_TRY(xgk_attn_bwd_post(st, w.P, w.vproj, p.a2w_w, w.DE, w.DVPROJ, g.a2w_w, T, B, K, A));
+    XG_TRY(gemm_tn(st, N, A, R, w.DVPROJ, A, w.Venc, R, g.v2a_w, R));
+    XG_TRY(xgk_colsum(st, w.DVPROJ, A, N, A, g.v2a_b));
+    XG_TRY(gemm_nn(st, N, R, A, w.DVPROJ, A, p.v2a_w, R, w.DV, R, false));
+    XG_TRY(xgk_attn_dV(st, w.ALPHA, w.DAF, R, (int64_t)BR, w.DV, T, B, K, R, true));
+    return XG_OK;
+}
+
+// heads backward from dlogits (rows,V) in w.LOGITS and dcl (rows,C) in w.DCL -> DH2OUT, head param grads
+int heads_bwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgParams& g, const XgRun& run, Ws& w, int rows,
+              bool have_cls) {
+    const int B = d.B, R = d.R, TB = d.T * B;
+    const float* Hout = w.H2 + (size_t)B * R;
+    if (rows < TB) ZERO(w.DH2OUT + (size_t)rows * R, (size_t)(TB - rows) * R);
+    XG_TRY(gemm_nn(st, rows, R, d.V, w.LOGITS, d.V, p.logit_w, R, w.DH2OUT, R, false));
+    XG_TRY(gemm_tn(st, rows, d.V, R, w.LOGITS, d.V, Hout, R, g.logit_w, R));
+    XG_TRY(xgk_colsum(st, w.LOGITS, d.V, rows, d.V, g.logit_b));
+    if (have_cls) {
+        XG_TRY(gemm_tn(st, rows, d.C, d.H, w.DCL, d.C, w.HC, d.H, g.cls3_w, d.H));
+        XG_TRY(xgk_colsum(st, w.DCL, d.C, rows, d.C, g.cls3_b));
+        XG_TRY(gemm_nn(st, rows, d.H, d.C, w.DCL, d.C, p.cls3_w, d.H, w.DHC, d.H, false));
+        XG_TRY(xgk_relu_drop_bwd(st, w.DHC, w.HC, (int64_t)rows * d.H, xg_make_drop(&run, XG_SITE_CLS, 0)));
+        XG_TRY(gemm_tn(st, rows, d.H, R, w.DHC, d.H, Hout, R, g.cls0_w, R));
+        XG_TRY(xgk_colsum(st, w.DHC, d.H, rows, d.H, g.cls0_b));
+        XG_TRY(gemm_nn(st, rows, R, d.H, w.DHC, d.H, p.cls0_w, R, w.DH2OUT, R, true));
+    }
+    return XG_OK;
+}
+
+__global__ void losses_kernel(const float* s, float wc, float* out) {
+    // s[0..1] = xe sums, s[2..3] = cls sums
+    const float lx = s[0] / s[1];
+    const float lc = s[3] > 0.f ? s[2] / s[3] : 0.f;
+    out[0] = lx + wc * lc; out[1] = lx; out[2] = lc;
+}
+__global__ void init_rollout_kernel(int32_t* n_steps, int32_t* alive, int Tm1) {
+    n_steps[0] = Tm1; alive[0] = 1;
+}
+
+int check(const XgDims* d, const void* ws, size_t ws_bytes, Ws* w) {
+    if (!dims_ok(d) || !ws) return XG_EINVAL;
+    *w = carve(*d, const_cast<void*>(ws));
+    if (ws_bytes < w->bytes) return XG_EWORKSPACE;
+    if ((uintptr_t)ws % 256 != 0) return XG_EINVAL;
+    return XG_OK;
+}
+
+}  // namespace
+
+// ================================================================== C ABI
+static const char* kParamNames[] = {
+    "two_spatial_encoder.visual_emb_rgb.0.weight", "two_spatial_encoder.visual_emb_rgb.0.bias",
+    "two_spatial_encoder.visual_emb_rgb.1.weight", "two_spatial_encoder.visual_emb_rgb.1.bias",
+    "two_spatial_encoder.visual_emb_opfl.0.weight", "two_spatial_encoder.visual_emb_opfl.0.bias",
+    "two_spatial_encoder.visual_emb_opfl.1.weight", "two_spatial_encoder.visual_emb_opfl.1.bias",
+    "two_spatial_encoder.lstmcell_rgb.weight_ih", "two_spatial_encoder.lstmcell_rgb.weight_hh",
+    "two_spatial_encoder.lstmcell_rgb.bias_ih", "two_spatial_encoder.lstmcell_rgb.bias_hh",
+    "two_spatial_encoder.lstmcell_opfl.weight_ih", "two_spatial_encoder.lstmcell_opfl.weight_hh",
+    "two_spatial_encoder.lstmcell_opfl.bias_ih", "two_spatial_encoder.lstmcell_opfl.bias_hh",
+    "two_spatial_encoder.gate_rgb.gate.0.weight", "two_spatial_encoder.gate_rgb.gate.0.bias",
+    "two_spatial_encoder.gate_opfl.gate.0.weight", "two_spatial_encoder.gate_opfl.gate.0.bias",
+    "two_spatial_encoder.fusion.late_fusion.0.weight", "two_spatial_encoder.fusion.late_fusion.0.bias",
+    "img_embed_h_1.weight", "img_embed_h_1.bias", "img_embed_c_1.weight", "img_embed_c_1.bias",
+    "img_embed_h_2.weight", "img_embed_h_2.bias", "img_embed_c_2.weight", "img_embed_c_2.bias",
+    "lstmcore.gate.gate.0.weight", "lstmcore.gate.gate.0.bias",
+    "lstmcore.lstm_1.i2h.weight", "lstmcore.lstm_1.i2h.bias", "lstmcore.lstm_1.a2h.weight", "lstmcore.lstm_1.a2h.bias",
+    "lstmcore.lstm_1.h2h.weight", "lstmcore.lstm_1.h2h.bias",
+    "lstmcore.lstm_2.i2h.weight", "lstmcore.lstm_2.i2h.bias", "lstmcore.lstm_2.a2h.weight", "lstmcore.lstm_2.a2h.bias",
+    "lstmcore.lstm_2.h2h.weight", "lstmcore.lstm_2.h2h.bias",
+    "lstmcore.v2a.weight", "lstmcore.v2a.bias", "lstmcore.h2a.weight", "lstmcore.h2a.bias",
+    "lstmcore.a2w.weight", "lstmcore.a2w.bias",
+    "embed.weight", "logit.weight", "logit.bias",
+    "classifer.0.weight", "classifer.0.bias", "classifer.3.weight", "classifer.3.bias"};
+static_assert(sizeof(kParamNames) / sizeof(kParamNames[0]) == sizeof(XgParams) / sizeof(float*),
+              "XgParams field count must match the state_dict name table");
+
+extern "C" int xg_version(void) { return XG_VERSION; }
+extern "C" const char* xg_strerror(int code) {
+    switch (code) {
+        case XG_OK: return "ok";
+        case XG_EINVAL: return "invalid argument (dimension, null or misaligned pointer)";
+        case XG_EARCH: return "device is not gfx950";
+        case XG_EHIP: return "HIP runtime / kernel launch error";
+        case XG_EWORKSPACE: return "workspace too small (see xg_workspace_bytes)";
+        default: return "unknown error";
+    }
+}
+extern "C" int xg_param_count(void) { return (int)(sizeof(kParamNames) / sizeof(kParamNames[0])); }
+extern "C" const char* xg_param_name(int i) { return (i >= 0 && i < xg_param_count()) ? kParamNames[i] : nullptr; }
+extern "C" int xg_param_numel(const XgDims* d, int i, int64_t* numel) {
+    if (!dims_ok(d) || !numel || i < 0 || i >= xg_param_count()) return XG_EINVAL;
+    const int64_t R = d->R, A = d->A, E = d->E, V = d->V, C = d->C, H = d->H;
+    const int64_t n[] = {R * d->F1, R, R, R, R * d->F2, R, R, R,
+                         4 * R * R, 4 * R * R, 4 * R, 4 * R, 4 * R * R, 4 * R * R, 4 * R, 4 * R,
+                         R * R, R, R * R, R, R * 2 * R, R,
+                         R * R, R, R * R, R, R * R, R, R * R, R,
+                         R * E, R,
+                         4 * R * E, 4 * R, 4 * R * R, 4 * R, 4 * R * R, 4 * R,
+                         4 * R * R, 4 * R, 4 * R * R, 4 * R, 4 * R * R, 4 * R,
+                         A * R, A, A * 2 * R, A, A, 1,
+                         V * E, V * R, V, H * R, H, C * H, C};
+    static_assert(sizeof(n) / sizeof(n[0]) == sizeof(XgParams) / sizeof(float*), "numel table size");
+    *numel = n[i];
+    return XG_OK;
+}
+extern "C" size_t xg_workspace_bytes(const XgDims* d) {
+    if (!dims_ok(d)) return 0;
+    return carve(*d, nullptr).bytes;
+}
+
+extern "C" int xg_encoder_fwd(void* stream, const XgDims* d, const XgParams* p, const XgBnState* bn, const XgBatch* x,
+                              const XgRun* run, void* ws, size_t ws_bytes, float* V) {
+    Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
+    if (!p || !x || !run || !V || !x->feats_rgb || !x->feats_opfl || !x->feat_mask) return XG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w));
+    if (hipMemcpyAsync(V, w.Venc, sizeof(float) * (size_t)d->B * d->K * d->R, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
+    return XG_OK;
+}
+extern "C" int xg_encoder_bwd(void* stream, const XgDims* d, const XgParams* p, const XgParams* g, const XgBatch* x,
+                              const XgRun* run, void* ws, size_t ws_bytes, const float* dV) {
+    Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
+    if (!p || !g || !x || !run || !dV) return XG_EINVAL;
+    return encoder_bwd((hipStream_t)stream, *d, *p, *g, *x, *run, w, dV);
+}
+extern "C" int xg_init_hidden(void* stream, const XgDims* d, const XgParams* p, const float* V, const float* feat_mask,
+                              void* ws, size_t ws_bytes, float* state) {
+    Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
+    if (!p || !V || !feat_mask || !state) return XG_EINVAL;
+    const size_t BR = (size_t)d->B * d->R;
+    return init_hidden((hipStream_t)stream, *d, *p, V, feat_mask, w, state, state + BR, state + 2 * BR, state + 3 * BR);
+}
+extern "C" int xg_vproj(void* stream, const XgDims* d, const XgParams* p, const float* V, float* vproj) {
+    if (!dims_ok(d) || !p || !V || !vproj) return XG_EINVAL;
+    return xgk_linear((hipStream_t)stream, d->B * d->K, d->A, d->R, V, d->R, p->v2a_w, p->v2a_b, vproj, d->A);
+}
+
+extern "C" int xg_step_fwd(void* stream, const XgDims* d, const XgParams* p, const int64_t* tokens, const float* xt_mask,
+                           const float* V, const float* vproj, const float* pos_feats, const XgRun* run, int step,
+                           void* ws, size_t ws_bytes, float* state, float* logp, float* alpha) {
+    Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
+    if (!p || !tokens || !V || !vproj || !pos_feats || !run || !state) return XG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = d->B, R = d->R, E = d->E;
+    const size_t BR = (size_t)B * R;
+    XG_TRY(xgk_embed_gather(st, p->embed_w, E, tokens, B, 1, 0, B, d->V, w.Xe, E));
+    XG_TRY(xgk_linear(st, B, R, E, w.Xe, E, p->dgate_w, p->dgate_b, w.GP, R, true));
+    XG_TRY(xgk_gate_fwd(st, w.GP, R, pos_feats, R, 0, w.POSG, R, B, R, xg_make_drop(run, XG_SITE_DGATE, step), B, 1 << 30, 1, B));
+    StepIO s{};
+    s.xt = w.Xe; s.posg = w.POSG; s.pre1 = nullptr; s.mask = xt_mask; s.ldm = 1;
+    s.h1 = state; s.c1 = state + BR; s.h2 = state + 2 * BR; s.c2 = state + 3 * BR;
+    s.h1o = state; s.c1o = state + BR; s.h2o = state + 2 * BR; s.c2o = state + 3 * BR;
+    s.P = w.P; s.alpha = alpha ? alpha : w.ALPHA; s.af = w.AF; s.g1 = nullptr; s.g2 = nullptr; s.t = step;
+    XG_TRY(core_step(st, *d, *p, *run, w, V, vproj, s));
+    if (logp) {
+        XG_TRY(xgk_linear(st, B, d->V, R, state + 2 * BR, R, p->logit_w, p->logit_b, w.LOGITS, d->V));
+        XG_TRY(xgk_log_softmax(st, w.LOGITS, d->V, logp, d->V, B, d->V, 1, 1, false));
+    }
+    return XG_OK;
+}
+
+extern "C" int xg_forward_xe(void* stream, const XgDims* d, const XgParams* p, const XgBnState* bn, const XgBatch* x,
+                             const XgRun* run, void* ws, size_t ws_bytes, float* logp, float* cat_logp) {
+    Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
+    if (!p || !x || !run || !logp || !x->seq || !x->seq_mask || !x->pos_feats) return XG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int TB = d->T * d->B;
+    XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w));
+    XG_TRY(decoder_fwd_xe(st, *d, *p, *x, *run, w));
+    XG_TRY(heads_fwd_logits(st, *d, *p, *run, w, TB));
+    XG_TRY(xgk_log_softmax(st, w.LOGITS, d->V, logp, d->V, TB, d->V, d->B, d->T, true));
+    if (cat_logp) XG_TRY(xgk_log_softmax(st, w.CL, d->C, cat_logp, d->C, TB, d->C, d->B, d->T, true));
+    return XG_OK;
+}
+
+extern "C" int xg_backward_xe(void* stream, const XgDims* d, const XgParams* p, const XgParams* g, const XgBatch* x,
+                              const XgRun* run, void* ws, size_t ws_bytes, const float* dlogp, const float* dcat_logp) {
+    Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
+    if (!p || !g || !x || !run || !x->seq || !x->seq_mask) return XG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = d->B, T = d->T, TB = T * B;
+    // log-softmax backward needs logp = logits - lse: recompute lse rows from the saved logits (in place)
+    if (dlogp) {
+        XG_TRY(xgk_log_softmax(st, w.LOGITS, d->V, w.LOGITS, d->V, TB, d->V, 1, 1, false));
+        XG_TRY(xgk_log_softmax_bwd(st, dlogp, w.LOGITS, d->V, w.LOGITS, d->V, TB, d->V, B, T, 2));
+    } else {
+        ZERO(w.LOGITS, (size_t)TB * d->V);
+    }
+    if (dcat_logp) {
+        XG_TRY(xgk_log_softmax(st, w.CL, d->C, w.CL, d->C, TB, d->C, 1, 1, false));
+        XG_TRY(xgk_log_softmax_bwd(st, dcat_logp, w.CL, d->C, w.DCL, d->C, TB, d->C, B, T, 2));
+    }
+    XG_TRY(heads_bwd(st, *d, *p, *g, *run, w, TB, dcat_logp != nullptr));
+    XG_TRY(decoder_bwd_core(st, *d, *p, *g, *x, *run, w, x->seq_mask, T, 1, x->seq, T, 1));
+    XG_TRY(encoder_bwd(st, *d, *p, *g, *x, *run, w, w.DV));
+    return XG_OK;
+}
+
+extern "C" int xg_xe_loss_fwd(void* stream, const XgDims* d, const XgParams* p, const XgBnState* bn, const XgBatch* x,
+                              const int64_t* cap_classes, const float* class_mask, float weight_class, const XgRun* run,
+                              void* ws, size_t ws_bytes, float* losses) {
+    Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
+    if (!p || !x || !run || !losses || !x->seq || !x->seq_mask || !x->pos_feats) return XG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int TB = d->T * d->B;
+    XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w));
+    XG_TRY(decoder_fwd_xe(st, *d, *p, *x, *run, w));
+    XG_TRY(heads_fwd_logits(st, *d, *p, *run, w, TB));
+    XG_TRY(xgk_xent_fwd(st, w.LOGITS, d->V, x->seq, x->seq_mask, nullptr, d->B, d->T, d->V, 1, w.LSE, w.sums));
+    if (cap_classes) {
+        XG_TRY(xgk_xent_fwd(st, w.CL, d->C, cap_classes, x->seq_mask, class_mask, d->B, d->T, d->C, 0, w.LSEC, w.sums + 2));
+    } else {
+        ZERO(w.sums + 2, 2);
+    }
+    hipLaunchKernelGGL(losses_kernel, dim3(1), dim3(1), 0, st, w.sums, cap_classes ? weight_class : 0.f, losses);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+extern "C" int xg_xe_loss_bwd(void* stream, const XgDims* d, const XgParams* p, const XgParams* g, const XgBatch* x,
+                              const int64_t* cap_classes, const float* class_mask, float weight_class,
+                              const float* dloss_dev, const XgRun* run, void* ws, size_t ws_bytes) {
+    Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
+    if (!p || !g || !x || !run || !x->seq || !x->seq_mask) return XG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = d->B, T = d->T, TB = T * B;
+    XG_TRY(xgk_xent_bwd(st, w.LOGITS, d->V, x->seq, x->seq_mask, nullptr, B, T, d->V, 1, w.LSE, w.sums, dloss_dev, 1.0f));
+    const bool cls = cap_classes != nullptr && weight_class != 0.f;
+    if (cls) {
+        if (hipMemcpyAsync(w.DCL, w.CL, sizeof(float) * (size_t)TB * d->C, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
+        XG_TRY(xgk_xent_bwd(st, w.DCL, d->C, cap_classes, x->seq_mask, class_mask, B, T, d->C, 0, w.LSEC, w.sums + 2,
+                            dloss_dev, weight_class));
+    }
+    XG_TRY(heads_bwd(st, *d, *p, *g, *run, w, TB, cls));
+    XG_TRY(decoder_bwd_core(st, *d, *p, *g, *x, *run, w, x->seq_mask, T, 1, x->seq, T, 1));
+    XG_TRY(encoder_bwd(st, *d, *p, *g, *x, *run, w, w.DV));
+    return XG_OK;
+}
+
+extern "C" int xg_rollout(void* stream, const XgDims* d, const XgParams* p, const XgBnState* bn, const XgBatch* x,
+                          const XgRun* run, int mode, const float* uniforms, const int64_t* forced, float temperature,
+                          void* ws, size_t ws_bytes, int64_t* seq, float* seq_logp, int32_t* n_steps) {
+    Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
+    if (!p || !x || !run || !seq || !seq_logp || !n_steps || !x->pos_feats || d->T < 2) return XG_EINVAL;
+    if (mode == XG_ROLLOUT_SAMPLE && (!uniforms || !(temperature > 0.f))) return XG_EINVAL;
+    if (mode == XG_ROLLOUT_REPLAY && !forced) return XG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = d->B, R = d->R, E = d->E, A = d->A, T = d->T, N = B * d->K;
+    const size_t BR = (size_t)B * R;
+    XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w));
+    XG_TRY(init_hidden(st, *d, *p, w.Venc, x->feat_mask, w, w.H1, w.C1, w.H2, w.C2));
+    XG_TRY(xgk_linear(st, N, A, R, w.Venc, R, p->v2a_w, p->v2a_b, w.vproj, A));
+    hipLaunchKernelGGL(init_rollout_kernel, dim3(1), dim3(1), 0, st, n_steps, w.alive, T - 1);
+    XG_CHECK_LAUNCH();
+    if (hipMemsetAsync(w.TOK, 0, sizeof(int64_t) * B, st) != hipSuccess) return XG_EHIP;    // t = 0 feeds BOS = 0 (:183-184)
+    XG_TRY(xgk_fill(st, w.UNF, 1.0f, B));
+    for (int t = 0; t < T; ++t) {
+        int64_t* tok = w.TOK + (size_t)t * B;
+        float* unf = w.UNF + (size_t)t * B;
+        if (t >= 1) {
+            const float* lp_prev = w.LOGITS + (size_t)(t - 1) * B * d->V;
+            XG_TRY(xgk_choose(st, lp_prev, B, d->V, mode, uniforms ? uniforms + (size_t)t * B : nullptr,
+                              forced ? forced + (t - 1) : nullptr, T - 1, temperature, tok, w.TOKLP + (size_t)t * B));
+            if (t >= 2 && hipMemcpyAsync(unf, unf - B, sizeof(float) * B, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
+            XG_TRY(xgk_rollout_book(st, t, B, T - 1, mode == XG_ROLLOUT_REPLAY, tok, w.TOKLP + (size_t)t * B, unf, seq,
+                                    seq_logp, n_steps, w.alive));
+        }
+        float* xt = w.Xe + (size_t)t * B * E;
+        float* gp = w.GP + t * BR;
+        float* posg = w.POSG + t * BR;
+        XG_TRY(xgk_embed_gather(st, p->embed_w, E, tok, B, 1, 0, B, d->V, xt, E));                       // :198
+        XG_TRY(xgk_linear(st, B, R, E, xt, E, p->dgate_w, p->dgate_b, gp, R, true));
+        XG_TRY(xgk_gate_fwd(st, gp, R, x->pos_feats, R, 0, posg, R, B, R, xg_make_drop(run, XG_SITE_DGATE, t), B, 1 << 30, 1, B));
+        StepIO s{};
+        s.xt = xt; s.posg = posg; s.pre1 = nullptr; s.mask = unf; s.ldm = 1;
+        s.h1 = w.H1 + t * BR; s.c1 = w.C1 + t * BR; s.h2 = w.H2 + t * BR; s.c2 = w.C2 + t * BR;
+        s.h1o = w.H1 + (t + 1) * BR; s.c1o = w.C1 + (t + 1) * BR; s.h2o = w.H2 + (t + 1) * BR; s.c2o = w.C2 + (t + 1) * BR;
+        s.P = w.P + (size_t)t * B * A; s.alpha = w.ALPHA + (size_t)t * B * d->K; s.af = w.AF + t * BR;
+        s.g1 = w.G1 + (size_t)t * B * 4 * R; s.g2 = w.G2 + (size_t)t * B * 4 * R; s.t = t;
+        XG_TRY(core_step(st, *d, *p, *run, w, w.Venc, w.vproj, s));
+        if (t + 1 < T) {   // the step at t = L is computed and its logits discarded in the reference (:182,:217)
+            float* lg = w.LOGITS + (size_t)t * B * d->V;
+            XG_TRY(xgk_linear(st, B, d->V, R, s.h2o, R, p->logit_w, p->logit_b, lg, d->V));
+            XG_TRY(xgk_log_softmax(st, lg, d->V, lg, d->V, B, d->V, 1, 1, false));
+        }
+    }
+    return XG_OK;
+}
+
+extern "C" int xg_rollout_bwd(void* stream, const XgDims* d, const XgParams* p, const XgParams* g, const XgBatch* x,
+                              const XgRun* run, void* ws, size_t ws_bytes, const float* dseq_logp) {
+    Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
+    if (!p || !g || !x || !run || !dseq_logp || d->T < 2) return XG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = d->B, T = d->T;
+    // dlogits of step t-1's output from the token drawn at step t (SAModel.py:195)
+    for (int t = 1; t < T; ++t) {
+        float* lg = w.LOGITS + (size_t)(t - 1) * B * d->V;
+        XG_TRY(xgk_rollout_dlogits(st, lg, w.TOK + (size_t)t * B, dseq_logp + (t - 1), T - 1, lg, B, d->V));
+    }
+    XG_TRY(heads_bwd(st, *d, *p, *g, *run, w, (T - 1) * B, false));
+    XG_TRY(decoder_bwd_core(st, *d, *p, *g, *x, *run, w, w.UNF, 1, B, w.TOK, 1, B));
+    XG_TRY(encoder_bwd(st, *d, *p, *g, *x, *run, w, w.DV));
+    return XG_OK;
+}

@@ -1,0 +1,42 @@
+// clip_gradient + Adam in one pass (reference caption_src/myutils.py:79-85 elementwise clamp,
+// caption_src/starttrain.py:76,137 torch.optim.Adam with default betas/eps).
+// HBM-bound: 4 streams read (p,g,m,v), 3 written; float4 per thread.
+#include "xg_common.h"
+#include "xg_kernels.h"
+
+namespace {
+__global__ void clip_adam_kernel(int64_t n, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
+                                 float* __restrict__ v, float lr, float b1, float b2, float eps, float wd, float bc1,
+                                 float sqrt_bc2, float clip) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float gi = g[i];
+    if (clip > 0.f) { gi = fminf(fmaxf(gi, -clip), clip); g[i] = gi; }   // clamp_ is in place on .grad
+    const float pi = p[i];
+    if (wd != 0.f) gi += wd * pi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / sqrt_bc2 + eps;
+    p[i] = pi - (lr / bc1) * (mi / denom);
+}
+}  // namespace
+
+int xgk_clip_adam(hipStream_t st, int64_t n, float* p, float* g, float* m, float* v, float lr, float b1, float b2,
+                  float eps, float wd, int step, float clip) {
+    if (n <= 0) return XG_OK;
+    const double bc1 = 1.0 - pow((double)b1, (double)step);
+    const double bc2 = 1.0 - pow((double)b2, (double)step);
+    hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)xg_cdiv64(n, 256)), dim3(256), 0, st, n, p, g, m, v, lr, b1, b2,
+                       eps, wd, (float)bc1, (float)sqrt(bc2), clip);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+
+extern "C" int xg_clip_adam(void* stream, int64_t n, float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+                            float lr, float beta1, float beta2, float eps, float weight_decay, int step, float clip) {
+    if (n < 0 || step < 1 || (n > 0 && (!param || !grad || !exp_avg || !exp_avg_sq))) return XG_EINVAL;
+    return xgk_clip_adam((hipStream_t)stream, n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay,
+                         step, clip);
+}

@@ -1,0 +1,403 @@
+// Element-wise / reduction kernels of the CG encoder and the decoder cells (gfx950).
+// All of them are HBM/L2-bound byte movers: one thread per element (or float4), coalesced along
+// the feature dimension, 256-thread workgroups, grids sized to the element count.
+#include "xg_common.h"
+#include "xg_kernels.h"
+
+namespace {
+
+constexpr int TPB = 256;
+inline dim3 grid1(int64_t n) { return dim3((unsigned)xg_cdiv64(n, TPB)); }
+
+// ------------------------------------------------------------------ LSTM cell pointwise
+// column blocks of s: order IFOG -> [i f o g], IFGO -> [i f g o]
+__global__ void lstm_fwd_kernel(LstmFwdArgs a) {
+    const int idx = blockIdx.x * TPB + threadIdx.x;
+    if (idx >= a.B * a.R) return;
+    const int b = idx / a.R, j = idx % a.R, R = a.R;
+    const float* s = a.s + (size_t)b * a.lds_;
+    float si = s[j], sf = s[R + j], s2 = s[2 * R + j], s3 = s[3 * R + j];
+    if (a.add) {
+        const float* ad = a.add + (size_t)b * a.ldadd;
+        si += ad[j]; sf += ad[R + j]; s2 += ad[2 * R + j]; s3 += ad[3 * R + j];
+    }
+    const float so = a.order == XG_ORDER_IFOG ? s2 : s3;
+    const float sg = a.order == XG_ORDER_IFOG ? s3 : s2;
+    const float ig = xg_sigmoid(si), fg = xg_sigmoid(sf), og = xg_sigmoid(so), gg = xg_tanh(sg);
+    const float cp = a.c_prev[(size_t)b * a.ldcp + j];
+    const float m = a.mask ? a.mask[(size_t)b * a.ldm] : 1.0f;
+    float cn = fg * cp + ig * gg;
+    float hn;
+    if (a.mask_mode == XG_MASK_HOLD) {
+        cn = cn * m + cp * (1.0f - m);                       // sub_modules.py:762
+        hn = og * xg_tanh(cn);
+        const float hp = a.h_prev[(size_t)b * a.ldhp + j];
+        hn = hn * m + hp * (1.0f - m);                       // sub_modules.py:765
+    } else {
+        hn = og * xg_tanh(cn) * m;                           // sub_modules.py:139-140
+        cn = cn * m;
+    }
+    hn *= xg_keep(a.drop, (uint32_t)idx);                    // sub_modules.py:767
+    if (a.gates) {
+        float* g = a.gates + (size_t)b * a.ldg;
+        g[j] = ig; g[R + j] = fg;
+        if (a.order == XG_ORDER_IFOG) { g[2 * R + j] = og; g[3 * R + j] = gg; }
+        else                          { g[2 * R + j] = gg; g[3 * R + j] = og; }
+    }
+    a.c_out[(size_t)b * a.ldco + j] = cn;
+    a.h_out[(size_t)b * a.ldho + j] = hn;
+}
+
+__global__ void lstm_bwd_kernel(LstmBwdArgs a) {
+    const int idx = blockIdx.x * TPB + threadIdx.x;
+    if (idx >= a.B * a.R) return;
+    const int b = idx / a.R, j = idx % a.R, R = a.R;
+    const float* g = a.gates + (size_t)b * a.ldg;
+    const float ig = g[j], fg = g[R + j];
+    const float og = a.order == XG_ORDER_IFOG ? g[2 * R + j] : g[3 * R + j];
+    const float gg = a.order == XG_ORDER_IFOG ? g[3 * R + j] : g[2 * R + j];
+    const float cp = a.c_prev[(size_t)b * a.ldcp + j];
+    const float cn = a.c_out[(size_t)b * a.ldco + j];
+    const float m = a.mask ? a.mask[(size_t)b * a.ldm] : 1.0f;
+    const float dh = a.dh_out[(size_t)b * a.lddh + j] * xg_keep(a.drop, (uint32_t)idx);
+    float dc = a.dc_out ? a.dc_out[(size_t)b * a.lddc + j] : 0.0f;
+    float dht, dct, dcp;
+    // tanh(c'): HOLD uses the post-mask cell (sub_modules.py:763); ZERO: m in {0,1} so m*tanh(c_out) == m*tanh(cn)
+    const float tc = xg_tanh(cn);
+    if (a.mask_mode == XG_MASK_HOLD) {
+        if (a.dh_prev) a.dh_prev[(size_t)b * a.lddhp + j] = (1.0f - m) * dh;
+        dht = m * dh;
+        dc += dht * og * (1.0f - tc * tc);
+        dcp = (1.0f - m) * dc;
+        dct = m * dc;
+    } else {
+        dht = m * dh;
+        dct = m * dc + dht * og * (1.0f - tc * tc);
+        dcp = 0.0f;
+    }
+    const float d_o = dht * tc;
+    dcp += dct * fg;
+    const float d_f = dct * cp, d_i = dct * gg, d_g = dct * ig;
+    float* ds = a.ds + (size_t)b * a.ldds;
+    ds[j] = d_i * ig * (1.0f - ig);
+    ds[R + j] = d_f * fg * (1.0f - fg);
+    const float dso = d_o * og * (1.0f - og), dsg = d_g * (1.0f - gg * gg);
+    if (a.order == XG_ORDER_IFOG) { ds[2 * R + j] = dso; ds[3 * R + j] = dsg; }
+    else                          { ds[2 * R + j] = dsg; ds[3 * R + j] = dso; }
+    a.dc_prev[(size_t)b * a.lddcp + j] = dcp;
+}
+
+// ------------------------------------------------------------------ gates
+__global__ void gate_fwd_kernel(float* pre_g, int ldp, const float* t, int ldt, int t_mod, float* y, int ldy, int rows,
+                                int R, XgDrop drop, int s_div, int s_mod, int b_div, int b_mod) {
+    const int64_t idx = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (idx >= (int64_t)rows * R) return;
+    const int r = (int)(idx / R), j = (int)(idx % R);
+    XgDrop dr = drop;
+    dr.step = drop.step + (uint32_t)((r / s_div) % s_mod);
+    const uint32_t e = (uint32_t)((r / b_div) % b_mod) * (uint32_t)R + (uint32_t)j;
+    const float g = pre_g[(size_t)r * ldp + j] * xg_keep(dr, e);
+    pre_g[(size_t)r * ldp + j] = g;
+    if (y) {
+        const float tv = t[(size_t)(t_mod > 0 ? r % t_mod : r) * ldt + j];
+        y[(size_t)r * ldy + j] = g * tv + tv;                // sub_modules.py:45
+    }
+}
+__global__ void gate_bwd_kernel(const float* dy, int lddy, const float* g, int ldg, const float* t, int ldt, int t_mod,
+                                float* dpre, int lddp, float* dt, int lddt, int dt_acc, int rows, int R, XgDrop drop) {
+    const int64_t idx = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (idx >= (int64_t)rows * R) return;
+    const int r = (int)(idx / R), j = (int)(idx % R);
+    const float d = dy[(size_t)r * lddy + j];
+    const float gv = g[(size_t)r * ldg + j];
+    const float tv = t[(size_t)(t_mod > 0 ? r % t_mod : r) * ldt + j];
+    if (dpre) dpre[(size_t)r * lddp + j] = gv > 0.f ? d * tv * drop.scale : 0.f;   // g>0 <=> relu active & kept
+    if (dt) {
+        float* q = dt + (size_t)r * lddt + j;
+        const float v = d * (gv + 1.0f);
+        *q = dt_acc ? *q + v : v;
+    }
+}
+
+__global__ void relu_drop_fwd_kernel(float* x, int64_t n, XgDrop drop) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i < n) x[i] *= xg_keep(drop, (uint32_t)i);
+}
+__global__ void relu_drop_bwd_kernel(float* dy, const float* y, int64_t n, XgDrop drop) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i < n) dy[i] = y[i] > 0.f ? dy[i] * drop.scale : 0.f;
+}
+
+// ------------------------------------------------------------------ column reductions
+// block = 64 columns x 4 row lanes; grid.y chunks of rows; atomic accumulate into out.
+template <int MODE>   // 0: sum x ; 1: sum x*y ; 2: sum (x-mean)^2
+__global__ void colreduce_kernel(const float* X, int ldx, const float* Y, int ldy, int N, int Cn, float* out,
+                                 int rows_per_chunk) {
+    __shared__ float red[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r1 = min(N, r0 + rows_per_chunk);
+    float acc = 0.f;
+    if (c < Cn) {
+        const float mu = MODE == 2 ? Y[c] : 0.f;
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const float x = X[(size_t)r * ldx + c];
+            if (MODE == 0) acc += x;
+            else if (MODE == 1) acc += x * Y[(size_t)r * ldy + c];
+            else { const float d = x - mu; acc += d * d; }
+        }
+    }
+    red[rl][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (rl == 0 && c < Cn) {
+        const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+        atomicAdd(out + c, s);
+    }
+}
+
+template <int MODE>
+int colreduce(hipStream_t st, const float* X, int ldx, const float* Y, int ldy, int N, int Cn, float* out) {
+    if (N <= 0 || Cn <= 0) return XG_OK;
+    const int rpc = 64;
+    dim3 grid(xg_cdiv(Cn, 64), xg_cdiv(N, rpc));
+    hipLaunchKernelGGL((colreduce_kernel<MODE>), grid, dim3(256), 0, st, X, ldx, Y, ldy, N, Cn, out, rpc);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+
+// ------------------------------------------------------------------ BatchNorm
+__global__ void scale_kernel(float* x, float s, int n) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i < n) x[i] *= s;
+}
+__global__ void bn_running_kernel(const float* mean, const float* var, float* rmean, float* rvar, int N, int R,
+                                  float mom) {
+    const int i = blockIdx.x * TPB + threadIdx.x;
+    if (i >= R) return;
+    const float unb = var[i] * ((float)N / (float)max(N - 1, 1));
+    rmean[i] = (1.f - mom) * rmean[i] + mom * mean[i];
+    rvar[i] = (1.f - mom) * rvar[i] + mom * unb;
+}
+__global__ void bn_apply_kernel(const float* Z, const float* mean, const float* var, const float* gamma,
+                                const float* beta, const float* rowmask, float* X, int N, int R, float eps,
+                                XgDrop drop) {
+    const int64_t idx = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (idx >= (int64_t)N * R) return;
+    const int r = (int)(idx / R), c = (int)(idx % R);
+    const float xh = (Z[idx] - mean[c]) / sqrtf(var[c] + eps);
+    float y = fmaxf(xh * gamma[c] + beta[c], 0.f);
+    y *= xg_keep(drop, (uint32_t)idx);
+    X[idx] = y * rowmask[r];
+}
+// in place dX -> dY (grad wrt BN output), plus column sums of dY and dY*xhat
+__global__ void bn_bwd_reduce_kernel(float* dX, const float* X, const float* Z, const float* mean, const float* var,
+                                     const float* rowmask, int N, int R, float eps, XgDrop drop, float* sum_dy,
+                                     float* sum_dyxhat, int rows_per_chunk) {
+    __shared__ float red[2][4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
+    const int r0 = blockIdx.y * rows_per_chunk;
+    const int r1 = min(N, r0 + rows_per_chunk);
+    float a0 = 0.f, a1 = 0.f;
+    if (c < R) {
+        const float mu = mean[c], is = 1.0f / sqrtf(var[c] + eps);
+        for (int r = r0 + rl; r < r1; r += 4) {
+            const size_t i = (size_t)r * R + c;
+            // X = relu(.)*keep*rowmask ; X>0 <=> relu active, kept, row unmasked
+            const float dy = X[i] > 0.f ? dX[i] * drop.scale * rowmask[r] : 0.f;
+            dX[i] = dy;
+            a0 += dy;
+            a1 += dy * (Z[i] - mu) * is;
+        }
+    }
+    red[0][rl][threadIdx.x & 63] = a0;
+    red[1][rl][threadIdx.x & 63] = a1;
+    __syncthreads();
+    if (rl == 0 && c < R) {
+        const int t = threadIdx.x;
+        atomicAdd(sum_dy + c, red[0][0][t] + red[0][1][t] + red[0][2][t] + red[0][3][t]);
+        atomicAdd(sum_dyxhat + c, red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t]);
+    }
+}
+__global__ void bn_bwd_apply_kernel(float* dY, const float* Z, const float* mean, const float* var,
+                                    const float* gamma, const float* sum_dy, const float* sum_dyxhat, int N, int R,
+                                    float eps, int train) {
+    const int64_t idx = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (idx >= (int64_t)N * R) return;
+    const int c = (int)(idx % R);
+    const float is = 1.0f / sqrtf(var[c] + eps);
+    float d = dY[idx];
+    if (train) {
+        const float xh = (Z[idx] - mean[c]) * is;
+        d = d - sum_dy[c] / (float)N - xh * sum_dyxhat[c] / (float)N;
+    }
+    dY[idx] = d * gamma[c] * is;
+}
+
+// ------------------------------------------------------------------ embedding, means, misc
+__device__ __forceinline__ int64_t tok_at(const int64_t* tok, int i, int inner, int64_t s_inner, int64_t s_outer, int V) {
+    int64_t t = tok[(int64_t)(i % inner) * s_inner + (int64_t)(i / inner) * s_outer];
+    return t < 0 ? 0 : (t >= V ? V - 1 : t);
+}
+__global__ void embed_gather_kernel(const float* table, int E, const int64_t* tok, int inner, int64_t s_inner,
+                                    int64_t s_outer, int V, float* out, int ldo) {
+    const int i = blockIdx.x;
+    const int64_t t = tok_at(tok, i, inner, s_inner, s_outer, V);
+    for (int e = threadIdx.x; e < E; e += blockDim.x) out[(size_t)i * ldo + e] = table[(size_t)t * E + e];
+}
+__global__ void embed_scatter_kernel(float* dtable, int E, const int64_t* tok, int inner, int64_t s_inner,
+                                     int64_t s_outer, int V, const float* dX, int ldx) {
+    const int i = blockIdx.x;
+    const int64_t t = tok_at(tok, i, inner, s_inner, s_outer, V);
+    for (int e = threadIdx.x; e < E; e += blockDim.x) atomicAdd(dtable + (size_t)t * E + e, dX[(size_t)i * ldx + e]);
+}
+__global__ void masked_mean_kernel(const float* V, const float* mask, float* out, int B, int K, int R) {
+    const int idx = blockIdx.x * TPB + threadIdx.x;
+    if (idx >= B * R) return;
+    const int b = idx / R, r = idx % R;
+    float s = 0.f, ms = 0.f;
+    for (int k = 0; k < K; ++k) { s += V[((size_t)b * K + k) * R + r]; ms += mask[b * K + k]; }
+    out[idx] = s / ms;                                       // SAModel.py:59-61
+}
+__global__ void axpy_kernel(float* y, const float* x, float a, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i < n) y[i] += a * x[i];
+}
+__global__ void fill_kernel(float* y, float v, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i < n) y[i] = v;
+}
+__global__ void copy2d_kernel(float* dst, int ldd, const float* src, int lds, int rows, int cols, int add) {
+    const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= (int64_t)rows * cols) return;
+    const int r = (int)(i / cols), c = (int)(i % cols);
+    const float v = src[(size_t)r * lds + c];
+    float* d = dst + (size_t)r * ldd + c;
+    *d = add ? *d + v : v;
+}
+
+}  // namespace
+
+int xgk_lstm_fwd(hipStream_t st, const LstmFwdArgs& a) {
+    hipLaunchKernelGGL(lstm_fwd_kernel, grid1((int64_t)a.B * a.R), dim3(TPB), 0, st, a);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_lstm_bwd(hipStream_t st, const LstmBwdArgs& a) {
+    hipLaunchKernelGGL(lstm_bwd_kernel, grid1((int64_t)a.B * a.R), dim3(TPB), 0, st, a);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_gate_fwd(hipStream_t st, float* pre_g, int ldp, const float* t, int ldt, int t_mod, float* y, int ldy,
+                 int rows, int R, XgDrop drop, int s_div, int s_mod, int b_div, int b_mod) {
+    if (!y && drop.thresh == 0u) return XG_OK;   // pure dropout with p = 0: nothing to do
+    hipLaunchKernelGGL(gate_fwd_kernel, grid1((int64_t)rows * R), dim3(TPB), 0, st, pre_g, ldp, t, ldt, t_mod, y, ldy,
+                       rows, R, drop, s_div, s_mod, b_div, b_mod);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_gate_bwd(hipStream_t st, const float* dy, int lddy, const float* g, int ldg, const float* t, int ldt, int t_mod,
+                 float* dpre, int lddp, float* dt, int lddt, bool dt_accumulate, int rows, int R, XgDrop drop) {
+    hipLaunchKernelGGL(gate_bwd_kernel, grid1((int64_t)rows * R), dim3(TPB), 0, st, dy, lddy, g, ldg, t, ldt, t_mod, dpre,
+                       lddp, dt, lddt, dt_accumulate ? 1 : 0, rows, R, drop);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_relu_drop_fwd(hipStream_t st, float* x, int64_t n, XgDrop drop) {
+    if (drop.thresh == 0u || n <= 0) return XG_OK;
+    hipLaunchKernelGGL(relu_drop_fwd_kernel, grid1(n), dim3(TPB), 0, st, x, n, drop);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_relu_drop_bwd(hipStream_t st, float* dy, const float* y, int64_t n, XgDrop drop) {
+    if (n <= 0) return XG_OK;
+    hipLaunchKernelGGL(relu_drop_bwd_kernel, grid1(n), dim3(TPB), 0, st, dy, y, n, drop);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_colsum(hipStream_t st, const float* X, int ld, int N, int Cn, float* out) {
+    return colreduce<0>(st, X, ld, nullptr, 0, N, Cn, out);
+}
+int xgk_colsum_prod(hipStream_t st, const float* X, int ldx, const float* Y, int ldy, int N, int Cn, float* out) {
+    return colreduce<1>(st, X, ldx, Y, ldy, N, Cn, out);
+}
+int xgk_bn_stats(hipStream_t st, const float* Z, int N, int R, float* mean, float* var, float* scratch) {
+    (void)scratch;
+    if (hipMemsetAsync(mean, 0, sizeof(float) * R, st) != hipSuccess) return XG_EHIP;
+    if (hipMemsetAsync(var, 0, sizeof(float) * R, st) != hipSuccess) return XG_EHIP;
+    XG_TRY(colreduce<0>(st, Z, R, nullptr, 0, N, R, mean));
+    hipLaunchKernelGGL(scale_kernel, grid1(R), dim3(TPB), 0, st, mean, 1.0f / (float)N, R);
+    XG_TRY(colreduce<2>(st, Z, R, mean, 0, N, R, var));
+    hipLaunchKernelGGL(scale_kernel, grid1(R), dim3(TPB), 0, st, var, 1.0f / (float)N, R);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_bn_running(hipStream_t st, const float* mean, const float* var, float* rmean, float* rvar, int N, int R,
+                   float momentum) {
+    hipLaunchKernelGGL(bn_running_kernel, grid1(R), dim3(TPB), 0, st, mean, var, rmean, rvar, N, R, momentum);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_bn_apply(hipStream_t st, const float* Z, const float* mean, const float* var, const float* gamma,
+                 const float* beta, const float* rowmask, float* X, int N, int R, float eps, XgDrop drop) {
+    hipLaunchKernelGGL(bn_apply_kernel, grid1((int64_t)N * R), dim3(TPB), 0, st, Z, mean, var, gamma, beta, rowmask, X,
+                       N, R, eps, drop);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_bn_bwd_reduce(hipStream_t st, float* dX, const float* X, const float* Z, const float* mean, const float* var,
+                      const float* rowmask, int N, int R, float eps, XgDrop drop, float* sum_dy, float* sum_dyxhat) {
+    const int rpc = 64;
+    dim3 grid(xg_cdiv(R, 64), xg_cdiv(N, rpc));
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, grid, dim3(256), 0, st, dX, X, Z, mean, var, rowmask, N, R, eps, drop,
+                       sum_dy, sum_dyxhat, rpc);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_bn_bwd_apply(hipStream_t st, float* dY, const float* Z, const float* mean, const float* var,
+                     const float* gamma, const float* sum_dy, const float* sum_dyxhat, int N, int R, float eps,
+                     bool train) {
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, grid1((int64_t)N * R), dim3(TPB), 0, st, dY, Z, mean, var, gamma, sum_dy,
+                       sum_dyxhat, N, R, eps, train ? 1 : 0);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_embed_gather(hipStream_t st, const float* table, int E, const int64_t* tok, int inner, int64_t s_inner,
+                     int64_t s_outer, int n, int V, float* out, int ldo) {
+    if (n <= 0) return XG_OK;
+    hipLaunchKernelGGL(embed_gather_kernel, dim3(n), dim3(128), 0, st, table, E, tok, inner, s_inner, s_outer, V, out, ldo);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_embed_scatter_add(hipStream_t st, float* dtable, int E, const int64_t* tok, int inner, int64_t s_inner,
+                          int64_t s_outer, int n, int V, const float* dX, int ldx) {
+    if (n <= 0) return XG_OK;
+    hipLaunchKernelGGL(embed_scatter_kernel, dim3(n), dim3(128), 0, st, dtable, E, tok, inner, s_inner, s_outer, V, dX, ldx);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_masked_mean(hipStream_t st, const float* V, const float* mask, float* out, int B, int K, int R) {
+    hipLaunchKernelGGL(masked_mean_kernel, grid1((int64_t)B * R), dim3(TPB), 0, st, V, mask, out, B, K, R);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_axpy(hipStream_t st, float* y, const float* x, float a, int64_t n) {
+    if (n <= 0) return XG_OK;
+    hipLaunchKernelGGL(axpy_kernel, grid1(n), dim3(TPB), 0, st, y, x, a, n);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_fill(hipStream_t st, float* y, float v, int64_t n) {
+    if (n <= 0) return XG_OK;
+    hipLaunchKernelGGL(fill_kernel, grid1(n), dim3(TPB), 0, st, y, v, n);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_copy2d(hipStream_t st, float* dst, int ldd, const float* src, int lds, int rows, int cols, bool add) {
+    if (rows <= 0 || cols <= 0) return XG_OK;
+    hipLaunchKernelGGL(copy2d_kernel, grid1((int64_t)rows * cols), dim3(TPB), 0, st, dst, ldd, src, lds, rows, cols,
+                       add ? 1 : 0);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}

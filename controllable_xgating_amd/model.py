@@ -1,0 +1,575 @@
+"""Host-side mirror of the reference's model surface (caption_src/SAModel.py:13-267) on top of the
+HIP C ABI (include/xgate.h).  Same class / method / attribute names, argument meaning, return
+shapes and ``state_dict`` keys as the reference, so ``starttrain.py`` / ``eval_utils.py`` style
+drivers run unchanged:
+
+    model = SAModel(opt); model.cuda(); model.train()
+    logp, cat_logp = model(feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask)
+    loss = LanguageModelCriterion()(logp, seq, seq_mask); loss.backward()
+    seq, seqLogprobs = model.sample(feats_rgb, feats_opfl, feat_mask, pos_feats, {'sample_max': 0})
+
+PyTorch is plumbing here: tensor allocation, the stream, autograd bookkeeping.  All arithmetic
+runs in hand-written gfx950 kernels behind ``libxgate_hip.so``; the nn.Linear / nn.LSTMCell /
+nn.BatchNorm1d sub-modules below are parameter CONTAINERS only (they give the reference's
+``state_dict`` names, shapes and default initialisation) and are never called.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+
+import torch
+import torch.nn as nn
+
+from . import _native as nv
+
+
+def make_opt(d=None, **kw):
+    """argparse-style namespace with the flags SAModel reads (caption_src/myopts.py:3-88)."""
+    base = dict(seed=1024, vocab_size=20000, category_size=14, input_encoding_size=468, rnn_size=512,
+                num_layers=1, drop_prob_lm=0.0, seq_length=20, feat_size=1536, feat_size2=1024,
+                att_size=1536, fusion_activity="ReLU")
+    if d is not None:
+        base.update(vocab_size=d.V, category_size=d.C, input_encoding_size=d.E, rnn_size=d.R,
+                    seq_length=d.L, feat_size=d.F1, feat_size2=d.F2, att_size=d.A)
+    base.update(kw)
+    return argparse.Namespace(**base)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class _Holder(nn.Module):
+    """Bare container so parameter names nest like the reference's sub-modules."""
+
+
+class _WorkspacePool:
+    """Caller-owned workspaces (xg_workspace_bytes).  A forward that saves activations for a
+    backward keeps its workspace until the backward has run; everything else shares scratch."""
+
+    def __init__(self):
+        self.free = {}
+        self.scratch = {}
+
+    @staticmethod
+    def _key(dims, device):
+        return (tuple(getattr(dims, f[0]) for f in dims._fields_), str(device))
+
+    def _alloc(self, dims, device):
+        n = nv.lib().xg_workspace_bytes(C.byref(dims))
+        if n == 0:
+            raise nv.XgError("xg_workspace_bytes: invalid dims")
+        return torch.empty(n + 256, dtype=torch.uint8, device=device)
+
+    def take(self, dims, device):
+        lst = self.free.setdefault(self._key(dims, device), [])
+        return lst.pop() if lst else self._alloc(dims, device)
+
+    def give(self, dims, device, ws):
+        self.free.setdefault(self._key(dims, device), []).append(ws)
+
+    def shared(self, dims, device):
+        k = self._key(dims, device)
+        if k not in self.scratch:
+            self.scratch[k] = self._alloc(dims, device)
+        return self.scratch[k]
+
+
+def _ws_ptr(ws):
+    p = ws.data_ptr()
+    p = (p + 255) & ~255
+    return C.c_void_p(p), C.c_size_t(ws.numel() - 256)
+
+
+class SAModel(nn.Module):
+    """Drop-in for reference caption_src/SAModel.py:SAModel (CaptionModel(nn.Module))."""
+
+    def __init__(self, opt):
+        super().__init__()
+        nv.lib()  # fail loudly, right here, if the HIP library is missing
+        seed = opt.seed
+        torch.manual_seed(seed)
+        self.vocab_size = opt.vocab_size
+        self.category_size = opt.category_size
+        self.input_encoding_size = opt.input_encoding_size
+        self.rnn_size = opt.rnn_size
+        self.visual_size = opt.rnn_size
+        self.num_layers = opt.num_layers
+        self.drop_prob_lm = opt.drop_prob_lm
+        self.seq_length = opt.seq_length
+        self.att_size = opt.att_size
+        self.feat_size, self.feat_size2 = opt.feat_size, opt.feat_size2
+        self.ss_prob = 0.0
+        self.done_beams = []
+        R, E, A, p = opt.rnn_size, opt.input_encoding_size, opt.att_size, opt.drop_prob_lm
+
+        def gate(src, tgt):  # reference sub_modules.py:18-31 (re-seeds, so siblings start identical)
+            torch.manual_seed(seed)
+            h = _Holder()
+            h.gate = nn.Sequential(nn.Linear(src, tgt), nn.ReLU(), nn.Dropout(p))
+            return h
+
+        # construction order mirrors the reference so torch's default init consumes the RNG identically
+        enc = _Holder()
+        torch.manual_seed(seed)                                                    # sub_modules.py:86
+        enc.visual_emb_rgb = nn.Sequential(nn.Linear(opt.feat_size, R), nn.BatchNorm1d(R), nn.ReLU(True))
+        enc.visual_emb_opfl = nn.Sequential(nn.Linear(opt.feat_size2, R), nn.BatchNorm1d(R), nn.ReLU(True))
+        enc.drop_out = nn.Dropout(p)
+        enc.lstmcell_rgb = nn.LSTMCell(R, R)
+        enc.lstmcell_opfl = nn.LSTMCell(R, R)
+        enc.gate_rgb = gate(R, R)
+        enc.gate_opfl = gate(R, R)
+        torch.manual_seed(seed)                                                    # Fusion, sub_modules.py:55
+        enc.fusion = _Holder()
+        enc.fusion.late_fusion = nn.Sequential(nn.Linear(2 * R, R), getattr(nn, opt.fusion_activity)(), nn.Dropout(p))
+        self.two_spatial_encoder = enc
+        self.img_embed_h_1 = nn.Linear(R, R)
+        self.img_embed_c_1 = nn.Linear(R, R)
+        self.img_embed_h_2 = nn.Linear(R, R)
+        self.img_embed_c_2 = nn.Linear(R, R)
+        core = _Holder()
+        torch.manual_seed(seed)                                                    # sub_modules.py:648
+        core.gate = gate(E, R)
+
+        def cell(in1):
+            c = _Holder()
+            c.i2h, c.a2h, c.h2h = nn.Linear(in1, 4 * R), nn.Linear(R, 4 * R), nn.Linear(R, 4 * R)
+            c.dropout = nn.Dropout(p)
+            return c
+
+        core.lstm_1 = cell(E)
+        core.lstm_2 = cell(R)
+        core.dropout = nn.Dropout(p)
+        core.v2a = nn.Linear(R, A)
+        core.h2a = nn.Linear(2 * R, A)
+        core.a2w = nn.Linear(A, 1)
+        self.lstmcore = core
+        self.embed = nn.Embedding(self.vocab_size, E)
+        self.logit = nn.Linear(R, self.vocab_size)
+        self.classifer = nn.Sequential(nn.Linear(R, 128), nn.ReLU(), nn.Dropout(p), nn.Linear(128, self.category_size))
+        self.init_weights()
+        if getattr(opt, "fusion_activity", "ReLU") != "ReLU":
+            raise ValueError("only fusion_activity='ReLU' (the shipped recipe) is implemented in HIP")
+        self._pool = _WorkspacePool()
+        self._flat = None
+        self._call = 0
+
+    def init_weights(self):  # SAModel.py:52-56
+        initrange = 0.1
+        self.embed.weight.data.uniform_(-initrange, initrange)
+        self.logit.bias.data.fill_(0)
+        self.logit.weight.data.uniform_(-initrange, initrange)
+
+    # ------------------------------------------------------------------ plumbing
+    def _named(self):
+        return dict(self.named_parameters())
+
+    def _ensure_flat(self):
+        """All parameters live in ONE flat fp32 buffer (one RCCL all-reduce, one Adam launch);
+        the nn.Parameters are views into it.  Rebuilt if .cuda()/.to() replaced the storages."""
+        named = self._named()
+        names = nv.PARAM_NAMES
+        first = named[names[0]]
+        if self._flat is not None and self._flat.device == first.device:
+            off, ok = 0, True
+            for n in names:
+                p = named[n]
+                if p.data_ptr() != self._flat.data_ptr() + 4 * off:
+                    ok = False
+                    break
+                off += (p.numel() + 63) // 64 * 64
+            if ok:
+                return
+        if not first.is_cuda:
+            raise nv.XgError("SAModel runs on an MI355X only: call model.cuda() first (no CPU path)")
+        total = sum((named[n].numel() + 63) // 64 * 64 for n in names)
+        flat = torch.zeros(total, dtype=torch.float32, device=first.device)
+        gflat = torch.zeros(total, dtype=torch.float32, device=first.device)
+        off = 0
+        self._slices = {}
+        for n in names:
+            p = named[n]
+            if p.dtype != torch.float32:
+                raise nv.XgError("fp32 parameters only")
+            k = p.numel()
+            v = flat[off:off + k].view_as(p)
+            v.copy_(p.data)
+            had_grad = p.grad is not None
+            if had_grad:
+                gflat[off:off + k].view_as(p).copy_(p.grad)
+            p.data = v
+            p.grad = gflat[off:off + k].view_as(p) if had_grad else None
+            self._slices[n] = (off, k)
+            off += (k + 63) // 64 * 64
+        self._flat, self._gflat = flat, gflat
+
+    def flat_parameters(self):
+        self._ensure_flat()
+        return self._flat
+
+    def flat_grads(self):
+        """Flat gradient buffer; binds every p.grad to its slice (zeroing is the caller's zero_grad)."""
+        self._ensure_flat()
+        named = self._named()
+        for n, (off, k) in self._slices.items():
+            p = named[n]
+            if p.grad is None or p.grad.data_ptr() != self._gflat.data_ptr() + 4 * off:
+                v = self._gflat[off:off + k].view_as(p)
+                if p.grad is not None:
+                    v.copy_(p.grad)
+                else:
+                    v.zero_()
+                p.grad = v
+        return self._gflat
+
+    def _params_struct(self):
+        self._ensure_flat()
+        return nv.make_params_struct(self._named())
+
+    def _bn_struct(self):
+        e = self.two_spatial_encoder
+        s = nv.XgBnState()
+        s.rgb_mean, s.rgb_var = e.visual_emb_rgb[1].running_mean.data_ptr(), e.visual_emb_rgb[1].running_var.data_ptr()
+        s.opfl_mean, s.opfl_var = e.visual_emb_opfl[1].running_mean.data_ptr(), e.visual_emb_opfl[1].running_var.data_ptr()
+        return s
+
+    def _dims(self, B, K, T):
+        d = nv.XgDims()
+        d.B, d.K, d.R, d.A, d.E, d.V = B, K, self.rnn_size, self.att_size, self.input_encoding_size, self.vocab_size
+        d.C, d.H, d.F1, d.F2, d.T = self.category_size, 128, self.feat_size, self.feat_size2, T
+        return d
+
+    def _run(self, save, seed=None):
+        r = nv.XgRun()
+        r.train = 1 if self.training else 0
+        r.drop_p = float(self.drop_prob_lm)
+        if seed is None:
+            self._call += 1
+            seed = (int(torch.initial_seed()) * 2654435761 + self._call * 40503) & 0xFFFFFFFF
+        r.seed = seed
+        r.save = 1 if save else 0
+        r.bn_momentum, r.bn_eps = 0.1, 1e-5
+        return r
+
+    @staticmethod
+    def _batch(feats_rgb, feats_opfl, feat_mask, pos_feats, seq=None, seq_mask=None):
+        def f32(t):
+            return t.detach().contiguous().float()
+        keep = [f32(feats_rgb), f32(feats_opfl), f32(feat_mask), f32(pos_feats),
+                None if seq is None else seq.detach().contiguous().long(),
+                None if seq_mask is None else f32(seq_mask)]
+        for t in keep:
+            if t is not None and not t.is_cuda:
+                raise nv.XgError("inputs must be CUDA (HIP) tensors")
+        b = nv.XgBatch()
+        b.feats_rgb, b.feats_opfl, b.feat_mask, b.pos_feats = (t.data_ptr() for t in keep[:4])
+        b.seq = keep[4].data_ptr() if keep[4] is not None else None
+        b.seq_mask = keep[5].data_ptr() if keep[5] is not None else None
+        return b, keep
+
+    def _bump_bn(self):
+        if self.training:
+            for m in (self.two_spatial_encoder.visual_emb_rgb[1], self.two_spatial_encoder.visual_emb_opfl[1]):
+                if m.num_batches_tracked is not None:
+                    m.num_batches_tracked += 1
+
+    # ------------------------------------------------------------------ reference surface
+    def forward(self, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask):
+        """SAModel.forward (SAModel.py:67-115): (m,K,F) x2, (m,K), (m,R), (m,T) int64, (m,T) ->
+        log-probs (m,T,V) and category log-probs (m,T,C).  ss_prob must be 0 (scheduled sampling is
+        SURVEY.md 8f-3, not built yet)."""
+        if self.training and self.ss_prob > 0.0:
+            raise NotImplementedError("scheduled sampling (ss_prob > 0) is not implemented in the HIP path yet")
+        params = [self._named()[n] for n in nv.PARAM_NAMES]
+        return _XEFunction.apply(self, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, *params)
+
+    def xe_loss(self, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, cap_classes=None,
+                class_mask=None, weight_class=0.0):
+        """Fused fast path: forward + LanguageModelCriterion (+ weight_class * ClassiferCriterion)
+        without materialising the (m,T,V) log-prob tensor or its gradient
+        (starttrain.py:125-129).  Returns the scalar loss tensor; .backward() works."""
+        params = [self._named()[n] for n in nv.PARAM_NAMES]
+        return _XELossFunction.apply(self, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, cap_classes,
+                                     class_mask, float(weight_class), *params)
+
+    def init_hidden(self, feat, feat_mask):
+        """SAModel.init_hidden (SAModel.py:58-65) -> [(h1,c1),(h2,c2)], each (1,m,R)."""
+        B, K, R = feat.shape
+        d = self._dims(B, K, 1)
+        ws = self._pool.shared(d, feat.device)
+        wp, wn = _ws_ptr(ws)
+        state = torch.empty(4, B, R, dtype=torch.float32, device=feat.device)
+        fm = feat_mask.detach().contiguous().float()
+        if fm.dim() == 1:
+            fm = fm.unsqueeze(0).expand(B, K).contiguous()
+        ps = self._params_struct()
+        nv.check(nv.lib().xg_init_hidden(_stream(), C.byref(d), C.byref(ps), nv.ptr(feat.detach().contiguous().float()),
+                                         nv.ptr(fm), wp, wn, nv.ptr(state)), "xg_init_hidden")
+        return [(state[0:1], state[1:2]), (state[2:3], state[3:4])]
+
+    def encode(self, feats_rgb, feats_opfl, feat_mask):
+        """two_spatial_encoder(feats_rgb, feats_opfl, feat_mask) (sub_modules.py:118-159), no grad."""
+        B, K, _ = feats_rgb.shape
+        d = self._dims(B, K, 1)
+        ws = self._pool.shared(d, feats_rgb.device)
+        wp, wn = _ws_ptr(ws)
+        b, keep = self._batch(feats_rgb, feats_opfl, feat_mask, feats_rgb.new_zeros(B, self.rnn_size))
+        V = torch.empty(B, K, self.rnn_size, dtype=torch.float32, device=feats_rgb.device)
+        ps, bn, run = self._params_struct(), self._bn_struct(), self._run(False)
+        nv.check(nv.lib().xg_encoder_fwd(_stream(), C.byref(d), C.byref(ps), C.byref(bn), C.byref(b), C.byref(run),
+                                         wp, wn, nv.ptr(V)), "xg_encoder_fwd")
+        self._bump_bn()
+        return V
+
+    def get_logprobs_state(self, it, feats, pos_feats, state):
+        """SAModel.get_logprobs_state (SAModel.py:117-127): one step, mask of ones."""
+        B, K, R = feats.shape
+        d = self._dims(B, K, 1)
+        ws = self._pool.shared(d, feats.device)
+        wp, wn = _ws_ptr(ws)
+        feats = feats.detach().contiguous().float()
+        st = torch.cat([state[0][0], state[0][1], state[1][0], state[1][1]], 0).contiguous().float()
+        key = (feats.data_ptr(), feats._version, B, K)
+        if getattr(self, "_vproj_key", None) != key:
+            self._vproj_cache = torch.empty(B, K, self.att_size, dtype=torch.float32, device=feats.device)
+            ps = self._params_struct()
+            nv.check(nv.lib().xg_vproj(_stream(), C.byref(d), C.byref(ps), nv.ptr(feats), nv.ptr(self._vproj_cache)), "xg_vproj")
+            self._vproj_key = key
+            self._vproj_feats = feats
+        logp = torch.empty(B, self.vocab_size, dtype=torch.float32, device=feats.device)
+        ps, run = self._params_struct(), self._run(False)
+        pos = pos_feats.detach().contiguous().float()
+        tok = it.detach().contiguous().long().to(feats.device)
+        nv.check(nv.lib().xg_step_fwd(_stream(), C.byref(d), C.byref(ps), nv.ptr(tok), None, nv.ptr(feats),
+                                      nv.ptr(self._vproj_cache), nv.ptr(pos), C.byref(run), 0, wp, wn, nv.ptr(st),
+                                      nv.ptr(logp), None), "xg_step_fwd")
+        return logp, [(st[0:1], st[1:2]), (st[2:3], st[3:4])]
+
+    def sample(self, feats_rgb, feats_opfl, feat_mask, pos_feats, opt={}):
+        """SAModel.sample (SAModel.py:163-219) -> seq (m,n) int64, seqLogprobs (m,n)."""
+        sample_max = opt.get("sample_max", 1)
+        beam_size = opt.get("beam_size", 1)
+        temperature = opt.get("temperature", 1.0)
+        if beam_size > 1:
+            from .beam import sample_beam
+            feats = self.encode(feats_rgb, feats_opfl, feat_mask)
+            return sample_beam(self, feats, feat_mask, pos_feats, opt)
+        mode = nv.XG_ROLLOUT_GREEDY if sample_max else nv.XG_ROLLOUT_SAMPLE
+        forced = opt.get("forced_tokens", None)
+        if forced is not None:
+            mode = nv.XG_ROLLOUT_REPLAY
+        need_grad = torch.is_grad_enabled() and mode != nv.XG_ROLLOUT_GREEDY and any(p.requires_grad for p in self.parameters())
+        params = [self._named()[n] for n in nv.PARAM_NAMES]
+        uniforms = opt.get("uniforms", None)
+        seq, slp, n = _RolloutFunction.apply(self, feats_rgb, feats_opfl, feat_mask, pos_feats, mode, uniforms, forced,
+                                             float(temperature), need_grad, *params)
+        n = int(n.item())                      # ONE host sync per rollout (the reference syncs every step, :206)
+        return seq[:, :n], slp[:, :n]
+
+    def sample_beam(self, feats, feat_masks, pos_feats, opt={}):
+        from .beam import sample_beam
+        return sample_beam(self, feats, feat_masks, pos_feats, opt)
+
+
+# ====================================================================== autograd glue
+def _grads_struct(model, device):
+    """Fresh zero flat buffer + XgParams struct of views into it (the C ABI accumulates)."""
+    model._ensure_flat()
+    g = torch.zeros_like(model._flat)
+    s = nv.XgParams()
+    for i, n in enumerate(nv.PARAM_NAMES):
+        off, k = model._slices[n]
+        setattr(s, "p%d" % i, g.data_ptr() + 4 * off)
+    return g, s
+
+
+def _grad_views(model, g):
+    named = model._named()
+    out = []
+    for n in nv.PARAM_NAMES:
+        off, k = model._slices[n]
+        out.append(g[off:off + k].view_as(named[n]))
+    return out
+
+
+class _XEFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, *params):
+        B, K, _ = feats_rgb.shape
+        T = seq.shape[1]
+        dev = feats_rgb.device
+        d = model._dims(B, K, T)
+        save = any(p.requires_grad for p in params) and torch.is_grad_enabled()
+        ws = model._pool.take(d, dev) if save else model._pool.shared(d, dev)
+        wp, wn = _ws_ptr(ws)
+        b, keep = model._batch(feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask)
+        logp = torch.empty(B, T, model.vocab_size, dtype=torch.float32, device=dev)
+        cat = torch.empty(B, T, model.category_size, dtype=torch.float32, device=dev)
+        ps, bn, run = model._params_struct(), model._bn_struct(), model._run(save)
+        nv.check(nv.lib().xg_forward_xe(_stream(), C.byref(d), C.byref(ps), C.byref(bn), C.byref(b), C.byref(run),
+                                        wp, wn, nv.ptr(logp), nv.ptr(cat)), "xg_forward_xe")
+        model._bump_bn()
+        ctx.model, ctx.d, ctx.ws, ctx.keep, ctx.run, ctx.saved_ws = model, d, ws, keep, run, save
+        return logp, cat
+
+    @staticmethod
+    def backward(ctx, dlogp, dcat):
+        model, d = ctx.model, ctx.d
+        if not ctx.saved_ws:
+            raise nv.XgError("backward without saved activations")
+        dev = ctx.keep[0].device
+        g, gs = _grads_struct(model, dev)
+        b, keep = model._batch(*ctx.keep)
+        wp, wn = _ws_ptr(ctx.ws)
+        ps = model._params_struct()
+        dl = None if dlogp is None else dlogp.contiguous().float()
+        dc = None if dcat is None else dcat.contiguous().float()
+        nv.check(nv.lib().xg_backward_xe(_stream(), C.byref(d), C.byref(ps), C.byref(gs), C.byref(b), C.byref(ctx.run),
+                                         wp, wn, nv.ptr(dl), nv.ptr(dc)), "xg_backward_xe")
+        model._pool.give(d, dev, ctx.ws)
+        ctx.ws = None
+        return (None,) * 7 + tuple(_grad_views(model, g))
+
+
+class _XELossFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, cap_classes, class_mask,
+                weight_class, *params):
+        B, K, _ = feats_rgb.shape
+        T = seq.shape[1]
+        dev = feats_rgb.device
+        d = model._dims(B, K, T)
+        save = any(p.requires_grad for p in params) and torch.is_grad_enabled()
+        ws = model._pool.take(d, dev) if save else model._pool.shared(d, dev)
+        wp, wn = _ws_ptr(ws)
+        b, keep = model._batch(feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask)
+        cc = None if cap_classes is None else cap_classes.detach().contiguous().long()
+        cm = None if class_mask is None else class_mask.detach().contiguous().float()
+        losses = torch.empty(3, dtype=torch.float32, device=dev)
+        ps, bn, run = model._params_struct(), model._bn_struct(), model._run(save)
+        nv.check(nv.lib().xg_xe_loss_fwd(_stream(), C.byref(d), C.byref(ps), C.byref(bn), C.byref(b), nv.ptr(cc),
+                                         nv.ptr(cm), weight_class, C.byref(run), wp, wn, nv.ptr(losses)), "xg_xe_loss_fwd")
+        model._bump_bn()
+        ctx.model, ctx.d, ctx.ws, ctx.keep, ctx.run, ctx.saved_ws = model, d, ws, keep, run, save
+        ctx.cc, ctx.cm, ctx.wc = cc, cm, weight_class
+        model.last_losses = losses
+        return losses[0].clone()
+
+    @staticmethod
+    def backward(ctx, dloss):
+        model, d = ctx.model, ctx.d
+        dev = ctx.keep[0].device
+        g, gs = _grads_struct(model, dev)
+        b, keep = model._batch(*ctx.keep)
+        wp, wn = _ws_ptr(ctx.ws)
+        ps = model._params_struct()
+        nv.check(nv.lib().xg_xe_loss_bwd(_stream(), C.byref(d), C.byref(ps), C.byref(gs), C.byref(b), nv.ptr(ctx.cc),
+                                         nv.ptr(ctx.cm), ctx.wc, nv.ptr(dloss.detach().contiguous().float().to(dev)),
+                                         C.byref(ctx.run), wp, wn), "xg_xe_loss_bwd")
+        model._pool.give(d, dev, ctx.ws)
+        ctx.ws = None
+        return (None,) * 10 + tuple(_grad_views(model, g))
+
+
+class _RolloutFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, feats_rgb, feats_opfl, feat_mask, pos_feats, mode, uniforms, forced, temperature,
+                need_grad, *params):
+        B, K, _ = feats_rgb.shape
+        T = model.seq_length + 1
+        dev = feats_rgb.device
+        d = model._dims(B, K, T)
+        ws = model._pool.take(d, dev) if need_grad else model._pool.shared(d, dev)
+        wp, wn = _ws_ptr(ws)
+        b, keep = model._batch(feats_rgb, feats_opfl, feat_mask, pos_feats)
+        seq = torch.zeros(B, T - 1, dtype=torch.int64, device=dev)
+        slp = torch.zeros(B, T - 1, dtype=torch.float32, device=dev)
+        n = torch.zeros(1, dtype=torch.int32, device=dev)
+        if mode == nv.XG_ROLLOUT_SAMPLE and uniforms is None:
+            uniforms = torch.rand(T, B, device=dev, dtype=torch.float32)
+        if uniforms is not None:
+            uniforms = uniforms.detach().contiguous().float()
+        if forced is not None:
+            f = torch.zeros(B, T - 1, dtype=torch.int64, device=dev)
+            f[:, :forced.shape[1]] = forced.to(dev)
+            forced = f
+        ps, bn, run = model._params_struct(), model._bn_struct(), model._run(need_grad)
+        nv.check(nv.lib().xg_rollout(_stream(), C.byref(d), C.byref(ps), C.byref(bn), C.byref(b), C.byref(run), mode,
+                                     nv.ptr(uniforms), nv.ptr(forced), temperature, wp, wn, nv.ptr(seq), nv.ptr(slp),
+                                     nv.ptr(n)), "xg_rollout")
+        model._bump_bn()
+        ctx.model, ctx.d, ctx.ws, ctx.keep, ctx.run, ctx.need_grad = model, d, ws, keep, run, need_grad
+        ctx.mark_non_differentiable(seq, n)
+        if not need_grad:
+            ctx.mark_non_differentiable(slp)
+        return seq, slp, n
+
+    @staticmethod
+    def backward(ctx, dseq, dslp, dn):
+        model, d = ctx.model, ctx.d
+        if not ctx.need_grad:
+            raise nv.XgError("rollout ran without saved activations")
+        dev = ctx.keep[0].device
+        g, gs = _grads_struct(model, dev)
+        b, keep = model._batch(*ctx.keep)
+        wp, wn = _ws_ptr(ctx.ws)
+        ps = model._params_struct()
+        T = d.T
+        full = torch.zeros(d.B, T - 1, dtype=torch.float32, device=dev)
+        full[:, :dslp.shape[1]] = dslp
+        nv.check(nv.lib().xg_rollout_bwd(_stream(), C.byref(d), C.byref(ps), C.byref(gs), C.byref(b), C.byref(ctx.run),
+                                         wp, wn, nv.ptr(full)), "xg_rollout_bwd")
+        model._pool.give(d, dev, ctx.ws)
+        ctx.ws = None
+        return (None,) * 10 + tuple(_grad_views(model, g))
+
+
+# ====================================================================== criteria
+class _NLLFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logp, target, mask, mask2, roll):
+        B, T, V = logp.shape
+        logp = logp.contiguous()
+        target = target.detach().contiguous().long()
+        mask = mask.detach().contiguous().float()
+        m2 = None if mask2 is None else mask2.detach().contiguous().float()
+        sums = torch.empty(2, dtype=torch.float32, device=logp.device)
+        nv.check(nv.lib().xg_nll_fwd(_stream(), nv.ptr(logp), nv.ptr(target), nv.ptr(mask), nv.ptr(m2), B, T, V, roll,
+                                     nv.ptr(sums)), "xg_nll_fwd")
+        ctx.meta = (B, T, V, roll, target, mask, m2, sums)
+        return sums[0] / sums[1]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        B, T, V, roll, target, mask, m2, sums = ctx.meta
+        dlogp = torch.empty(B, T, V, dtype=torch.float32, device=sums.device)
+        nv.check(nv.lib().xg_nll_bwd(_stream(), nv.ptr(target), nv.ptr(mask), nv.ptr(m2), B, T, V, roll, nv.ptr(sums),
+                                     1.0, nv.ptr(dlogp)), "xg_nll_bwd")
+        return dlogp * dloss, None, None, None, None
+
+
+class LanguageModelCriterion(nn.Module):
+    """reference caption_src/SAModel.py:221-234: masked NLL with the target rolled left by one."""
+
+    def forward(self, input, target, mask):
+        return _NLLFunction.apply(input, target, mask, None, 1)
+
+
+class ClassiferCriterion(nn.Module):
+    """reference caption_src/SAModel.py:236-253: masked NLL, target not rolled, optional class mask."""
+
+    def forward(self, input, target, mask, class_mask=None):
+        return _NLLFunction.apply(input, target, mask, class_mask, 0)
+
+
+class RewardCriterion(nn.Module):
+    """reference caption_src/SAModel.py:255-267 (policy-gradient loss on (m,n) tensors; a few KB of
+    element-wise work, left to the tensor runtime)."""
+
+    def forward(self, input, seq, reward):
+        mask = (seq > 0).float()
+        mask = torch.cat([mask.new_ones(mask.size(0), 1), mask[:, :-1]], 1)
+        reward = torch.as_tensor(reward, dtype=torch.float32, device=input.device)
+        out = -input * reward * mask
+        return out.sum() / mask.sum()

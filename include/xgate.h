@@ -1,0 +1,206 @@
+/*
+ * xgate.h -- C ABI of libxgate_hip.so: the MI355X (gfx950) implementation of the
+ * gated-fusion caption decoder hot path of vsislab/Controllable_XGating.
+ *
+ * The reference has no FFI / operator layer: its hot path sits behind the
+ * Python class SAModel (reference caption_src/SAModel.py:13-219).  This header is the
+ * boundary that sits UNDER that class surface: every entry point below replaces the stock
+ * PyTorch kernels the reference launches from the cited lines.  A reference maintainer
+ * binds it with ctypes (INTEGRATION.md shows the stub).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types.
+ *   - All tensor pointers are DEVICE pointers (HIP), fp32 unless noted, row-major,
+ *     contiguous in the documented shape.  Token / index tensors are int64.
+ *   - The caller owns all memory.  The library allocates nothing; scratch and saved
+ *     activations live in one caller-provided workspace sized by xg_workspace_bytes().
+ *     The workspace written by a *_fwd call must be handed unchanged to the matching *_bwd.
+ *   - `stream` is a hipStream_t passed as void*.  Every entry point only ENQUEUES work on
+ *     that stream and returns; there is no host synchronisation inside the library.
+ *   - Return value: 0 on success, a negative XG_E* code otherwise (xg_strerror()).
+ *   - Re-entrant across devices / streams; not across concurrent calls sharing a workspace.
+ *
+ * Dimension names: B batch, K frames, R rnn_size, A att_size, E input_encoding_size,
+ * V vocab, C categories, H classifier hidden (128), F1/F2 rgb/opfl feature sizes,
+ * T decoder steps of this call (seq.size(1) for XE, seq_length+1 for rollouts).
+ */
+#ifndef XGATE_H
+#define XGATE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XG_VERSION 100
+
+enum {
+    XG_OK = 0,
+    XG_EINVAL = -1,     /* bad dimension / null pointer / misaligned pointer */
+    XG_EARCH = -2,      /* device is not gfx950 */
+    XG_EHIP = -3,       /* a HIP call or kernel launch failed (hipGetLastError) */
+    XG_EWORKSPACE = -4  /* workspace too small */
+};
+
+typedef struct XgDims {
+    int32_t B, K, R, A, E, V, C, H, F1, F2, T;
+} XgDims;
+
+/*
+ * Parameter block: one device pointer per state_dict entry of the reference model, in the
+ * order of SURVEY.md Appendix B (reference caption_src/SAModel.py:32-49,
+ * caption_src/sub_modules.py:94-110,661-669,741-745).  The same struct type carries the
+ * gradients (each pointer then addresses the .grad buffer of that parameter).  Field order
+ * is part of the ABI; xg_param_name(i) returns the state_dict key of field i.
+ */
+typedef struct XgParams {
+    float *emb_rgb_w, *emb_rgb_b, *bn_rgb_g, *bn_rgb_b;       /* two_spatial_encoder.visual_emb_rgb.{0,1} */
+    float *emb_opfl_w, *emb_opfl_b, *bn_opfl_g, *bn_opfl_b;   /* two_spatial_encoder.visual_emb_opfl.{0,1} */
+    float *lstm_rgb_wih, *lstm_rgb_whh, *lstm_rgb_bih, *lstm_rgb_bhh;     /* lstmcell_rgb  (gate order i,f,g,o) */
+    float *lstm_opfl_wih, *lstm_opfl_whh, *lstm_opfl_bih, *lstm_opfl_bhh; /* lstmcell_opfl */
+    float *gate_rgb_w, *gate_rgb_b, *gate_opfl_w, *gate_opfl_b;           /* gate_{rgb,opfl}.gate.0 */
+    float *fusion_w, *fusion_b;                                           /* fusion.late_fusion.0 */
+    float *ih1_w, *ih1_b, *ic1_w, *ic1_b, *ih2_w, *ih2_b, *ic2_w, *ic2_b; /* img_embed_{h_1,c_1,h_2,c_2} */
+    float *dgate_w, *dgate_b;                                             /* lstmcore.gate.gate.0 */
+    float *l1_i2h_w, *l1_i2h_b, *l1_a2h_w, *l1_a2h_b, *l1_h2h_w, *l1_h2h_b; /* lstmcore.lstm_1 (order i,f,o,g) */
+    float *l2_i2h_w, *l2_i2h_b, *l2_a2h_w, *l2_a2h_b, *l2_h2h_w, *l2_h2h_b; /* lstmcore.lstm_2 */
+    float *v2a_w, *v2a_b, *h2a_w, *h2a_b, *a2w_w, *a2w_b;                 /* lstmcore.{v2a,h2a,a2w} */
+    float *embed_w;                                                       /* embed.weight */
+    float *logit_w, *logit_b;                                             /* logit */
+    float *cls0_w, *cls0_b, *cls3_w, *cls3_b;                             /* classifer.{0,3} */
+} XgParams;
+
+/* BatchNorm running statistics (buffers of visual_emb_{rgb,opfl}.1); updated in train mode. */
+typedef struct XgBnState {
+    float *rgb_mean, *rgb_var, *opfl_mean, *opfl_var;
+} XgBnState;
+
+/* One batch of inputs (reference caption_src/starttrain.py:114-121). */
+typedef struct XgBatch {
+    const float *feats_rgb;   /* (B,K,F1) */
+    const float *feats_opfl;  /* (B,K,F2) */
+    const float *feat_mask;   /* (B,K) 0/1 */
+    const float *pos_feats;   /* (B,R) */
+    const int64_t *seq;       /* (B,T) teacher-forced tokens, col 0 = BOS = 0; NULL for rollouts */
+    const float *seq_mask;    /* (B,T) 0/1; NULL for rollouts */
+} XgBatch;
+
+/* Run-time options. */
+typedef struct XgRun {
+    int32_t train;        /* 1: BatchNorm batch statistics + dropout active (model.train()) */
+    float drop_p;         /* drop_prob_lm; 0 disables dropout */
+    uint32_t seed;        /* dropout stream for this call (integer hash, see csrc/xg_common.h) */
+    int32_t save;         /* 1: keep activations in the workspace for a following *_bwd */
+    float bn_momentum;    /* 0.1 */
+    float bn_eps;         /* 1e-5 */
+} XgRun;
+
+enum { XG_ROLLOUT_GREEDY = 0, XG_ROLLOUT_SAMPLE = 1, XG_ROLLOUT_REPLAY = 2 };
+
+/* ---- library / ABI introspection ------------------------------------------------- */
+int xg_version(void);
+const char *xg_strerror(int code);
+int xg_param_count(void);
+const char *xg_param_name(int index);                 /* state_dict key of XgParams field `index` */
+int xg_param_numel(const XgDims *d, int index, int64_t *numel);
+size_t xg_workspace_bytes(const XgDims *d);           /* covers every entry point below for dims d */
+
+/* ---- building block: fp32 GEMM on MFMA -------------------------------------------
+ * C[M,N] = op(A) * op(B) (+ bias[n]) (+ C if accumulate), optional ReLU.
+ *   transA = 0: A is (M,K) row-major lda;  transA = 1: A is (K,M) row-major lda.
+ *   transB = 0: B is (K,N) row-major ldb;  transB = 1: B is (N,K) row-major ldb  (nn.Linear weight).
+ * Replaces the stock GEMMs behind nn.Linear (e.g. caption_src/SAModel.py:109). */
+int xg_gemm(void *stream, int transA, int transB, int M, int N, int K,
+            const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+            const float *bias, int relu, int accumulate);
+
+/* ---- CG encoder: EncoderLstm_two_fc.forward (caption_src/sub_modules.py:118-159) ---- */
+int xg_encoder_fwd(void *stream, const XgDims *d, const XgParams *p, const XgBnState *bn,
+                   const XgBatch *x, const XgRun *run, void *ws, size_t ws_bytes,
+                   float *V /* out (B,K,R) */);
+/* dV: (B,K,R) gradient wrt the encoder output; parameter gradients are ACCUMULATED into g. */
+int xg_encoder_bwd(void *stream, const XgDims *d, const XgParams *p, const XgParams *g,
+                   const XgBatch *x, const XgRun *run, void *ws, size_t ws_bytes,
+                   const float *dV);
+
+/* ---- decoder init: SAModel.init_hidden (caption_src/SAModel.py:58-65) ----
+ * state: (4,B,R) = h1,c1,h2,c2.  The masked mean is detached, as in the reference. */
+int xg_init_hidden(void *stream, const XgDims *d, const XgParams *p, const float *V,
+                   const float *feat_mask, void *ws, size_t ws_bytes, float *state);
+
+/* ---- hoisted attention projection: lstmcore.v2a(V) (caption_src/sub_modules.py:677) ---- */
+int xg_vproj(void *stream, const XgDims *d, const XgParams *p, const float *V, float *vproj /* (B,K,A) */);
+
+/* ---- one decoder step: LSTMCore_two_layer_gate.forward + logit/log_softmax
+ *      (caption_src/sub_modules.py:671-687, caption_src/SAModel.py:117-127 get_logprobs_state).
+ * tokens (B) int64; xt_mask (B) 0/1 or NULL (= ones); state (4,B,R) updated in place;
+ * logp (B,V) out or NULL; alpha (B,K) out or NULL.  `step` selects the dropout stream. */
+int xg_step_fwd(void *stream, const XgDims *d, const XgParams *p, const int64_t *tokens,
+                const float *xt_mask, const float *V, const float *vproj, const float *pos_feats,
+                const XgRun *run, int step, void *ws, size_t ws_bytes,
+                float *state, float *logp, float *alpha);
+
+/* ---- teacher-forced forward: SAModel.forward (caption_src/SAModel.py:67-115), ss_prob = 0 ----
+ * Runs encoder, init_hidden, T decoder steps and both heads.
+ * logp (B,T,V), cat_logp (B,T,C) out. */
+int xg_forward_xe(void *stream, const XgDims *d, const XgParams *p, const XgBnState *bn,
+                  const XgBatch *x, const XgRun *run, void *ws, size_t ws_bytes,
+                  float *logp, float *cat_logp);
+/* Backward of xg_forward_xe given dlogp (B,T,V) and dcat_logp (B,T,C) (either may be NULL = 0).
+ * Parameter gradients are ACCUMULATED into g (caller zeroes them: optimizer.zero_grad(),
+ * caption_src/starttrain.py:123). */
+int xg_backward_xe(void *stream, const XgDims *d, const XgParams *p, const XgParams *g,
+                   const XgBatch *x, const XgRun *run, void *ws, size_t ws_bytes,
+                   const float *dlogp, const float *dcat_logp);
+
+/* ---- fused XE loss path (same maths as forward_xe + LanguageModelCriterion +
+ *      ClassiferCriterion, caption_src/SAModel.py:225-253, caption_src/starttrain.py:126-129)
+ *      without materialising d(logp): loss = L_xe + weight_class * L_cls.
+ * losses: device float[3] = {loss, L_xe, L_cls}.  cap_classes (B,T) int64, class_mask (B,T) or NULL. */
+int xg_xe_loss_fwd(void *stream, const XgDims *d, const XgParams *p, const XgBnState *bn,
+                   const XgBatch *x, const int64_t *cap_classes, const float *class_mask,
+                   float weight_class, const XgRun *run, void *ws, size_t ws_bytes, float *losses);
+/* dloss_dev: DEVICE scalar d(objective)/d(loss) (NULL = 1), so loss.backward() needs no host sync. */
+int xg_xe_loss_bwd(void *stream, const XgDims *d, const XgParams *p, const XgParams *g,
+                   const XgBatch *x, const int64_t *cap_classes, const float *class_mask,
+                   float weight_class, const float *dloss_dev, const XgRun *run, void *ws, size_t ws_bytes);
+
+/* ---- rollouts: SAModel.sample (caption_src/SAModel.py:163-219), beam_size = 1 ----
+ * mode GREEDY: argmax (ties -> lowest index, :186); SAMPLE: inverse-CDF draw from
+ * exp(logp/temperature) with caller-supplied uniforms (T,B) in [0,1) (:190-194);
+ * REPLAY: take `forced` (B,T-1) tokens.  T = seq_length+1 core steps are always run
+ * (no per-step host sync, cf. :206); seq / seq_logp are (B,T-1), rows past the reference's
+ * early exit are zero tokens.  n_steps (device int32) receives the reference's n. */
+int xg_rollout(void *stream, const XgDims *d, const XgParams *p, const XgBnState *bn,
+               const XgBatch *x, const XgRun *run, int mode, const float *uniforms,
+               const int64_t *forced, float temperature, void *ws, size_t ws_bytes,
+               int64_t *seq, float *seq_logp, int32_t *n_steps);
+/* Backward of a rollout run with run->save = 1, given d(seq_logp) (B,T-1)
+ * (RewardCriterion, caption_src/SAModel.py:259-267; caption_src/starttrain.py:131-134). */
+int xg_rollout_bwd(void *stream, const XgDims *d, const XgParams *p, const XgParams *g,
+                   const XgBatch *x, const XgRun *run, void *ws, size_t ws_bytes,
+                   const float *dseq_logp);
+
+/* ---- criteria (caption_src/SAModel.py:221-267) ---- */
+/* out: device float[2] = {sum(-logp[target]*mask), sum(mask)}; loss = out[0]/out[1].
+ * roll = 1 rolls the target left by one (LanguageModelCriterion :228); mask2 optional
+ * second mask (ClassiferCriterion class_mask :250). */
+int xg_nll_fwd(void *stream, const float *logp, const int64_t *target, const float *mask,
+               const float *mask2, int B, int T, int V, int roll, float *out);
+/* dlogp (B,T,V) is OVERWRITTEN with the dense gradient scale * d(loss)/d(logp). */
+int xg_nll_bwd(void *stream, const int64_t *target, const float *mask, const float *mask2,
+               int B, int T, int V, int roll, const float *sums, float scale, float *dlogp);
+
+/* ---- update: clip_gradient + Adam (caption_src/myutils.py:79-85, caption_src/starttrain.py:76,137) ----
+ * Elementwise clamp of g to +-clip (clip <= 0 disables), then torch.optim.Adam semantics
+ * (L2 weight decay folded into the gradient, bias correction with `step` >= 1). */
+int xg_clip_adam(void *stream, int64_t n, float *param, float *grad, float *exp_avg,
+                 float *exp_avg_sq, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int step, float clip);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XGATE_H */

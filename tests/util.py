@@ -1,0 +1,65 @@
+"""Shared helpers for the parity tests (test infrastructure)."""
+import os
+import re
+
+import numpy as np
+import torch
+
+from oracle import paramgen as pg
+from oracle import xgate_oracle as xo
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+CFG = {
+    "c1": dict(B=8, K=26, R=512, A=1536, E=468, V=20000, C=14, L=20, F1=1536, F2=1024, H=128),
+    "tiny": dict(B=5, K=7, R=24, A=40, E=18, V=61, C=5, L=6, F1=20, F2=12, H=128),
+    "c5": dict(B=4, K=40, R=1024, A=1536, E=468, V=20000, C=14, L=6, F1=1536, F2=1024, H=128),
+    # mid-size, everything 16-byte aligned: exercises the vector-load GEMM paths quickly
+    "mid": dict(B=12, K=9, R=64, A=96, E=36, V=500, C=14, L=7, F1=48, F2=40, H=128),
+}
+WEIGHT_CLASS = 0.5
+
+
+def load_golden(name):
+    return np.load(os.path.join(GOLD, name))
+
+
+def header_symbols():
+    """Function names declared in include/xgate.h."""
+    txt = open(os.path.join(ROOT, "include", "xgate.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(xg_[a-z_0-9]+)\s*\(", txt)))
+
+
+def make_model(d, P=None, device="cuda", p_drop=0.0, train=True):
+    from controllable_xgating_amd import SAModel, make_opt
+    model = SAModel(make_opt(d, drop_prob_lm=p_drop))
+    if P is None:
+        P = pg.make_params(d)
+    missing = model.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()}, strict=False)
+    assert not missing.unexpected_keys
+    model = model.to(device)
+    model.train(train)
+    return model
+
+
+def to_dev(x, device="cuda"):
+    return {k: torch.from_numpy(v).to(device) for k, v in x.items()}
+
+
+def oracle_grads(P):
+    return {k: (v.grad.numpy() if v.grad is not None else np.zeros(tuple(v.shape), np.float32)) for k, v in P.items()}
+
+
+def assert_grads_close(model, ref, rtol=2e-3, atol=2e-6):
+    bad = []
+    for name, prm in model.named_parameters():
+        g = prm.grad
+        g = g.detach().cpu().numpy() if g is not None else np.zeros(tuple(prm.shape), np.float32)
+        r = ref[name]
+        scale = np.abs(r).max()
+        err = np.abs(g - r).max()
+        if not err <= atol + rtol * scale:
+            bad.append((name, float(err), float(scale)))
+    assert not bad, bad
