@@ -282,7 +282,8 @@ class SAModel(nn.Module):
         if self.training and self.ss_prob > 0.0:
             raise NotImplementedError("scheduled sampling (ss_prob > 0) is not implemented in the HIP path yet")
         params = [self._named()[n] for n in nv.PARAM_NAMES]
-        return _XEFunction.apply(self, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, *params)
+        save = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _XEFunction.apply(self, save, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, *params)
 
     def xe_loss(self, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, cap_classes=None,
                 class_mask=None, weight_class=0.0):
@@ -290,7 +291,8 @@ class SAModel(nn.Module):
         without materialising the (m,T,V) log-prob tensor or its gradient
         (starttrain.py:125-129).  Returns the scalar loss tensor; .backward() works."""
         params = [self._named()[n] for n in nv.PARAM_NAMES]
-        return _XELossFunction.apply(self, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, cap_classes,
+        save = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _XELossFunction.apply(self, save, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, cap_classes,
                                      class_mask, float(weight_class), *params)
 
     def init_hidden(self, feat, feat_mask):
@@ -395,12 +397,11 @@ def _grad_views(model, g):
 
 class _XEFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, *params):
+    def forward(ctx, model, save, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, *params):
         B, K, _ = feats_rgb.shape
         T = seq.shape[1]
         dev = feats_rgb.device
         d = model._dims(B, K, T)
-        save = any(p.requires_grad for p in params) and torch.is_grad_enabled()
         ws = model._pool.take(d, dev) if save else model._pool.shared(d, dev)
         wp, wn = _ws_ptr(ws)
         b, keep = model._batch(feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask)
@@ -429,18 +430,17 @@ class _XEFunction(torch.autograd.Function):
                                          wp, wn, nv.ptr(dl), nv.ptr(dc)), "xg_backward_xe")
         model._pool.give(d, dev, ctx.ws)
         ctx.ws = None
-        return (None,) * 7 + tuple(_grad_views(model, g))
+        return (None,) * 8 + tuple(_grad_views(model, g))
 
 
 class _XELossFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, cap_classes, class_mask,
+    def forward(ctx, model, save, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, cap_classes, class_mask,
                 weight_class, *params):
         B, K, _ = feats_rgb.shape
         T = seq.shape[1]
         dev = feats_rgb.device
         d = model._dims(B, K, T)
-        save = any(p.requires_grad for p in params) and torch.is_grad_enabled()
         ws = model._pool.take(d, dev) if save else model._pool.shared(d, dev)
         wp, wn = _ws_ptr(ws)
         b, keep = model._batch(feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask)
@@ -469,7 +469,7 @@ class _XELossFunction(torch.autograd.Function):
                                          C.byref(ctx.run), wp, wn), "xg_xe_loss_bwd")
         model._pool.give(d, dev, ctx.ws)
         ctx.ws = None
-        return (None,) * 10 + tuple(_grad_views(model, g))
+        return (None,) * 11 + tuple(_grad_views(model, g))
 
 
 class _RolloutFunction(torch.autograd.Function):

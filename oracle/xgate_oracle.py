@@ -227,7 +227,10 @@ def sample(P, feats_rgb, feats_opfl, feat_mask, pos_feats, L, mode="greedy",
         out, state, _ = core_step(P, xt, mk, V, pos_feats, state, p, seed, t, train, vproj)
         logp = torch.log_softmax(_lin(out, P, "logit"), dim=1)                        # :217
         logps.append(logp)
-    res = (torch.stack(seqs, 1), torch.stack(slps, 1))
+    if not seqs:                      # every row finished at t = 1 (the reference's torch.cat would raise here)
+        res = (torch.zeros(B, 0, dtype=torch.int64), torch.zeros(B, 0))
+    else:
+        res = (torch.stack(seqs, 1), torch.stack(slps, 1))
     return res + (logps,) if return_logp else res
 
 

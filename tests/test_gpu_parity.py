@@ -231,8 +231,9 @@ def test_greedy_token_for_token_vs_reference(name, tag, ragged):
     np.testing.assert_allclose(slp, g["seqLogprobs"], atol=3e-4)
 
 
-def test_greedy_early_stop_matches_oracle():
-    """Bias token 0 (EOS) up so every row finishes early: n < L, trailing zeros, same n as the oracle."""
+def test_greedy_all_rows_finish_at_first_step():
+    """Edge case: EOS wins at t = 1 for every row -> n = 0 (the reference would fail in torch.cat on an
+    empty list, SAModel.py:219; the HIP path returns empty (m,0) tensors like the oracle)."""
     d = pg.make_dims(**CFG["mid"])
     Pn = pg.make_params(d)
     Pn["logit.bias"] = Pn["logit.bias"].copy(); Pn["logit.bias"][0] += 6.0
@@ -240,13 +241,7 @@ def test_greedy_early_stop_matches_oracle():
     x = to_dev(pg.make_inputs(d, seed=0))
     with torch.no_grad():
         seq, slp = model.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"sample_max": 1})
-    xi = xo.to_torch_inputs(pg.make_inputs(d, seed=0))
-    with torch.no_grad():
-        so, lo = xo.sample(xo.to_torch_params(Pn), xi["feats_rgb"], xi["feats_opfl"], xi["feat_mask"], xi["pos_feats"],
-                           d.L, mode="greedy", train=False, running=xo.new_running(d))
-    assert seq.shape == so.shape and seq.shape[1] < d.L
-    assert np.array_equal(seq.cpu().numpy(), so.numpy())
-    np.testing.assert_allclose(slp.cpu().numpy(), lo.numpy(), atol=3e-4)
+    assert tuple(seq.shape) == (d.B, 0) and tuple(slp.shape) == (d.B, 0)
 
 
 @pytest.mark.parametrize("tag", ["tiny", "c1"])
@@ -278,11 +273,16 @@ def test_scst_replay_vs_reference_golden(tag):
                                        err_msg=name)
 
 
-def test_sampling_inverse_cdf_brackets_uniform():
-    """Multinomial rollout with supplied uniforms: every drawn token's CDF interval (recomputed in
-    float64 from the step's own log-probs via replay) contains its uniform."""
-    d = pg.make_dims(**CFG["mid"])
-    model = make_model(d, train=False)
+def test_sampling_inverse_cdf_and_ragged_early_stop():
+    """Multinomial rollout with supplied uniforms, EOS probability ~0.3 per step so rows finish at
+    different steps and the loop exits early (SAModel.py:200-210): same n as the oracle, finished rows
+    emit 0, and every drawn token's CDF interval (float64, from the step's own log-probs) contains its
+    uniform."""
+    cfg = dict(CFG["mid"]); cfg["L"] = 24
+    d = pg.make_dims(**cfg)
+    Pn = pg.make_params(d, logit_gain=1.0)
+    Pn["logit.bias"] = Pn["logit.bias"].copy(); Pn["logit.bias"][0] += 5.4
+    model = make_model(d, P=Pn, train=False)
     x = to_dev(pg.make_inputs(d, seed=0))
     T = d.L + 1
     u = torch.from_numpy(pg.uniform("uni", (T, d.B), 77)).cuda()
@@ -290,24 +290,30 @@ def test_sampling_inverse_cdf_brackets_uniform():
         seq, slp = model.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"],
                                 {"sample_max": 0, "uniforms": u})
     xi = xo.to_torch_inputs(pg.make_inputs(d, seed=0))
+    Po = xo.to_torch_params(Pn)
     with torch.no_grad():
-        so, lo, logps = xo.sample(xo.to_torch_params(pg.make_params(d)), xi["feats_rgb"], xi["feats_opfl"], xi["feat_mask"],
-                                  xi["pos_feats"], d.L, mode="replay", forced=seq.cpu(), train=False,
-                                  running=xo.new_running(d), return_logp=True)
+        s_or, _ = xo.sample(Po, xi["feats_rgb"], xi["feats_opfl"], xi["feat_mask"], xi["pos_feats"], d.L, mode="sample",
+                            uniforms=u.cpu().numpy(), train=False, running=xo.new_running(d))
+        so, lo, logps = xo.sample(Po, xi["feats_rgb"], xi["feats_opfl"], xi["feat_mask"], xi["pos_feats"], d.L,
+                                  mode="replay", forced=seq.cpu(), train=False, running=xo.new_running(d), return_logp=True)
+    assert 0 < seq.shape[1] < d.L, seq.shape                     # early exit happened
+    assert seq.shape == s_or.shape                               # same n as the oracle's own sampler
     seqn = seq.cpu().numpy(); un = u.cpu().numpy()
     alive = np.ones(d.B, bool)
     for t in range(1, seqn.shape[1] + 1):
         lp = logps[t - 1].numpy().astype(np.float64)
         cdf = np.cumsum(np.exp(lp), axis=1); tot = cdf[:, -1]
         for b in range(d.B):
-            if not alive[b]:
-                continue
             tok = seqn[b, t - 1]
+            if not alive[b]:
+                assert tok == 0                                  # it * unfinished (SAModel.py:208)
+                continue
             lo_ = (cdf[b, tok - 1] if tok > 0 else 0.0) / tot[b]; hi_ = cdf[b, tok] / tot[b]
             assert lo_ - 1e-4 <= un[t, b] <= hi_ + 1e-4, (t, b, tok, lo_, un[t, b], hi_)
             if tok == 0:
                 alive[b] = False
-    np.testing.assert_allclose(slp.cpu().numpy(), lo.numpy(), atol=3e-4)
+    mism = (seqn != s_or.numpy()).sum()
+    assert mism <= 1, mism                                       # identical up to a CDF-boundary coin flip
 
 
 def test_greedy_ties_take_lowest_index():
