@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- decoder timesteps/sec (train fwd+bwd) at batch 128, MSRVTT-shaped 26 x (1536+1024).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one full teacher-forced XE training iteration of BASELINE.json configs[1] on each rank's
+batch of 128 videos: zero_grad -> CG encoder fwd -> 21 decoder steps -> both heads + loss -> full
+backward -> (N>1: ONE RCCL all-reduce of the flat gradient) -> clip + Adam.  Inputs are synthetic
+ and already resident in HBM.  value = N * B * T * K / max-over-ranks wall time.
+
+Besides the contract line it reports
+  roofline     : the decoder-step launch group (xg_step_fwd = attention + POS gate + 2 LSTM cells, the
+                 unit of SURVEY.md 8d) timed with stream events; ALGORITHMIC bytes / duration vs 8 TB/s
+  cpu_baseline : the oracle (CPU restatement of the reference, v2a recomputed per step like the
+                 reference) timed on this box's host cores on a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def synth_inputs(B, K, L, V, R, F1, F2, C_, seed, device):
+    """feats U[0,1), pos U(-1,1), seq[:,0]=0, words UniformInt[2,V), masks of ones."""
+    g = torch.Generator().manual_seed(seed)
+    x = dict(
+        feats_rgb=torch.rand(B, K, F1, generator=g),
+        feats_opfl=torch.rand(B, K, F2, generator=g),
+        feat_mask=torch.ones(B, K),
+        pos_feats=torch.rand(B, R, generator=g) * 2 - 1,
+        seq=torch.cat([torch.zeros(B, 1, dtype=torch.int64), torch.randint(2, V, (B, L), generator=g)], 1),
+        seq_mask=torch.ones(B, L + 1),
+        cap_classes=torch.randint(0, C_, (B, L + 1), generator=g),
+        class_mask=torch.ones(B, L + 1),
+    )
+    return {k: v.to(device) for k, v in x.items()}
+
+
+def step_bytes(B, K, R, A, E, save):
+    """ALGORITHMIC bytes of one decoder step: lstmcore weights once + per-video streams."""
+    w_core = (2 * R * A + A) + (A + 1) + (E * R + R) + ((E + 2 * R) * 4 * R + 12 * R) + (3 * R * 4 * R + 12 * R)
+    per = K * A + K * R + 4 * R + 4 * R + E + R + 1
+    s_save = (2 * 4 * R + K + R + R + 2 * R) if save else 0
+    return 4 * (w_core + B * (per + s_save))
+
+
+def measure_step_group(model, x, reps=200):
+    """Average duration of ONE decoder-step launch group (xg_step_fwd) with events on the library's stream."""
+    from controllable_xgating_amd import _native as nv
+    from controllable_xgating_amd.model import _stream, _ws_ptr
+    B, K = x["feats_rgb"].shape[:2]
+    with torch.no_grad():
+        V = model.encode(x["feats_rgb"], x["feats_opfl"], x["feat_mask"])
+        st = model.init_hidden(V, x["feat_mask"])
+        state = torch.cat([st[0][0], st[0][1], st[1][0], st[1][1]], 0).contiguous()
+        d = model._dims(B, K, 1)
+        ps, run = model._params_struct(), model._run(False)
+        vproj = torch.empty(B, K, model.att_size, device=V.device)
+        nv.check(nv.lib().xg_vproj(_stream(), C.byref(d), C.byref(ps), nv.ptr(V), nv.ptr(vproj)), "xg_vproj")
+        ws = model._pool.shared(d, V.device)
+        wp, wn = _ws_ptr(ws)
+        tok = x["seq"][:, 1].contiguous()
+        pos = x["pos_feats"].contiguous()
+
+        def call():
+            nv.check(nv.lib().xg_step_fwd(_stream(), C.byref(d), C.byref(ps), nv.ptr(tok), None, nv.ptr(V), nv.ptr(vproj),
+                                          nv.ptr(pos), C.byref(run), 0, wp, wn, nv.ptr(state), None, None), "xg_step_fwd")
+        for _ in range(10):
+            call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize()
+        e0.record()
+        for _ in range(reps):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e-3 / reps
+
+
+def cpu_baseline(cfg, budget_s=20.0):
+    """Oracle (port of the reference's CPU path; reference-faithful: v2a(V) recomputed every step)."""
+    from oracle import paramgen as pg
+    from oracle import xgate_oracle as xo
+    d = pg.make_dims(B=cfg["B"], K=cfg["K"], R=cfg["R"], A=cfg["A"], E=cfg["E"], V=cfg["V"], C=cfg["C"], L=cfg["L"],
+                     F1=cfg["F1"], F2=cfg["F2"])
+    P = xo.to_torch_params(pg.make_params(d), requires_grad=True)
+    x = {k: v.cpu() for k, v in synth_inputs(cfg["B"], cfg["K"], cfg["L"], cfg["V"], cfg["R"], cfg["F1"], cfg["F2"], cfg["C"],
+                                           0, "cpu").items()}
+    running = xo.new_running(d)
+
+    def it():
+        for p_ in P.values():
+            p_.grad = None
+        logp, cat, _ = xo.forward_xe(P, x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"],
+                                     x["seq_mask"], train=True, running=running, hoist=False)
+        loss = xo.lm_criterion(logp, x["seq"], x["seq_mask"])
+        loss.backward()
+    t0 = time.time(); it(); warm = time.time() - t0
+    n, t0 = 0, time.time()
+    while True:
+        it(); n += 1
+        if time.time() - t0 > budget_s or n >= 5:
+            break
+    dt = (time.time() - t0) / n
+    T = cfg["L"] + 1
+    return dict(value=round(cfg["B"] * T / dt, 1), unit="decoder timesteps/s", cores=torch.get_num_threads(), kind="port",
+                sample="%d full XE fwd+bwd iterations of the same workload (B=%d, T=%d, V=%d) after 1 warm-up (%.1f s); "
+                       "oracle with v2a(V) recomputed per step like the reference" % (n, cfg["B"], T, cfg["V"], warm),
+                ms_per_step=round(dt * 1e3, 1))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--path", choices=["fused", "surface"], default="fused",
+                    help="fused: model.xe_loss (no (m,T,V) gradient tensor); surface: model() + criterion, reference call sequence")
+    ap.add_argument("--batch", type=int, default=128)
+    ap.add_argument("--drop", type=float, default=0.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=15.0)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    import __graft_entry__ as ge
+    if rank == 0:
+        ge.build()
+    if world > 1:
+        dist.barrier()
+    from controllable_xgating_amd import LanguageModelCriterion, SAModel, make_opt
+    from controllable_xgating_amd.train import ClipAdam, allreduce_gradients, broadcast_parameters
+
+    cfg = dict(B=args.batch, K=26, R=512, A=1536, E=468, V=20000, C=14, L=20, F1=1536, F2=1024)
+    T = cfg["L"] + 1
+    opt = make_opt(None, vocab_size=cfg["V"], seq_length=cfg["L"], drop_prob_lm=args.drop)
+    model = SAModel(opt).to(dev)
+    model.train()
+    broadcast_parameters(model)
+    x = synth_inputs(cfg["B"], cfg["K"], cfg["L"], cfg["V"], cfg["R"], cfg["F1"], cfg["F2"], cfg["C"], seed=rank, device=dev)
+    optim = ClipAdam(model, lr=4e-4, grad_clip=0.1)
+    crit = LanguageModelCriterion()
+
+    def step():
+        optim.zero_grad()
+        if args.path == "fused":
+            loss = model.xe_loss(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+        else:
+            logp, _ = model(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+            loss = crit(logp, x["seq"], x["seq_mask"])
+        loss.backward()
+        allreduce_gradients(model)
+        optim.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    final_loss = float(loss.item())
+
+    t_step = measure_step_group(model, x) if rank == 0 else None
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * cfg["B"] * T * args.steps / dt
+        bytes_step = step_bytes(cfg["B"], cfg["K"], cfg["R"], cfg["A"], cfg["E"], save=False)
+        achieved = bytes_step / t_step / 1e9
+        out = {
+            "metric": "decoder timesteps/sec (train fwd+bwd) at batch 128, MSRVTT 26x1536+1024",
+            "value": round(value, 1), "unit": "decoder timesteps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "configs[1]: 1xMI355X batch %d teacher-forced XE train, 26 frames x (1536+1024), hidden 512, "
+                                   "att 1536, emb 468, vocab 20000, seq_len 20 (T=21), fp32" % cfg["B"],
+                       "global_batch": world * cfg["B"], "per_gpu_batch": cfg["B"], "parallelism": "dp%d" % world,
+                       "path": args.path, "drop_prob_lm": args.drop,
+                       "timed_region": "zero_grad + encoder fwd + 21 decoder steps + heads/loss + full backward"
+                                       + (" + RCCL grad all-reduce" if world > 1 else "") + " + clip + Adam"},
+            "final_loss": round(final_loss, 5),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                         "frac": round(achieved / 8000.0, 4), "traffic": None,
+                         "kernel": "decoder step launch group (xg_step_fwd: attention + POS gate + lstm_1 + lstm_2)",
+                         "algorithmic_bytes_per_launch": bytes_step, "avg_launch_us": round(t_step * 1e6, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_budget)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

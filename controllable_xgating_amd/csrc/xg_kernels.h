@@ -35,6 +35,7 @@ struct LstmBwdArgs {
     const float* c_out;  int ldco;    // post-mask new cell state
     const float* mask;   int ldm;
     const float* dh_out; int lddh;    // grad wrt post-dropout hidden
+    const float* dh_add; int lddha;   // optional second term added to dh_out (e.g. the heads' gradient); may be null
     const float* dc_out; int lddc;    // grad wrt new cell state (from the next step); may be null (= 0)
     float* ds;           int ldds;    // (B,4R) out
     float* dc_prev;      int lddcp;   // out (overwritten)
@@ -43,6 +44,7 @@ struct LstmBwdArgs {
     XgDrop drop;
 };
 int xgk_lstm_bwd(hipStream_t st, const LstmBwdArgs& a);
+int xgk_lstm_bwd2(hipStream_t st, const LstmBwdArgs& a, const LstmBwdArgs& b);   // two independent cells, one launch
 
 // y = g*t + t with g = dropout(pre) (pre already ReLU'd by the GEMM epilogue).  g is written back in place of pre.
 // Row r of the (rows,R) operands: dropout step = drop.step + (r / s_div) % s_mod, dropout element index =
@@ -90,6 +92,27 @@ int xgk_axpy(hipStream_t st, float* y, const float* x, float a, int64_t n);     
 int xgk_fill(hipStream_t st, float* y, float v, int64_t n);
 // strided 2-D copy / add: dst[r*ldd + c] (=|+=) src[r*lds + c]
 int xgk_copy2d(hipStream_t st, float* dst, int ldd, const float* src, int lds, int rows, int cols, bool add);
+
+// ---- xg_step.hip : multi-job skinny split-K MFMA GEMM with optional LSTM-cell epilogue
+enum { SK_EPI_STORE = 0, SK_EPI_LSTM = 1 };
+constexpr int SK_MAX_JOBS = 4;
+struct SkSeg {
+    const float* A; const float* B;   // A (M,K) row-major lda ; B (N,K) row-major ldb, or (K,N) when b_ncontig
+    int lda, ldb, K, b_ncontig;
+};
+struct SkJob {
+    SkSeg seg[3];
+    const float* bias[3];
+    float* C;                          // STORE epilogue output (M,N) ldc
+    // LSTM epilogue (N must be 4R; weight rows / bias / add columns in gate-major order like the reference)
+    const float* add; const float* c_prev; const float* h_prev; const float* mask;
+    float* gates; float* c_out; float* h_out;
+    int ldadd, ldcp, ldhp, ldm, ldg, ldco, ldho;
+    int nseg, M, N, ldc, accumulate, relu, epi, R, order, mask_mode, tile0;
+    XgDrop drop;
+};
+struct SkArgs { SkJob job[SK_MAX_JOBS]; int njobs; };
+int xgk_skinny(hipStream_t st, SkArgs& a);
 
 // ---- xg_attn.hip
 // per-sample additive attention: e_k = w . tanh(p + q_k), alpha = softmax_k(e), af = sum_k alpha_k V_k

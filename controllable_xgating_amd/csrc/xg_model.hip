@@ -99,6 +99,23 @@ inline int gemm_tn(hipStream_t st, int Mrows, int N, int K, const float* dY, int
     return xgk_gemm(st, true, false, N, K, Mrows, dY, lddy, X, ldx, dW, lddw, nullptr, false, true);
 }
 
+// ---- skinny-job builders
+inline SkSeg seg_nt(const float* A, int lda, const float* W, int ldw, int K) { return SkSeg{A, W, lda, ldw, K, 0}; }
+inline SkSeg seg_nn(const float* dY, int lddy, const float* W, int ldw, int Kc) { return SkSeg{dY, W, lddy, ldw, Kc, 1}; }
+inline SkJob job_store(int M, int N, float* C, int ldc, bool acc, bool relu = false) {
+    SkJob j{};
+    j.M = M; j.N = N; j.C = C; j.ldc = ldc; j.accumulate = acc ? 1 : 0; j.relu = relu ? 1 : 0; j.epi = SK_EPI_STORE;
+    return j;
+}
+inline SkJob job_lstm(const LstmFwdArgs& a) {
+    SkJob j{};
+    j.M = a.B; j.N = 4 * a.R; j.R = a.R; j.epi = SK_EPI_LSTM; j.order = a.order; j.mask_mode = a.mask_mode;
+    j.add = a.add; j.ldadd = a.ldadd; j.c_prev = a.c_prev; j.ldcp = a.ldcp; j.h_prev = a.h_prev; j.ldhp = a.ldhp;
+    j.mask = a.mask; j.ldm = a.ldm; j.gates = a.gates; j.ldg = a.ldg; j.c_out = a.c_out; j.ldco = a.ldco;
+    j.h_out = a.h_out; j.ldho = a.ldho; j.drop = a.drop;
+    return j;
+}
+
 // ================================================================== encoder
 int encoder_fwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgBnState* bn, const XgBatch& x,
                 const XgRun& run, Ws& w) {
@@ -133,14 +150,14 @@ int encoder_fwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgBnSt
     ZERO(w.zeroBR, (size_t)B * R);
     XgRun nodrop = run; nodrop.drop_p = 0.f;
     for (int i = 0; i < K; ++i) {                                                                  // sub_modules.py:132-148
+        SkArgs sk{};
+        sk.njobs = 2;                                           // both modalities' cells in ONE launch
         for (int m = 0; m < 2; ++m) {
             const float* hp = i == 0 ? w.zeroBR : w.Hs[m] + (size_t)(i - 1) * R;
             const float* cp = i == 0 ? w.zeroBR : w.Cs[m] + (size_t)(i - 1) * R;
             const int ldp = i == 0 ? R : K * R;
-            float* S = m == 0 ? w.S : w.S2;
-            XG_TRY(xgk_linear(st, B, 4 * R, R, hp, ldp, whh[m], bhh[m], S, 4 * R));
             LstmFwdArgs a{};
-            a.s = S; a.lds_ = 4 * R; a.add = w.PRE[m] + (size_t)i * 4 * R; a.ldadd = K * 4 * R;
+            a.add = w.PRE[m] + (size_t)i * 4 * R; a.ldadd = K * 4 * R;
             a.c_prev = cp; a.ldcp = ldp; a.h_prev = hp; a.ldhp = ldp;
             a.mask = x.feat_mask + i; a.ldm = K;
             a.gates = w.G[m] + (size_t)i * 4 * R; a.ldg = K * 4 * R;
@@ -148,8 +165,17 @@ int encoder_fwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgBnSt
             a.h_out = w.Hs[m] + (size_t)i * R; a.ldho = K * R;
             a.B = B; a.R = R; a.order = XG_ORDER_IFGO; a.mask_mode = XG_MASK_ZERO;
             a.drop = xg_make_drop(&nodrop, 0, 0);
-            XG_TRY(xgk_lstm_fwd(st, a));
+            if (R % 8 == 0) {
+                sk.job[m] = job_lstm(a);
+                sk.job[m].nseg = 1; sk.job[m].seg[0] = seg_nt(hp, ldp, whh[m], R, R); sk.job[m].bias[0] = bhh[m];
+            } else {
+                float* S = m == 0 ? w.S : w.S2;
+                XG_TRY(xgk_linear(st, B, 4 * R, R, hp, ldp, whh[m], bhh[m], S, 4 * R));
+                a.s = S; a.lds_ = 4 * R;
+                XG_TRY(xgk_lstm_fwd(st, a));
+            }
         }
+        if (R % 8 == 0) XG_TRY(xgk_skinny(st, sk));
     }
     // cross gates, all frames at once (gated values are not fed back): sub_modules.py:151-152
     XG_TRY(xgk_linear(st, N, R, R, w.Hs[1], R, p.gate_rgb_w, p.gate_rgb_b, w.GG[0], R, true));
@@ -201,28 +227,40 @@ int encoder_bwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgPara
         XG_TRY(gemm_nn(st, N, R, R, w.dGG[m], R, gate_w[m], R, w.dHs[o], R, true));
     }
     XgRun nodrop = run; nodrop.drop_p = 0.f;
-    for (int m = 0; m < 2; ++m) {
-        ZERO(w.dHrec[m], (size_t)B * R);
-        ZERO(w.dCrec[m][0], (size_t)B * R);
-        int cur = 0;
-        for (int i = K - 1; i >= 0; --i) {
-            XG_TRY(xgk_copy2d(st, w.dHs[m] + (size_t)i * R, K * R, w.dHrec[m], R, B, R, true));
+    int curc = 0;
+    for (int m = 0; m < 2; ++m) { ZERO(w.dHrec[m], (size_t)B * R); ZERO(w.dCrec[m][0], (size_t)B * R); }
+    for (int i = K - 1; i >= 0; --i) {                          // both modalities per launch
+        LstmBwdArgs ab[2];
+        for (int m = 0; m < 2; ++m) {
             LstmBwdArgs a{};
             a.gates = w.G[m] + (size_t)i * 4 * R; a.ldg = K * 4 * R;
             a.c_prev = i == 0 ? w.zeroBR : w.Cs[m] + (size_t)(i - 1) * R; a.ldcp = i == 0 ? R : K * R;
             a.c_out = w.Cs[m] + (size_t)i * R; a.ldco = K * R;
             a.mask = x.feat_mask + i; a.ldm = K;
             a.dh_out = w.dHs[m] + (size_t)i * R; a.lddh = K * R;
-            a.dc_out = w.dCrec[m][cur]; a.lddc = R;
+            a.dh_add = w.dHrec[m]; a.lddha = R;
+            a.dc_out = w.dCrec[m][curc]; a.lddc = R;
             a.ds = w.dS[m] + (size_t)i * 4 * R; a.ldds = K * 4 * R;
-            a.dc_prev = w.dCrec[m][cur ^ 1]; a.lddcp = R;
+            a.dc_prev = w.dCrec[m][curc ^ 1]; a.lddcp = R;
             a.dh_prev = nullptr; a.lddhp = 0;
             a.B = B; a.R = R; a.order = XG_ORDER_IFGO; a.mask_mode = XG_MASK_ZERO;
             a.drop = xg_make_drop(&nodrop, 0, 0);
-            XG_TRY(xgk_lstm_bwd(st, a));
-            cur ^= 1;
-            if (i > 0) XG_TRY(gemm_nn(st, B, R, 4 * R, w.dS[m] + (size_t)i * 4 * R, K * 4 * R, whh[m], R, w.dHrec[m], R, false));
+            ab[m] = a;
         }
+        XG_TRY(xgk_lstm_bwd2(st, ab[0], ab[1]));
+        curc ^= 1;
+        if (i > 0) {
+            SkArgs sk{};
+            sk.njobs = 2;
+            for (int m = 0; m < 2; ++m) {
+                sk.job[m] = job_store(B, R, w.dHrec[m], R, false);
+                sk.job[m].nseg = 1;
+                sk.job[m].seg[0] = seg_nn(w.dS[m] + (size_t)i * 4 * R, K * 4 * R, whh[m], R, 4 * R);
+            }
+            XG_TRY(xgk_skinny(st, sk));
+        }
+    }
+    for (int m = 0; m < 2; ++m) {
         // Hprev[b,k] = H[b,k-1], zero at k = 0 : one clean TN GEMM for dW_hh
         ZERO(w.Hprev[m], (size_t)N * R);
         if (K > 1)   // one strided 2-D copy covers all videos: rows = B, cols = (K-1)*R
@@ -269,36 +307,68 @@ struct StepIO {
     int t;
 };
 
-// attention + the two cells for one step (sub_modules.py:677-684)
+// attention + the two cells for one step (sub_modules.py:677-684): 3 launches
+//   [p = h2a([h1;h2])  ||  cell 1]  ->  attention  ->  cell 2
 int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& run, Ws& w, const float* V,
               const float* vproj, const StepIO& s) {
     const int B = d.B, R = d.R, A = d.A, E = d.E;
+    LstmFwdArgs a{};
+    a.add = s.pre1; a.ldadd = 4 * R;
+    a.c_prev = s.c1; a.ldcp = R; a.h_prev = s.h1; a.ldhp = R; a.mask = s.mask; a.ldm = s.ldm;
+    a.gates = s.g1; a.ldg = 4 * R; a.c_out = s.c1o; a.ldco = R; a.h_out = s.h1o; a.ldho = R;
+    a.B = B; a.R = R; a.order = XG_ORDER_IFOG; a.mask_mode = XG_MASK_HOLD;
+    a.drop = xg_make_drop(&run, XG_SITE_L1, s.t);
+    LstmFwdArgs c{};
+    c.add = nullptr; c.ldadd = 0;
+    c.c_prev = s.c2; c.ldcp = R; c.h_prev = s.h2; c.ldhp = R; c.mask = s.mask; c.ldm = s.ldm;
+    c.gates = s.g2; c.ldg = 4 * R; c.c_out = s.c2o; c.ldco = R; c.h_out = s.h2o; c.ldho = R;
+    c.B = B; c.R = R; c.order = XG_ORDER_IFOG; c.mask_mode = XG_MASK_HOLD;
+    c.drop = xg_make_drop(&run, XG_SITE_L2, s.t);
+    if (R % 8 == 0) {
+        SkArgs k1{};
+        k1.njobs = 2;
+        k1.job[0] = job_store(B, A, s.P, A, false);
+        k1.job[0].nseg = 2;
+        k1.job[0].seg[0] = seg_nt(s.h1, R, p.h2a_w, 2 * R, R);
+        k1.job[0].seg[1] = seg_nt(s.h2, R, p.h2a_w + R, 2 * R, R);
+        k1.job[0].bias[0] = p.h2a_b;
+        k1.job[1] = job_lstm(a);
+        if (s.pre1) {
+            k1.job[1].nseg = 1;
+            k1.job[1].seg[0] = seg_nt(s.h1, R, p.l1_h2h_w, R, R); k1.job[1].bias[0] = p.l1_h2h_b;
+        } else {
+            k1.job[1].nseg = 3;
+            k1.job[1].seg[0] = seg_nt(s.xt, E, p.l1_i2h_w, E, E); k1.job[1].bias[0] = p.l1_i2h_b;
+            k1.job[1].seg[1] = seg_nt(s.posg, R, p.l1_a2h_w, R, R); k1.job[1].bias[1] = p.l1_a2h_b;
+            k1.job[1].seg[2] = seg_nt(s.h1, R, p.l1_h2h_w, R, R); k1.job[1].bias[2] = p.l1_h2h_b;
+        }
+        XG_TRY(xgk_skinny(st, k1));
+        XG_TRY(xgk_attn_fwd(st, s.P, vproj, V, p.a2w_w, s.alpha, s.af, B, d.K, R, A));
+        SkArgs k2{};
+        k2.njobs = 1;
+        k2.job[0] = job_lstm(c);
+        k2.job[0].nseg = 3;
+        k2.job[0].seg[0] = seg_nt(s.h1o, R, p.l2_i2h_w, R, R); k2.job[0].bias[0] = p.l2_i2h_b;
+        k2.job[0].seg[1] = seg_nt(s.af, R, p.l2_a2h_w, R, R); k2.job[0].bias[1] = p.l2_a2h_b;
+        k2.job[0].seg[2] = seg_nt(s.h2, R, p.l2_h2h_w, R, R); k2.job[0].bias[2] = p.l2_h2h_b;
+        XG_TRY(xgk_skinny(st, k2));
+        return XG_OK;
+    }
+    // generic path (R not a multiple of 8): plain GEMMs + pointwise cell kernels
     XG_TRY(xgk_gemm(st, false, true, B, A, R, s.h1, R, p.h2a_w, 2 * R, s.P, A, p.h2a_b, false, false));
     XG_TRY(xgk_gemm(st, false, true, B, A, R, s.h2, R, p.h2a_w + R, 2 * R, s.P, A, nullptr, false, true));
     XG_TRY(xgk_attn_fwd(st, s.P, vproj, V, p.a2w_w, s.alpha, s.af, B, d.K, R, A));
-    // cell 1: lstm_1(xt, pos', h1)
     XG_TRY(xgk_linear(st, B, 4 * R, R, s.h1, R, p.l1_h2h_w, p.l1_h2h_b, w.S, 4 * R));
     if (!s.pre1) {
         XG_TRY(xgk_linear(st, B, 4 * R, E, s.xt, E, p.l1_i2h_w, p.l1_i2h_b, w.S, 4 * R, false, true));
         XG_TRY(xgk_linear(st, B, 4 * R, R, s.posg, R, p.l1_a2h_w, p.l1_a2h_b, w.S, 4 * R, false, true));
     }
-    LstmFwdArgs a{};
-    a.s = w.S; a.lds_ = 4 * R; a.add = s.pre1; a.ldadd = 4 * R;
-    a.c_prev = s.c1; a.ldcp = R; a.h_prev = s.h1; a.ldhp = R; a.mask = s.mask; a.ldm = s.ldm;
-    a.gates = s.g1; a.ldg = 4 * R; a.c_out = s.c1o; a.ldco = R; a.h_out = s.h1o; a.ldho = R;
-    a.B = B; a.R = R; a.order = XG_ORDER_IFOG; a.mask_mode = XG_MASK_HOLD;
-    a.drop = xg_make_drop(&run, XG_SITE_L1, s.t);
+    a.s = w.S; a.lds_ = 4 * R;
     XG_TRY(xgk_lstm_fwd(st, a));
-    // cell 2: lstm_2(h1', af, h2)
     XG_TRY(xgk_linear(st, B, 4 * R, R, s.h1o, R, p.l2_i2h_w, p.l2_i2h_b, w.S2, 4 * R));
     XG_TRY(xgk_linear(st, B, 4 * R, R, s.af, R, p.l2_a2h_w, p.l2_a2h_b, w.S2, 4 * R, false, true));
     XG_TRY(xgk_linear(st, B, 4 * R, R, s.h2, R, p.l2_h2h_w, p.l2_h2h_b, w.S2, 4 * R, false, true));
-    LstmFwdArgs c{};
-    c.s = w.S2; c.lds_ = 4 * R; c.add = nullptr; c.ldadd = 0;
-    c.c_prev = s.c2; c.ldcp = R; c.h_prev = s.h2; c.ldhp = R; c.mask = s.mask; c.ldm = s.ldm;
-    c.gates = s.g2; c.ldg = 4 * R; c.c_out = s.c2o; c.ldco = R; c.h_out = s.h2o; c.ldho = R;
-    c.B = B; c.R = R; c.order = XG_ORDER_IFOG; c.mask_mode = XG_MASK_HOLD;
-    c.drop = xg_make_drop(&run, XG_SITE_L2, s.t);
+    c.s = w.S2; c.lds_ = 4 * R;
     XG_TRY(xgk_lstm_fwd(st, c));
     return XG_OK;
 }
@@ -357,18 +427,23 @@ int decoder_bwd_core(hipStream_t st, const XgDims& d, const XgParams& p, const X
         float* dp = w.DP + (size_t)t * B * A;
         float* daf = w.DAF + t * BR;
         const float* mk = mask + (size_t)t * mask_tstride;
-        XG_TRY(xgk_axpy(st, dh2n, w.DH2OUT + t * BR, 1.f, BR));
         LstmBwdArgs a{};
         a.gates = w.G2 + (size_t)t * B * 4 * R; a.ldg = 4 * R;
         a.c_prev = w.C2 + t * BR; a.ldcp = R; a.c_out = w.C2 + (t + 1) * BR; a.ldco = R;
-        a.mask = mk; a.ldm = ldm; a.dh_out = dh2n; a.lddh = R; a.dc_out = dc2n; a.lddc = R;
+        a.mask = mk; a.ldm = ldm; a.dh_out = dh2n; a.lddh = R; a.dh_add = w.DH2OUT + t * BR; a.lddha = R;
+        a.dc_out = dc2n; a.lddc = R;
         a.ds = ds2; a.ldds = 4 * R; a.dc_prev = dc2p; a.lddcp = R; a.dh_prev = dh2p; a.lddhp = R;
         a.B = B; a.R = R; a.order = XG_ORDER_IFOG; a.mask_mode = XG_MASK_HOLD;
         a.drop = xg_make_drop(&run, XG_SITE_L2, t);
         XG_TRY(xgk_lstm_bwd(st, a));
-        XG_TRY(gemm_nn(st, B, R, 4 * R, ds2, 4 * R, p.l2_i2h_w, R, dh1n, R, true));     // d h1'_t
-        XG_TRY(gemm_nn(st, B, R, 4 * R, ds2, 4 * R, p.l2_a2h_w, R, daf, R, false));     // d af_t
-        XG_TRY(gemm_nn(st, B, R, 4 * R, ds2, 4 * R, p.l2_h2h_w, R, dh2p, R, true));     // d h2_{t-1}
+        {   // s2 = h1' Wi + af Wa + h2 Wh : three data gradients, one launch
+            SkArgs sk{};
+            sk.njobs = 3;
+            sk.job[0] = job_store(B, R, dh1n, R, true);  sk.job[0].nseg = 1; sk.job[0].seg[0] = seg_nn(ds2, 4 * R, p.l2_i2h_w, R, 4 * R);
+            sk.job[1] = job_store(B, R, daf, R, false);  sk.job[1].nseg = 1; sk.job[1].seg[0] = seg_nn(ds2, 4 * R, p.l2_a2h_w, R, 4 * R);
+            sk.job[2] = job_store(B, R, dh2p, R, true);  sk.job[2].nseg = 1; sk.job[2].seg[0] = seg_nn(ds2, 4 * R, p.l2_h2h_w, R, 4 * R);
+            XG_TRY(xgk_skinny(st, sk));
+        }
         XG_TRY(xgk_attn_bwd(st, daf, R, w.P + (size_t)t * B * A, w.vproj, w.Venc, p.a2w_w, w.ALPHA + (size_t)t * B * K,
                             w.DE + (size_t)t * B * K, dp, B, K, R, A));
         LstmBwdArgs c{};
@@ -379,9 +454,18 @@ int decoder_bwd_core(hipStream_t st, const XgDims& d, const XgParams& p, const X
         c.B = B; c.R = R; c.order = XG_ORDER_IFOG; c.mask_mode = XG_MASK_HOLD;
         c.drop = xg_make_drop(&run, XG_SITE_L1, t);
         XG_TRY(xgk_lstm_bwd(st, c));
-        XG_TRY(gemm_nn(st, B, R, 4 * R, ds1, 4 * R, p.l1_h2h_w, R, dh1p, R, true));
-        XG_TRY(gemm_nn(st, B, R, A, dp, A, p.h2a_w, 2 * R, dh1p, R, true));             // p_t = h2a([h1;h2])
-        XG_TRY(gemm_nn(st, B, R, A, dp, A, p.h2a_w + R, 2 * R, dh2p, R, true));
+        {   // into step t-1: dh1 += ds1 Wh1 + dp Wh2a[:, :R] ; dh2 += dp Wh2a[:, R:]
+            SkArgs sk{};
+            sk.njobs = 2;
+            sk.job[0] = job_store(B, R, dh1p, R, true);
+            sk.job[0].nseg = 2;
+            sk.job[0].seg[0] = seg_nn(ds1, 4 * R, p.l1_h2h_w, R, 4 * R);
+            sk.job[0].seg[1] = seg_nn(dp, A, p.h2a_w, 2 * R, A);
+            sk.job[1] = job_store(B, R, dh2p, R, true);
+            sk.job[1].nseg = 1;
+            sk.job[1].seg[0] = seg_nn(dp, A, p.h2a_w + R, 2 * R, A);
+            XG_TRY(xgk_skinny(st, sk));
+        }
         cur ^= 1;
     }
     // gradients wrt the initial state -> img_embed_* (init_hidden; vbar is detached: SAModel.py:59-62)
@@ -568,9 +652,11 @@ extern "C" int xg_step_fwd(void* stream, const XgDims* d, const XgParams* p, con
     XG_TRY(xgk_embed_gather(st, p->embed_w, E, tokens, B, 1, 0, B, d->V, w.Xe, E));
     XG_TRY(xgk_linear(st, B, R, E, w.Xe, E, p->dgate_w, p->dgate_b, w.GP, R, true));
     XG_TRY(xgk_gate_fwd(st, w.GP, R, pos_feats, R, 0, w.POSG, R, B, R, xg_make_drop(run, XG_SITE_DGATE, step), B, 1 << 30, 1, B));
+    // the step reads the OLD state while cell 1 already writes the new h1 in the same launch: work from a copy
+    if (hipMemcpyAsync(w.state_tmp, state, sizeof(float) * 4 * BR, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
     StepIO s{};
     s.xt = w.Xe; s.posg = w.POSG; s.pre1 = nullptr; s.mask = xt_mask; s.ldm = 1;
-    s.h1 = state; s.c1 = state + BR; s.h2 = state + 2 * BR; s.c2 = state + 3 * BR;
+    s.h1 = w.state_tmp; s.c1 = w.state_tmp + BR; s.h2 = w.state_tmp + 2 * BR; s.c2 = w.state_tmp + 3 * BR;
     s.h1o = state; s.c1o = state + BR; s.h2o = state + 2 * BR; s.c2o = state + 3 * BR;
     s.P = w.P; s.alpha = alpha ? alpha : w.ALPHA; s.af = w.AF; s.g1 = nullptr; s.g2 = nullptr; s.t = step;
     XG_TRY(core_step(st, *d, *p, *run, w, V, vproj, s));

@@ -48,7 +48,7 @@ __global__ void lstm_fwd_kernel(LstmFwdArgs a) {
     a.h_out[(size_t)b * a.ldho + j] = hn;
 }
 
-__global__ void lstm_bwd_kernel(LstmBwdArgs a) {
+__device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgs& a) {
     const int idx = blockIdx.x * TPB + threadIdx.x;
     if (idx >= a.B * a.R) return;
     const int b = idx / a.R, j = idx % a.R, R = a.R;
@@ -59,7 +59,9 @@ __global__ void lstm_bwd_kernel(LstmBwdArgs a) {
     const float cp = a.c_prev[(size_t)b * a.ldcp + j];
     const float cn = a.c_out[(size_t)b * a.ldco + j];
     const float m = a.mask ? a.mask[(size_t)b * a.ldm] : 1.0f;
-    const float dh = a.dh_out[(size_t)b * a.lddh + j] * xg_keep(a.drop, (uint32_t)idx);
+    float dh = a.dh_out[(size_t)b * a.lddh + j];
+    if (a.dh_add) dh += a.dh_add[(size_t)b * a.lddha + j];
+    dh *= xg_keep(a.drop, (uint32_t)idx);
     float dc = a.dc_out ? a.dc_out[(size_t)b * a.lddc + j] : 0.0f;
     float dht, dct, dcp;
     // tanh(c'): HOLD uses the post-mask cell (sub_modules.py:763); ZERO: m in {0,1} so m*tanh(c_out) == m*tanh(cn)
@@ -85,6 +87,10 @@ __global__ void lstm_bwd_kernel(LstmBwdArgs a) {
     if (a.order == XG_ORDER_IFOG) { ds[2 * R + j] = dso; ds[3 * R + j] = dsg; }
     else                          { ds[2 * R + j] = dsg; ds[3 * R + j] = dso; }
     a.dc_prev[(size_t)b * a.lddcp + j] = dcp;
+}
+__global__ void lstm_bwd_kernel(LstmBwdArgs a) { lstm_bwd_body(a); }
+__global__ void lstm_bwd2_kernel(LstmBwdArgs a, LstmBwdArgs b) {
+    if (blockIdx.y == 0) lstm_bwd_body(a); else lstm_bwd_body(b);
 }
 
 // ------------------------------------------------------------------ gates
@@ -286,6 +292,12 @@ int xgk_lstm_fwd(hipStream_t st, const LstmFwdArgs& a) {
 }
 int xgk_lstm_bwd(hipStream_t st, const LstmBwdArgs& a) {
     hipLaunchKernelGGL(lstm_bwd_kernel, grid1((int64_t)a.B * a.R), dim3(TPB), 0, st, a);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_lstm_bwd2(hipStream_t st, const LstmBwdArgs& a, const LstmBwdArgs& b) {
+    const int64_t n = (int64_t)(a.B * a.R > b.B * b.R ? a.B * a.R : b.B * b.R);
+    hipLaunchKernelGGL(lstm_bwd2_kernel, dim3((unsigned)xg_cdiv64(n, TPB), 2), dim3(TPB), 0, st, a, b);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }

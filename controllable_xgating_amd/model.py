@@ -375,18 +375,33 @@ class SAModel(nn.Module):
 
 
 # ====================================================================== autograd glue
+def _grads_bound(model):
+    named = model._named()
+    base = model._gflat.data_ptr()
+    for n, (off, k) in model._slices.items():
+        g = named[n].grad
+        if g is None or g.data_ptr() != base + 4 * off:
+            return False
+    return True
+
+
 def _grads_struct(model, device):
-    """Fresh zero flat buffer + XgParams struct of views into it (the C ABI accumulates)."""
+    """XgParams struct of gradient pointers (the C ABI accumulates into them).  If every p.grad is
+    already bound to the model's flat gradient buffer (model.flat_grads()), accumulate there directly
+    and hand autograd nothing; otherwise use a fresh zero buffer and return views for autograd."""
     model._ensure_flat()
-    g = torch.zeros_like(model._flat)
+    g = None if _grads_bound(model) else torch.zeros_like(model._flat)
+    base = model._gflat if g is None else g
     s = nv.XgParams()
     for i, n in enumerate(nv.PARAM_NAMES):
         off, k = model._slices[n]
-        setattr(s, "p%d" % i, g.data_ptr() + 4 * off)
+        setattr(s, "p%d" % i, base.data_ptr() + 4 * off)
     return g, s
 
 
 def _grad_views(model, g):
+    if g is None:
+        return [None] * len(nv.PARAM_NAMES)
     named = model._named()
     out = []
     for n in nv.PARAM_NAMES:

@@ -1,0 +1,72 @@
+"""Training-side counterparts of the reference's driver utilities:
+clip_gradient + Adam (caption_src/myutils.py:79-85, caption_src/starttrain.py:76,136-137) as ONE
+fused HIP launch over the model's flat parameter buffer, and the data-parallel gradient
+all-reduce (RCCL over xGMI; the reference itself is single-GPU)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _native as nv
+from .model import _stream
+
+
+class ClipAdam:
+    """optimizer = optim.Adam(model.parameters(), lr, weight_decay) + clip_gradient(optimizer, clip):
+    elementwise clamp of every gradient to +-grad_clip, then Adam with torch defaults
+    (betas 0.9/0.999, eps 1e-8; the reference ignores its --optim_* flags, starttrain.py:76)."""
+
+    def __init__(self, model, lr=4e-4, weight_decay=0.0, grad_clip=0.1, betas=(0.9, 0.999), eps=1e-8):
+        self.model, self.lr, self.wd, self.clip, self.betas, self.eps = model, lr, weight_decay, grad_clip, betas, eps
+        flat = model.flat_parameters()
+        self.exp_avg = torch.zeros_like(flat)
+        self.exp_avg_sq = torch.zeros_like(flat)
+        self.step_count = 0
+
+    def zero_grad(self):
+        self.model.flat_grads().zero_()
+
+    def set_lr(self, lr):                      # myutils.set_lr
+        self.lr = lr
+
+    def step(self):
+        flat, g = self.model.flat_parameters(), self.model.flat_grads()
+        self.step_count += 1
+        nv.check(nv.lib().xg_clip_adam(_stream(), flat.numel(), nv.ptr(flat), nv.ptr(g), nv.ptr(self.exp_avg),
+                                       nv.ptr(self.exp_avg_sq), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                                       self.step_count, self.clip), "xg_clip_adam")
+
+    def state_dict(self):
+        return dict(exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, step=self.step_count, lr=self.lr)
+
+    def load_state_dict(self, sd):
+        self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        self.step_count, self.lr = sd["step"], sd["lr"]
+
+
+def allreduce_gradients(model, group=None):
+    """Data parallel by video: ONE all-reduce(sum) of the flat gradient buffer,
+    scaled by 1/world, BEFORE the clamp.  No other collective; BatchNorm statistics stay per replica."""
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized():
+        return
+    world = dist.get_world_size(group)
+    if world == 1:
+        return
+    g = model.flat_grads()
+    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
+    g.mul_(1.0 / world)
+
+
+def broadcast_parameters(model, src=0, group=None):
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+        dist.broadcast(model.flat_parameters(), src=src, group=group)
+        for b in model.buffers():
+            dist.broadcast(b, src=src, group=group)
+
+
+def shard_batch(x: dict, rank: int, world: int):
+    """rank r takes videos r::world."""
+    return {k: v[rank::world].contiguous() for k, v in x.items()}
