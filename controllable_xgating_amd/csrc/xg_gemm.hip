@@ -108,6 +108,8 @@ __device__ __forceinline__ f32x4 read_frag(const float* __restrict__ lds, int ro
 struct GemmArgs {
     const float* A; const float* B; float* C; const float* bias;
     int M, N, K, lda, ldb, ldc, relu, accumulate;
+    int splitk;   // > 1: the K slabs are divided over `splitk` workgroups per tile; partial tiles are added
+                  // into C with hardware fp32 atomics (C pre-zeroed by the launcher unless accumulating)
 };
 
 template <int BM, int BN, bool AKC, bool BKC, bool VEC>
@@ -121,12 +123,14 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
 
     // XCD-aware tile order: consecutive tiles (sharing an A row panel) stay on one XCD's L2.
     const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
-    const int nwg = ntm * ntn;
+    const int nwg = ntm * ntn * g.splitk;
     int bid = blockIdx.x;
     {
         const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
+    const int ks = bid % g.splitk;          // K split index (fastest: the splits of one tile share an XCD)
+    bid /= g.splitk;
     const int tm = bid / ntn, tn = bid % ntn;
     const int m0 = tm * BM, n0 = tn * BN;
 
@@ -143,15 +147,17 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     f32x4 ra[TileGeom<BM, AKC>::nvec], rb[TileGeom<BN, BKC>::nvec];
-    const int nslab = (g.K + BKS - 1) / BKS;
-    load_tile<BM, AKC, VEC>(g.A, g.lda, m0, 0, g.M, g.K, ra);
-    load_tile<BN, BKC, VEC>(g.B, g.ldb, n0, 0, g.N, g.K, rb);
+    const int nslab_all = (g.K + BKS - 1) / BKS;
+    const int s_begin = (int)(((long)ks * nslab_all) / g.splitk), s_end = (int)(((long)(ks + 1) * nslab_all) / g.splitk);
+    const int nslab = s_end;
+    load_tile<BM, AKC, VEC>(g.A, g.lda, m0, s_begin * BKS, g.M, g.K, ra);
+    load_tile<BN, BKC, VEC>(g.B, g.ldb, n0, s_begin * BKS, g.N, g.K, rb);
     store_tile<BM, AKC>(smem, ra);
     store_tile<BN, BKC>(smem + A_FL, rb);
     __syncthreads();
 
-    for (int s = 0; s < nslab; ++s) {
-        const int cur = s & 1;
+    for (int s = s_begin; s < nslab; ++s) {
+        const int cur = (s - s_begin) & 1;
         if (s + 1 < nslab) {
             load_tile<BM, AKC, VEC>(g.A, g.lda, m0, (s + 1) * BKS, g.M, g.K, ra);
             load_tile<BN, BKC, VEC>(g.B, g.ldb, n0, (s + 1) * BKS, g.N, g.K, rb);
@@ -187,13 +193,14 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
         for (int j = 0; j < NT; ++j) {
             const int col = n0 + wn * WN + j * 32 + l31;
             if (col >= g.N) continue;
-            const float bv = g.bias ? g.bias[col] : 0.f;
+            const float bv = (g.bias && ks == 0) ? g.bias[col] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (row < g.M) {
                     float* dst = g.C + (size_t)row * g.ldc + col;
                     float v = acc[i][j][r] + bv;
+                    if (g.splitk > 1) { unsafeAtomicAdd(dst, v); continue; }
                     if (g.accumulate) v += *dst;
                     if (g.relu) v = fmaxf(v, 0.f);
                     *dst = v;
@@ -205,6 +212,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
 template <int BM, int BN, bool AKC, bool BKC, bool VEC>
 int launch(hipStream_t st, const GemmArgs& g) {
     const int ntm = xg_cdiv(g.M, BM), ntn = xg_cdiv(g.N, BN);
+    if (g.splitk > 1 && !g.accumulate) {      // partial tiles are atomically added: start from zero
+        if (g.ldc == g.N) { if (hipMemsetAsync(g.C, 0, sizeof(float) * (size_t)g.M * g.N, st) != hipSuccess) return XG_EHIP; }
+        else if (hipMemset2DAsync(g.C, sizeof(float) * g.ldc, 0, sizeof(float) * g.N, g.M, st) != hipSuccess) return XG_EHIP;
+    }
     const size_t lds = 2 * (TileGeom<BM, AKC>::lds_floats + TileGeom<BN, BKC>::lds_floats) * sizeof(float);
     static bool attr_done = false;   // > 64 KiB of dynamic LDS must be opted into once per kernel
     if (!attr_done && lds > 65536) {
@@ -212,16 +223,25 @@ int launch(hipStream_t st, const GemmArgs& g) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XG_EHIP;
         attr_done = true;
     }
-    hipLaunchKernelGGL((gemm_kernel<BM, BN, AKC, BKC, VEC>), dim3(ntm * ntn), dim3(256), lds, st, g);
+    hipLaunchKernelGGL((gemm_kernel<BM, BN, AKC, BKC, VEC>), dim3(ntm * ntn * g.splitk), dim3(256), lds, st, g);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
 
 template <bool AKC, bool BKC>
-int dispatch(hipStream_t st, const GemmArgs& g, bool vec) {
-    // 128x128 tiles when they already fill the chip (>= 2 tiles per CU), else 64x64.
+int dispatch(hipStream_t st, GemmArgs g, bool vec) {
+    // 128x128 tiles (2x2 MFMA tiles per wave: half the LDS and global traffic per flop of 64x64) whenever the
+    // chip can be filled: by the tile count alone, or -- for deep reductions with few output tiles (weight
+    // gradients, dH = dlogits * W) -- by splitting K over several workgroups per tile.
     const long t128 = (long)xg_cdiv(g.M, 128) * xg_cdiv(g.N, 128);
-    const bool big = t128 >= 384;
+    const int nslab = xg_cdiv(g.K, BKS);
+    g.splitk = 1;
+    bool big = t128 >= 384;
+    if (!big && !g.relu && t128 >= 8 && nslab >= 16 && g.M >= 96 && g.N >= 96) {
+        int sk = (int)((512 + t128 - 1) / t128);
+        if (sk > nslab / 8) sk = nslab / 8;       // keep >= 8 slabs (K = 256) per split
+        if (sk >= 2) { g.splitk = sk; big = true; }
+    }
     if (big) return vec ? launch<128, 128, AKC, BKC, true>(st, g) : launch<128, 128, AKC, BKC, false>(st, g);
     return vec ? launch<64, 64, AKC, BKC, true>(st, g) : launch<64, 64, AKC, BKC, false>(st, g);
 }
@@ -232,7 +252,7 @@ int xgk_gemm(hipStream_t st, bool transA, bool transB, int M, int N, int K, cons
              const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate) {
     if (M <= 0 || N <= 0) return XG_OK;
     if (K < 0 || !A || !B || !C) return XG_EINVAL;
-    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0};
+    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1};
     const bool akc = !transA;   // A (M,K) row-major -> k contiguous
     const bool bkc = transB;    // B (N,K) row-major -> k contiguous
     // 16-byte vector loads need aligned bases, ld % 4 == 0 and the vectorised extent % 4 == 0

@@ -3,9 +3,11 @@
 // The per-timestep products are (B x K) x (K x N) with B = 128: too few output tiles to fill 256 CUs
 // with an ordinary tiled GEMM, and each 32x32 MFMA tile needs K/2 dependent 64-cycle MFMAs.  So the
 // parallelism comes from K: one workgroup = one 32x32 output tile, its 8 waves split the reduction
-// dimension 8-way, stream their A / W fragments straight from L2 into registers (nothing is shared
-// between waves, so LDS staging would be pure overhead), and the 8 partial tiles are reduced through
-// LDS.  Several independent products ("jobs") ride in ONE launch so a decoder step is a handful of
+// dimension 8-way.  Each wave streams ITS OWN 32-deep chunks of the A / W rows with fully coalesced
+// 128-B row loads (8 lanes per line), parks them in a wave-private LDS image ([32][36] floats, the
+// conflict-free b128 fragment layout), and feeds the MFMAs from there -- fragment-shaped loads straight
+// to registers touch 32 cache lines per instruction and thrash the 32 KB L1 (measured 5x slower).  No
+// workgroup barrier inside the K loop; the 8 partial tiles are reduced through LDS at the end.  Several independent products ("jobs") ride in ONE launch so a decoder step is a handful of
 // launches, and the LSTM cell arithmetic (reference caption_src/sub_modules.py:752-767) runs in the
 // epilogue of the product that feeds it: tiles of the cell products are laid out as 8 hidden units
 // x 4 gates so one tile holds everything a unit's cell update needs.
@@ -22,33 +24,53 @@ namespace {
 
 constexpr int SKW = 8;            // waves per workgroup (K split)
 constexpr int SKT = SKW * 64;     // threads
-constexpr int NPF = 4;            // 8-deep k blocks in flight per wave
+constexpr int CK = 32;            // k-chunk depth staged per wave
+constexpr int LDR = CK + 4;       // LDS row stride (floats): 9 16-B slots -> conflict-free b128 fragment reads
+constexpr int OPF = 32 * LDR;     // floats of one staged operand chunk
+
+// A staged chunk is 32 rows x 32 k (k-contiguous operand) or 32 k x 32 n (n-contiguous operand); either way lane l
+// moves 16 B pieces (i*8 + l/8, 4*(l%8)) for i = 0..3 -- every 8 lanes read one full 128-B line -- and the chunk
+// lands in LDS as [i*8 + l/8][4*(l%8)..+3] with row stride LDR.  Out-of-range ROWS are clamped to a valid row
+// (their products land in output rows / columns that are never stored), so only the k tail needs predication.
+struct ChunkPtr {
+    const float* p[4];     // this lane's four piece pointers at chunk 0
+    int step;              // floats to advance per chunk
+};
 
 template <bool VEC>
-__device__ __forceinline__ f32x4 ld4_k(const float* __restrict__ row, int k, int K, bool ok) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (ok) {
-        if (VEC) { if (k < K) v = *reinterpret_cast<const f32x4*>(row + k); }
-        else {
+__device__ __forceinline__ void ld_chunk(const ChunkPtr& cp, int c, bool tail, int valid /*floats valid from the piece start*/,
+                                         int tail_stride /* validity shrink per i (n-contig: 8 rows per i) */, f32x4 (&v)[4]) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (k + j < K) v[j] = row[k + j];
+    for (int i = 0; i < 4; ++i) {
+        const float* src = cp.p[i] + (size_t)c * cp.step;
+        if (!tail) {
+            if (VEC) v[i] = *reinterpret_cast<const f32x4*>(src);
+            else { v[i][0] = src[0]; v[i][1] = src[1]; v[i][2] = src[2]; v[i][3] = src[3]; }
+        } else {
+            const int ok = valid - i * tail_stride;   // k-contig: #valid floats from this piece; n-contig: #valid k rows
+            f32x4 t = {0.f, 0.f, 0.f, 0.f};
+            if (tail_stride == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) if (q < ok) t[q] = src[q];
+            } else if (ok > 0) {
+                if (VEC) t = *reinterpret_cast<const f32x4*>(src);
+                else { t[0] = src[0]; t[1] = src[1]; t[2] = src[2]; t[3] = src[3]; }
+            }
+            v[i] = t;
         }
     }
-    return v;
 }
-// B stored (K,N): element (k, n) at B[k*ldb + n]; 4 consecutive k for a fixed column
-__device__ __forceinline__ f32x4 ld4_n(const float* __restrict__ col, int ldb, int k, int K, bool ok) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (ok) {
+__device__ __forceinline__ void st_chunk(float* __restrict__ lds, int lane, const f32x4 (&v)[4]) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) if (k + j < K) v[j] = col[(size_t)(k + j) * ldb];
-    }
-    return v;
+    for (int i = 0; i < 4; ++i)
+        *reinterpret_cast<f32x4*>(lds + (i * 8 + (lane >> 3)) * LDR + ((lane & 7) << 2)) = v[i];
 }
 
 template <bool VEC>
 __global__ void __launch_bounds__(SKT) sk_kernel(SkArgs args) {
-    __shared__ __attribute__((aligned(16))) float red[SKW][32][32];
+    // wave-private staging (A chunk + B chunk per wave), re-used as the [SKW][32][32] reduction buffer
+    __shared__ __attribute__((aligned(16))) float smem[SKW * 2 * OPF];
+    float (*red)[32][32] = reinterpret_cast<float (*)[32][32]>(smem);
     // ---- which job / tile (XCD-aware: the m-tiles that share a weight slice stay on one XCD's L2)
     int bid = blockIdx.x;
     {
@@ -64,60 +86,90 @@ __global__ void __launch_bounds__(SKT) sk_kernel(SkArgs args) {
     const int tm = tile % ntm, tn = tile / ntm;
     const int m0 = tm * 32, n0 = tn * 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
-
-    // B row / output column owned by this lane.  LSTM tiles: 8 units x 4 gates.
     const int R = job.R;
-    int ncol;
-    if (job.epi == SK_EPI_LSTM) ncol = (l31 >> 3) * R + tn * 8 + (l31 & 7);
-    else ncol = n0 + l31;
-    const bool n_ok = job.epi == SK_EPI_LSTM ? (tn * 8 + (l31 & 7)) < R : ncol < job.N;
-    const int mrow = m0 + l31;
-    const bool m_ok = mrow < job.M;
+    const bool lstm = job.epi == SK_EPI_LSTM;
+    float* As = smem + wave * 2 * OPF;
+    float* Bs = As + OPF;
+    const int lrow = lane >> 3, lcol = (lane & 7) << 2;
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    // ---- K loop: this wave's share of the 8-deep blocks of every segment
-    int nb_total = 0;
+    // ---- K loop: this wave's share of the 32-deep chunks of every segment
+    int nc_total = 0;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) if (s < job.nseg) nb_total += (job.seg[s].K + 7) >> 3;
-    const int wb0 = (wave * nb_total) / SKW, wb1 = ((wave + 1) * nb_total) / SKW;
+    for (int s = 0; s < 3; ++s) if (s < job.nseg) nc_total += (job.seg[s].K + CK - 1) / CK;
+    const int wc0 = (wave * nc_total) / SKW, wc1 = ((wave + 1) * nc_total) / SKW;
     int seg_start = 0;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         if (s >= job.nseg) break;
         const SkSeg sg = job.seg[s];
-        const int nb = (sg.K + 7) >> 3;
-        const int b0 = max(wb0, seg_start) - seg_start, b1 = min(wb1, seg_start + nb) - seg_start;
-        seg_start += nb;
-        if (b0 >= b1) continue;
-        const float* arow = sg.A + (size_t)mrow * sg.lda;
-        const float* brow = sg.b_ncontig ? sg.B + ncol : sg.B + (size_t)ncol * sg.ldb;
-        f32x4 fa[NPF], fb[NPF];
+        const int nc = (sg.K + CK - 1) / CK;
+        const int c0 = max(wc0, seg_start) - seg_start, c1 = min(wc1, seg_start + nc) - seg_start;
+        seg_start += nc;
+        if (c0 >= c1) continue;
+        const bool bn = sg.b_ncontig != 0;
+        ChunkPtr pa, pb;
+        pa.step = CK;
 #pragma unroll
-        for (int j = 0; j < NPF; ++j) {
-            const int k = (b0 + j) * 8 + half * 4;
-            const bool live = b0 + j < b1;
-            fa[j] = ld4_k<VEC>(arow, k, sg.K, m_ok && live);
-            fb[j] = sg.b_ncontig ? ld4_n(brow, sg.ldb, k, sg.K, n_ok && live) : ld4_k<VEC>(brow, k, sg.K, n_ok && live);
-        }
-        for (int i = b0; i < b1; i += NPF) {
-#pragma unroll
-            for (int j = 0; j < NPF; ++j) {
-                const f32x4 a = fa[j], b = fb[j];
-                const int nxt = i + NPF + j;
-                const int k = nxt * 8 + half * 4;
-                const bool live = nxt < b1;
-                fa[j] = ld4_k<VEC>(arow, k, sg.K, m_ok && live);
-                fb[j] = sg.b_ncontig ? ld4_n(brow, sg.ldb, k, sg.K, n_ok && live) : ld4_k<VEC>(brow, k, sg.K, n_ok && live);
-                if (i + j < b1) {
-#pragma unroll
-                    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], acc, 0, 0, 0);
-                }
+        for (int i = 0; i < 4; ++i) {
+            const int r = i * 8 + lrow;
+            pa.p[i] = sg.A + (size_t)min(m0 + r, job.M - 1) * sg.lda + lcol;
+            if (bn) {          // piece = k row (i*8 + lrow) of the chunk, 4 consecutive n
+                int n = n0 + lcol;
+                if (n + 3 >= job.N) n = max(job.N - 4, 0);     // clamped columns are never stored (N >= 4 on this path)
+                pb.p[i] = sg.B + (size_t)r * sg.ldb + n;
+            } else {
+                int wrow;
+                if (lstm) wrow = (r >> 3) * R + min(tn * 8 + (r & 7), R - 1);
+                else wrow = min(n0 + r, job.N - 1);
+                pb.p[i] = sg.B + (size_t)wrow * sg.ldb + lcol;
             }
         }
+        pb.step = bn ? CK * sg.ldb : CK;
+        const int nfull = sg.K / CK;                         // chunks < nfull need no k predication
+        // validity of this lane's pieces inside the (single) tail chunk
+        const int ktail = sg.K - nfull * CK;
+        const int va = ktail - lcol;                         // k-contig: valid floats from the piece start
+        const int vb = bn ? ktail - lrow : ktail - lcol;     // n-contig: valid k rows below this piece's row
+        f32x4 ra[4], rb[4];
+        ld_chunk<VEC>(pa, c0, c0 >= nfull, va, 0, ra);
+        ld_chunk<VEC>(pb, c0, c0 >= nfull, vb, bn ? 8 : 0, rb);
+        for (int c = c0; c < c1; ++c) {
+            st_chunk(As, lane, ra);
+            st_chunk(Bs, lane, rb);
+#ifndef SK_NO_LOAD
+            if (c + 1 < c1) {   // next chunk's global loads fly while this chunk's MFMAs run
+                ld_chunk<VEC>(pa, c + 1, c + 1 >= nfull, va, 0, ra);
+                ld_chunk<VEC>(pb, c + 1, c + 1 >= nfull, vb, bn ? 8 : 0, rb);
+            }
+#endif
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int kb = 0; kb < CK / 8; ++kb) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(As + l31 * LDR + kb * 8 + half * 4);
+                f32x4 b;
+                if (bn) {
+                    const float* q = Bs + (kb * 8 + half * 4) * LDR + l31;
+                    b[0] = q[0]; b[1] = q[LDR]; b[2] = q[2 * LDR]; b[3] = q[3 * LDR];
+                } else {
+                    b = *reinterpret_cast<const f32x4*>(Bs + l31 * LDR + kb * 8 + half * 4);
+                }
+#ifdef SK_NO_MFMA
+                acc[0] += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
+#else
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], acc, 0, 0, 0);
+#endif
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
     }
+    __syncthreads();   // every wave is done with its staging area before it becomes the reduction buffer
     // ---- reduce the SKW partial tiles through LDS
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[r];
@@ -191,9 +243,23 @@ __global__ void __launch_bounds__(SKT) sk_kernel(SkArgs args) {
 
 }  // namespace
 
+// Generic route for shapes the tile layout cannot take (n-contiguous B with N % 4 != 0): plain tiled GEMMs.
+static int skinny_fallback(hipStream_t st, const SkJob& jb) {
+    if (jb.epi != SK_EPI_STORE) return XG_EINVAL;     // callers only send LSTM jobs when R % 8 == 0
+    for (int s = 0; s < jb.nseg; ++s) {
+        const SkSeg& sg = jb.seg[s];
+        const bool last = s == jb.nseg - 1;
+        XG_TRY(xgk_gemm(st, false, !sg.b_ncontig, jb.M, jb.N, sg.K, sg.A, sg.lda, sg.B, sg.ldb, jb.C, jb.ldc,
+                        s == 0 ? jb.bias[0] : nullptr, last && jb.relu && !jb.bias[1] && !jb.bias[2],
+                        s > 0 || jb.accumulate));
+    }
+    if (jb.bias[1] || jb.bias[2]) return XG_EINVAL;
+    return XG_OK;
+}
+
 int xgk_skinny(hipStream_t st, SkArgs& a) {
     if (a.njobs <= 0 || a.njobs > SK_MAX_JOBS) return XG_EINVAL;
-    bool vec = true;
+    bool vec = true, generic = false;
     int tiles = 0;
     for (int j = 0; j < a.njobs; ++j) {
         SkJob& jb = a.job[j];
@@ -202,8 +268,8 @@ int xgk_skinny(hipStream_t st, SkArgs& a) {
         const int ntm = xg_cdiv(jb.M, 32);
         int ntn;
         if (jb.epi == SK_EPI_LSTM) {
-            if (jb.N != 4 * jb.R) return XG_EINVAL;
-            ntn = xg_cdiv(jb.R, 8);
+            if (jb.N != 4 * jb.R || jb.R % 8 != 0) return XG_EINVAL;
+            ntn = jb.R / 8;
         } else {
             ntn = xg_cdiv(jb.N, 32);
         }
@@ -212,8 +278,13 @@ int xgk_skinny(hipStream_t st, SkArgs& a) {
             const SkSeg& sg = jb.seg[s];
             if (!sg.A || !sg.B || sg.K <= 0) return XG_EINVAL;
             vec = vec && ((uintptr_t)sg.A % 16 == 0) && (sg.lda % 4 == 0) && (sg.K % 4 == 0);
-            if (!sg.b_ncontig) vec = vec && ((uintptr_t)sg.B % 16 == 0) && (sg.ldb % 4 == 0);
+            vec = vec && ((uintptr_t)sg.B % 16 == 0) && (sg.ldb % 4 == 0);
+            if (sg.b_ncontig && (jb.N % 4 != 0 || jb.N < 4)) generic = true;
         }
+    }
+    if (generic) {
+        for (int j = 0; j < a.njobs; ++j) XG_TRY(skinny_fallback(st, a.job[j]));
+        return XG_OK;
     }
     if (vec) hipLaunchKernelGGL((sk_kernel<true>), dim3(tiles), dim3(SKT), 0, st, a);
     else hipLaunchKernelGGL((sk_kernel<false>), dim3(tiles), dim3(SKT), 0, st, a);
