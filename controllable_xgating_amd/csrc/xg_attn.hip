@@ -148,11 +148,160 @@ __global__ void attn_dV_kernel(const float* __restrict__ ALPHA, const float* __r
     dV[idx] = acc ? dV[idx] + s : s;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fast paths (A % 4 == 0, A <= 2048, R % 4 == 0): one 1024-thread workgroup per video, every global
+// load issued up front so the kernel pays ONE memory round trip: each wave keeps its slice of p and
+// w_a in registers and streams whole q rows (lane = 16 B, wave = 1 KB per instruction), the V tile of
+// the context pass is already in flight while the scores are computed.
+constexpr int FT = 1024, FW = FT / 64;
+
+template <int NI>
+__global__ void __launch_bounds__(FT) attn_fwd_fast(const float* __restrict__ p, const float* __restrict__ vproj,
+                                                     const float* __restrict__ V, const float* __restrict__ w,
+                                                     float* __restrict__ alpha, float* __restrict__ af, int K, int R, int A) {
+    extern __shared__ float sm[];                     // e[K] | part[nkp][R]
+    float* se = sm;
+    float* part = sm + ((K + 3) & ~3);
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* pb = p + (size_t)b * A;
+    const float* qb = vproj + (size_t)b * K * A;
+    const float* Vb = V + (size_t)b * K * R;
+    // context pass mapping: thread -> (4 consecutive r, k-part); its V loads go out first
+    const int r4n = R >> 2, nkp = FT / r4n > 0 ? min(FT / r4n, K) : 1;
+    const int myr = (tid % r4n) << 2, mykp = tid / r4n;
+    constexpr int VMAX = 8;                           // V rows held per thread (K <= 8 * nkp, checked by the launcher)
+    float4 vreg[VMAX];
+#pragma unroll
+    for (int j = 0; j < VMAX; ++j) {
+        const int k = mykp + j * nkp;
+        vreg[j] = (mykp < nkp && k < K) ? *reinterpret_cast<const float4*>(Vb + (size_t)k * R + myr) : make_float4(0, 0, 0, 0);
+    }
+    float4 pr[NI], wr[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int a = lane * 4 + 256 * i;
+        const bool ok = a < A;
+        pr[i] = ok ? *reinterpret_cast<const float4*>(pb + a) : make_float4(0, 0, 0, 0);
+        wr[i] = ok ? *reinterpret_cast<const float4*>(w + a) : make_float4(0, 0, 0, 0);
+    }
+    for (int k = wave; k < K; k += FW) {
+        const float* qk = qb + (size_t)k * A;
+        float4 q[NI];
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int a = lane * 4 + 256 * i;
+            q[i] = a < A ? *reinterpret_cast<const float4*>(qk + a) : make_float4(0, 0, 0, 0);
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            acc += wr[i].x * xg_tanh(pr[i].x + q[i].x) + wr[i].y * xg_tanh(pr[i].y + q[i].y) +
+                   wr[i].z * xg_tanh(pr[i].z + q[i].z) + wr[i].w * xg_tanh(pr[i].w + q[i].w);
+        acc = wave_sum(acc);
+        if (lane == 0) se[k] = acc;
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, se[k]);
+    float den = 0.f;
+    for (int k = 0; k < K; ++k) den += expf(se[k] - mx);
+    const float inv = 1.0f / den;
+    float4 s4 = make_float4(0, 0, 0, 0);
+#pragma unroll
+    for (int j = 0; j < VMAX; ++j) {
+        const int k = mykp + j * nkp;
+        if (mykp < nkp && k < K) {
+            const float al = expf(se[k] - mx) * inv;
+            s4.x += al * vreg[j].x; s4.y += al * vreg[j].y; s4.z += al * vreg[j].z; s4.w += al * vreg[j].w;
+        }
+    }
+    if (alpha && tid < K) alpha[(size_t)b * K + tid] = expf(se[tid] - mx) * inv;
+    if (mykp < nkp) *reinterpret_cast<float4*>(part + (size_t)mykp * R + myr) = s4;
+    __syncthreads();
+    for (int r = tid; r < R; r += FT) {
+        float s = 0.f;
+        for (int j = 0; j < nkp; ++j) s += part[(size_t)j * R + r];
+        af[(size_t)b * R + r] = s;
+    }
+}
+
+// backward: de_k = alpha_k (dalpha_k - sum_j alpha_j dalpha_j), dalpha_k = daf . V_k ; dp_a = w_a sum_k de_k (1 - th^2)
+template <int NQ>   // q values per thread per row: thread owns a = tid*2 (+1), rows looped; NQ = ceil(K / 1) held rows
+__global__ void __launch_bounds__(FT) attn_bwd_fast(const float* __restrict__ daf, int lddaf, const float* __restrict__ p,
+                                                     const float* __restrict__ vproj, const float* __restrict__ V,
+                                                     const float* __restrict__ w, const float* __restrict__ alpha,
+                                                     float* __restrict__ de, float* __restrict__ dp, int K, int R, int A) {
+    extern __shared__ float sm[];                     // dalpha[K] then de[K]
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* qb = vproj + (size_t)b * K * A;
+    const float* Vb = V + (size_t)b * K * R;
+    const float* dafb = daf + (size_t)b * lddaf;
+    // thread -> two consecutive attention columns; all K rows of q for them go to registers up front
+    const int a0 = tid * 2;
+    const bool a_ok = a0 < A;
+    float2 q[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) q[k] = (a_ok && k < K) ? *reinterpret_cast<const float2*>(qb + (size_t)k * A + a0) : make_float2(0, 0);
+    const float2 pa = a_ok ? *reinterpret_cast<const float2*>(p + (size_t)b * A + a0) : make_float2(0, 0);
+    const float2 wa = a_ok ? *reinterpret_cast<const float2*>(w + a0) : make_float2(0, 0);
+    for (int k = wave; k < K; k += FW) {
+        float acc = 0.f;
+        for (int r = lane * 4; r < R; r += 256) {
+            const float4 d4 = *reinterpret_cast<const float4*>(dafb + r);
+            const float4 v4 = *reinterpret_cast<const float4*>(Vb + (size_t)k * R + r);
+            acc += d4.x * v4.x + d4.y * v4.y + d4.z * v4.z + d4.w * v4.w;
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) sm[k] = acc;
+    }
+    __syncthreads();
+    float dot = 0.f;
+    for (int k = 0; k < K; ++k) dot += alpha[(size_t)b * K + k] * sm[k];
+    __syncthreads();
+    if (tid < K) {
+        const float d = alpha[(size_t)b * K + tid] * (sm[tid] - dot);
+        sm[tid] = d;
+        de[(size_t)b * K + tid] = d;
+    }
+    __syncthreads();
+    if (a_ok) {
+        float sx = 0.f, sy = 0.f;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            if (k < K) {
+                const float dk = sm[k];
+                const float tx = xg_tanh(pa.x + q[k].x), ty = xg_tanh(pa.y + q[k].y);
+                sx += dk * (1.0f - tx * tx);
+                sy += dk * (1.0f - ty * ty);
+            }
+        }
+        *reinterpret_cast<float2*>(dp + (size_t)b * A + a0) = make_float2(sx * wa.x, sy * wa.y);
+    }
+}
+
 }  // namespace
 
 int xgk_attn_fwd(hipStream_t st, const float* p, const float* vproj, const float* V, const float* w, float* alpha,
                  float* af, int B, int K, int R, int A) {
     if (K > 8192) return XG_EINVAL;
+    const bool al16 = ((uintptr_t)p % 16 == 0) && ((uintptr_t)vproj % 16 == 0) && ((uintptr_t)V % 16 == 0) && ((uintptr_t)w % 16 == 0);
+    if (al16 && A % 4 == 0 && A <= 2048 && R % 4 == 0 && R <= 4 * FT && R >= 4) {
+        const int r4n = R / 4;
+        const int nkp = FT / r4n > 0 ? (FT / r4n < K ? FT / r4n : K) : 1;
+        if (K <= 8 * nkp) {
+            const size_t lds = (size_t)(((K + 3) & ~3) + (size_t)nkp * R) * sizeof(float);
+            if (lds <= 60000) {
+                const int ni = (A + 255) / 256;
+                if (ni <= 2) hipLaunchKernelGGL((attn_fwd_fast<2>), dim3(B), dim3(FT), lds, st, p, vproj, V, w, alpha, af, K, R, A);
+                else if (ni <= 4) hipLaunchKernelGGL((attn_fwd_fast<4>), dim3(B), dim3(FT), lds, st, p, vproj, V, w, alpha, af, K, R, A);
+                else if (ni <= 6) hipLaunchKernelGGL((attn_fwd_fast<6>), dim3(B), dim3(FT), lds, st, p, vproj, V, w, alpha, af, K, R, A);
+                else hipLaunchKernelGGL((attn_fwd_fast<8>), dim3(B), dim3(FT), lds, st, p, vproj, V, w, alpha, af, K, R, A);
+                XG_CHECK_LAUNCH();
+                return XG_OK;
+            }
+        }
+    }
     hipLaunchKernelGGL(attn_fwd_kernel, dim3(B), dim3(ATPB), K * sizeof(float), st, p, vproj, V, w, alpha, af, K, R, A);
     XG_CHECK_LAUNCH();
     return XG_OK;
@@ -160,6 +309,16 @@ int xgk_attn_fwd(hipStream_t st, const float* p, const float* vproj, const float
 int xgk_attn_bwd(hipStream_t st, const float* daf, int lddaf, const float* p, const float* vproj, const float* V,
                  const float* w, const float* alpha, float* de, float* dp, int B, int K, int R, int A) {
     if (K > 8192) return XG_EINVAL;
+    const bool al16 = ((uintptr_t)p % 16 == 0) && ((uintptr_t)vproj % 16 == 0) && ((uintptr_t)V % 16 == 0) &&
+                      ((uintptr_t)w % 16 == 0) && ((uintptr_t)daf % 16 == 0) && ((uintptr_t)dp % 16 == 0);
+    if (al16 && A % 4 == 0 && A <= 2 * FT && R % 4 == 0 && lddaf % 4 == 0 && K <= 48) {
+        const size_t lds = (size_t)K * sizeof(float);
+        if (K <= 16) hipLaunchKernelGGL((attn_bwd_fast<16>), dim3(B), dim3(FT), lds, st, daf, lddaf, p, vproj, V, w, alpha, de, dp, K, R, A);
+        else if (K <= 32) hipLaunchKernelGGL((attn_bwd_fast<32>), dim3(B), dim3(FT), lds, st, daf, lddaf, p, vproj, V, w, alpha, de, dp, K, R, A);
+        else hipLaunchKernelGGL((attn_bwd_fast<48>), dim3(B), dim3(FT), lds, st, daf, lddaf, p, vproj, V, w, alpha, de, dp, K, R, A);
+        XG_CHECK_LAUNCH();
+        return XG_OK;
+    }
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(B), dim3(ATPB), K * sizeof(float), st, daf, lddaf, p, vproj, V, w, alpha,
                        de, dp, K, R, A);
     XG_CHECK_LAUNCH();

@@ -18,6 +18,8 @@
 // for A and B, which leaves the dot product unchanged.
 #include "xg_common.h"
 #include "xg_kernels.h"
+#include <cstdio>
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -230,17 +232,26 @@ int launch(hipStream_t st, const GemmArgs& g) {
 
 template <bool AKC, bool BKC>
 int dispatch(hipStream_t st, GemmArgs g, bool vec) {
-    // 128x128 tiles (2x2 MFMA tiles per wave: half the LDS and global traffic per flop of 64x64) whenever the
-    // chip can be filled: by the tile count alone, or -- for deep reductions with few output tiles (weight
-    // gradients, dH = dlogits * W) -- by splitting K over several workgroups per tile.
     const long t128 = (long)xg_cdiv(g.M, 128) * xg_cdiv(g.N, 128);
+    const long t64 = (long)xg_cdiv(g.M, 64) * xg_cdiv(g.N, 64);
     const int nslab = xg_cdiv(g.K, BKS);
     g.splitk = 1;
-    bool big = t128 >= 384;
-    if (!big && !g.relu && t128 >= 8 && nslab >= 16 && g.M >= 96 && g.N >= 96) {
-        int sk = (int)((512 + t128 - 1) / t128);
-        if (sk > nslab / 8) sk = nslab / 8;       // keep >= 8 slabs (K = 256) per split
-        if (sk >= 2) { g.splitk = sk; big = true; }
+    bool big = false;
+    // measured on MI355X (tools/ubench/gemm_bench.py): 128x128 wins only with >= ~400 tiles (x2 split when the
+    // reduction is deep); below that 64x64 tiles with enough K splits to put ~1000-1500 workgroups in flight.
+    if (t128 >= 1024) big = true;
+    else if (t128 >= 384) { big = true; if (!g.relu && nslab >= 32) g.splitk = 2; }
+    else if (!g.relu && t64 >= 4) {
+        const long target = (AKC && BKC) ? 768 : 1536;
+        long sk = target / t64;
+        if (sk > nslab / 16) sk = nslab / 16;      // keep K >= 512 per split
+        if (sk >= 2) g.splitk = (int)sk;
+    }
+    // tuning hook for tools/ubench/gemm_bench.py: XG_GEMM_FORCE="<tile>,<splitk>"
+    static const char* force = getenv("XG_GEMM_FORCE");
+    if (force) {
+        int t = 0, sk = 1;
+        if (sscanf(force, "%d,%d", &t, &sk) == 2) { big = t == 128; g.splitk = g.relu ? 1 : (sk < 1 ? 1 : sk); }
     }
     if (big) return vec ? launch<128, 128, AKC, BKC, true>(st, g) : launch<128, 128, AKC, BKC, false>(st, g);
     return vec ? launch<64, 64, AKC, BKC, true>(st, g) : launch<64, 64, AKC, BKC, false>(st, g);

@@ -1,0 +1,40 @@
+"""Time xg_gemm on the iteration's big shapes; XG_GEMM_FORCE="tile,splitk" overrides the heuristic."""
+import os, sys, subprocess, json
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+SHAPES = [  # name, ta, tb, M, N, K, acc
+    ("logits fwd NT", 0, 1, 2688, 20000, 512, 0),
+    ("dW_logit TN", 1, 0, 20000, 512, 2688, 1),
+    ("dH NN K=20000", 0, 0, 2688, 512, 20000, 0),
+    ("wgrad TN 2048x512 K=2688", 1, 0, 2048, 512, 2688, 1),
+    ("enc embed NT 3328x512 K=1536", 0, 1, 3328, 512, 1536, 0),
+    ("PRE NT 3328x2048 K=512", 0, 1, 3328, 2048, 512, 0),
+    ("vproj NT 3328x1536 K=512", 0, 1, 3328, 1536, 512, 0),
+    ("dX NN 3328x512 K=2048", 0, 0, 3328, 512, 2048, 0),
+]
+def run():
+    import torch
+    from controllable_xgating_amd import _native as nv
+    L = nv.lib()
+    out = {}
+    for name, ta, tb, M, N, K, acc in SHAPES:
+        A = torch.randn((K, M) if ta else (M, K), device="cuda"); B = torch.randn((N, K) if tb else (K, N), device="cuda")
+        Cc = torch.zeros(M, N, device="cuda")
+        def call():
+            assert L.xg_gemm(None, ta, tb, M, N, K, nv.ptr(A), A.shape[1], nv.ptr(B), B.shape[1], nv.ptr(Cc), N, None, 0, acc) == 0
+        for _ in range(3): call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(20): call()
+        e1.record(); torch.cuda.synchronize()
+        us = e0.elapsed_time(e1) * 1e3 / 20
+        out[name] = (round(us, 1), round(2.0 * M * N * K / us / 1e6, 1))
+    print(os.environ.get("XG_GEMM_FORCE", "auto").ljust(8), json.dumps(out))
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "one":
+        run()
+    else:
+        for f in ["auto", "64,1", "128,1", "128,2", "128,4", "128,8", "64,2", "64,4"]:
+            env = dict(os.environ)
+            if f != "auto": env["XG_GEMM_FORCE"] = f
+            subprocess.run([sys.executable, __file__, "one"], env=env)
