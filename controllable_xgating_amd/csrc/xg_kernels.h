@@ -94,7 +94,7 @@ int xgk_fill(hipStream_t st, float* y, float v, int64_t n);
 int xgk_copy2d(hipStream_t st, float* dst, int ldd, const float* src, int lds, int rows, int cols, bool add);
 
 // ---- xg_step.hip : multi-job skinny split-K MFMA GEMM with optional LSTM-cell epilogue
-enum { SK_EPI_STORE = 0, SK_EPI_LSTM = 1 };
+enum { SK_EPI_STORE = 0, SK_EPI_LSTM = 1, SK_EPI_GATE = 2 };
 constexpr int SK_MAX_JOBS = 4;
 struct SkSeg {
     const float* A; const float* B;   // A (M,K) row-major lda ; B (N,K) row-major ldb, or (K,N) when b_ncontig
@@ -108,10 +108,12 @@ struct SkJob {
     const float* add; const float* c_prev; const float* h_prev; const float* mask;
     float* gates; float* c_out; float* h_out;
     int ldadd, ldcp, ldhp, ldm, ldg, ldco, ldho;
+    // GATE epilogue (sub_modules.py:42-47): g = dropout(relu(.)) -> C ; y = g*t + t
+    const float* gate_t; float* gate_y; int ldt, ldy;
     int nseg, M, N, ldc, accumulate, relu, epi, R, order, mask_mode, tile0;
     XgDrop drop;
 };
-struct SkArgs { SkJob job[SK_MAX_JOBS]; int njobs; };
+struct SkArgs { int njobs; int tile0[SK_MAX_JOBS]; SkJob job[SK_MAX_JOBS]; };
 int xgk_skinny(hipStream_t st, SkArgs& a);
 
 // ---- xg_attn.hip

@@ -298,7 +298,9 @@ int init_hidden(hipStream_t st, const XgDims& d, const XgParams& p, const float*
 
 struct StepIO {
     const float* xt;      // (B,E)
-    const float* posg;    // (B,R) gated POS feature
+    const float* pos;     // (B,R) raw POS feature: the gate runs inside the step when pre1 == null
+    float* gp;            // (B,R) gate values g (saved for backward), written when pre1 == null
+    float* posg;          // (B,R) gated POS feature (input when pre1 != null, output otherwise)
     const float* pre1;    // (B,4R) hoisted xt/pos' contribution of cell 1, or null (computed here)
     const float* mask; int ldm;
     const float *h1, *c1, *h2, *c2;   // previous state (B,R) contiguous
@@ -336,13 +338,25 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         if (s.pre1) {
             k1.job[1].nseg = 1;
             k1.job[1].seg[0] = seg_nt(s.h1, R, p.l1_h2h_w, R, R); k1.job[1].bias[0] = p.l1_h2h_b;
+            XG_TRY(xgk_skinny(st, k1));
         } else {
-            k1.job[1].nseg = 3;
-            k1.job[1].seg[0] = seg_nt(s.xt, E, p.l1_i2h_w, E, E); k1.job[1].bias[0] = p.l1_i2h_b;
-            k1.job[1].seg[1] = seg_nt(s.posg, R, p.l1_a2h_w, R, R); k1.job[1].bias[1] = p.l1_a2h_b;
-            k1.job[1].seg[2] = seg_nt(s.h1, R, p.l1_h2h_w, R, R); k1.job[1].bias[2] = p.l1_h2h_b;
+            // rollout form: [p || POS gate] first (the gate feeds cell 1), then cell 1 with all three products
+            SkJob cell1 = k1.job[1];
+            k1.job[1] = job_store(B, R, s.gp, R, false);
+            k1.job[1].epi = SK_EPI_GATE; k1.job[1].nseg = 1;
+            k1.job[1].seg[0] = seg_nt(s.xt, E, p.dgate_w, E, E); k1.job[1].bias[0] = p.dgate_b;
+            k1.job[1].gate_t = s.pos; k1.job[1].ldt = R; k1.job[1].gate_y = s.posg; k1.job[1].ldy = R;
+            k1.job[1].drop = xg_make_drop(&run, XG_SITE_DGATE, s.t);
+            XG_TRY(xgk_skinny(st, k1));
+            SkArgs k1b{};
+            k1b.njobs = 1;
+            k1b.job[0] = cell1;
+            k1b.job[0].nseg = 3;
+            k1b.job[0].seg[0] = seg_nt(s.xt, E, p.l1_i2h_w, E, E); k1b.job[0].bias[0] = p.l1_i2h_b;
+            k1b.job[0].seg[1] = seg_nt(s.posg, R, p.l1_a2h_w, R, R); k1b.job[0].bias[1] = p.l1_a2h_b;
+            k1b.job[0].seg[2] = seg_nt(s.h1, R, p.l1_h2h_w, R, R); k1b.job[0].bias[2] = p.l1_h2h_b;
+            XG_TRY(xgk_skinny(st, k1b));
         }
-        XG_TRY(xgk_skinny(st, k1));
         XG_TRY(xgk_attn_fwd(st, s.P, vproj, V, p.a2w_w, s.alpha, s.af, B, d.K, R, A));
         SkArgs k2{};
         k2.njobs = 1;
@@ -355,6 +369,10 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         return XG_OK;
     }
     // generic path (R not a multiple of 8): plain GEMMs + pointwise cell kernels
+    if (!s.pre1) {
+        XG_TRY(xgk_linear(st, B, R, E, s.xt, E, p.dgate_w, p.dgate_b, s.gp, R, true));
+        XG_TRY(xgk_gate_fwd(st, s.gp, R, s.pos, R, 0, s.posg, R, B, R, xg_make_drop(&run, XG_SITE_DGATE, s.t), B, 1 << 30, 1, B));
+    }
     XG_TRY(xgk_gemm(st, false, true, B, A, R, s.h1, R, p.h2a_w, 2 * R, s.P, A, p.h2a_b, false, false));
     XG_TRY(xgk_gemm(st, false, true, B, A, R, s.h2, R, p.h2a_w + R, 2 * R, s.P, A, nullptr, false, true));
     XG_TRY(xgk_attn_fwd(st, s.P, vproj, V, p.a2w_w, s.alpha, s.af, B, d.K, R, A));
@@ -650,12 +668,10 @@ extern "C" int xg_step_fwd(void* stream, const XgDims* d, const XgParams* p, con
     const int B = d->B, R = d->R, E = d->E;
     const size_t BR = (size_t)B * R;
     XG_TRY(xgk_embed_gather(st, p->embed_w, E, tokens, B, 1, 0, B, d->V, w.Xe, E));
-    XG_TRY(xgk_linear(st, B, R, E, w.Xe, E, p->dgate_w, p->dgate_b, w.GP, R, true));
-    XG_TRY(xgk_gate_fwd(st, w.GP, R, pos_feats, R, 0, w.POSG, R, B, R, xg_make_drop(run, XG_SITE_DGATE, step), B, 1 << 30, 1, B));
     // the step reads the OLD state while cell 1 already writes the new h1 in the same launch: work from a copy
     if (hipMemcpyAsync(w.state_tmp, state, sizeof(float) * 4 * BR, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
     StepIO s{};
-    s.xt = w.Xe; s.posg = w.POSG; s.pre1 = nullptr; s.mask = xt_mask; s.ldm = 1;
+    s.xt = w.Xe; s.pos = pos_feats; s.gp = w.GP; s.posg = w.POSG; s.pre1 = nullptr; s.mask = xt_mask; s.ldm = 1;
     s.h1 = w.state_tmp; s.c1 = w.state_tmp + BR; s.h2 = w.state_tmp + 2 * BR; s.c2 = w.state_tmp + 3 * BR;
     s.h1o = state; s.c1o = state + BR; s.h2o = state + 2 * BR; s.c2o = state + 3 * BR;
     s.P = w.P; s.alpha = alpha ? alpha : w.ALPHA; s.af = w.AF; s.g1 = nullptr; s.g2 = nullptr; s.t = step;
@@ -776,10 +792,8 @@ extern "C" int xg_rollout(void* stream, const XgDims* d, const XgParams* p, cons
         float* gp = w.GP + t * BR;
         float* posg = w.POSG + t * BR;
         XG_TRY(xgk_embed_gather(st, p->embed_w, E, tok, B, 1, 0, B, d->V, xt, E));                       // :198
-        XG_TRY(xgk_linear(st, B, R, E, xt, E, p->dgate_w, p->dgate_b, gp, R, true));
-        XG_TRY(xgk_gate_fwd(st, gp, R, x->pos_feats, R, 0, posg, R, B, R, xg_make_drop(run, XG_SITE_DGATE, t), B, 1 << 30, 1, B));
         StepIO s{};
-        s.xt = xt; s.posg = posg; s.pre1 = nullptr; s.mask = unf; s.ldm = 1;
+        s.xt = xt; s.pos = x->pos_feats; s.gp = gp; s.posg = posg; s.pre1 = nullptr; s.mask = unf; s.ldm = 1;
         s.h1 = w.H1 + t * BR; s.c1 = w.C1 + t * BR; s.h2 = w.H2 + t * BR; s.c2 = w.C2 + t * BR;
         s.h1o = w.H1 + (t + 1) * BR; s.c1o = w.C1 + (t + 1) * BR; s.h2o = w.H2 + (t + 1) * BR; s.c2o = w.C2 + (t + 1) * BR;
         s.P = w.P + (size_t)t * B * A; s.alpha = w.ALPHA + (size_t)t * B * d->K; s.af = w.AF + t * BR;

@@ -79,9 +79,9 @@ __global__ void __launch_bounds__(SKT) sk_kernel(SkArgs args) {
     }
     int ji = 0;
 #pragma unroll
-    for (int j = 1; j < SK_MAX_JOBS; ++j) if (j < args.njobs && bid >= args.job[j].tile0) ji = j;
+    for (int j = 1; j < SK_MAX_JOBS; ++j) if (j < args.njobs && bid >= args.tile0[j]) ji = j;
     const SkJob& job = args.job[ji];
-    const int tile = bid - job.tile0;
+    const int tile = bid - args.tile0[ji];
     const int ntm = (job.M + 31) >> 5;
     const int tm = tile % ntm, tn = tile / ntm;
     const int m0 = tm * 32, n0 = tn * 32;
@@ -95,6 +95,27 @@ __global__ void __launch_bounds__(SKT) sk_kernel(SkArgs args) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    // ---- LSTM epilogue operands are requested NOW so their (cold-L2) latency hides under the K loop
+    float e_b[4] = {0.f, 0.f, 0.f, 0.f}, e_cp = 0.f, e_hp = 0.f, e_mk = 1.f;
+    const int em = threadIdx.x >> 3, eu = threadIdx.x & 7;
+    const int eb = m0 + em, ej = tn * 8 + eu;
+    const bool e_on = lstm && threadIdx.x < 256 && eb < job.M && ej < R;
+    if (e_on) {
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+            const int col = gi * R + ej;
+            float v = 0.f;
+            if (job.bias[0]) v += job.bias[0][col];
+            if (job.bias[1]) v += job.bias[1][col];
+            if (job.bias[2]) v += job.bias[2][col];
+            if (job.add) v += job.add[(size_t)eb * job.ldadd + col];
+            e_b[gi] = v;
+        }
+        e_cp = job.c_prev[(size_t)eb * job.ldcp + ej];
+        if (job.mask) e_mk = job.mask[(size_t)eb * job.ldm];
+        if (job.mask_mode == XG_MASK_HOLD) e_hp = job.h_prev[(size_t)eb * job.ldhp + ej];
+    }
 
     // ---- K loop: this wave's share of the 32-deep chunks of every segment
     int nc_total = 0;
@@ -194,49 +215,57 @@ __global__ void __launch_bounds__(SKT) sk_kernel(SkArgs args) {
                 *dst = v;
             }
         }
-    } else {
-        // LSTM cell epilogue: thread -> (row m, unit u); its four gate pre-activations sit at columns u + 8*gate
-        if (threadIdx.x < 256) {
-            const int m = threadIdx.x >> 3, u = threadIdx.x & 7;
-            const int b = m0 + m, j = tn * 8 + u;
-            if (b < job.M && j < R) {
-                float s[4];
+    } else if (job.epi == SK_EPI_GATE) {
 #pragma unroll
-                for (int gi = 0; gi < 4; ++gi) {
-                    float v = 0.f;
+        for (int e = 0; e < 1024 / SKT; ++e) {
+            const int idx = threadIdx.x + SKT * e;
+            const int m = idx >> 5, c = idx & 31;
+            float v = 0.f;
 #pragma unroll
-                    for (int w = 0; w < SKW; ++w) v += red[w][m][gi * 8 + u];
-                    const int col = gi * R + j;
-                    if (job.bias[0]) v += job.bias[0][col];
-                    if (job.bias[1]) v += job.bias[1][col];
-                    if (job.bias[2]) v += job.bias[2][col];
-                    if (job.add) v += job.add[(size_t)b * job.ldadd + col];
-                    s[gi] = v;
-                }
-                const float so = job.order == XG_ORDER_IFOG ? s[2] : s[3];
-                const float sg_ = job.order == XG_ORDER_IFOG ? s[3] : s[2];
-                const float ig = xg_sigmoid(s[0]), fg = xg_sigmoid(s[1]), og = xg_sigmoid(so), gg = xg_tanh(sg_);
-                const float cp = job.c_prev[(size_t)b * job.ldcp + j];
-                const float mk = job.mask ? job.mask[(size_t)b * job.ldm] : 1.0f;
-                float cn = fg * cp + ig * gg, hn;
-                if (job.mask_mode == XG_MASK_HOLD) {
-                    cn = cn * mk + cp * (1.0f - mk);
-                    hn = og * xg_tanh(cn);
-                    hn = hn * mk + job.h_prev[(size_t)b * job.ldhp + j] * (1.0f - mk);
-                } else {
-                    hn = og * xg_tanh(cn) * mk;
-                    cn = cn * mk;
-                }
-                hn *= xg_keep(job.drop, (uint32_t)(b * R + j));
-                if (job.gates) {
-                    float* g = job.gates + (size_t)b * job.ldg;
-                    g[j] = ig; g[R + j] = fg;
-                    if (job.order == XG_ORDER_IFOG) { g[2 * R + j] = og; g[3 * R + j] = gg; }
-                    else                            { g[2 * R + j] = gg; g[3 * R + j] = og; }
-                }
-                job.c_out[(size_t)b * job.ldco + j] = cn;
-                job.h_out[(size_t)b * job.ldho + j] = hn;
+            for (int w = 0; w < SKW; ++w) v += red[w][m][c];
+            const int row = m0 + m, col = n0 + c;
+            if (row < job.M && col < job.N) {
+                if (job.bias[0]) v += job.bias[0][col];
+                const float g = fmaxf(v, 0.f) * xg_keep(job.drop, (uint32_t)(row * job.N + col));
+                job.C[(size_t)row * job.ldc + col] = g;
+                const float tv = job.gate_t[(size_t)row * job.ldt + col];
+                job.gate_y[(size_t)row * job.ldy + col] = g * tv + tv;
             }
+        }
+    } else {
+        // LSTM cell epilogue: thread -> (row em, unit eu); its four gate pre-activations sit at columns eu + 8*gate
+        if (e_on) {
+            const int b = eb, j = ej;
+            float s4[4];
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                float v = e_b[gi];
+#pragma unroll
+                for (int w = 0; w < SKW; ++w) v += red[w][em][gi * 8 + eu];
+                s4[gi] = v;
+            }
+            const float so = job.order == XG_ORDER_IFOG ? s4[2] : s4[3];
+            const float sg_ = job.order == XG_ORDER_IFOG ? s4[3] : s4[2];
+            const float ig = xg_sigmoid(s4[0]), fg = xg_sigmoid(s4[1]), og = xg_sigmoid(so), gg = xg_tanh(sg_);
+            const float cp = e_cp, mk = e_mk;
+            float cn = fg * cp + ig * gg, hn;
+            if (job.mask_mode == XG_MASK_HOLD) {
+                cn = cn * mk + cp * (1.0f - mk);
+                hn = og * xg_tanh(cn);
+                hn = hn * mk + e_hp * (1.0f - mk);
+            } else {
+                hn = og * xg_tanh(cn) * mk;
+                cn = cn * mk;
+            }
+            hn *= xg_keep(job.drop, (uint32_t)(b * R + j));
+            if (job.gates) {
+                float* g = job.gates + (size_t)b * job.ldg;
+                g[j] = ig; g[R + j] = fg;
+                if (job.order == XG_ORDER_IFOG) { g[2 * R + j] = og; g[3 * R + j] = gg; }
+                else                            { g[2 * R + j] = gg; g[3 * R + j] = og; }
+            }
+            job.c_out[(size_t)b * job.ldco + j] = cn;
+            job.h_out[(size_t)b * job.ldho + j] = hn;
         }
     }
 }
@@ -245,7 +274,7 @@ __global__ void __launch_bounds__(SKT) sk_kernel(SkArgs args) {
 
 // Generic route for shapes the tile layout cannot take (n-contiguous B with N % 4 != 0): plain tiled GEMMs.
 static int skinny_fallback(hipStream_t st, const SkJob& jb) {
-    if (jb.epi != SK_EPI_STORE) return XG_EINVAL;     // callers only send LSTM jobs when R % 8 == 0
+    if (jb.epi != SK_EPI_STORE) return XG_EINVAL;     // LSTM / GATE jobs never use an n-contiguous B
     for (int s = 0; s < jb.nseg; ++s) {
         const SkSeg& sg = jb.seg[s];
         const bool last = s == jb.nseg - 1;
@@ -264,7 +293,7 @@ int xgk_skinny(hipStream_t st, SkArgs& a) {
     for (int j = 0; j < a.njobs; ++j) {
         SkJob& jb = a.job[j];
         if (jb.M <= 0 || jb.N <= 0 || jb.nseg < 1 || jb.nseg > 3) return XG_EINVAL;
-        jb.tile0 = tiles;
+        jb.tile0 = tiles; a.tile0[j] = tiles;
         const int ntm = xg_cdiv(jb.M, 32);
         int ntn;
         if (jb.epi == SK_EPI_LSTM) {
