@@ -1,0 +1,131 @@
+"""Train / eval driver counterpart: the CALL SEQUENCE of the reference's py2-only
+``caption_src/starttrain.py:84-241`` and ``caption_src/myutils.py:41-85`` restated on top of the HIP model surface.
+Data loading, TensorBoard and the coco-caption metrics are out of scope:
+batches are handed in as dicts of CUDA tensors and the SCST reward scorer is a caller-supplied callable
+(BASELINE.json config 3 stubs CIDEr).
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import torch
+
+from .model import ClassiferCriterion, LanguageModelCriterion, RewardCriterion
+from .train import ClipAdam, allreduce_gradients
+
+
+def lr_for_epoch(opt, epoch):
+    """starttrain.py:88-94: step decay lr * rate ** int((epoch - start) / every) once epoch > start >= 0."""
+    start = getattr(opt, "learning_rate_decay_start", -1)
+    if epoch > start and start >= 0:
+        frac = int((epoch - start) / opt.learning_rate_decay_every)
+        return opt.learning_rate * (opt.learning_rate_decay_rate ** frac)
+    return opt.learning_rate
+
+
+def ss_prob_for_epoch(opt, epoch, current=0.0):
+    """starttrain.py:96-100: scheduled-sampling ramp (kept at its last value before the start epoch)."""
+    start = getattr(opt, "scheduled_sampling_start", -1)
+    if epoch > start and start >= 0:
+        frac = int((epoch - start) / opt.scheduled_sampling_increase_every)
+        return min(opt.scheduled_sampling_increase_prob * frac, opt.scheduled_sampling_max_prob)
+    return current
+
+
+def sc_flag_for_epoch(opt, epoch):
+    """starttrain.py:102-106."""
+    after = getattr(opt, "self_critical_after", -1)
+    return after != -1 and epoch >= after
+
+
+def get_self_critical_reward(model, feat1, feat2, feat_mask, pos_feat, gen_result, scorer):
+    """myutils.get_self_critical_reward (myutils.py:41-77): greedy baseline rollout (model stays in whatever mode it
+    is in -- the reference never leaves train mode, starttrain.py:68), scores = scorer(sampled (m,n), greedy (m,n'))
+    -> (2m,) array, reward = score[:m] - score[m:], repeated over the n positions (:75-76)."""
+    with torch.no_grad():
+        greedy_res, _ = model.sample(feat1, feat2, feat_mask, pos_feat, {"sample_max": 1})
+    gen = gen_result.detach().cpu().numpy()
+    greedy = greedy_res.detach().cpu().numpy()
+    scores = np.asarray(scorer(gen, greedy), dtype=np.float64)
+    m = gen.shape[0]
+    diff = scores[:m] - scores[m:]
+    return np.repeat(diff[:, np.newaxis], gen.shape[1], 1)
+
+
+class Trainer:
+    """One object = the body of ``train(opt)`` (starttrain.py:19-242) without the data loader."""
+
+    def __init__(self, model, opt, reward_scorer=None):
+        self.model, self.opt, self.scorer = model, opt, reward_scorer
+        self.crit, self.classify_crit, self.rl_crit = LanguageModelCriterion(), ClassiferCriterion(), RewardCriterion()
+        self.optimizer = ClipAdam(model, lr=opt.learning_rate, weight_decay=getattr(opt, "weight_decay", 0.0),
+                                  grad_clip=getattr(opt, "grad_clip", 0.1))
+        self.iteration, self.epoch = 1, 0
+        self.sc_flag = False
+        self.best_val_score = None
+        self.patience = 0
+        self.fused = getattr(opt, "fused_xe_loss", False)
+
+    def start_epoch(self, epoch):
+        """the update_lr_flag block, starttrain.py:85-107"""
+        self.epoch = epoch
+        self.opt.current_lr = lr_for_epoch(self.opt, epoch)
+        self.optimizer.set_lr(self.opt.current_lr)
+        self.model.ss_prob = ss_prob_for_epoch(self.opt, epoch, self.model.ss_prob)
+        self.sc_flag = sc_flag_for_epoch(self.opt, epoch)
+
+    def train_batch(self, b):
+        """starttrain.py:123-137.  b: dict with feat1, feat2, feat_mask, pos_feat, cap, cap_mask, cap_classes, class_mask."""
+        model, opt = self.model, self.opt
+        self.optimizer.zero_grad()                                                           # :123
+        info = {}
+        if not self.sc_flag:
+            wc = getattr(opt, "weight_class", 0.0)
+            if self.fused:
+                loss = model.xe_loss(b["feat1"], b["feat2"], b["feat_mask"], b["pos_feat"], b["cap"], b["cap_mask"],
+                                     b.get("cap_classes"), b.get("class_mask"), wc)
+            else:
+                out, category = model(b["feat1"], b["feat2"], b["feat_mask"], b["pos_feat"], b["cap"], b["cap_mask"])   # :125
+                loss_language = self.crit(out, b["cap"], b["cap_mask"])                      # :126
+                loss_classify = self.classify_crit(category, b["cap_classes"], b["cap_mask"], b["class_mask"])       # :127
+                loss = loss_language + wc * loss_classify                                    # :129
+                info.update(loss_language=loss_language, loss_classify=loss_classify)
+        else:
+            gen_result, sample_logprobs = model.sample(b["feat1"], b["feat2"], b["feat_mask"], b["pos_feat"],
+                                                       {"sample_max": 0})                   # :131
+            reward = get_self_critical_reward(model, b["feat1"], b["feat2"], b["feat_mask"], b["pos_feat"], gen_result,
+                                              self.scorer)                                   # :132
+            loss = self.rl_crit(sample_logprobs, gen_result,
+                                torch.from_numpy(reward).float().to(sample_logprobs.device))  # :133
+            info["avg_reward"] = float(np.mean(reward[:, 0])) if reward.size else 0.0
+        loss.backward()                                                                      # :134
+        allreduce_gradients(model)                                                           # data parallel only
+        self.optimizer.step()                                                                # :136-137 (clamp + Adam)
+        self.iteration += 1
+        info["loss"] = loss
+        return info
+
+    # ------------------------------------------------------------ checkpoints (starttrain.py:201-231, :29-66)
+    def save_checkpoint(self, path, val_score=None, tag=""):
+        os.makedirs(path, exist_ok=True)
+        torch.save(self.model.state_dict(), os.path.join(path, "model%s.pth" % tag))
+        infos = dict(iter=self.iteration, epoch=self.epoch, best_val_score=self.best_val_score, opt=vars(self.opt),
+                     val_score=val_score)
+        torch.save(infos, os.path.join(path, "infos%s.pkl" % tag))
+
+    def update_best(self, path, current_score):
+        """best-checkpoint + patience bookkeeping, starttrain.py:194-238; returns True when training should stop."""
+        if self.best_val_score is None or current_score > self.best_val_score:
+            self.best_val_score = current_score
+            self.patience = 0
+            self.save_checkpoint(path, current_score, tag="-best")
+            return False
+        self.patience += 1
+        return self.patience >= getattr(self.opt, "patience", 1 << 30)
+
+    @staticmethod
+    def resume(model, path, tag="-best", strict=True):
+        """--start_from: state_dict only (the reference does not save optimizer state)."""
+        model.load_state_dict(torch.load(os.path.join(path, "model%s.pth" % tag)), strict=strict)
+        return torch.load(os.path.join(path, "infos%s.pkl" % tag), weights_only=False)
