@@ -77,6 +77,8 @@ def lib():
         "xg_step_fwd": [vp, PD, PP, vp, vp, vp, vp, vp, PR, i32, vp, C.c_size_t, vp, vp, vp],
         "xg_forward_xe": [vp, PD, PP, PB, PX, PR, vp, C.c_size_t, vp, vp],
         "xg_backward_xe": [vp, PD, PP, PP, PX, PR, vp, C.c_size_t, vp, vp],
+        "xg_forward_ss": [vp, PD, PP, PB, PX, PR, f32, vp, vp, vp, C.c_size_t, vp, vp],
+        "xg_backward_ss": [vp, PD, PP, PP, PX, PR, vp, C.c_size_t, vp, vp],
         "xg_xe_loss_fwd": [vp, PD, PP, PB, PX, vp, vp, f32, PR, vp, C.c_size_t, vp],
         "xg_xe_loss_bwd": [vp, PD, PP, PP, PX, vp, vp, f32, vp, PR, vp, C.c_size_t],
         "xg_rollout": [vp, PD, PP, PB, PX, PR, i32, vp, vp, f32, vp, C.c_size_t, vp, vp, vp],

@@ -208,6 +208,14 @@ __global__ void __launch_bounds__(RT) choose_kernel(const float* __restrict__ lo
     }
 }
 
+__global__ void ss_select_kernel(const int64_t* seq, int T, int t, int B, const float* u_sel, float ss_prob,
+                                 const int64_t* sampled, int64_t* tok) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    const bool take = sampled != nullptr && u_sel[b] < ss_prob;      // sample_mask = sample_prob < ss_prob (:91)
+    tok[b] = take ? sampled[b] : seq[(size_t)b * T + t];
+}
+
 // SAModel.py:200-215: unfinished &= it>0 ; it *= unfinished ; append ; n = first t with none unfinished
 __global__ void rollout_book_kernel(int t, int B, int Tm1, int replay, const int64_t* tok, const float* tok_logp,
                                     float* unfinished, int64_t* seq, float* seq_logp, int32_t* n_steps,
@@ -305,6 +313,12 @@ int xgk_choose(hipStream_t st, const float* logp, int B, int V, int mode, const 
                const int64_t* forced, int64_t forced_stride, float temperature, int64_t* tok, float* tok_logp) {
     hipLaunchKernelGGL(choose_kernel, dim3(B), dim3(RT), 0, st, logp, V, mode, uniforms, forced, forced_stride,
                        temperature, tok, tok_logp);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_ss_select(hipStream_t st, const int64_t* seq, int T, int t, int B, const float* u_sel, float ss_prob,
+                  const int64_t* sampled, int64_t* tok) {
+    hipLaunchKernelGGL(ss_select_kernel, dim3(xg_cdiv(B, 256)), dim3(256), 0, st, seq, T, t, B, u_sel, ss_prob, sampled, tok);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }

@@ -150,6 +150,9 @@ int xgk_xent_bwd(hipStream_t st, float* logits_inout, int ld, const int64_t* seq
 // rollout token choice from a (B,V) log-prob matrix
 int xgk_choose(hipStream_t st, const float* logp, int B, int V, int mode, const float* uniforms,
                const int64_t* forced, int64_t forced_stride, float temperature, int64_t* tok, float* tok_logp);
+// scheduled sampling (SAModel.py:89-99): tok[b] = u_sel[b] < ss_prob ? sampled[b] : seq[b*T + t]
+int xgk_ss_select(hipStream_t st, const int64_t* seq, int T, int t, int B, const float* u_sel, float ss_prob,
+                  const int64_t* sampled, int64_t* tok);
 // rollout bookkeeping (SAModel.py:200-215)
 int xgk_rollout_book(hipStream_t st, int t, int B, int Tm1, int replay, const int64_t* tok, const float* tok_logp,
                      float* unfinished, int64_t* seq, float* seq_logp, int32_t* n_steps, int32_t* alive);

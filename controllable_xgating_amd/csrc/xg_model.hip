@@ -720,6 +720,72 @@ extern "C" int xg_backward_xe(void* stream, const XgDims* d, const XgParams* p, 
     return XG_OK;
 }
 
+extern "C" int xg_forward_ss(void* stream, const XgDims* d, const XgParams* p, const XgBnState* bn, const XgBatch* x,
+                             const XgRun* run, float ss_prob, const float* u_sel, const float* u_tok, void* ws,
+                             size_t ws_bytes, float* logp, float* cat_logp) {
+    Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
+    if (!p || !x || !run || !logp || !x->seq || !x->seq_mask || !x->pos_feats) return XG_EINVAL;
+    const bool ss = run->train && ss_prob > 0.f;
+    if (ss && (!u_sel || !u_tok)) return XG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = d->B, R = d->R, E = d->E, A = d->A, T = d->T, TB = T * B, N = B * d->K;
+    const size_t BR = (size_t)B * R;
+    XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w));
+    XG_TRY(init_hidden(st, *d, *p, w.Venc, x->feat_mask, w, w.H1, w.C1, w.H2, w.C2));
+    XG_TRY(xgk_linear(st, N, A, R, w.Venc, R, p->v2a_w, p->v2a_b, w.vproj, A));
+    int64_t* sampled = reinterpret_cast<int64_t*>(w.DXe);       // scratch (free until the backward pass)
+    for (int t = 0; t < T; ++t) {
+        int64_t* tok = w.TOK + (size_t)t * B;
+        const bool draw = ss && t >= 1;
+        if (draw)     // draw for every row from the previous step's distribution, keep it where the coin says so (:93-98)
+            XG_TRY(xgk_choose(st, w.LOGITS + (size_t)(t - 1) * B * d->V, B, d->V, XG_ROLLOUT_SAMPLE, u_tok + (size_t)t * B,
+                              nullptr, 0, 1.0f, sampled, w.TOKLP));
+        XG_TRY(xgk_ss_select(st, x->seq, T, t, B, draw ? u_sel + (size_t)t * B : nullptr, ss_prob, draw ? sampled : nullptr, tok));
+        float* xt = w.Xe + (size_t)t * B * E;
+        XG_TRY(xgk_embed_gather(st, p->embed_w, E, tok, B, 1, 0, B, d->V, xt, E));
+        StepIO s{};
+        s.xt = xt; s.pos = x->pos_feats; s.gp = w.GP + t * BR; s.posg = w.POSG + t * BR; s.pre1 = nullptr;
+        s.mask = x->seq_mask + t; s.ldm = T;
+        s.h1 = w.H1 + t * BR; s.c1 = w.C1 + t * BR; s.h2 = w.H2 + t * BR; s.c2 = w.C2 + t * BR;
+        s.h1o = w.H1 + (t + 1) * BR; s.c1o = w.C1 + (t + 1) * BR; s.h2o = w.H2 + (t + 1) * BR; s.c2o = w.C2 + (t + 1) * BR;
+        s.P = w.P + (size_t)t * B * A; s.alpha = w.ALPHA + (size_t)t * B * d->K; s.af = w.AF + t * BR;
+        s.g1 = w.G1 + (size_t)t * B * 4 * R; s.g2 = w.G2 + (size_t)t * B * 4 * R; s.t = t;
+        XG_TRY(core_step(st, *d, *p, *run, w, w.Venc, w.vproj, s));
+        float* lg = w.LOGITS + (size_t)t * B * d->V;
+        XG_TRY(xgk_linear(st, B, d->V, R, s.h2o, R, p->logit_w, p->logit_b, lg, d->V));
+        XG_TRY(xgk_log_softmax(st, lg, d->V, lg, d->V, B, d->V, 1, 1, false));        // LOGITS now holds log-probs (time-major)
+    }
+    // (T*B,V) time-major log-probs -> (B,T,V); classifier head batched over T as in xg_forward_xe
+    XG_TRY(xgk_log_softmax(st, w.LOGITS, d->V, logp, d->V, TB, d->V, B, T, true));    // log_softmax of log-probs = identity
+    const float* Hout = w.H2 + BR;
+    XG_TRY(xgk_linear(st, TB, d->H, R, Hout, R, p->cls0_w, p->cls0_b, w.HC, d->H, true));
+    XG_TRY(xgk_gate_fwd(st, w.HC, d->H, nullptr, 0, 0, nullptr, 0, TB, d->H, xg_make_drop(run, XG_SITE_CLS, 0), B, 1 << 30, 1, B));
+    XG_TRY(xgk_linear(st, TB, d->C, d->H, w.HC, d->H, p->cls3_w, p->cls3_b, w.CL, d->C));
+    if (cat_logp) XG_TRY(xgk_log_softmax(st, w.CL, d->C, cat_logp, d->C, TB, d->C, B, T, true));
+    return XG_OK;
+}
+
+extern "C" int xg_backward_ss(void* stream, const XgDims* d, const XgParams* p, const XgParams* g, const XgBatch* x,
+                              const XgRun* run, void* ws, size_t ws_bytes, const float* dlogp, const float* dcat_logp) {
+    Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
+    if (!p || !g || !x || !run || !x->seq || !x->seq_mask) return XG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const int B = d->B, T = d->T, TB = T * B;
+    if (dlogp) {   // LOGITS already holds the time-major log-probs
+        XG_TRY(xgk_log_softmax_bwd(st, dlogp, w.LOGITS, d->V, w.LOGITS, d->V, TB, d->V, B, T, 2));
+    } else {
+        ZERO(w.LOGITS, (size_t)TB * d->V);
+    }
+    if (dcat_logp) {
+        XG_TRY(xgk_log_softmax(st, w.CL, d->C, w.CL, d->C, TB, d->C, 1, 1, false));
+        XG_TRY(xgk_log_softmax_bwd(st, dcat_logp, w.CL, d->C, w.DCL, d->C, TB, d->C, B, T, 2));
+    }
+    XG_TRY(heads_bwd(st, *d, *p, *g, *run, w, TB, dcat_logp != nullptr));
+    XG_TRY(decoder_bwd_core(st, *d, *p, *g, *x, *run, w, x->seq_mask, T, 1, w.TOK, 1, B));
+    XG_TRY(encoder_bwd(st, *d, *p, *g, *x, *run, w, w.DV));
+    return XG_OK;
+}
+
 extern "C" int xg_xe_loss_fwd(void* stream, const XgDims* d, const XgParams* p, const XgBnState* bn, const XgBatch* x,
                               const int64_t* cap_classes, const float* class_mask, float weight_class, const XgRun* run,
                               void* ws, size_t ws_bytes, float* losses) {

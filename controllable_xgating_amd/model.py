@@ -279,11 +279,16 @@ class SAModel(nn.Module):
         """SAModel.forward (SAModel.py:67-115): (m,K,F) x2, (m,K), (m,R), (m,T) int64, (m,T) ->
         log-probs (m,T,V) and category log-probs (m,T,C).  ss_prob must be 0 (scheduled sampling is
         SURVEY.md 8f-3, not built yet)."""
-        if self.training and self.ss_prob > 0.0:
-            raise NotImplementedError("scheduled sampling (ss_prob > 0) is not implemented in the HIP path yet")
         params = [self._named()[n] for n in nv.PARAM_NAMES]
         save = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        return _XEFunction.apply(self, save, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, *params)
+        if self.training and self.ss_prob > 0.0:                                 # scheduled sampling, SAModel.py:89-99
+            T, B = seq.shape[1], seq.shape[0]
+            u = getattr(self, "ss_uniforms", None)                               # test hook: (u_sel, u_tok), each (T,B)
+            if u is None:
+                u = (torch.rand(T, B, device=seq.device), torch.rand(T, B, device=seq.device))
+            ss = (float(self.ss_prob), u[0].contiguous().float(), u[1].contiguous().float())
+            return _XEFunction.apply(self, save, ss, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, *params)
+        return _XEFunction.apply(self, save, None, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, *params)
 
     def xe_loss(self, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, cap_classes=None,
                 class_mask=None, weight_class=0.0):
@@ -412,7 +417,7 @@ def _grad_views(model, g):
 
 class _XEFunction(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, model, save, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, *params):
+    def forward(ctx, model, save, ss, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, *params):
         B, K, _ = feats_rgb.shape
         T = seq.shape[1]
         dev = feats_rgb.device
@@ -423,10 +428,15 @@ class _XEFunction(torch.autograd.Function):
         logp = torch.empty(B, T, model.vocab_size, dtype=torch.float32, device=dev)
         cat = torch.empty(B, T, model.category_size, dtype=torch.float32, device=dev)
         ps, bn, run = model._params_struct(), model._bn_struct(), model._run(save)
-        nv.check(nv.lib().xg_forward_xe(_stream(), C.byref(d), C.byref(ps), C.byref(bn), C.byref(b), C.byref(run),
-                                        wp, wn, nv.ptr(logp), nv.ptr(cat)), "xg_forward_xe")
+        if ss is None:
+            nv.check(nv.lib().xg_forward_xe(_stream(), C.byref(d), C.byref(ps), C.byref(bn), C.byref(b), C.byref(run),
+                                            wp, wn, nv.ptr(logp), nv.ptr(cat)), "xg_forward_xe")
+        else:
+            nv.check(nv.lib().xg_forward_ss(_stream(), C.byref(d), C.byref(ps), C.byref(bn), C.byref(b), C.byref(run),
+                                            ss[0], nv.ptr(ss[1]), nv.ptr(ss[2]), wp, wn, nv.ptr(logp), nv.ptr(cat)),
+                     "xg_forward_ss")
         model._bump_bn()
-        ctx.model, ctx.d, ctx.ws, ctx.keep, ctx.run, ctx.saved_ws = model, d, ws, keep, run, save
+        ctx.model, ctx.d, ctx.ws, ctx.keep, ctx.run, ctx.saved_ws, ctx.ss = model, d, ws, keep, run, save, ss is not None
         return logp, cat
 
     @staticmethod
@@ -441,11 +451,12 @@ class _XEFunction(torch.autograd.Function):
         ps = model._params_struct()
         dl = None if dlogp is None else dlogp.contiguous().float()
         dc = None if dcat is None else dcat.contiguous().float()
-        nv.check(nv.lib().xg_backward_xe(_stream(), C.byref(d), C.byref(ps), C.byref(gs), C.byref(b), C.byref(ctx.run),
-                                         wp, wn, nv.ptr(dl), nv.ptr(dc)), "xg_backward_xe")
+        fn = nv.lib().xg_backward_ss if ctx.ss else nv.lib().xg_backward_xe
+        nv.check(fn(_stream(), C.byref(d), C.byref(ps), C.byref(gs), C.byref(b), C.byref(ctx.run),
+                    wp, wn, nv.ptr(dl), nv.ptr(dc)), "xg_backward_ss" if ctx.ss else "xg_backward_xe")
         model._pool.give(d, dev, ctx.ws)
         ctx.ws = None
-        return (None,) * 8 + tuple(_grad_views(model, g))
+        return (None,) * 9 + tuple(_grad_views(model, g))
 
 
 class _XELossFunction(torch.autograd.Function):

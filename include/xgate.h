@@ -155,6 +155,17 @@ int xg_backward_xe(void *stream, const XgDims *d, const XgParams *p, const XgPar
                    const XgBatch *x, const XgRun *run, void *ws, size_t ws_bytes,
                    const float *dlogp, const float *dcat_logp);
 
+/* ---- teacher forcing with scheduled sampling: SAModel.forward, ss_prob > 0 (caption_src/SAModel.py:89-99) ----
+ * At steps t >= 1 a row whose u_sel[t,b] < ss_prob is fed a token drawn from exp(log-probs of step t-1) by inverse
+ * CDF with u_tok[t,b] (the reference draws both from torch's global RNG; the caller supplies the uniforms, (T,B) each).
+ * The vocabulary head therefore runs inside the time loop.  Same outputs as xg_forward_xe. */
+int xg_forward_ss(void *stream, const XgDims *d, const XgParams *p, const XgBnState *bn,
+                  const XgBatch *x, const XgRun *run, float ss_prob, const float *u_sel, const float *u_tok,
+                  void *ws, size_t ws_bytes, float *logp, float *cat_logp);
+int xg_backward_ss(void *stream, const XgDims *d, const XgParams *p, const XgParams *g,
+                   const XgBatch *x, const XgRun *run, void *ws, size_t ws_bytes,
+                   const float *dlogp, const float *dcat_logp);
+
 /* ---- fused XE loss path (same maths as forward_xe + LanguageModelCriterion +
  *      ClassiferCriterion, caption_src/SAModel.py:225-253, caption_src/starttrain.py:126-129)
  *      without materialising d(logp): loss = L_xe + weight_class * L_cls.

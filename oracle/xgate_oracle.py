@@ -152,9 +152,12 @@ def heads(P, out, p=0.0, seed=0, t=0, train=True):
 
 # ------------------------------------------------------------------ teacher-forced forward
 def forward_xe(P, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask,
-               train=True, p=0.0, seed=0, running=None, hoist=True, trace=None):
-    """SAModel.forward (SAModel.py:67-115) with ss_prob == 0.  ``hoist=False``
-    recomputes v2a(V) every step exactly as the reference does (:677)."""
+               train=True, p=0.0, seed=0, running=None, hoist=True, trace=None,
+               ss_prob=0.0, u_sel=None, u_tok=None, forced_it=None, it_trace=None):
+    """SAModel.forward (SAModel.py:67-115).  ``hoist=False`` recomputes v2a(V) every step exactly as the
+    reference does (:677).  Scheduled sampling (:89-99): at steps i >= 1 in train mode, rows with
+    u_sel[i,b] < ss_prob feed a token drawn (inverse CDF with u_tok[i,b]) from exp(previous step's log-probs)
+    instead of seq[b,i]; ``forced_it`` (T,B) replays recorded input tokens instead (golden test)."""
     V = encoder_fwd(P, feats_rgb, feats_opfl, feat_mask, train, p, seed, running)
     state = init_hidden(P, V, feat_mask)
     vproj = _lin(V, P, "lstmcore.v2a") if hoist else None
@@ -162,7 +165,17 @@ def forward_xe(P, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask,
     for i in range(seq.shape[1]):
         if i >= 1 and int(seq[:, i].sum()) == 0:                                      # :103
             break
-        xt = P["embed.weight"][seq[:, i]]
+        it = seq[:, i].clone()
+        if forced_it is not None:
+            it = forced_it[i].clone()
+        elif train and i >= 1 and ss_prob > 0.0:
+            lp = outs[-1].detach().numpy()
+            for b in range(it.shape[0]):
+                if float(u_sel[i, b]) < ss_prob:
+                    it[b] = sample_token(lp[b], float(u_tok[i, b]))
+        if it_trace is not None:
+            it_trace.append(it.clone())
+        xt = P["embed.weight"][it]
         mk = seq_mask[:, i].unsqueeze(1)
         out, state, alpha = core_step(P, xt, mk, V, pos_feats, state, p, seed, i, train, vproj)
         logp, cat = heads(P, out, p, seed, i, train)

@@ -440,3 +440,44 @@ def test_scst_iteration_and_checkpoint_roundtrip(tmp_path):
     for k, v in model.state_dict().items():
         assert torch.equal(v, saved[k]), k
     assert tr.update_best(str(tmp_path), 0.4) is False and tr.update_best(str(tmp_path), 0.3) is True   # patience 2
+
+
+# ---------------------------------------------------------------- scheduled sampling
+def test_scheduled_sampling_vs_oracle():
+    """ss_prob = 0.5 with supplied uniforms: same replaced tokens, loss and gradients as the oracle (whose
+    scheduled-sampling semantics are pinned by the reference replay golden ss_tiny.npz)."""
+    from controllable_xgating_amd import LanguageModelCriterion
+    d = pg.make_dims(**CFG["mid"])
+    T = d.L + 1
+    u_sel = pg.uniform("ss.sel", (T, d.B), 31)
+    u_tok = pg.uniform("ss.tok", (T, d.B), 32)
+    P = xo.to_torch_params(pg.make_params(d), requires_grad=True)
+    xi = xo.to_torch_inputs(pg.make_inputs(d, seed=0, ragged=True))
+    its = []
+    logp_o, cat_o, _ = xo.forward_xe(P, xi["feats_rgb"], xi["feats_opfl"], xi["feat_mask"], xi["pos_feats"], xi["seq"],
+                                     xi["seq_mask"], train=True, running=xo.new_running(d), ss_prob=0.5, u_sel=u_sel,
+                                     u_tok=u_tok, it_trace=its)
+    loss_o = xo.lm_criterion(logp_o, xi["seq"], xi["seq_mask"])
+    loss_o.backward()
+    its = torch.stack(its).numpy()
+    assert (its != xi["seq"].numpy().T).sum() > 10                   # tokens really were replaced
+    model = make_model(d)
+    model.ss_prob = 0.5
+    model.ss_uniforms = (torch.from_numpy(u_sel).cuda(), torch.from_numpy(u_tok).cuda())
+    x = to_dev(pg.make_inputs(d, seed=0, ragged=True))
+    logp, cat = model(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+    loss = LanguageModelCriterion()(logp, x["seq"], x["seq_mask"])
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_o.item()) < 1e-4, (loss.item(), loss_o.item())
+    np.testing.assert_allclose(logp.detach().cpu().numpy(), logp_o.detach().numpy(), atol=3e-4)
+    np.testing.assert_allclose(cat.detach().cpu().numpy(), cat_o.detach().numpy(), atol=1e-4)
+    assert_grads_close(model, oracle_grads(P))
+    # eval mode ignores ss_prob (SAModel.py:89: `if self.training and ...`)
+    model.eval()
+    with torch.no_grad():
+        l_eval, _ = model(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+    model.ss_prob = 0.0
+    with torch.no_grad():
+        l_ref, _ = model(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+    assert torch.equal(l_eval, l_ref)

@@ -162,3 +162,20 @@ def test_dropout_hash_statistics_and_determinism():
     assert not np.array_equal(m1, pg.keep_mask(11, 6, 4, (64, 512), 0.5))
     assert not np.array_equal(m1, pg.keep_mask(11, 7, 3, (64, 512), 0.5))
     assert np.all(pg.keep_mask(1, 1, 1, (8, 8), 0.0) == 1.0)
+
+
+def test_scheduled_sampling_replay_matches_reference():
+    """f-3: the reference's own draws (recorded input tokens per step) replayed through the oracle."""
+    g = load("ss_tiny.npz")
+    d, P, x = setup("tiny", ragged=True, grad=True)
+    assert int(g["n_replaced"]) > 0
+    logp, cat, _ = xo.forward_xe(P, x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"],
+                                 train=True, running=xo.new_running(d), forced_it=torch.from_numpy(g["it"]))
+    loss = xo.lm_criterion(logp, x["seq"], x["seq_mask"])
+    assert abs(loss.item() - float(g["loss"])) < 2e-6
+    loss.backward()
+    for name, prm in P.items():
+        gr = prm.grad.numpy() if prm.grad is not None else np.zeros(prm.shape, np.float32)
+        gn = np.sqrt((gr.astype(np.float64) ** 2).sum())
+        ref_n = float(g["gnorm/" + name])
+        assert abs(gn - ref_n) <= 3e-4 * ref_n + 2e-7, (name, gn, ref_n)

@@ -232,6 +232,29 @@ def gen_eval_bn(ref, tag):
     print("wrote", f"evalbn_{tag}.npz", "loss", g["loss"])
 
 
+def gen_ss(ref, tag):
+    """f-3: scheduled sampling (SAModel.py:89-99) with ss_prob = 0.5; the tokens fed to embed at every step are
+    recorded (the draws come from torch's global RNG) and replayed by the oracle."""
+    d = pg.make_dims(**CFG[tag])
+    P = pg.make_params(d)
+    x = tt(pg.make_inputs(d, seed=0, ragged=True))
+    model = build_ref(ref, d, P)
+    model.train()
+    model.ss_prob = 0.5
+    its = []
+    hk = model.embed.register_forward_hook(lambda m, i, o: its.append(i[0].detach().numpy().copy()))
+    torch.manual_seed(4321)
+    logp, cat = model(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+    hk.remove()
+    loss = ref.LanguageModelCriterion()(logp, x["seq"], x["seq_mask"])
+    model.zero_grad(); loss.backward()
+    its = np.array(its)                                        # (T,B)
+    g = dict(it=its, loss=np.float64(loss.item()), n_replaced=np.int64((its != x["seq"].numpy().T).sum()))
+    g.update(grads_summary(model, full=False))
+    np.savez_compressed(os.path.join(GOLD, f"ss_{tag}.npz"), **g)
+    print("wrote", f"ss_{tag}.npz", "loss", g["loss"], "replaced tokens", g["n_replaced"])
+
+
 def gen_beam(ref, tag, beam_size=3):
     """f-2: beam search (CaptionModel.py:22-128) tokens / logps, eval mode."""
     cfg = dict(CFG[tag]); cfg["B"] = min(cfg["B"], 3)
@@ -270,6 +293,7 @@ def main():
     gen_eval_bn(ref, "c1")
     gen_beam(ref, "tiny")
     gen_beam(ref, "c1")
+    gen_ss(ref, "tiny")
     return 0
 
 
