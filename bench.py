@@ -151,6 +151,10 @@ def main():
                     help="fused: model.xe_loss (no (m,T,V) gradient tensor); surface: model() + criterion, reference call sequence")
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--drop", type=float, default=0.0)
+    ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16"], default="fp32",
+                    help="arithmetic of the large GEMMs (XgRun.gemm_mode); the headline number is fp32")
+    ap.add_argument("--workload", choices=["xe", "scst"], default="xe",
+                    help="xe: BASELINE configs[1] (the metric); scst: configs[2] (sample + greedy rollouts + RL backward, B=64, L=30)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -176,8 +180,10 @@ def main():
     from controllable_xgating_amd.train import ClipAdam, allreduce_gradients, broadcast_parameters
 
     cfg = dict(B=args.batch, K=26, R=512, A=1536, E=468, V=20000, C=14, L=20, F1=1536, F2=1024)
+    if args.workload == "scst":
+        cfg.update(B=64 if args.batch == 128 else args.batch, L=30)
     T = cfg["L"] + 1
-    opt = make_opt(None, vocab_size=cfg["V"], seq_length=cfg["L"], drop_prob_lm=args.drop)
+    opt = make_opt(None, vocab_size=cfg["V"], seq_length=cfg["L"], drop_prob_lm=args.drop, precision=args.precision)
     model = SAModel(opt).to(dev)
     model.train()
     broadcast_parameters(model)
@@ -185,7 +191,24 @@ def main():
     optim = ClipAdam(model, lr=4e-4, grad_clip=0.1)
     crit = LanguageModelCriterion()
 
+    from controllable_xgating_amd import RewardCriterion
+    rl_crit = RewardCriterion()
+    reward_b = torch.randn(cfg["B"], 1, generator=torch.Generator().manual_seed(7)).to(dev)   # CIDEr stubbed (configs[2])
+
+    def step_scst():
+        optim.zero_grad()
+        gen, slp = model.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"sample_max": 0})
+        with torch.no_grad():
+            model.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"sample_max": 1})   # greedy baseline
+        loss = rl_crit(slp, gen, reward_b.expand(-1, gen.shape[1]))
+        loss.backward()
+        allreduce_gradients(model)
+        optim.step()
+        return loss
+
     def step():
+        if args.workload == "scst":
+            return step_scst()
         optim.zero_grad()
         if args.path == "fused":
             loss = model.xe_loss(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
@@ -218,19 +241,21 @@ def main():
     t_step = measure_step_group(model, x) if rank == 0 else None
     if rank == 0:
         ms = dt / args.steps * 1e3
-        value = world * cfg["B"] * T * args.steps / dt
+        value = world * cfg["B"] * T * args.steps / dt * (2 if args.workload == "scst" else 1)
         bytes_step = step_bytes(cfg["B"], cfg["K"], cfg["R"], cfg["A"], cfg["E"], save=False)
         achieved = bytes_step / t_step / 1e9
         traffic, traffic_src = load_traffic() if cfg["B"] == 128 else (None, None)
         out = {
-            "metric": "decoder timesteps/sec (train fwd+bwd) at batch 128, MSRVTT 26x1536+1024",
+            "metric": "decoder timesteps/sec (train fwd+bwd) at batch 128, MSRVTT 26x1536+1024" if args.workload == "xe" else
+                      "rollout timesteps/sec, SCST iteration (sample + greedy + RL backward) at batch 64, seq_len 30",
             "value": round(value, 1), "unit": "decoder timesteps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "f32 via split-bf16 (3 planes, 6 MFMAs)", "bf16": "bf16"}[args.precision],
+            "data": "synthetic",
             "config": {"workload": "configs[1]: 1xMI355X batch %d teacher-forced XE train, 26 frames x (1536+1024), hidden 512, "
                                    "att 1536, emb 468, vocab 20000, seq_len 20 (T=21), fp32" % cfg["B"],
                        "global_batch": world * cfg["B"], "per_gpu_batch": cfg["B"], "parallelism": "dp%d" % world,
-                       "path": args.path, "drop_prob_lm": args.drop,
+                       "path": args.path, "drop_prob_lm": args.drop, "gemm_precision": args.precision,
                        "timed_region": "zero_grad + encoder fwd + 21 decoder steps + heads/loss + full backward"
                                        + (" + RCCL grad all-reduce" if world > 1 else "") + " + clip + Adam"},
             "final_loss": round(final_loss, 5),

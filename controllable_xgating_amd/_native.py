@@ -28,7 +28,7 @@ class XgBatch(C.Structure):
 
 class XgRun(C.Structure):
     _fields_ = [("train", C.c_int32), ("drop_p", C.c_float), ("seed", C.c_uint32), ("save", C.c_int32),
-                ("bn_momentum", C.c_float), ("bn_eps", C.c_float)]
+                ("bn_momentum", C.c_float), ("bn_eps", C.c_float), ("gemm_mode", C.c_int32)]
 
 
 class XgError(RuntimeError):
@@ -70,6 +70,7 @@ def lib():
     PD, PP, PB, PX, PR = C.POINTER(XgDims), C.POINTER(_XgParams), C.POINTER(XgBnState), C.POINTER(XgBatch), C.POINTER(XgRun)
     sigs = {
         "xg_gemm": [vp, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32],
+        "xg_gemm_mode": [vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32],
         "xg_encoder_fwd": [vp, PD, PP, PB, PX, PR, vp, C.c_size_t, vp],
         "xg_encoder_bwd": [vp, PD, PP, PP, PX, PR, vp, C.c_size_t, vp],
         "xg_init_hidden": [vp, PD, PP, vp, vp, vp, C.c_size_t, vp],

@@ -259,10 +259,16 @@ int dispatch(hipStream_t st, GemmArgs g, bool vec) {
 
 }  // namespace
 
+static thread_local int tl_gemm_mode = 0;
+void xgk_set_gemm_mode(int mode) { tl_gemm_mode = (mode == 1 || mode == 3) ? mode : 0; }
+
 int xgk_gemm(hipStream_t st, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
              const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate) {
     if (M <= 0 || N <= 0) return XG_OK;
     if (K < 0 || !A || !B || !C) return XG_EINVAL;
+    // large products may run on the bf16 matrix cores (split-bf16 or plain bf16); skinny / tiny ones stay fp32
+    if (tl_gemm_mode != 0 && M >= 256 && N >= 64 && K >= 64)
+        return xgk_gemm_bf16(st, tl_gemm_mode, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate);
     GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1};
     const bool akc = !transA;   // A (M,K) row-major -> k contiguous
     const bool bkc = transB;    // B (N,K) row-major -> k contiguous
@@ -273,6 +279,16 @@ int xgk_gemm(hipStream_t st, bool transA, bool transB, int M, int N, int K, cons
     if (akc && !bkc) return dispatch<true, false>(st, g, vec);
     if (!akc && !bkc) return dispatch<false, false>(st, g, vec);
     return dispatch<false, true>(st, g, vec);
+}
+
+extern "C" int xg_gemm_mode(void* stream, int mode, int transA, int transB, int M, int N, int K, const float* A, int lda,
+                            const float* B, int ldb, float* C, int ldc, const float* bias, int relu, int accumulate) {
+    if (mode != 0 && mode != 1 && mode != 3) return XG_EINVAL;
+    if (mode == 0 || M <= 0 || N <= 0)
+        return xgk_gemm((hipStream_t)stream, transA != 0, transB != 0, M, N, K, A, lda, B, ldb, C, ldc, bias, relu != 0, accumulate != 0);
+    if (K < 0 || !A || !B || !C) return XG_EINVAL;
+    return xgk_gemm_bf16((hipStream_t)stream, mode, transA != 0, transB != 0, M, N, K, A, lda, B, ldb, C, ldc, bias,
+                         relu != 0, accumulate != 0);
 }
 
 extern "C" int xg_gemm(void* stream, int transA, int transB, int M, int N, int K, const float* A, int lda,

@@ -1,0 +1,261 @@
+// Split-bf16 GEMM on the gfx950 bf16 matrix cores (v_mfma_f32_32x32x16_bf16, ~2.5 PF dense = 16x the fp32 MFMA rate).
+//
+// fp32 operands are split ON THE FLY, while a tile is staged from registers into LDS, into NP bf16 planes
+//     x = x0 + x1 + x2,   x0 = trunc_bf16(x), x1 = trunc_bf16(x - x0), x2 = round_bf16(x - x0 - x1)
+// (8 significand bits per plane, 24 in total: the split of an fp32 value is exact), and the product is
+// assembled from the plane products whose weight is above fp32 round-off:
+//     NP = 3:  a*b ~= sum_{i+j<=2} a_i*b_j   -- 6 bf16 MFMAs, fp32 accumulate: fp32-class accuracy at 16/6 = 2.7x
+//              the fp32-MFMA rate (SURVEY.md 7.2 option a, "split-bf16");
+//     NP = 1:  a*b ~= a_0*b_0 (round-to-nearest-even planes) -- plain bf16 compute, fp32 accumulate, for
+//              BASELINE.json configs[4] (bf16, tolerance 1e-2).
+// Tile 128x128x32, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles; global -> registers (prefetched
+// one slab ahead) -> split -> LDS planes -> fragments.  LDS images:
+//   k-contiguous operand:  plane[rows][40] bf16 (80-B rows, 5 16-B slots: odd -> conflict-free ds_read_b128 fragments)
+//   m-contiguous operand:  plane[32][rows+8] bf16, fragments gathered with 8 ds_read_u16 (lanes read consecutive rows).
+// Same argument struct, XCD-aware tile order, split-K (fp32 atomics) and epilogue as xg_gemm.hip.
+#include "xg_common.h"
+#include "xg_kernels.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 32;
+constexpr int LDKC = BK + 8;       // k-contiguous image: row stride in bf16 (80 B)
+constexpr int LDMC = BM + 8;       // m-contiguous image: row stride in bf16
+
+struct BArgs {
+    const float* A; const float* B; float* C; const float* bias;
+    int M, N, K, lda, ldb, ldc, relu, accumulate, splitk;
+};
+
+template <bool KC> constexpr int plane_elems() { return KC ? BM * LDKC : BK * LDMC; }
+
+// ---- fp32 -> bf16 planes
+template <int NP>
+__device__ __forceinline__ void split(float x, unsigned short (&h)[NP]) {
+    if constexpr (NP == 1) {
+        unsigned u = __float_as_uint(x);
+        u += 0x7FFFu + ((u >> 16) & 1u);                 // round to nearest even
+        h[0] = (unsigned short)(u >> 16);
+    } else {
+        unsigned u0 = __float_as_uint(x) & 0xFFFF0000u;
+        const float r1 = x - __uint_as_float(u0);        // exact
+        unsigned u1 = __float_as_uint(r1) & 0xFFFF0000u;
+        const float r2 = r1 - __uint_as_float(u1);       // exact
+        unsigned u2 = __float_as_uint(r2);
+        u2 += 0x7FFFu + ((u2 >> 16) & 1u);
+        h[0] = (unsigned short)(u0 >> 16);
+        h[1] = (unsigned short)(u1 >> 16);
+        h[NP - 1] = (unsigned short)(u2 >> 16);
+    }
+}
+
+// ---- global -> registers: 4 float4 per thread per operand per slab (same index maps as xg_gemm.hip)
+template <bool KC, bool VEC>
+__device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int r0, int k0, int nrows, int K, f32x4 (&regs)[4]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = t + 256 * i;
+        int r, k;
+        if (KC) { r = f >> 3; k = (f & 7) << 2; }
+        else    { k = f >> 5; r = (f & 31) << 2; }
+        const int gr = r0 + r, gk = k0 + k;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (KC) {
+            if (gr < nrows) {
+                const float* src = P + (size_t)gr * ld + gk;
+                if (VEC) { if (gk < K) v = *reinterpret_cast<const f32x4*>(src); }
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (gk + j < K) v[j] = src[j];
+                }
+            }
+        } else {
+            if (gk < K) {
+                const float* src = P + (size_t)gk * ld + gr;
+                if (VEC) { if (gr < nrows) v = *reinterpret_cast<const f32x4*>(src); }
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (gr + j < nrows) v[j] = src[j];
+                }
+            }
+        }
+        regs[i] = v;
+    }
+}
+
+// ---- registers -> split -> LDS planes (4 consecutive elements of the contiguous dimension = one 8-byte store per plane)
+template <int NP, bool KC>
+__device__ __forceinline__ void store_tile(unsigned short* __restrict__ lds, const f32x4 (&regs)[4]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = t + 256 * i;
+        unsigned short h[4][NP];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) split<NP>(regs[i][j], h[j]);
+        int off;
+        if (KC) { const int r = f >> 3, k = (f & 7) << 2; off = r * LDKC + k; }
+        else    { const int k = f >> 5, r = (f & 31) << 2; off = k * LDMC + r; }
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            uint2 w;
+            w.x = (unsigned)h[0][p] | ((unsigned)h[1][p] << 16);
+            w.y = (unsigned)h[2][p] | ((unsigned)h[3][p] << 16);
+            *reinterpret_cast<uint2*>(lds + p * plane_elems<KC>() + off) = w;
+        }
+    }
+}
+
+// ---- LDS -> MFMA fragment: 8 consecutive k (k0..k0+7) of row `row`
+template <bool KC>
+__device__ __forceinline__ bf16x8 read_frag(const unsigned short* __restrict__ plane, int row, int k0) {
+    if (KC) {
+        return *reinterpret_cast<const bf16x8*>(plane + row * LDKC + k0);
+    } else {
+        bf16x8 v;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (short)plane[(k0 + j) * LDMC + row];
+        return v;
+    }
+}
+
+template <int NP, bool AKC, bool BKC, bool VEC>
+__global__ void __launch_bounds__(256) gemm_bs_kernel(BArgs g) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_bs[];
+    unsigned short* As = smem_bs;
+    unsigned short* Bs = smem_bs + NP * plane_elems<AKC>();
+
+    const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
+    const int nwg = ntm * ntn * g.splitk;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int ks = bid % g.splitk;
+    bid /= g.splitk;
+    const int tm = bid / ntn, tn = bid % ntn;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nslab_all = (g.K + BK - 1) / BK;
+    const int s_begin = (int)(((long)ks * nslab_all) / g.splitk), s_end = (int)(((long)(ks + 1) * nslab_all) / g.splitk);
+    f32x4 ra[4], rb[4];
+    load_tile<AKC, VEC>(g.A, g.lda, m0, s_begin * BK, g.M, g.K, ra);
+    load_tile<BKC, VEC>(g.B, g.ldb, n0, s_begin * BK, g.N, g.K, rb);
+    for (int s = s_begin; s < s_end; ++s) {
+        __syncthreads();                                   // everyone is done reading the previous slab
+        store_tile<NP, AKC>(As, ra);
+        store_tile<NP, BKC>(Bs, rb);
+        __syncthreads();
+        if (s + 1 < s_end) {                               // next slab's loads fly under this slab's MFMAs
+            load_tile<AKC, VEC>(g.A, g.lda, m0, (s + 1) * BK, g.M, g.K, ra);
+            load_tile<BKC, VEC>(g.B, g.ldb, n0, (s + 1) * BK, g.N, g.K, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            const int k0 = kk * 16 + half * 8;
+            bf16x8 fa[2][NP], fb[2][NP];
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) fa[i][p] = read_frag<AKC>(As + p * plane_elems<AKC>(), wm * 64 + i * 32 + l31, k0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) fb[j][p] = read_frag<BKC>(Bs + p * plane_elems<BKC>(), wn * 64 + j * 32 + l31, k0);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    // smallest terms first; only plane pairs with pa + pb <= NP - 1 are above fp32 round-off
+#pragma unroll
+                    for (int sum = NP - 1; sum >= 0; --sum)
+#pragma unroll
+                        for (int pa = 0; pa <= sum; ++pa)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa], fb[j][sum - pa], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + l31;
+            if (col >= g.N) continue;
+            const float bv = (g.bias && ks == 0) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < g.M) {
+                    float* dst = g.C + (size_t)row * g.ldc + col;
+                    float v = acc[i][j][r] + bv;
+                    if (g.splitk > 1) { unsafeAtomicAdd(dst, v); continue; }
+                    if (g.accumulate) v += *dst;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    *dst = v;
+                }
+            }
+        }
+}
+
+template <int NP, bool AKC, bool BKC, bool VEC>
+int launch(hipStream_t st, const BArgs& g) {
+    const int ntm = xg_cdiv(g.M, BM), ntn = xg_cdiv(g.N, BN);
+    if (g.splitk > 1 && !g.accumulate) {
+        if (g.ldc == g.N) { if (hipMemsetAsync(g.C, 0, sizeof(float) * (size_t)g.M * g.N, st) != hipSuccess) return XG_EHIP; }
+        else if (hipMemset2DAsync(g.C, sizeof(float) * g.ldc, 0, sizeof(float) * g.N, g.M, st) != hipSuccess) return XG_EHIP;
+    }
+    const size_t lds = (size_t)NP * (plane_elems<AKC>() + plane_elems<BKC>()) * sizeof(unsigned short);
+    static bool attr_done = false;
+    if (!attr_done && lds > 65536) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bs_kernel<NP, AKC, BKC, VEC>),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XG_EHIP;
+        attr_done = true;
+    }
+    hipLaunchKernelGGL((gemm_bs_kernel<NP, AKC, BKC, VEC>), dim3(ntm * ntn * g.splitk), dim3(256), lds, st, g);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+
+template <int NP>
+int dispatch(hipStream_t st, const BArgs& g, bool akc, bool bkc, bool vec) {
+#define XG_BS(a, b) (vec ? launch<NP, a, b, true>(st, g) : launch<NP, a, b, false>(st, g))
+    if (akc && bkc) return XG_BS(true, true);
+    if (akc && !bkc) return XG_BS(true, false);
+    if (!akc && !bkc) return XG_BS(false, false);
+    return XG_BS(false, true);
+#undef XG_BS
+}
+
+}  // namespace
+
+// planes: 1 = bf16 compute, 3 = split-bf16 (fp32-class accuracy).  Only called for products large enough to tile.
+int xgk_gemm_bf16(hipStream_t st, int planes, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
+                  const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate) {
+    BArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1};
+    const bool akc = !transA, bkc = transB;
+    bool vec = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && (lda % 4 == 0) && (ldb % 4 == 0);
+    vec = vec && ((akc ? K : M) % 4 == 0) && ((bkc ? K : N) % 4 == 0);
+    const long tiles = (long)xg_cdiv(M, BM) * xg_cdiv(N, BN);
+    const int nslab = xg_cdiv(K, BK);
+    if (!relu && tiles < 512) {                     // fill the chip (2 workgroups per CU) by splitting deep reductions
+        long sk = (512 + tiles - 1) / tiles;
+        if (sk > nslab / 8) sk = nslab / 8;
+        if (sk >= 2) g.splitk = (int)sk;
+    }
+    return planes == 1 ? dispatch<1>(st, g, akc, bkc, vec) : dispatch<3>(st, g, akc, bkc, vec);
+}

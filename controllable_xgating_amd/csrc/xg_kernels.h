@@ -5,6 +5,15 @@
 // ---- xg_gemm.hip
 int xgk_gemm(hipStream_t st, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
              const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate);
+// xg_gemm_bf16.hip: split-bf16 / bf16 arithmetic for large products (planes = 3 or 1)
+int xgk_gemm_bf16(hipStream_t st, int planes, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
+                  const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate);
+// arithmetic mode of xgk_gemm for the current host thread (set by the C-ABI entry points from XgRun.gemm_mode)
+void xgk_set_gemm_mode(int mode);
+struct XgGemmModeGuard {
+    explicit XgGemmModeGuard(int m) { xgk_set_gemm_mode(m); }
+    ~XgGemmModeGuard() { xgk_set_gemm_mode(0); }
+};
 // Y[M,N] (+)= X[M,K] W[N,K]^T + bias   (nn.Linear forward)
 static inline int xgk_linear(hipStream_t st, int M, int N, int K, const float* X, int ldx, const float* W,
                              const float* bias, float* Y, int ldy, bool relu = false, bool acc = false) {

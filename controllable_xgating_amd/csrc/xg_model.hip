@@ -636,6 +636,7 @@ extern "C" int xg_encoder_fwd(void* stream, const XgDims* d, const XgParams* p, 
                               const XgRun* run, void* ws, size_t ws_bytes, float* V) {
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !x || !run || !V || !x->feats_rgb || !x->feats_opfl || !x->feat_mask) return XG_EINVAL;
+    XgGemmModeGuard mode_guard(run->gemm_mode);
     hipStream_t st = (hipStream_t)stream;
     XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w));
     if (hipMemcpyAsync(V, w.Venc, sizeof(float) * (size_t)d->B * d->K * d->R, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
@@ -645,6 +646,7 @@ extern "C" int xg_encoder_bwd(void* stream, const XgDims* d, const XgParams* p, 
                               const XgRun* run, void* ws, size_t ws_bytes, const float* dV) {
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !g || !x || !run || !dV) return XG_EINVAL;
+    XgGemmModeGuard mode_guard(run->gemm_mode);
     return encoder_bwd((hipStream_t)stream, *d, *p, *g, *x, *run, w, dV);
 }
 extern "C" int xg_init_hidden(void* stream, const XgDims* d, const XgParams* p, const float* V, const float* feat_mask,
@@ -664,6 +666,7 @@ extern "C" int xg_step_fwd(void* stream, const XgDims* d, const XgParams* p, con
                            void* ws, size_t ws_bytes, float* state, float* logp, float* alpha) {
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !tokens || !V || !vproj || !pos_feats || !run || !state) return XG_EINVAL;
+    XgGemmModeGuard mode_guard(run->gemm_mode);
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, R = d->R, E = d->E;
     const size_t BR = (size_t)B * R;
@@ -687,6 +690,7 @@ extern "C" int xg_forward_xe(void* stream, const XgDims* d, const XgParams* p, c
                              const XgRun* run, void* ws, size_t ws_bytes, float* logp, float* cat_logp) {
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !x || !run || !logp || !x->seq || !x->seq_mask || !x->pos_feats) return XG_EINVAL;
+    XgGemmModeGuard mode_guard(run->gemm_mode);
     hipStream_t st = (hipStream_t)stream;
     const int TB = d->T * d->B;
     XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w));
@@ -701,6 +705,7 @@ extern "C" int xg_backward_xe(void* stream, const XgDims* d, const XgParams* p, 
                               const XgRun* run, void* ws, size_t ws_bytes, const float* dlogp, const float* dcat_logp) {
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !g || !x || !run || !x->seq || !x->seq_mask) return XG_EINVAL;
+    XgGemmModeGuard mode_guard(run->gemm_mode);
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, T = d->T, TB = T * B;
     // log-softmax backward needs logp = logits - lse: recompute lse rows from the saved logits (in place)
@@ -727,6 +732,7 @@ extern "C" int xg_forward_ss(void* stream, const XgDims* d, const XgParams* p, c
     if (!p || !x || !run || !logp || !x->seq || !x->seq_mask || !x->pos_feats) return XG_EINVAL;
     const bool ss = run->train && ss_prob > 0.f;
     if (ss && (!u_sel || !u_tok)) return XG_EINVAL;
+    XgGemmModeGuard mode_guard(run->gemm_mode);
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, R = d->R, E = d->E, A = d->A, T = d->T, TB = T * B, N = B * d->K;
     const size_t BR = (size_t)B * R;
@@ -769,6 +775,7 @@ extern "C" int xg_backward_ss(void* stream, const XgDims* d, const XgParams* p, 
                               const XgRun* run, void* ws, size_t ws_bytes, const float* dlogp, const float* dcat_logp) {
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !g || !x || !run || !x->seq || !x->seq_mask) return XG_EINVAL;
+    XgGemmModeGuard mode_guard(run->gemm_mode);
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, T = d->T, TB = T * B;
     if (dlogp) {   // LOGITS already holds the time-major log-probs
@@ -791,6 +798,7 @@ extern "C" int xg_xe_loss_fwd(void* stream, const XgDims* d, const XgParams* p, 
                               void* ws, size_t ws_bytes, float* losses) {
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !x || !run || !losses || !x->seq || !x->seq_mask || !x->pos_feats) return XG_EINVAL;
+    XgGemmModeGuard mode_guard(run->gemm_mode);
     hipStream_t st = (hipStream_t)stream;
     const int TB = d->T * d->B;
     XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w));
@@ -811,6 +819,7 @@ extern "C" int xg_xe_loss_bwd(void* stream, const XgDims* d, const XgParams* p, 
                               const float* dloss_dev, const XgRun* run, void* ws, size_t ws_bytes) {
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !g || !x || !run || !x->seq || !x->seq_mask) return XG_EINVAL;
+    XgGemmModeGuard mode_guard(run->gemm_mode);
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, T = d->T, TB = T * B;
     XG_TRY(xgk_xent_bwd(st, w.LOGITS, d->V, x->seq, x->seq_mask, nullptr, B, T, d->V, 1, w.LSE, w.sums, dloss_dev, 1.0f));
@@ -833,6 +842,7 @@ extern "C" int xg_rollout(void* stream, const XgDims* d, const XgParams* p, cons
     if (!p || !x || !run || !seq || !seq_logp || !n_steps || !x->pos_feats || d->T < 2) return XG_EINVAL;
     if (mode == XG_ROLLOUT_SAMPLE && (!uniforms || !(temperature > 0.f))) return XG_EINVAL;
     if (mode == XG_ROLLOUT_REPLAY && !forced) return XG_EINVAL;
+    XgGemmModeGuard mode_guard(run->gemm_mode);
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, R = d->R, E = d->E, A = d->A, T = d->T, N = B * d->K;
     const size_t BR = (size_t)B * R;
@@ -878,6 +888,7 @@ extern "C" int xg_rollout_bwd(void* stream, const XgDims* d, const XgParams* p, 
                               const XgRun* run, void* ws, size_t ws_bytes, const float* dseq_logp) {
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !g || !x || !run || !dseq_logp || d->T < 2) return XG_EINVAL;
+    XgGemmModeGuard mode_guard(run->gemm_mode);
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, T = d->T;
     // dlogits of step t-1's output from the token drawn at step t (SAModel.py:195)

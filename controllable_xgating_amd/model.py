@@ -154,6 +154,11 @@ class SAModel(nn.Module):
         self._pool = _WorkspacePool()
         self._flat = None
         self._call = 0
+        # arithmetic of the large GEMMs: 'fp32' (exact fp32 MFMA), 'bf16x3' (split-bf16, fp32-class accuracy, faster),
+        # 'bf16' (bf16 operands / fp32 accumulate: BASELINE.json configs[4]).  Recurrent steps are always fp32.
+        self.precision = getattr(opt, "precision", "fp32")
+        if self.precision not in ("fp32", "bf16", "bf16x3"):
+            raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16'")
 
     def init_weights(self):  # SAModel.py:52-56
         initrange = 0.1
@@ -250,6 +255,7 @@ class SAModel(nn.Module):
         r.seed = seed
         r.save = 1 if save else 0
         r.bn_momentum, r.bn_eps = 0.1, 1e-5
+        r.gemm_mode = {"fp32": 0, "bf16": 1, "bf16x3": 3}[self.precision]
         return r
 
     @staticmethod

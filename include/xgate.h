@@ -95,6 +95,10 @@ typedef struct XgRun {
     int32_t save;         /* 1: keep activations in the workspace for a following *_bwd */
     float bn_momentum;    /* 0.1 */
     float bn_eps;         /* 1e-5 */
+    int32_t gemm_mode;    /* arithmetic of the LARGE products (tiled GEMMs): 0 = fp32 MFMA, exact fp32 (default);
+                             3 = split-bf16 (three bf16 planes, 6 MFMAs, fp32-class accuracy); 1 = bf16 operands,
+                             fp32 accumulate (BASELINE.json configs[4], tolerance 1e-2).  The recurrent per-step
+                             products, the cells and all reductions are always fp32. */
 } XgRun;
 
 enum { XG_ROLLOUT_GREEDY = 0, XG_ROLLOUT_SAMPLE = 1, XG_ROLLOUT_REPLAY = 2 };
@@ -115,6 +119,10 @@ size_t xg_workspace_bytes(const XgDims *d);           /* covers every entry poin
 int xg_gemm(void *stream, int transA, int transB, int M, int N, int K,
             const float *A, int lda, const float *B, int ldb, float *C, int ldc,
             const float *bias, int relu, int accumulate);
+/* same product with the arithmetic of XgRun.gemm_mode (0, 1 or 3) */
+int xg_gemm_mode(void *stream, int mode, int transA, int transB, int M, int N, int K,
+                 const float *A, int lda, const float *B, int ldb, float *C, int ldc,
+                 const float *bias, int relu, int accumulate);
 
 /* ---- CG encoder: EncoderLstm_two_fc.forward (caption_src/sub_modules.py:118-159) ---- */
 int xg_encoder_fwd(void *stream, const XgDims *d, const XgParams *p, const XgBnState *bn,

@@ -481,3 +481,58 @@ def test_scheduled_sampling_vs_oracle():
     with torch.no_grad():
         l_ref, _ = model(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
     assert torch.equal(l_eval, l_ref)
+
+
+# ---------------------------------------------------------------- bf16 matrix-core modes (BASELINE.json configs[4])
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(512, 384, 300), (300, 200, 129), (2688, 512, 468)])
+def test_gemm_bf16_modes(M, N, K, ta, tb):
+    """mode 3 (split-bf16, 6 MFMAs) must be fp32-class; mode 1 (bf16 operands) within bf16 round-off."""
+    from controllable_xgating_amd import _native as nv
+    L = nv.lib()
+    g = torch.Generator().manual_seed(M + N + K + ta * 2 + tb)
+    A = torch.randn((K, M) if ta else (M, K), generator=g); Bm = torch.randn((N, K) if tb else (K, N), generator=g)
+    bias = torch.randn(N, generator=g); C0 = torch.randn(M, N, generator=g)
+    ref = (A.t() if ta else A).double() @ (Bm.t() if tb else Bm).double() + bias.double()
+    Ad, Bd, bd = A.cuda(), Bm.cuda(), bias.cuda()
+    for mode, tol in ((3, 4e-6), (1, 2e-2)):
+        for relu, acc in ((0, 0), (1, 0), (0, 1)):
+            Cd = C0.clone().cuda()
+            assert L.xg_gemm_mode(None, mode, ta, tb, M, N, K, nv.ptr(Ad), A.shape[1], nv.ptr(Bd), Bm.shape[1], nv.ptr(Cd), N,
+                                  nv.ptr(bd), relu, acc) == 0
+            want = ref + (C0.double() if acc else 0)
+            if relu:
+                want = want.clamp(min=0)
+            err = float((Cd.cpu().double() - want).abs().max()) / float(want.abs().max())
+            assert err < tol, (mode, relu, acc, err)
+
+
+def test_config5_bf16_within_1e2_of_fp32_reference_golden():
+    """BASELINE.json configs[4]: hidden 1024, 40 frames, vocab 20k with the large products on the bf16 matrix cores;
+    loss within 1e-2 of the reference's fp32 result (north_star tolerance for the bf16 config)."""
+    from controllable_xgating_amd import LanguageModelCriterion, SAModel, make_opt
+    g = load_golden("xe_c5.npz")
+    d = pg.make_dims(**CFG["c5"])
+    model = SAModel(make_opt(d, precision="bf16"))
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in pg.make_params(d).items()}, strict=False)
+    model = model.cuda(); model.train()
+    x = to_dev(pg.make_inputs(d, seed=0))
+    from controllable_xgating_amd import ClassiferCriterion
+    logp, cat = model(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+    loss = LanguageModelCriterion()(logp, x["seq"], x["seq_mask"])
+    total = loss + WEIGHT_CLASS * ClassiferCriterion()(cat, x["cap_classes"], x["seq_mask"], x["class_mask"])
+    total.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(g["loss_xe"])) < 1e-2, (loss.item(), float(g["loss_xe"]))
+    assert abs(total.item() - float(g["loss"])) < 1e-2
+    for name, prm in model.named_parameters():
+        gn = float(prm.grad.double().norm())
+        ref_n = float(g["gnorm/" + name])
+        assert abs(gn - ref_n) <= 5e-2 * ref_n + 1e-5, (name, gn, ref_n)
+    # and the split-bf16 mode is fp32-class on the same config
+    model3 = SAModel(make_opt(d, precision="bf16x3"))
+    model3.load_state_dict({k: torch.from_numpy(v) for k, v in pg.make_params(d).items()}, strict=False)
+    model3 = model3.cuda(); model3.train()
+    logp3, _ = model3(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+    loss3 = LanguageModelCriterion()(logp3, x["seq"], x["seq_mask"])
+    assert abs(loss3.item() - float(g["loss_xe"])) < 1e-4, (loss3.item(), float(g["loss_xe"]))

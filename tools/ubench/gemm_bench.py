@@ -1,4 +1,5 @@
-"""Time xg_gemm on the iteration's big shapes; XG_GEMM_FORCE="tile,splitk" overrides the heuristic."""
+"""Time xg_gemm / xg_gemm_mode on the iteration's big shapes and report the max error vs an fp64 reference.
+XG_GEMM_FORCE="tile,splitk" overrides the fp32 kernel's heuristic.  usage: gemm_bench.py [one] [mode]"""
 import os, sys, subprocess, json
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -12,7 +13,7 @@ SHAPES = [  # name, ta, tb, M, N, K, acc
     ("vproj NT 3328x1536 K=512", 0, 1, 3328, 1536, 512, 0),
     ("dX NN 3328x512 K=2048", 0, 0, 3328, 512, 2048, 0),
 ]
-def run():
+def run(mode):
     import torch
     from controllable_xgating_amd import _native as nv
     L = nv.lib()
@@ -21,20 +22,22 @@ def run():
         A = torch.randn((K, M) if ta else (M, K), device="cuda"); B = torch.randn((N, K) if tb else (K, N), device="cuda")
         Cc = torch.zeros(M, N, device="cuda")
         def call():
-            assert L.xg_gemm(None, ta, tb, M, N, K, nv.ptr(A), A.shape[1], nv.ptr(B), B.shape[1], nv.ptr(Cc), N, None, 0, acc) == 0
+            assert L.xg_gemm_mode(None, mode, ta, tb, M, N, K, nv.ptr(A), A.shape[1], nv.ptr(B), B.shape[1], nv.ptr(Cc), N, None, 0, acc) == 0
+        Cc.zero_(); call()
+        sl = slice(0, 256)
+        ref = ((A.t() if ta else A)[sl].double() @ (B.t() if tb else B).double())
+        err = float((Cc[sl].double() - ref).abs().max() / ref.abs().max())
         for _ in range(3): call()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(); e0.record()
         for _ in range(20): call()
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / 20
-        out[name] = (round(us, 1), round(2.0 * M * N * K / us / 1e6, 1))
-    print(os.environ.get("XG_GEMM_FORCE", "auto").ljust(8), json.dumps(out))
+        out[name] = (round(us, 1), round(2.0 * M * N * K / us / 1e6, 1), float("%.2g" % err))
+    print(("mode %d %s" % (mode, os.environ.get("XG_GEMM_FORCE", "auto"))).ljust(14), json.dumps(out))
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "one":
-        run()
+        run(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
     else:
-        for f in ["auto", "64,1", "128,1", "128,2", "128,4", "128,8", "64,2", "64,4"]:
-            env = dict(os.environ)
-            if f != "auto": env["XG_GEMM_FORCE"] = f
-            subprocess.run([sys.executable, __file__, "one"], env=env)
+        for m in (0, 3, 1):
+            subprocess.run([sys.executable, __file__, "one", str(m)])
