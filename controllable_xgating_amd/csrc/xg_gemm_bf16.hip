@@ -53,7 +53,10 @@ __device__ __forceinline__ void split(float x, unsigned short (&h)[NP]) {
     }
 }
 
-// ---- global -> registers: 4 float4 per thread per operand per slab (same index maps as xg_gemm.hip)
+// ---- global -> registers: 4 float4 per thread per operand per slab (same index maps as xg_gemm.hip).
+// Loads are UNCONDITIONAL (out-of-range rows / k are clamped to a valid address) so the compiler keeps all eight in
+// flight under the MFMAs -- a predicated load makes it wait for each one (measured: 8 serialized round trips per
+// slab); the out-of-range lanes are zeroed later, when the registers are split into LDS.
 template <bool KC, bool VEC>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int r0, int k0, int nrows, int K, f32x4 (&regs)[4]) {
     const int t = threadIdx.x;
@@ -64,43 +67,47 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
         if (KC) { r = f >> 3; k = (f & 7) << 2; }
         else    { k = f >> 5; r = (f & 31) << 2; }
         const int gr = r0 + r, gk = k0 + k;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (KC) {
-            if (gr < nrows) {
-                const float* src = P + (size_t)gr * ld + gk;
-                if (VEC) { if (gk < K) v = *reinterpret_cast<const f32x4*>(src); }
-                else {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) if (gk + j < K) v[j] = src[j];
-                }
-            }
+        if (VEC) {
+            // the vectorised extent is a multiple of 4, so a float4 is entirely in or entirely out: clamp to the last one
+            const int cr = KC ? min(gr, nrows - 1) : min(gr, nrows - 4);
+            const int ck = KC ? min(gk, K - 4) : min(gk, K - 1);
+            const float* src = KC ? P + (size_t)cr * ld + ck : P + (size_t)ck * ld + cr;
+            regs[i] = *reinterpret_cast<const f32x4*>(src);
         } else {
-            if (gk < K) {
-                const float* src = P + (size_t)gk * ld + gr;
-                if (VEC) { if (gr < nrows) v = *reinterpret_cast<const f32x4*>(src); }
-                else {
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) if (gr + j < nrows) v[j] = src[j];
-                }
+            for (int j = 0; j < 4; ++j) {
+                const int cr = KC ? min(gr, nrows - 1) : min(gr + j, nrows - 1);
+                const int ck = KC ? min(gk + j, K - 1) : min(gk, K - 1);
+                regs[i][j] = KC ? P[(size_t)cr * ld + ck] : P[(size_t)ck * ld + cr];
             }
         }
-        regs[i] = v;
     }
 }
 
-// ---- registers -> split -> LDS planes (4 consecutive elements of the contiguous dimension = one 8-byte store per plane)
+// ---- registers -> (zero the out-of-range lanes) -> split -> LDS planes: 4 consecutive elements of the contiguous
+// dimension = one 8-byte store per plane
 template <int NP, bool KC>
-__device__ __forceinline__ void store_tile(unsigned short* __restrict__ lds, const f32x4 (&regs)[4]) {
+__device__ __forceinline__ void store_tile(unsigned short* __restrict__ lds, const f32x4 (&regs)[4], int r0, int k0, int nrows,
+                                           int K, bool edge) {
     const int t = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = t + 256 * i;
+        int r, k;
+        if (KC) { r = f >> 3; k = (f & 7) << 2; }
+        else    { k = f >> 5; r = (f & 31) << 2; }
+        f32x4 v = regs[i];
+        if (edge) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const bool ok = KC ? (r0 + r < nrows && k0 + k + j < K) : (r0 + r + j < nrows && k0 + k < K);
+                v[j] = ok ? v[j] : 0.f;
+            }
+        }
         unsigned short h[4][NP];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) split<NP>(regs[i][j], h[j]);
-        int off;
-        if (KC) { const int r = f >> 3, k = (f & 7) << 2; off = r * LDKC + k; }
-        else    { const int k = f >> 5, r = (f & 31) << 2; off = k * LDMC + r; }
+        for (int j = 0; j < 4; ++j) split<NP>(v[j], h[j]);
+        const int off = KC ? r * LDKC + k : k * LDMC + r;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             uint2 w;
@@ -155,12 +162,14 @@ __global__ void __launch_bounds__(256) gemm_bs_kernel(BArgs g) {
     const int nslab_all = (g.K + BK - 1) / BK;
     const int s_begin = (int)(((long)ks * nslab_all) / g.splitk), s_end = (int)(((long)(ks + 1) * nslab_all) / g.splitk);
     f32x4 ra[4], rb[4];
+    const bool edge_a = m0 + BM > g.M, edge_b = n0 + BN > g.N;     // wave-uniform: interior tiles skip the masking
     load_tile<AKC, VEC>(g.A, g.lda, m0, s_begin * BK, g.M, g.K, ra);
     load_tile<BKC, VEC>(g.B, g.ldb, n0, s_begin * BK, g.N, g.K, rb);
     for (int s = s_begin; s < s_end; ++s) {
+        const bool ktail = (s + 1) * BK > g.K;
         __syncthreads();                                   // everyone is done reading the previous slab
-        store_tile<NP, AKC>(As, ra);
-        store_tile<NP, BKC>(Bs, rb);
+        store_tile<NP, AKC>(As, ra, m0, s * BK, g.M, g.K, edge_a || ktail);
+        store_tile<NP, BKC>(Bs, rb, n0, s * BK, g.N, g.K, edge_b || ktail);
         __syncthreads();
         if (s + 1 < s_end) {                               // next slab's loads fly under this slab's MFMAs
             load_tile<AKC, VEC>(g.A, g.lda, m0, (s + 1) * BK, g.M, g.K, ra);
