@@ -12,7 +12,68 @@
 #include "xg_common.h"
 #include "xg_kernels.h"
 
+#include <mutex>
+#include <cstdlib>
+
 namespace {
+
+// ---- one auxiliary stream per device: weight-gradient / token-side GEMMs that nothing downstream waits for run there,
+// under the latency-bound recurrent kernels of the main chain.  Everything is joined back onto the caller's stream
+// before an entry point returns, so the stream semantics of the C ABI are unchanged.  XG_NO_OVERLAP=1 disables it.
+constexpr int XG_NEV = 16;
+struct XgAux { hipStream_t s = nullptr; hipEvent_t ev[XG_NEV]; bool ok = false; };
+XgAux* aux_for_current_device() {
+    static XgAux table[64];
+    static std::mutex mu;
+    static const bool disabled = getenv("XG_NO_OVERLAP") != nullptr;
+    if (disabled) return nullptr;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lk(mu);
+    XgAux& a = table[dev];
+    if (!a.ok) {
+        if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        for (int i = 0; i < XG_NEV; ++i)
+            if (hipEventCreateWithFlags(&a.ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
+        a.ok = true;
+    }
+    return &a;
+}
+struct Streams {
+    hipStream_t main, aux;
+    XgAux* a;
+    int next = 0;
+    bool forked = false;
+    int dh_split_step = 0, dh_mark = -1;      // heads_bwd -> decoder_bwd_core hand-off (see heads_bwd)
+    explicit Streams(hipStream_t m) : main(m), aux(m), a(aux_for_current_device()) { if (a) aux = a->s; }
+    bool overlap() const { return a != nullptr; }
+    // aux may start work that depends on everything enqueued on main so far
+    int fork() {
+        if (!a) return XG_OK;
+        hipEvent_t e = a->ev[next++ % XG_NEV];
+        if (hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(aux, e, 0) != hipSuccess) return XG_EHIP;
+        forked = true;
+        return XG_OK;
+    }
+    // record a point on aux that main can wait for later (returns an event slot, or -1 when not overlapping)
+    int mark() {
+        if (!a) return -1;
+        const int i = next++ % XG_NEV;
+        if (hipEventRecord(a->ev[i], aux) != hipSuccess) return -2;
+        return i;
+    }
+    int wait_mark(int i) {
+        if (!a || i < 0) return XG_OK;
+        return hipStreamWaitEvent(main, a->ev[i], 0) == hipSuccess ? XG_OK : XG_EHIP;
+    }
+    // main waits for everything enqueued on aux so far
+    int join() {
+        if (!a || !forked) return XG_OK;
+        hipEvent_t e = a->ev[next++ % XG_NEV];
+        if (hipEventRecord(e, aux) != hipSuccess || hipStreamWaitEvent(main, e, 0) != hipSuccess) return XG_EHIP;
+        return XG_OK;
+    }
+};
 
 struct Ws {
     // ---- encoder
@@ -190,8 +251,9 @@ int encoder_fwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgBnSt
     return XG_OK;
 }
 
-int encoder_bwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgParams& g, const XgBatch& x,
+int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams& g, const XgBatch& x,
                 const XgRun& run, Ws& w, const float* dV_in) {
+    hipStream_t st = ss.main, sx = ss.aux;     // sx: parameter-gradient work nothing downstream waits for
     const int B = d.B, K = d.K, R = d.R, N = B * K;
     const float* feats[2] = {x.feats_rgb, x.feats_opfl};
     const int F[2] = {d.F1, d.F2};
@@ -212,18 +274,20 @@ int encoder_bwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgPara
 
     if (hipMemcpyAsync(w.dVw, dV_in, sizeof(float) * (size_t)N * R, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
     XG_TRY(xgk_relu_drop_bwd(st, w.dVw, w.Venc, (int64_t)N * R, xg_make_drop(&run, XG_SITE_FUSION, 0)));
-    XG_TRY(gemm_tn(st, N, R, 2 * R, w.dVw, R, w.Y, 2 * R, g.fusion_w, 2 * R));
-    XG_TRY(xgk_colsum(st, w.dVw, R, N, R, g.fusion_b));
+    XG_TRY(ss.fork());
+    XG_TRY(gemm_tn(sx, N, R, 2 * R, w.dVw, R, w.Y, 2 * R, g.fusion_w, 2 * R));
+    XG_TRY(xgk_colsum(sx, w.dVw, R, N, R, g.fusion_b));
     XG_TRY(gemm_nn(st, N, 2 * R, R, w.dVw, R, p.fusion_w, 2 * R, w.dY, 2 * R, false));
     for (int m = 0; m < 2; ++m) {   // y = g*h + h : dpre -> dGG, dh -> dHs (overwrite)
         XgDrop dr = xg_make_drop(&run, m == 0 ? XG_SITE_GATE_RGB : XG_SITE_GATE_OPFL, 0);
         XG_TRY(xgk_gate_bwd(st, w.dY + (size_t)m * R, 2 * R, w.GG[m], R, w.Hs[m], R, 0, w.dGG[m], R, w.dHs[m], R, false,
                             N, R, dr));
     }
+    XG_TRY(ss.fork());
     for (int m = 0; m < 2; ++m) {   // gate m takes source = hidden of the OTHER modality
         const int o = 1 - m;
-        XG_TRY(gemm_tn(st, N, R, R, w.dGG[m], R, w.Hs[o], R, g_gate_w[m], R));
-        XG_TRY(xgk_colsum(st, w.dGG[m], R, N, R, g_gate_b[m]));
+        XG_TRY(gemm_tn(sx, N, R, R, w.dGG[m], R, w.Hs[o], R, g_gate_w[m], R));
+        XG_TRY(xgk_colsum(sx, w.dGG[m], R, N, R, g_gate_b[m]));
         XG_TRY(gemm_nn(st, N, R, R, w.dGG[m], R, gate_w[m], R, w.dHs[o], R, true));
     }
     XgRun nodrop = run; nodrop.drop_p = 0.f;
@@ -262,13 +326,14 @@ int encoder_bwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgPara
     }
     for (int m = 0; m < 2; ++m) {
         // Hprev[b,k] = H[b,k-1], zero at k = 0 : one clean TN GEMM for dW_hh
-        ZERO(w.Hprev[m], (size_t)N * R);
+        if (m == 0) XG_TRY(ss.fork());           // dS of both modalities is final after the loop
+        if (hipMemsetAsync(w.Hprev[m], 0, sizeof(float) * (size_t)N * R, sx) != hipSuccess) return XG_EHIP;
         if (K > 1)   // one strided 2-D copy covers all videos: rows = B, cols = (K-1)*R
-            XG_TRY(xgk_copy2d(st, w.Hprev[m] + R, K * R, w.Hs[m], K * R, B, (K - 1) * R, false));
-        XG_TRY(gemm_tn(st, N, 4 * R, R, w.dS[m], 4 * R, w.Hprev[m], R, g_whh[m], R));
-        XG_TRY(gemm_tn(st, N, 4 * R, R, w.dS[m], 4 * R, w.X[m], R, g_wih[m], R));
-        XG_TRY(xgk_colsum(st, w.dS[m], 4 * R, N, 4 * R, g_bih[m]));
-        XG_TRY(xgk_colsum(st, w.dS[m], 4 * R, N, 4 * R, g_bhh[m]));
+            XG_TRY(xgk_copy2d(sx, w.Hprev[m] + R, K * R, w.Hs[m], K * R, B, (K - 1) * R, false));
+        XG_TRY(gemm_tn(sx, N, 4 * R, R, w.dS[m], 4 * R, w.Hprev[m], R, g_whh[m], R));
+        XG_TRY(gemm_tn(sx, N, 4 * R, R, w.dS[m], 4 * R, w.X[m], R, g_wih[m], R));
+        XG_TRY(xgk_colsum(sx, w.dS[m], 4 * R, N, 4 * R, g_bih[m]));
+        XG_TRY(xgk_colsum(sx, w.dS[m], 4 * R, N, 4 * R, g_bhh[m]));
         XG_TRY(gemm_nn(st, N, R, 4 * R, w.dS[m], 4 * R, wih[m], R, w.dX[m], R, false));
         // BatchNorm + ReLU + dropout + mask backward (sub_modules.py:121-123)
         ZERO(w.bn_s1[m], R); ZERO(w.bn_s2[m], R);
@@ -392,17 +457,32 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
 }
 
 // teacher-forced decoder, states into w.H1/C1/H2/C2 (SAModel.py:85-112)
-int decoder_fwd_xe(hipStream_t st, const XgDims& d, const XgParams& p, const XgBatch& x, const XgRun& run, Ws& w) {
-    const int B = d.B, R = d.R, A = d.A, E = d.E, T = d.T, TB = T * B, N = B * d.K;
+// everything of the teacher-forced decoder that depends only on the tokens (SAModel.py:105, sub_modules.py:682 and
+// the xt / pos' products of lstm_1): runs on the auxiliary stream under the CG encoder
+int decoder_tokens_xe(hipStream_t sx, const XgDims& d, const XgParams& p, const XgBatch& x, const XgRun& run, Ws& w) {
+    const int B = d.B, R = d.R, E = d.E, T = d.T, TB = T * B;
+    XG_TRY(xgk_embed_gather(sx, p.embed_w, E, x.seq, /*inner=*/B, /*s_inner=*/T, /*s_outer=*/1, TB, d.V, w.Xe, E));
+    XG_TRY(xgk_linear(sx, TB, R, E, w.Xe, E, p.dgate_w, p.dgate_b, w.GP, R, true));                 // :682 gate, all steps
+    XG_TRY(xgk_gate_fwd(sx, w.GP, R, x.pos_feats, R, B, w.POSG, R, TB, R, xg_make_drop(&run, XG_SITE_DGATE, 0),
+                        /*step=row/B*/ B, 1 << 30, /*b=row%B*/ 1, B));
+    XG_TRY(xgk_linear(sx, TB, 4 * R, E, w.Xe, E, p.l1_i2h_w, p.l1_i2h_b, w.PRE1, 4 * R));
+    XG_TRY(xgk_linear(sx, TB, 4 * R, R, w.POSG, R, p.l1_a2h_w, p.l1_a2h_b, w.PRE1, 4 * R, false, true));
+    return XG_OK;
+}
+
+// teacher-forced decoder, states into w.H1/C1/H2/C2 (SAModel.py:85-112).  The vocabulary product of the first half of
+// the steps is issued on the auxiliary stream as soon as those steps are done; *logit_rows_done receives the number of
+// (t,b) rows whose logits are already under way there.
+int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatch& x, const XgRun& run, Ws& w,
+                   int* logit_rows_done) {
+    hipStream_t st = ss.main;
+    const int B = d.B, R = d.R, A = d.A, E = d.E, T = d.T, N = B * d.K;
     const size_t BR = (size_t)B * R;
     XG_TRY(init_hidden(st, d, p, w.Venc, x.feat_mask, w, w.H1, w.C1, w.H2, w.C2));
     XG_TRY(xgk_linear(st, N, A, R, w.Venc, R, p.v2a_w, p.v2a_b, w.vproj, A));                       // hoisted v2a(V), :677
-    XG_TRY(xgk_embed_gather(st, p.embed_w, E, x.seq, /*inner=*/B, /*s_inner=*/T, /*s_outer=*/1, TB, d.V, w.Xe, E));
-    XG_TRY(xgk_linear(st, TB, R, E, w.Xe, E, p.dgate_w, p.dgate_b, w.GP, R, true));                 // :682 gate, all steps
-    XG_TRY(xgk_gate_fwd(st, w.GP, R, x.pos_feats, R, B, w.POSG, R, TB, R, xg_make_drop(&run, XG_SITE_DGATE, 0),
-                        /*step=row/B*/ B, 1 << 30, /*b=row%B*/ 1, B));
-    XG_TRY(xgk_linear(st, TB, 4 * R, E, w.Xe, E, p.l1_i2h_w, p.l1_i2h_b, w.PRE1, 4 * R));
-    XG_TRY(xgk_linear(st, TB, 4 * R, R, w.POSG, R, p.l1_a2h_w, p.l1_a2h_b, w.PRE1, 4 * R, false, true));
+    XG_TRY(ss.join());                                                                              // token-side products
+    const int th = (ss.overlap() && T >= 4) ? T / 2 : 0;
+    *logit_rows_done = 0;
     for (int t = 0; t < T; ++t) {
         StepIO s{};
         s.xt = w.Xe + (size_t)t * B * E; s.posg = w.POSG + t * BR; s.pre1 = w.PRE1 + (size_t)t * B * 4 * R;
@@ -412,32 +492,42 @@ int decoder_fwd_xe(hipStream_t st, const XgDims& d, const XgParams& p, const XgB
         s.P = w.P + (size_t)t * B * A; s.alpha = w.ALPHA + (size_t)t * B * d.K; s.af = w.AF + t * BR;
         s.g1 = w.G1 + (size_t)t * B * 4 * R; s.g2 = w.G2 + (size_t)t * B * 4 * R; s.t = t;
         XG_TRY(core_step(st, d, p, run, w, w.Venc, w.vproj, s));
+        if (th > 0 && t == th - 1) {
+            XG_TRY(ss.fork());
+            XG_TRY(xgk_linear(ss.aux, th * B, d.V, R, w.H2 + BR, R, p.logit_w, p.logit_b, w.LOGITS, d.V));
+            *logit_rows_done = th * B;
+        }
     }
     return XG_OK;
 }
 
 // classifier hidden + logits for the stacked outputs H2[1..T] (SAModel.py:109-110)
-int heads_fwd_logits(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& run, Ws& w, int rows) {
+int heads_fwd_logits(Streams& ss, const XgDims& d, const XgParams& p, const XgRun& run, Ws& w, int rows, int rows_done) {
+    hipStream_t st = ss.main;
     const int B = d.B, R = d.R;
     const float* Hout = w.H2 + (size_t)B * R;
-    XG_TRY(xgk_linear(st, rows, d.V, R, Hout, R, p.logit_w, p.logit_b, w.LOGITS, d.V));
+    XG_TRY(xgk_linear(st, rows - rows_done, d.V, R, Hout + (size_t)rows_done * R, R, p.logit_w, p.logit_b,
+                      w.LOGITS + (size_t)rows_done * d.V, d.V));
     XG_TRY(xgk_linear(st, rows, d.H, R, Hout, R, p.cls0_w, p.cls0_b, w.HC, d.H, true));
     XG_TRY(xgk_gate_fwd(st, w.HC, d.H, nullptr, 0, 0, nullptr, 0, rows, d.H, xg_make_drop(&run, XG_SITE_CLS, 0), B, 1 << 30,
                         1, B));
     XG_TRY(xgk_linear(st, rows, d.C, d.H, w.HC, d.H, p.cls3_w, p.cls3_b, w.CL, d.C));
-    return XG_OK;
+    return ss.join();                         // first-half logits from the auxiliary stream
 }
 
 // Shared reverse-time pass.  On entry: DH2OUT (TB,R) holds d(loss)/d(h2'_t) from the heads.
 // mask: element (b,t) at mask[b*ldm + t*tstride].  tokens likewise for the embedding scatter.
-int decoder_bwd_core(hipStream_t st, const XgDims& d, const XgParams& p, const XgParams& g, const XgBatch& x,
+int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgParams& g, const XgBatch& x,
                      const XgRun& run, Ws& w, const float* mask, int ldm, int mask_tstride, const int64_t* tok,
                      int tok_bstride, int tok_tstride) {
+    hipStream_t st = ss.main;
     const int B = d.B, K = d.K, R = d.R, A = d.A, E = d.E, T = d.T, TB = T * B, N = B * K;
+    (void)TB;
     const size_t BR = (size_t)B * R;
     int cur = 0;
     for (int j = 0; j < 4; ++j) ZERO(w.dst[0][j], BR);
     for (int t = T - 1; t >= 0; --t) {
+        if (t == ss.dh_split_step - 1) XG_TRY(ss.wait_mark(ss.dh_mark));   // dH of the early steps (auxiliary stream)
         float *dh1n = w.dst[cur][0], *dc1n = w.dst[cur][1], *dh2n = w.dst[cur][2], *dc2n = w.dst[cur][3];
         float *dh1p = w.dst[cur ^ 1][0], *dc1p = w.dst[cur ^ 1][1], *dh2p = w.dst[cur ^ 1][2], *dc2p = w.dst[cur ^ 1][3];
         float* ds1 = w.DS1 + (size_t)t * B * 4 * R;
@@ -486,59 +576,77 @@ int decoder_bwd_core(hipStream_t st, const XgDims& d, const XgParams& p, const X
         }
         cur ^= 1;
     }
+    // ---- after the loop.  Main chain (the encoder backward waits for it): dVproj -> dV.  Everything else is a
+    // parameter gradient and goes to the auxiliary stream, under the encoder's recurrent backward.
+    XG_TRY(ss.fork());
+    hipStream_t sx = ss.aux;
+    XG_TRY(xgk_attn_bwd_post(st, w.P, w.vproj, p.a2w_w, w.DE, w.DVPROJ, g.a2w_w, T, B, K, A));
+    XG_TRY(gemm_nn(st, N, R, A, w.DVPROJ, A, p.v2a_w, R, w.DV, R, false));
+    XG_TRY(xgk_attn_dV(st, w.ALPHA, w.DAF, R, (int64_t)BR, w.DV, T, B, K, R, true));
     // gradients wrt the initial state -> img_embed_* (init_hidden; vbar is detached: SAModel.py:59-62)
     {
         float* gst[4] = {w.dst[cur][0], w.dst[cur][1], w.dst[cur][2], w.dst[cur][3]};
         float* gw[4] = {g.ih1_w, g.ic1_w, g.ih2_w, g.ic2_w};
         float* gb[4] = {g.ih1_b, g.ic1_b, g.ih2_b, g.ic2_b};
         for (int j = 0; j < 4; ++j) {
-            XG_TRY(gemm_tn(st, B, R, R, gst[j], R, w.vbar, R, gw[j], R));
-            XG_TRY(xgk_colsum(st, gst[j], R, B, R, gb[j]));
+            XG_TRY(gemm_tn(sx, B, R, R, gst[j], R, w.vbar, R, gw[j], R));
+            XG_TRY(xgk_colsum(sx, gst[j], R, B, R, gb[j]));
         }
     }
     // batched weight gradients over all T steps
-    XG_TRY(gemm_tn(st, TB, 4 * R, R, w.DS2, 4 * R, w.H1 + BR, R, g.l2_i2h_w, R));
-    XG_TRY(gemm_tn(st, TB, 4 * R, R, w.DS2, 4 * R, w.AF, R, g.l2_a2h_w, R));
-    XG_TRY(gemm_tn(st, TB, 4 * R, R, w.DS2, 4 * R, w.H2, R, g.l2_h2h_w, R));
-    XG_TRY(xgk_colsum(st, w.DS2, 4 * R, TB, 4 * R, g.l2_i2h_b));
-    XG_TRY(xgk_colsum(st, w.DS2, 4 * R, TB, 4 * R, g.l2_a2h_b));
-    XG_TRY(xgk_colsum(st, w.DS2, 4 * R, TB, 4 * R, g.l2_h2h_b));
-    XG_TRY(gemm_tn(st, TB, 4 * R, R, w.DS1, 4 * R, w.H1, R, g.l1_h2h_w, R));
-    XG_TRY(gemm_tn(st, TB, 4 * R, E, w.DS1, 4 * R, w.Xe, E, g.l1_i2h_w, E));
-    XG_TRY(gemm_tn(st, TB, 4 * R, R, w.DS1, 4 * R, w.POSG, R, g.l1_a2h_w, R));
-    XG_TRY(xgk_colsum(st, w.DS1, 4 * R, TB, 4 * R, g.l1_i2h_b));
-    XG_TRY(xgk_colsum(st, w.DS1, 4 * R, TB, 4 * R, g.l1_a2h_b));
-    XG_TRY(xgk_colsum(st, w.DS1, 4 * R, TB, 4 * R, g.l1_h2h_b));
-    XG_TRY(gemm_tn(st, TB, A, R, w.DP, A, w.H1, R, g.h2a_w, 2 * R));
-    XG_TRY(gemm_tn(st, TB, A, R, w.DP, A, w.H2, R, g.h2a_w + R, 2 * R));
-    XG_TRY(xgk_colsum(st, w.DP, A, TB, A, g.h2a_b));
+    XG_TRY(gemm_tn(sx, TB, 4 * R, R, w.DS2, 4 * R, w.H1 + BR, R, g.l2_i2h_w, R));
+    XG_TRY(gemm_tn(sx, TB, 4 * R, R, w.DS2, 4 * R, w.AF, R, g.l2_a2h_w, R));
+    XG_TRY(gemm_tn(sx, TB, 4 * R, R, w.DS2, 4 * R, w.H2, R, g.l2_h2h_w, R));
+    XG_TRY(xgk_colsum(sx, w.DS2, 4 * R, TB, 4 * R, g.l2_i2h_b));
+    XG_TRY(xgk_colsum(sx, w.DS2, 4 * R, TB, 4 * R, g.l2_a2h_b));
+    XG_TRY(xgk_colsum(sx, w.DS2, 4 * R, TB, 4 * R, g.l2_h2h_b));
+    XG_TRY(gemm_tn(sx, TB, 4 * R, R, w.DS1, 4 * R, w.H1, R, g.l1_h2h_w, R));
+    XG_TRY(gemm_tn(sx, TB, 4 * R, E, w.DS1, 4 * R, w.Xe, E, g.l1_i2h_w, E));
+    XG_TRY(gemm_tn(sx, TB, 4 * R, R, w.DS1, 4 * R, w.POSG, R, g.l1_a2h_w, R));
+    XG_TRY(xgk_colsum(sx, w.DS1, 4 * R, TB, 4 * R, g.l1_i2h_b));
+    XG_TRY(xgk_colsum(sx, w.DS1, 4 * R, TB, 4 * R, g.l1_a2h_b));
+    XG_TRY(xgk_colsum(sx, w.DS1, 4 * R, TB, 4 * R, g.l1_h2h_b));
+    XG_TRY(gemm_tn(sx, TB, A, R, w.DP, A, w.H1, R, g.h2a_w, 2 * R));
+    XG_TRY(gemm_tn(sx, TB, A, R, w.DP, A, w.H2, R, g.h2a_w + R, 2 * R));
+    XG_TRY(xgk_colsum(sx, w.DP, A, TB, A, g.h2a_b));
     // input side of cell 1: pos' gate, embedding
-    XG_TRY(gemm_nn(st, TB, R, 4 * R, w.DS1, 4 * R, p.l1_a2h_w, R, w.DPOSG, R, false));
-    XG_TRY(gemm_nn(st, TB, E, 4 * R, w.DS1, 4 * R, p.l1_i2h_w, E, w.DXe, E, false));
-    XG_TRY(xgk_gate_bwd(st, w.DPOSG, R, w.GP, R, x.pos_feats, R, B, w.DGP, R, nullptr, 0, false, TB, R,
+    XG_TRY(gemm_nn(sx, TB, R, 4 * R, w.DS1, 4 * R, p.l1_a2h_w, R, w.DPOSG, R, false));
+    XG_TRY(gemm_nn(sx, TB, E, 4 * R, w.DS1, 4 * R, p.l1_i2h_w, E, w.DXe, E, false));
+    XG_TRY(xgk_gate_bwd(sx, w.DPOSG, R, w.GP, R, x.pos_feats, R, B, w.DGP, R, nullptr, 0, false, TB, R,
                         xg_make_drop(&run, XG_SITE_DGATE, 0)));
-    XG_TRY(gemm_tn(st, TB, R, E, w.DGP, R, w.Xe, E, g.dgate_w, E));
-    XG_TRY(xgk_colsum(st, w.DGP, R, TB, R, g.dgate_b));
-    XG_TRY(gemm_nn(st, TB, E, R, w.DGP, R, p.dgate_w, E, w.DXe, E, true));
-    XG_TRY(xgk_embed_scatter_add(st, g.embed_w, E, tok, B, tok_bstride, tok_tstride, TB, d.V, w.DXe, E));
-    // attention: dq in one pass, then the hoisted projection's gradients
-    XG_TRY(xgk_attn_bwd_post(st, w.P, w.vproj, p.a2w_w, w.DE, w.DVPROJ, g.a2w_w, T, B, K, A));
-    XG_TRY(gemm_tn(st, N, A, R, w.DVPROJ, A, w.Venc, R, g.v2a_w, R));
-    XG_TRY(xgk_colsum(st, w.DVPROJ, A, N, A, g.v2a_b));
-    XG_TRY(gemm_nn(st, N, R, A, w.DVPROJ, A, p.v2a_w, R, w.DV, R, false));
-    XG_TRY(xgk_attn_dV(st, w.ALPHA, w.DAF, R, (int64_t)BR, w.DV, T, B, K, R, true));
+    XG_TRY(gemm_tn(sx, TB, R, E, w.DGP, R, w.Xe, E, g.dgate_w, E));
+    XG_TRY(xgk_colsum(sx, w.DGP, R, TB, R, g.dgate_b));
+    XG_TRY(gemm_nn(sx, TB, E, R, w.DGP, R, p.dgate_w, E, w.DXe, E, true));
+    XG_TRY(xgk_embed_scatter_add(sx, g.embed_w, E, tok, B, tok_bstride, tok_tstride, TB, d.V, w.DXe, E));
+    // the hoisted projection's parameter gradients need dVproj (main stream, above)
+    XG_TRY(ss.fork());
+    XG_TRY(gemm_tn(sx, N, A, R, w.DVPROJ, A, w.Venc, R, g.v2a_w, R));
+    XG_TRY(xgk_colsum(sx, w.DVPROJ, A, N, A, g.v2a_b));
     return XG_OK;
 }
 
 // heads backward from dlogits (rows,V) in w.LOGITS and dcl (rows,C) in w.DCL -> DH2OUT, head param grads
-int heads_bwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgParams& g, const XgRun& run, Ws& w, int rows,
+int heads_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams& g, const XgRun& run, Ws& w, int rows,
               bool have_cls) {
+    hipStream_t st = ss.main;
     const int B = d.B, R = d.R, TB = d.T * B;
     const float* Hout = w.H2 + (size_t)B * R;
     if (rows < TB) ZERO(w.DH2OUT + (size_t)rows * R, (size_t)(TB - rows) * R);
-    XG_TRY(gemm_nn(st, rows, R, d.V, w.LOGITS, d.V, p.logit_w, R, w.DH2OUT, R, false));
-    XG_TRY(gemm_tn(st, rows, d.V, R, w.LOGITS, d.V, Hout, R, g.logit_w, R));
-    XG_TRY(xgk_colsum(st, w.LOGITS, d.V, rows, d.V, g.logit_b));
+    XG_TRY(ss.fork());                        // dlogits is final
+    // dH = dlogits * W: the reverse-time loop starts from the LAST step, so the rows of the late steps go first on the
+    // main stream and the early steps' rows are produced on the auxiliary stream while the loop is already running.
+    const int th = (ss.overlap() && !have_cls && rows == TB && d.T >= 4) ? d.T / 2 : 0;
+    const int r0 = th * B;
+    ss.dh_split_step = th; ss.dh_mark = -1;
+    if (th > 0) {
+        XG_TRY(gemm_nn(ss.aux, r0, R, d.V, w.LOGITS, d.V, p.logit_w, R, w.DH2OUT, R, false));
+        ss.dh_mark = ss.mark();
+        if (ss.dh_mark == -2) return XG_EHIP;
+    }
+    // dW_logit / db: parameter gradients, under the loop as well
+    XG_TRY(gemm_tn(ss.aux, rows, d.V, R, w.LOGITS, d.V, Hout, R, g.logit_w, R));
+    XG_TRY(xgk_colsum(ss.aux, w.LOGITS, d.V, rows, d.V, g.logit_b));
+    XG_TRY(gemm_nn(st, rows - r0, R, d.V, w.LOGITS + (size_t)r0 * d.V, d.V, p.logit_w, R, w.DH2OUT + (size_t)r0 * R, R, false));
     if (have_cls) {
         XG_TRY(gemm_tn(st, rows, d.C, d.H, w.DCL, d.C, w.HC, d.H, g.cls3_w, d.H));
         XG_TRY(xgk_colsum(st, w.DCL, d.C, rows, d.C, g.cls3_b));
@@ -647,7 +755,9 @@ extern "C" int xg_encoder_bwd(void* stream, const XgDims* d, const XgParams* p, 
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !g || !x || !run || !dV) return XG_EINVAL;
     XgGemmModeGuard mode_guard(run->gemm_mode);
-    return encoder_bwd((hipStream_t)stream, *d, *p, *g, *x, *run, w, dV);
+    Streams ss((hipStream_t)stream);
+    XG_TRY(encoder_bwd(ss, *d, *p, *g, *x, *run, w, dV));
+    return ss.join();
 }
 extern "C" int xg_init_hidden(void* stream, const XgDims* d, const XgParams* p, const float* V, const float* feat_mask,
                               void* ws, size_t ws_bytes, float* state) {
@@ -693,9 +803,13 @@ extern "C" int xg_forward_xe(void* stream, const XgDims* d, const XgParams* p, c
     XgGemmModeGuard mode_guard(run->gemm_mode);
     hipStream_t st = (hipStream_t)stream;
     const int TB = d->T * d->B;
+    Streams ss(st);
+    int rows_done = 0;
+    XG_TRY(ss.fork());
+    XG_TRY(decoder_tokens_xe(ss.aux, *d, *p, *x, *run, w));
     XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w));
-    XG_TRY(decoder_fwd_xe(st, *d, *p, *x, *run, w));
-    XG_TRY(heads_fwd_logits(st, *d, *p, *run, w, TB));
+    XG_TRY(decoder_fwd_xe(ss, *d, *p, *x, *run, w, &rows_done));
+    XG_TRY(heads_fwd_logits(ss, *d, *p, *run, w, TB, rows_done));
     XG_TRY(xgk_log_softmax(st, w.LOGITS, d->V, logp, d->V, TB, d->V, d->B, d->T, true));
     if (cat_logp) XG_TRY(xgk_log_softmax(st, w.CL, d->C, cat_logp, d->C, TB, d->C, d->B, d->T, true));
     return XG_OK;
@@ -719,10 +833,11 @@ extern "C" int xg_backward_xe(void* stream, const XgDims* d, const XgParams* p, 
         XG_TRY(xgk_log_softmax(st, w.CL, d->C, w.CL, d->C, TB, d->C, 1, 1, false));
         XG_TRY(xgk_log_softmax_bwd(st, dcat_logp, w.CL, d->C, w.DCL, d->C, TB, d->C, B, T, 2));
     }
-    XG_TRY(heads_bwd(st, *d, *p, *g, *run, w, TB, dcat_logp != nullptr));
-    XG_TRY(decoder_bwd_core(st, *d, *p, *g, *x, *run, w, x->seq_mask, T, 1, x->seq, T, 1));
-    XG_TRY(encoder_bwd(st, *d, *p, *g, *x, *run, w, w.DV));
-    return XG_OK;
+    Streams ss(st);
+    XG_TRY(heads_bwd(ss, *d, *p, *g, *run, w, TB, dcat_logp != nullptr));
+    XG_TRY(decoder_bwd_core(ss, *d, *p, *g, *x, *run, w, x->seq_mask, T, 1, x->seq, T, 1));
+    XG_TRY(encoder_bwd(ss, *d, *p, *g, *x, *run, w, w.DV));
+    return ss.join();
 }
 
 extern "C" int xg_forward_ss(void* stream, const XgDims* d, const XgParams* p, const XgBnState* bn, const XgBatch* x,
@@ -787,10 +902,11 @@ extern "C" int xg_backward_ss(void* stream, const XgDims* d, const XgParams* p, 
         XG_TRY(xgk_log_softmax(st, w.CL, d->C, w.CL, d->C, TB, d->C, 1, 1, false));
         XG_TRY(xgk_log_softmax_bwd(st, dcat_logp, w.CL, d->C, w.DCL, d->C, TB, d->C, B, T, 2));
     }
-    XG_TRY(heads_bwd(st, *d, *p, *g, *run, w, TB, dcat_logp != nullptr));
-    XG_TRY(decoder_bwd_core(st, *d, *p, *g, *x, *run, w, x->seq_mask, T, 1, w.TOK, 1, B));
-    XG_TRY(encoder_bwd(st, *d, *p, *g, *x, *run, w, w.DV));
-    return XG_OK;
+    Streams ss(st);
+    XG_TRY(heads_bwd(ss, *d, *p, *g, *run, w, TB, dcat_logp != nullptr));
+    XG_TRY(decoder_bwd_core(ss, *d, *p, *g, *x, *run, w, x->seq_mask, T, 1, w.TOK, 1, B));
+    XG_TRY(encoder_bwd(ss, *d, *p, *g, *x, *run, w, w.DV));
+    return ss.join();
 }
 
 extern "C" int xg_xe_loss_fwd(void* stream, const XgDims* d, const XgParams* p, const XgBnState* bn, const XgBatch* x,
@@ -801,9 +917,13 @@ extern "C" int xg_xe_loss_fwd(void* stream, const XgDims* d, const XgParams* p, 
     XgGemmModeGuard mode_guard(run->gemm_mode);
     hipStream_t st = (hipStream_t)stream;
     const int TB = d->T * d->B;
+    Streams ss(st);
+    int rows_done = 0;
+    XG_TRY(ss.fork());
+    XG_TRY(decoder_tokens_xe(ss.aux, *d, *p, *x, *run, w));
     XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w));
-    XG_TRY(decoder_fwd_xe(st, *d, *p, *x, *run, w));
-    XG_TRY(heads_fwd_logits(st, *d, *p, *run, w, TB));
+    XG_TRY(decoder_fwd_xe(ss, *d, *p, *x, *run, w, &rows_done));
+    XG_TRY(heads_fwd_logits(ss, *d, *p, *run, w, TB, rows_done));
     XG_TRY(xgk_xent_fwd(st, w.LOGITS, d->V, x->seq, x->seq_mask, nullptr, d->B, d->T, d->V, 1, w.LSE, w.sums));
     if (cap_classes) {
         XG_TRY(xgk_xent_fwd(st, w.CL, d->C, cap_classes, x->seq_mask, class_mask, d->B, d->T, d->C, 0, w.LSEC, w.sums + 2));
@@ -829,10 +949,11 @@ extern "C" int xg_xe_loss_bwd(void* stream, const XgDims* d, const XgParams* p, 
         XG_TRY(xgk_xent_bwd(st, w.DCL, d->C, cap_classes, x->seq_mask, class_mask, B, T, d->C, 0, w.LSEC, w.sums + 2,
                             dloss_dev, weight_class));
     }
-    XG_TRY(heads_bwd(st, *d, *p, *g, *run, w, TB, cls));
-    XG_TRY(decoder_bwd_core(st, *d, *p, *g, *x, *run, w, x->seq_mask, T, 1, x->seq, T, 1));
-    XG_TRY(encoder_bwd(st, *d, *p, *g, *x, *run, w, w.DV));
-    return XG_OK;
+    Streams ss(st);
+    XG_TRY(heads_bwd(ss, *d, *p, *g, *run, w, TB, cls));
+    XG_TRY(decoder_bwd_core(ss, *d, *p, *g, *x, *run, w, x->seq_mask, T, 1, x->seq, T, 1));
+    XG_TRY(encoder_bwd(ss, *d, *p, *g, *x, *run, w, w.DV));
+    return ss.join();
 }
 
 extern "C" int xg_rollout(void* stream, const XgDims* d, const XgParams* p, const XgBnState* bn, const XgBatch* x,
@@ -896,8 +1017,9 @@ extern "C" int xg_rollout_bwd(void* stream, const XgDims* d, const XgParams* p, 
         float* lg = w.LOGITS + (size_t)(t - 1) * B * d->V;
         XG_TRY(xgk_rollout_dlogits(st, lg, w.TOK + (size_t)t * B, dseq_logp + (t - 1), T - 1, lg, B, d->V));
     }
-    XG_TRY(heads_bwd(st, *d, *p, *g, *run, w, (T - 1) * B, false));
-    XG_TRY(decoder_bwd_core(st, *d, *p, *g, *x, *run, w, w.UNF, 1, B, w.TOK, 1, B));
-    XG_TRY(encoder_bwd(st, *d, *p, *g, *x, *run, w, w.DV));
-    return XG_OK;
+    Streams ss(st);
+    XG_TRY(heads_bwd(ss, *d, *p, *g, *run, w, (T - 1) * B, false));
+    XG_TRY(decoder_bwd_core(ss, *d, *p, *g, *x, *run, w, w.UNF, 1, B, w.TOK, 1, B));
+    XG_TRY(encoder_bwd(ss, *d, *p, *g, *x, *run, w, w.DV));
+    return ss.join();
 }
