@@ -107,6 +107,7 @@ __global__ void __launch_bounds__(ATPB) attn_bwd_kernel(const float* __restrict_
 // After the time loop (one pass over q instead of a read-modify-write of dq per step):
 //   dq[b,k,a] = w_a sum_t de_t[b,k] (1 - th_t^2),  dw[a] += sum_{t,b,k} de_t[b,k] th_t,  th_t = tanh(p_t[b,a] + q[b,k,a])
 // grid (ceil(A/256), B); thread = one a, loops k and t.
+template <int TMAX>
 __global__ void __launch_bounds__(256) attn_bwd_post_kernel(const float* __restrict__ P, const float* __restrict__ vproj,
                                                               const float* __restrict__ w, const float* __restrict__ DE,
                                                               float* __restrict__ dvproj, float* __restrict__ dw, int T,
@@ -118,16 +119,32 @@ __global__ void __launch_bounds__(256) attn_bwd_post_kernel(const float* __restr
     __syncthreads();
     if (a >= A) return;
     const float wa = w[a];
+    // this thread's column of p for every step lives in registers (TMAX > 0) so the inner loop is pure VALU
+    float pr[TMAX > 0 ? TMAX : 1];
+    if (TMAX > 0) {
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) pr[t] = t < T ? P[((size_t)t * B + b) * A + a] : 0.f;
+    }
     float dwa = 0.f;
     for (int k = 0; k < K; ++k) {
         const float q = vproj[((size_t)b * K + k) * A + a];
         float acc = 0.f;
-        for (int t = 0; t < T; ++t) {
-            const float d = sde[t * K + k];
-            if (d != 0.f) {
-                const float th = xg_tanh(P[((size_t)t * B + b) * A + a] + q);
+        if (TMAX > 0) {
+#pragma unroll
+            for (int t = 0; t < TMAX; ++t) {
+                const float d = t < T ? sde[t * K + k] : 0.f;
+                const float th = xg_tanh(pr[t] + q);
                 acc += d * (1.0f - th * th);
                 dwa += d * th;
+            }
+        } else {
+            for (int t = 0; t < T; ++t) {
+                const float d = sde[t * K + k];
+                if (d != 0.f) {
+                    const float th = xg_tanh(P[((size_t)t * B + b) * A + a] + q);
+                    acc += d * (1.0f - th * th);
+                    dwa += d * th;
+                }
             }
         }
         dvproj[((size_t)b * K + k) * A + a] = acc * wa;
@@ -327,8 +344,10 @@ int xgk_attn_bwd(hipStream_t st, const float* daf, int lddaf, const float* p, co
 int xgk_attn_bwd_post(hipStream_t st, const float* P, const float* vproj, const float* w, const float* DE,
                       float* dvproj, float* dw, int T, int B, int K, int A) {
     if ((size_t)T * K * sizeof(float) > 60000) return XG_EINVAL;
-    hipLaunchKernelGGL(attn_bwd_post_kernel, dim3(xg_cdiv(A, 256), B), dim3(256), (size_t)T * K * sizeof(float), st, P,
-                       vproj, w, DE, dvproj, dw, T, B, K, A);
+    const dim3 grid(xg_cdiv(A, 256), B);
+    const size_t lds = (size_t)T * K * sizeof(float);
+    if (T <= 32) hipLaunchKernelGGL((attn_bwd_post_kernel<32>), grid, dim3(256), lds, st, P, vproj, w, DE, dvproj, dw, T, B, K, A);
+    else hipLaunchKernelGGL((attn_bwd_post_kernel<0>), grid, dim3(256), lds, st, P, vproj, w, DE, dvproj, dw, T, B, K, A);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }

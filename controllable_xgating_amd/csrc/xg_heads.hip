@@ -101,14 +101,18 @@ __global__ void __launch_bounds__(RT) xent_fwd_kernel(const float* __restrict__ 
     __shared__ float red[RT / 64];
     const int i = blockIdx.x, t = i / B, b = i % B;
     const float* x = logits + (size_t)i * ld;
-    float mx = -INFINITY;
-    for (int v = threadIdx.x; v < V; v += RT) mx = fmaxf(mx, x[v]);
-    mx = block_max(mx, red);
-    float s = 0.f;
-    for (int v = threadIdx.x; v < V; v += RT) s += expf(x[v] - mx);
+    // one pass over the row: online max / sum-exp per thread, merged across the workgroup
+    float mx = -INFINITY, s = 0.f;
+    for (int v = threadIdx.x; v < V; v += RT) {
+        const float xv = x[v];
+        if (xv > mx) { s = s * expf(mx - xv) + 1.0f; mx = xv; }
+        else s += expf(xv - mx);
+    }
+    const float gmx = block_max(mx, red);
+    s = (mx == -INFINITY) ? 0.f : s * expf(mx - gmx);
     s = block_sum(s, red);
     if (threadIdx.x == 0) {
-        const float lse = mx + logf(s);
+        const float lse = gmx + logf(s);
         lse_out[i] = lse;
         const float m = mask[(size_t)b * T + t] * (mask2 ? mask2[(size_t)b * T + t] : 1.f);
         const int64_t tg = tgt_of(seq, b, t, T, roll);
