@@ -212,6 +212,136 @@ __global__ void __launch_bounds__(RT) choose_kernel(const float* __restrict__ lo
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// One launch per rollout step (SAModel.py:182-215): token choice straight from the RAW logits of the previous step
+// (log-probs are never materialised: logp[v] = logit[v] - lse), the unfinished / emit bookkeeping, the reference's
+// n (first step at which every row is finished) and the embedding gather of the chosen token.  One workgroup per video.
+struct RollStepArgs {
+    const float* logits;      // (B,V) raw logits of step t-1, null at t = 0
+    const float* uniforms;    // (B) for SAMPLE
+    const int64_t* forced;    // element b at forced[b * fstride], for REPLAY
+    int64_t fstride;
+    const float* unf_prev;    // (B) unfinished after step t-1 (t >= 2)
+    const float* table;       // embedding (V,E)
+    int64_t* tok; float* tok_logp; float* unf; float* lse;      // (B) each, step-t slices
+    int64_t* seq; float* seq_logp;                               // (B,Tm1)
+    int32_t* maxf;            // running max over rows of the step at which the row finished (T if it never does)
+    float* xt;                // (B,E) out
+    float temperature;
+    int V, E, t, T, mode;
+};
+
+__global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
+    __shared__ float red[RT / 64];
+    __shared__ int redi[RT / 64];
+    __shared__ float chunk_sum[RT];
+    __shared__ int64_t s_tok;
+    __shared__ float s_bcast[3];
+    __shared__ int s_owner;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (a.t == 0) {                                       // <bos> = 0, mask of ones (:183-184, :212-213)
+        if (tid == 0) { a.tok[b] = 0; a.unf[b] = 1.0f; s_tok = 0; }
+    } else {
+        const float* x = a.logits + (size_t)b * a.V;
+        // pass 1: row max (+ argmax, ties -> lowest index like torch.max) and sum exp for the log-sum-exp
+        float best = -INFINITY; int bi = 0x7fffffff;
+        for (int v = tid; v < a.V; v += RT) {
+            const float f = x[v];
+            if (f > best || (f == best && v < bi)) { best = f; bi = v; }
+        }
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+        }
+        const int lane = tid & 63, wave = tid >> 6;
+        if (lane == 0) { red[wave] = best; redi[wave] = bi; }
+        __syncthreads();
+        best = red[0]; bi = redi[0];
+        for (int i = 1; i < RT / 64; ++i)
+            if (red[i] > best || (red[i] == best && redi[i] < bi)) { best = red[i]; bi = redi[i]; }
+        const float mx = best;
+        float se = 0.f;
+        for (int v = tid; v < a.V; v += RT) se += expf(x[v] - mx);
+        se = block_sum(se, red);
+        const float lse = mx + logf(se);
+        int64_t tk;
+        if (a.mode == XG_ROLLOUT_GREEDY) {
+            tk = bi;
+        } else if (a.mode == XG_ROLLOUT_REPLAY) {
+            tk = a.forced[(size_t)b * a.fstride];
+            tk = tk < 0 ? 0 : (tk >= a.V ? a.V - 1 : tk);
+        } else {
+            // inverse CDF over w_v = exp((logit_v - max) / temperature) (= exp(logp_v / temperature) up to a constant, :190-194)
+            const int per = (a.V + RT - 1) / RT;
+            const int v0 = tid * per, v1 = min(a.V, v0 + per);
+            const float invt = 1.0f / a.temperature;
+            float cs = 0.f;
+            for (int v = v0; v < v1; ++v) cs += expf((x[v] - mx) * invt);
+            chunk_sum[tid] = cs;
+            __syncthreads();
+            if (tid == 0) {
+                double tot = 0.0;
+                for (int i = 0; i < RT; ++i) tot += chunk_sum[i];
+                const double target = (double)a.uniforms[b] * tot;
+                double run = 0.0, base = 0.0; int ow = RT - 1;
+                for (int i = 0; i < RT; ++i) {
+                    if (run + chunk_sum[i] > target) { ow = i; base = run; break; }
+                    run += chunk_sum[i];
+                    base = run;
+                }
+                s_owner = ow; s_bcast[0] = (float)base; s_bcast[1] = (float)target;
+            }
+            __syncthreads();
+            if (tid == s_owner) {
+                float run = s_bcast[0]; int pick = min(a.V, v1) - 1;
+                if (pick < v0) pick = a.V - 1;
+                for (int v = v0; v < v1; ++v) {
+                    run += expf((x[v] - mx) * invt);
+                    if (run > s_bcast[1]) { pick = v; break; }
+                }
+                s_tok = pick;
+            }
+            __syncthreads();
+            tk = s_tok;
+        }
+        if (tid == 0) {
+            const float lp = x[tk] - lse;
+            // unfinished &= it > 0 ; it *= unfinished ; append (:200-210)
+            const float u = (a.t == 1 ? 1.0f : a.unf_prev[b]) * (tk > 0 ? 1.0f : 0.0f);
+            if (a.mode != XG_ROLLOUT_REPLAY) {
+                const bool was = a.t == 1 ? true : a.unf_prev[b] > 0.f;
+                if (was && u == 0.f) atomicMax(a.maxf, a.t);                 // this row finishes at step t
+                else if (u > 0.f && a.t == a.T - 1) atomicMax(a.maxf, a.T);  // never finished
+            } else if (a.t == a.T - 1) {
+                atomicMax(a.maxf, a.T);
+            }
+            a.unf[b] = u;
+            a.lse[b] = lse;
+            a.tok[b] = tk;                                                   // xt = embed(it) uses the raw draw (:198)
+            a.tok_logp[b] = lp;
+            a.seq[(size_t)b * (a.T - 1) + (a.t - 1)] = a.mode == XG_ROLLOUT_REPLAY ? tk : (u > 0.f ? tk : 0);
+            a.seq_logp[(size_t)b * (a.T - 1) + (a.t - 1)] = lp;
+            s_tok = tk;
+        }
+    }
+    __syncthreads();
+    const int64_t tk = s_tok;
+    for (int e = tid; e < a.E; e += RT) a.xt[(size_t)b * a.E + e] = a.table[(size_t)tk * a.E + e];
+}
+__global__ void rollout_finalize_kernel(const int32_t* maxf, int32_t* n_steps, int Tm1) {
+    const int m = maxf[0];                        // = max over rows of their finishing step, or T
+    n_steps[0] = m <= 0 ? Tm1 : (m - 1 < Tm1 ? m - 1 : Tm1);
+}
+// dlogits row b = d * (onehot(tok) - softmax(logits)) from raw logits + lse, in place
+__global__ void __launch_bounds__(RT) rollout_dlogits_lse_kernel(float* __restrict__ logits, const float* lse, const int64_t* tok,
+                                                                   const float* dslp, int64_t dstride, int V) {
+    const int b = blockIdx.x;
+    const float d = dslp[(size_t)b * dstride], l = lse[b];
+    const int64_t tk = tok[b];
+    float* x = logits + (size_t)b * V;
+    for (int v = threadIdx.x; v < V; v += RT) x[v] = d * ((v == tk ? 1.f : 0.f) - expf(x[v] - l));
+}
+
 __global__ void ss_select_kernel(const int64_t* seq, int T, int t, int B, const float* u_sel, float ss_prob,
                                  const int64_t* sampled, int64_t* tok) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -317,6 +447,27 @@ int xgk_choose(hipStream_t st, const float* logp, int B, int V, int mode, const 
                const int64_t* forced, int64_t forced_stride, float temperature, int64_t* tok, float* tok_logp) {
     hipLaunchKernelGGL(choose_kernel, dim3(B), dim3(RT), 0, st, logp, V, mode, uniforms, forced, forced_stride,
                        temperature, tok, tok_logp);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_rollout_step(hipStream_t st, int B, const float* logits, const float* uniforms, const int64_t* forced,
+                     int64_t fstride, const float* unf_prev, const float* table, int64_t* tok, float* tok_logp, float* unf,
+                     float* lse, int64_t* seq, float* seq_logp, int32_t* maxf, float* xt, float temperature, int V, int E,
+                     int t, int T, int mode) {
+    RollStepArgs a{logits, uniforms, forced, fstride, unf_prev, table, tok, tok_logp, unf, lse, seq, seq_logp, maxf, xt,
+                   temperature, V, E, t, T, mode};
+    hipLaunchKernelGGL(rollout_step_kernel, dim3(B), dim3(RT), 0, st, a);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_rollout_finalize(hipStream_t st, const int32_t* maxf, int32_t* n_steps, int Tm1) {
+    hipLaunchKernelGGL(rollout_finalize_kernel, dim3(1), dim3(1), 0, st, maxf, n_steps, Tm1);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_rollout_dlogits_lse(hipStream_t st, float* logits, const float* lse, const int64_t* tok, const float* dslp,
+                            int64_t dstride, int B, int V) {
+    hipLaunchKernelGGL(rollout_dlogits_lse_kernel, dim3(B), dim3(RT), 0, st, logits, lse, tok, dslp, dstride, V);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }

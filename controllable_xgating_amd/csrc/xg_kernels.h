@@ -159,6 +159,14 @@ int xgk_xent_bwd(hipStream_t st, float* logits_inout, int ld, const int64_t* seq
 // rollout token choice from a (B,V) log-prob matrix
 int xgk_choose(hipStream_t st, const float* logp, int B, int V, int mode, const float* uniforms,
                const int64_t* forced, int64_t forced_stride, float temperature, int64_t* tok, float* tok_logp);
+// fused rollout step: choice from raw logits + bookkeeping + embedding gather (xg_heads.hip)
+int xgk_rollout_step(hipStream_t st, int B, const float* logits, const float* uniforms, const int64_t* forced,
+                     int64_t fstride, const float* unf_prev, const float* table, int64_t* tok, float* tok_logp, float* unf,
+                     float* lse, int64_t* seq, float* seq_logp, int32_t* maxf, float* xt, float temperature, int V, int E,
+                     int t, int T, int mode);
+int xgk_rollout_finalize(hipStream_t st, const int32_t* maxf, int32_t* n_steps, int Tm1);
+int xgk_rollout_dlogits_lse(hipStream_t st, float* logits, const float* lse, const int64_t* tok, const float* dslp,
+                            int64_t dstride, int B, int V);
 // scheduled sampling (SAModel.py:89-99): tok[b] = u_sel[b] < ss_prob ? sampled[b] : seq[b*T + t]
 int xgk_ss_select(hipStream_t st, const int64_t* seq, int T, int t, int B, const float* u_sel, float ss_prob,
                   const int64_t* sampled, int64_t* tok);

@@ -665,9 +665,6 @@ __global__ void losses_kernel(const float* s, float wc, float* out) {
     const float lc = s[3] > 0.f ? s[2] / s[3] : 0.f;
     out[0] = lx + wc * lc; out[1] = lx; out[2] = lc;
 }
-__global__ void init_rollout_kernel(int32_t* n_steps, int32_t* alive, int Tm1) {
-    n_steps[0] = Tm1; alive[0] = 1;
-}
 
 int check(const XgDims* d, const void* ws, size_t ws_bytes, Ws* w) {
     if (!dims_ok(d) || !ws) return XG_EINVAL;
@@ -970,25 +967,19 @@ extern "C" int xg_rollout(void* stream, const XgDims* d, const XgParams* p, cons
     XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w));
     XG_TRY(init_hidden(st, *d, *p, w.Venc, x->feat_mask, w, w.H1, w.C1, w.H2, w.C2));
     XG_TRY(xgk_linear(st, N, A, R, w.Venc, R, p->v2a_w, p->v2a_b, w.vproj, A));
-    hipLaunchKernelGGL(init_rollout_kernel, dim3(1), dim3(1), 0, st, n_steps, w.alive, T - 1);
-    XG_CHECK_LAUNCH();
-    if (hipMemsetAsync(w.TOK, 0, sizeof(int64_t) * B, st) != hipSuccess) return XG_EHIP;    // t = 0 feeds BOS = 0 (:183-184)
-    XG_TRY(xgk_fill(st, w.UNF, 1.0f, B));
+    if (hipMemsetAsync(w.alive, 0, sizeof(int32_t) * 4, st) != hipSuccess) return XG_EHIP;   // alive[0] = running max finishing step
     for (int t = 0; t < T; ++t) {
         int64_t* tok = w.TOK + (size_t)t * B;
         float* unf = w.UNF + (size_t)t * B;
-        if (t >= 1) {
-            const float* lp_prev = w.LOGITS + (size_t)(t - 1) * B * d->V;
-            XG_TRY(xgk_choose(st, lp_prev, B, d->V, mode, uniforms ? uniforms + (size_t)t * B : nullptr,
-                              forced ? forced + (t - 1) : nullptr, T - 1, temperature, tok, w.TOKLP + (size_t)t * B));
-            if (t >= 2 && hipMemcpyAsync(unf, unf - B, sizeof(float) * B, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
-            XG_TRY(xgk_rollout_book(st, t, B, T - 1, mode == XG_ROLLOUT_REPLAY, tok, w.TOKLP + (size_t)t * B, unf, seq,
-                                    seq_logp, n_steps, w.alive));
-        }
         float* xt = w.Xe + (size_t)t * B * E;
+        // token choice from the previous step's raw logits + bookkeeping + embedding gather: one launch (:183-215)
+        XG_TRY(xgk_rollout_step(st, B, t >= 1 ? w.LOGITS + (size_t)(t - 1) * B * d->V : nullptr,
+                                uniforms ? uniforms + (size_t)t * B : nullptr, (forced && t >= 1) ? forced + (t - 1) : nullptr,
+                                T - 1, t >= 2 ? unf - B : nullptr, p->embed_w, tok, w.TOKLP + (size_t)t * B, unf,
+                                t >= 1 ? w.LSE + (size_t)(t - 1) * B : nullptr, seq, seq_logp, w.alive, xt, temperature, d->V, E,
+                                t, T, mode));
         float* gp = w.GP + t * BR;
         float* posg = w.POSG + t * BR;
-        XG_TRY(xgk_embed_gather(st, p->embed_w, E, tok, B, 1, 0, B, d->V, xt, E));                       // :198
         StepIO s{};
         s.xt = xt; s.pos = x->pos_feats; s.gp = gp; s.posg = posg; s.pre1 = nullptr; s.mask = unf; s.ldm = 1;
         s.h1 = w.H1 + t * BR; s.c1 = w.C1 + t * BR; s.h2 = w.H2 + t * BR; s.c2 = w.C2 + t * BR;
@@ -996,12 +987,10 @@ extern "C" int xg_rollout(void* stream, const XgDims* d, const XgParams* p, cons
         s.P = w.P + (size_t)t * B * A; s.alpha = w.ALPHA + (size_t)t * B * d->K; s.af = w.AF + t * BR;
         s.g1 = w.G1 + (size_t)t * B * 4 * R; s.g2 = w.G2 + (size_t)t * B * 4 * R; s.t = t;
         XG_TRY(core_step(st, *d, *p, *run, w, w.Venc, w.vproj, s));
-        if (t + 1 < T) {   // the step at t = L is computed and its logits discarded in the reference (:182,:217)
-            float* lg = w.LOGITS + (size_t)t * B * d->V;
-            XG_TRY(xgk_linear(st, B, d->V, R, s.h2o, R, p->logit_w, p->logit_b, lg, d->V));
-            XG_TRY(xgk_log_softmax(st, lg, d->V, lg, d->V, B, d->V, 1, 1, false));
-        }
+        if (t + 1 < T)     // the step at t = L is computed and its logits discarded in the reference (:182,:217)
+            XG_TRY(xgk_linear(st, B, d->V, R, s.h2o, R, p->logit_w, p->logit_b, w.LOGITS + (size_t)t * B * d->V, d->V));
     }
+    XG_TRY(xgk_rollout_finalize(st, w.alive, n_steps, T - 1));
     return XG_OK;
 }
 
@@ -1013,9 +1002,9 @@ extern "C" int xg_rollout_bwd(void* stream, const XgDims* d, const XgParams* p, 
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, T = d->T;
     // dlogits of step t-1's output from the token drawn at step t (SAModel.py:195)
-    for (int t = 1; t < T; ++t) {
+    for (int t = 1; t < T; ++t) {   // LOGITS holds raw logits, LSE their log-sum-exp
         float* lg = w.LOGITS + (size_t)(t - 1) * B * d->V;
-        XG_TRY(xgk_rollout_dlogits(st, lg, w.TOK + (size_t)t * B, dseq_logp + (t - 1), T - 1, lg, B, d->V));
+        XG_TRY(xgk_rollout_dlogits_lse(st, lg, w.LSE + (size_t)(t - 1) * B, w.TOK + (size_t)t * B, dseq_logp + (t - 1), T - 1, B, d->V));
     }
     Streams ss(st);
     XG_TRY(heads_bwd(ss, *d, *p, *g, *run, w, (T - 1) * B, false));
