@@ -45,6 +45,10 @@ class ClipAdam:
         self.step_count, self.lr = sd["step"], sd["lr"]
 
 
+import os as _os
+_FORCE = _os.environ.get("XG_FORCE_DIST") == "1"      # run the collective even at world size 1 (single-GPU smoke of the path)
+
+
 def allreduce_gradients(model, group=None):
     """Data parallel by video: ONE all-reduce(sum) of the flat gradient buffer,
     scaled by 1/world, BEFORE the clamp.  No other collective; BatchNorm statistics stay per replica."""
@@ -52,7 +56,7 @@ def allreduce_gradients(model, group=None):
     if not dist.is_available() or not dist.is_initialized():
         return
     world = dist.get_world_size(group)
-    if world == 1:
+    if world == 1 and not _FORCE:
         return
     g = model.flat_grads()
     dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
@@ -61,7 +65,7 @@ def allreduce_gradients(model, group=None):
 
 def broadcast_parameters(model, src=0, group=None):
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or _FORCE):
         dist.broadcast(model.flat_parameters(), src=src, group=group)
         for b in model.buffers():
             dist.broadcast(b, src=src, group=group)
