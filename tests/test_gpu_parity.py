@@ -93,7 +93,8 @@ def run_hip_xe(d, ragged, p=0.0, seed=None, weight_class=WEIGHT_CLASS):
     return model, logp.detach().cpu().numpy(), cat.detach().cpu().numpy(), l_xe.item(), l_cls.item()
 
 
-@pytest.mark.parametrize("tag,ragged", [("tiny", False), ("tiny", True), ("mid", True), ("c1", False), ("c1", True)])
+@pytest.mark.parametrize("tag,ragged", [("tiny", False), ("tiny", True), ("odd", True), ("one", False), ("mid", True), ("c1", False),
+                                        ("c1", True)])
 def test_xe_forward_backward_vs_oracle(tag, ragged):
     d = pg.make_dims(**CFG[tag])
     P, lo, co, lxe_o, lcls_o, running = run_oracle_xe(d, ragged)
@@ -229,6 +230,32 @@ def test_greedy_token_for_token_vs_reference(name, tag, ragged):
     diff = seq != g["seq"]
     assert not diff.any(), (np.argwhere(diff), g["margin"].min())
     np.testing.assert_allclose(slp, g["seqLogprobs"], atol=3e-4)
+
+
+def test_rollouts_on_unaligned_dims_generic_path():
+    """R % 8 != 0 and nothing 16-byte aligned: the generic (non-skinny) step path; greedy tokens + replay gradients."""
+    from controllable_xgating_amd import RewardCriterion
+    d = pg.make_dims(**CFG["odd"])
+    model = make_model(d, train=False)
+    x = to_dev(pg.make_inputs(d, seed=0))
+    xi = xo.to_torch_inputs(pg.make_inputs(d, seed=0))
+    with torch.no_grad():
+        seq, slp = model.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"sample_max": 1})
+        so, lo = xo.sample(xo.to_torch_params(pg.make_params(d)), xi["feats_rgb"], xi["feats_opfl"], xi["feat_mask"],
+                           xi["pos_feats"], d.L, mode="greedy", train=False, running=xo.new_running(d))
+    assert np.array_equal(seq.cpu().numpy(), so.numpy())
+    np.testing.assert_allclose(slp.cpu().numpy(), lo.numpy(), atol=3e-4)
+    model.train()
+    forced = torch.from_numpy(pg.randint("odd.forced", (d.B, d.L), 3, 1, d.V)).cuda()
+    seq2, slp2 = model.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"sample_max": 0, "forced_tokens": forced})
+    reward = torch.from_numpy(pg.uniform("odd.rew", (d.B, d.L), 3, -1, 1)).cuda()
+    RewardCriterion()(slp2, seq2, reward).backward()
+    P = xo.to_torch_params(pg.make_params(d), requires_grad=True)
+    s3, l3 = xo.sample(P, xi["feats_rgb"], xi["feats_opfl"], xi["feat_mask"], xi["pos_feats"], d.L, mode="replay",
+                       forced=forced.cpu(), train=True, running=xo.new_running(d))
+    xo.reward_criterion(l3, s3, reward.cpu()).backward()
+    torch.cuda.synchronize()
+    assert_grads_close(model, oracle_grads(P))
 
 
 def test_greedy_all_rows_finish_at_first_step():

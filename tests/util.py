@@ -15,6 +15,10 @@ CFG = {
     "c1": dict(B=8, K=26, R=512, A=1536, E=468, V=20000, C=14, L=20, F1=1536, F2=1024, H=128),
     "tiny": dict(B=5, K=7, R=24, A=40, E=18, V=61, C=5, L=6, F1=20, F2=12, H=128),
     "c5": dict(B=4, K=40, R=1024, A=1536, E=468, V=20000, C=14, L=6, F1=1536, F2=1024, H=128),
+    # nothing aligned: R not a multiple of 8 (generic cell path, no skinny kernel), odd E / A / V, B = 3
+    "odd": dict(B=3, K=3, R=20, A=37, E=10, V=37, C=3, L=4, F1=9, F2=7, H=128),
+    # degenerate extents: one video, one frame, one word
+    "one": dict(B=1, K=1, R=8, A=8, E=4, V=5, C=2, L=1, F1=4, F2=4, H=128),
     # mid-size, everything 16-byte aligned: exercises the vector-load GEMM paths quickly
     "mid": dict(B=12, K=9, R=64, A=96, E=36, V=500, C=14, L=7, F1=48, F2=40, H=128),
 }
