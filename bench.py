@@ -197,11 +197,12 @@ def main():
     rl_crit = RewardCriterion()
     reward_b = torch.randn(cfg["B"], 1, generator=torch.Generator().manual_seed(7)).to(dev)   # CIDEr stubbed (configs[2])
 
+    from controllable_xgating_amd.driver import scst_rollouts
+
     def step_scst():
         optim.zero_grad()
-        gen, slp = model.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"sample_max": 0})
-        with torch.no_grad():
-            model.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"sample_max": 1})   # greedy baseline
+        gen, slp, greedy = scst_rollouts(model, x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"],
+                                         overlap=os.environ.get("XG_NO_OVERLAP") is None)
         loss = rl_crit(slp, gen, reward_b.expand(-1, gen.shape[1]))
         loss.backward()
         allreduce_gradients(model)

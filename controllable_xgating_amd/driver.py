@@ -39,18 +39,52 @@ def sc_flag_for_epoch(opt, epoch):
     return after != -1 and epoch >= after
 
 
-def get_self_critical_reward(model, feat1, feat2, feat_mask, pos_feat, gen_result, scorer):
+def get_self_critical_reward(model, feat1, feat2, feat_mask, pos_feat, gen_result, scorer, greedy_res=None):
     """myutils.get_self_critical_reward (myutils.py:41-77): greedy baseline rollout (model stays in whatever mode it
     is in -- the reference never leaves train mode, starttrain.py:68), scores = scorer(sampled (m,n), greedy (m,n'))
-    -> (2m,) array, reward = score[:m] - score[m:], repeated over the n positions (:75-76)."""
-    with torch.no_grad():
-        greedy_res, _ = model.sample(feat1, feat2, feat_mask, pos_feat, {"sample_max": 1})
+    -> (2m,) array, reward = score[:m] - score[m:], repeated over the n positions (:75-76).  ``greedy_res`` may be
+    handed in when the baseline rollout already ran (scst_rollouts)."""
+    if greedy_res is None:
+        with torch.no_grad():
+            greedy_res, _ = model.sample(feat1, feat2, feat_mask, pos_feat, {"sample_max": 1})
     gen = gen_result.detach().cpu().numpy()
     greedy = greedy_res.detach().cpu().numpy()
     scores = np.asarray(scorer(gen, greedy), dtype=np.float64)
     m = gen.shape[0]
     diff = scores[:m] - scores[m:]
     return np.repeat(diff[:, np.newaxis], gen.shape[1], 1)
+
+
+def scst_rollouts(model, feat1, feat2, feat_mask, pos_feat, overlap=True):
+    """The two rollouts of one SCST iteration (starttrain.py:131 + myutils.py:45-48): the sampled rollout (keeps its
+    activations for the policy-gradient backward) and the greedy baseline.  They are independent given the batch, and each
+    is a latency-bound chain of small launches, so with ``overlap`` the greedy one runs on a side stream UNDER the sampled
+    one (one host sync for both).  Results are those of the sequential reference order: both rollouts see the same batch
+    statistics (BatchNorm's input does not depend on dropout), and the running statistics receive the reference's TWO
+    momentum updates (the second one is reconstructed exactly: r2 = 1.9 r1 - 0.9 r0)."""
+    if not overlap or not model.training:
+        gen, slp = model.sample(feat1, feat2, feat_mask, pos_feat, {"sample_max": 0})
+        with torch.no_grad():
+            greedy, _ = model.sample(feat1, feat2, feat_mask, pos_feat, {"sample_max": 1})
+        return gen, slp, greedy
+    bns = [model.two_spatial_encoder.visual_emb_rgb[1], model.two_spatial_encoder.visual_emb_opfl[1]]
+    r0 = [(m.running_mean.clone(), m.running_var.clone()) for m in bns]
+    main = torch.cuda.current_stream()
+    side = torch.cuda.Stream()
+    side.wait_stream(main)
+    with torch.cuda.stream(side), torch.no_grad():
+        g_seq, _, g_n = model.sample(feat1, feat2, feat_mask, pos_feat, {"sample_max": 1, "async": True, "bn_update": False})
+    s_seq, s_slp, s_n = model.sample(feat1, feat2, feat_mask, pos_feat, {"sample_max": 0, "async": True})
+    main.wait_stream(side)
+    with torch.no_grad():                      # the baseline's (second) running-stat update
+        for m, (rm0, rv0) in zip(bns, r0):
+            m.running_mean.mul_(1.9).sub_(0.9 * rm0)
+            m.running_var.mul_(1.9).sub_(0.9 * rv0)
+            if m.num_batches_tracked is not None:
+                m.num_batches_tracked += 1
+    ns = torch.stack([s_n.reshape(()), g_n.reshape(())]).cpu()      # ONE host sync for both rollouts
+    n_s, n_g = int(ns[0]), int(ns[1])
+    return s_seq[:, :n_s], s_slp[:, :n_s], g_seq[:, :n_g]
 
 
 class Trainer:
@@ -92,10 +126,10 @@ class Trainer:
                 loss = loss_language + wc * loss_classify                                    # :129
                 info.update(loss_language=loss_language, loss_classify=loss_classify)
         else:
-            gen_result, sample_logprobs = model.sample(b["feat1"], b["feat2"], b["feat_mask"], b["pos_feat"],
-                                                       {"sample_max": 0})                   # :131
+            gen_result, sample_logprobs, greedy = scst_rollouts(model, b["feat1"], b["feat2"], b["feat_mask"], b["pos_feat"],
+                                                                overlap=getattr(opt, "overlap_rollouts", True))   # :131 + myutils.py:45
             reward = get_self_critical_reward(model, b["feat1"], b["feat2"], b["feat_mask"], b["pos_feat"], gen_result,
-                                              self.scorer)                                   # :132
+                                              self.scorer, greedy_res=greedy)                # :132
             loss = self.rl_crit(sample_logprobs, gen_result,
                                 torch.from_numpy(reward).float().to(sample_logprobs.device))  # :133
             info["avg_reward"] = float(np.mean(reward[:, 0])) if reward.size else 0.0

@@ -375,8 +375,11 @@ class SAModel(nn.Module):
         need_grad = torch.is_grad_enabled() and mode != nv.XG_ROLLOUT_GREEDY and any(p.requires_grad for p in self.parameters())
         params = [self._named()[n] for n in nv.PARAM_NAMES]
         uniforms = opt.get("uniforms", None)
+        bn_update = bool(opt.get("bn_update", True))
         seq, slp, n = _RolloutFunction.apply(self, feats_rgb, feats_opfl, feat_mask, pos_feats, mode, uniforms, forced,
-                                             float(temperature), need_grad, *params)
+                                             float(temperature), need_grad, bn_update, *params)
+        if opt.get("async", False):            # no host sync: full-width (m, L) tensors + the device-side n
+            return seq, slp, n
         n = int(n.item())                      # ONE host sync per rollout (the reference syncs every step, :206)
         return seq[:, :n], slp[:, :n]
 
@@ -507,7 +510,7 @@ class _XELossFunction(torch.autograd.Function):
 class _RolloutFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, feats_rgb, feats_opfl, feat_mask, pos_feats, mode, uniforms, forced, temperature,
-                need_grad, *params):
+                need_grad, bn_update, *params):
         B, K, _ = feats_rgb.shape
         T = model.seq_length + 1
         dev = feats_rgb.device
@@ -527,10 +530,13 @@ class _RolloutFunction(torch.autograd.Function):
             f[:, :forced.shape[1]] = forced.to(dev)
             forced = f
         ps, bn, run = model._params_struct(), model._bn_struct(), model._run(need_grad)
+        if not bn_update and model.training:   # batch statistics are used, the running buffers are left alone
+            bn = nv.XgBnState()
         nv.check(nv.lib().xg_rollout(_stream(), C.byref(d), C.byref(ps), C.byref(bn), C.byref(b), C.byref(run), mode,
                                      nv.ptr(uniforms), nv.ptr(forced), temperature, wp, wn, nv.ptr(seq), nv.ptr(slp),
                                      nv.ptr(n)), "xg_rollout")
-        model._bump_bn()
+        if bn_update:
+            model._bump_bn()
         ctx.model, ctx.d, ctx.ws, ctx.keep, ctx.run, ctx.need_grad = model, d, ws, keep, run, need_grad
         ctx.mark_non_differentiable(seq, n)
         if not need_grad:
@@ -554,7 +560,7 @@ class _RolloutFunction(torch.autograd.Function):
                                          wp, wn, nv.ptr(full)), "xg_rollout_bwd")
         model._pool.give(d, dev, ctx.ws)
         ctx.ws = None
-        return (None,) * 10 + tuple(_grad_views(model, g))
+        return (None,) * 11 + tuple(_grad_views(model, g))
 
 
 # ====================================================================== criteria
