@@ -172,12 +172,19 @@ __global__ void attn_dV_kernel(const float* __restrict__ ALPHA, const float* __r
 // w_a in registers and streams whole q rows (lane = 16 B, wave = 1 KB per instruction), the V tile of
 // the context pass is already in flight while the scores are computed.
 constexpr int FT = 1024, FW = FT / 64;
+#ifdef XG_ATTN_TRACE
+__device__ long long attn_trace_buf[1024 * 8];
+#define AT_STAMP(i) do { if (threadIdx.x == 0) attn_trace_buf[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define AT_STAMP(i) do {} while (0)
+#endif
 
 template <int NI>
 __global__ void __launch_bounds__(FT) attn_fwd_fast(const float* __restrict__ p, const float* __restrict__ vproj,
                                                      const float* __restrict__ V, const float* __restrict__ w,
                                                      float* __restrict__ alpha, float* __restrict__ af, int K, int R, int A) {
     extern __shared__ float sm[];                     // e[K] | part[nkp][R]
+    AT_STAMP(0);
     float* se = sm;
     float* part = sm + ((K + 3) & ~3);
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -202,6 +209,7 @@ __global__ void __launch_bounds__(FT) attn_fwd_fast(const float* __restrict__ p,
         pr[i] = ok ? *reinterpret_cast<const float4*>(pb + a) : make_float4(0, 0, 0, 0);
         wr[i] = ok ? *reinterpret_cast<const float4*>(w + a) : make_float4(0, 0, 0, 0);
     }
+    AT_STAMP(1);
     for (int k = wave; k < K; k += FW) {
         const float* qk = qb + (size_t)k * A;
         float4 q[NI];
@@ -218,29 +226,48 @@ __global__ void __launch_bounds__(FT) attn_fwd_fast(const float* __restrict__ p,
         acc = wave_sum(acc);
         if (lane == 0) se[k] = acc;
     }
+    AT_STAMP(2);
     __syncthreads();
-    float mx = -INFINITY;
-    for (int k = 0; k < K; ++k) mx = fmaxf(mx, se[k]);
-    float den = 0.f;
-    for (int k = 0; k < K; ++k) den += expf(se[k] - mx);
-    const float inv = 1.0f / den;
+    AT_STAMP(3);
     float4 s4 = make_float4(0, 0, 0, 0);
+    if (K <= 64) {
+        // softmax over the K scores, once per wave with lane k holding e_k (not K serial expf per thread)
+        const float e = lane < K ? se[lane] : -INFINITY;
+        const float mx = wave_max(e);
+        const float ex = lane < K ? expf(e - mx) : 0.f;
+        const float al_lane = ex * (1.0f / wave_sum(ex));
+        if (alpha && wave == 0 && lane < K) alpha[(size_t)b * K + lane] = al_lane;
 #pragma unroll
-    for (int j = 0; j < VMAX; ++j) {
-        const int k = mykp + j * nkp;
-        if (mykp < nkp && k < K) {
-            const float al = expf(se[k] - mx) * inv;
-            s4.x += al * vreg[j].x; s4.y += al * vreg[j].y; s4.z += al * vreg[j].z; s4.w += al * vreg[j].w;
+        for (int j = 0; j < VMAX; ++j) {
+            const int k = mykp + j * nkp;
+            const float al = __shfl(al_lane, k < K ? k : 0);
+            if (mykp < nkp && k < K) { s4.x += al * vreg[j].x; s4.y += al * vreg[j].y; s4.z += al * vreg[j].z; s4.w += al * vreg[j].w; }
         }
+    } else {
+        float mx = -INFINITY;
+        for (int k = 0; k < K; ++k) mx = fmaxf(mx, se[k]);
+        float den = 0.f;
+        for (int k = 0; k < K; ++k) den += expf(se[k] - mx);
+        const float inv = 1.0f / den;
+#pragma unroll
+        for (int j = 0; j < VMAX; ++j) {
+            const int k = mykp + j * nkp;
+            if (mykp < nkp && k < K) {
+                const float al = expf(se[k] - mx) * inv;
+                s4.x += al * vreg[j].x; s4.y += al * vreg[j].y; s4.z += al * vreg[j].z; s4.w += al * vreg[j].w;
+            }
+        }
+        if (alpha && tid < K) alpha[(size_t)b * K + tid] = expf(se[tid] - mx) * inv;
     }
-    if (alpha && tid < K) alpha[(size_t)b * K + tid] = expf(se[tid] - mx) * inv;
     if (mykp < nkp) *reinterpret_cast<float4*>(part + (size_t)mykp * R + myr) = s4;
+    AT_STAMP(4);
     __syncthreads();
     for (int r = tid; r < R; r += FT) {
         float s = 0.f;
         for (int j = 0; j < nkp; ++j) s += part[(size_t)j * R + r];
         af[(size_t)b * R + r] = s;
     }
+    AT_STAMP(5);
 }
 
 // backward: de_k = alpha_k (dalpha_k - sum_j alpha_j dalpha_j), dalpha_k = daf . V_k ; dp_a = w_a sum_k de_k (1 - th^2)

@@ -59,24 +59,39 @@ __device__ __forceinline__ float xg_keep(const XgDrop& d, uint32_t idx) {
 enum { XG_SITE_EMB_RGB = 0, XG_SITE_EMB_OPFL = 1, XG_SITE_GATE_RGB = 2, XG_SITE_GATE_OPFL = 3, XG_SITE_FUSION = 4,
        XG_SITE_DGATE = 5, XG_SITE_L1 = 6, XG_SITE_L2 = 7, XG_SITE_CLS = 8 };
 
-__device__ __forceinline__ float xg_sigmoid(float x) { return 1.0f / (1.0f + __expf(-x)); }
+// v_rcp_f32 (1 ulp) instead of an IEEE division: the division expands to ~10 instructions and the recurrent / attention
+// kernels are bound by exactly this arithmetic (26 x 1536 tanh per video per step).
+__device__ __forceinline__ float xg_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float xg_sigmoid(float x) { return xg_rcp(1.0f + __expf(-x)); }
 // tanh via exp: accurate to ~1e-7 relative on the value for |x| small because of the 2/(1+e) form
 __device__ __forceinline__ float xg_tanh(float x) {
     float ax = fabsf(x);
     float e = __expf(-2.0f * ax);
-    float t = (1.0f - e) / (1.0f + e);
+    float t = (1.0f - e) * xg_rcp(1.0f + e);
     return copysignf(t, x);
 }
 
+// Wave64 reductions on the DPP path (4 cross-lane adds inside each row of 16 + one readlane per row) instead of six
+// ds_bpermute round trips.  Every lane of the wave must be active (all call sites are wave-uniform); the result is
+// wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ float xg_dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float xg_readlane(float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); }
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    return v;
+    v += xg_dpp<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += xg_dpp<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += xg_dpp<0x141>(v);     // row_half_mirror
+    v += xg_dpp<0x140>(v);     // row_mirror
+    return (xg_readlane(v, 0) + xg_readlane(v, 16)) + (xg_readlane(v, 32) + xg_readlane(v, 48));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-    return v;
+    v = fmaxf(v, xg_dpp<0xB1>(v));
+    v = fmaxf(v, xg_dpp<0x4E>(v));
+    v = fmaxf(v, xg_dpp<0x141>(v));
+    v = fmaxf(v, xg_dpp<0x140>(v));
+    return fmaxf(fmaxf(xg_readlane(v, 0), xg_readlane(v, 16)), fmaxf(xg_readlane(v, 32), xg_readlane(v, 48)));
 }
 
 static inline int xg_cdiv(int a, int b) { return (a + b - 1) / b; }

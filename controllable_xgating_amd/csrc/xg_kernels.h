@@ -90,6 +90,8 @@ int xgk_bn_bwd_apply(hipStream_t st, float* dY, const float* Z, const float* mea
                      bool train);
 
 // row i uses token tok[(i % inner) * s_inner + (i / inner) * s_outer]
+int xgk_step_prep(hipStream_t st, const float* table, int E, const int64_t* tok, int V, float* xt, int B,
+                  const float* state, float* state_copy, int64_t nstate);
 int xgk_embed_gather(hipStream_t st, const float* table, int E, const int64_t* tok, int inner, int64_t s_inner,
                      int64_t s_outer, int n, int V, float* out, int ldo);
 // dtable[tok(i)] += dX[i]   (atomic)

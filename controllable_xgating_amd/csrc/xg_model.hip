@@ -12,25 +12,29 @@
 #include "xg_common.h"
 #include "xg_kernels.h"
 
+#include <map>
 #include <mutex>
+#include <utility>
 #include <cstdlib>
 
 namespace {
 
-// ---- one auxiliary stream per device: weight-gradient / token-side GEMMs that nothing downstream waits for run there,
-// under the latency-bound recurrent kernels of the main chain.  Everything is joined back onto the caller's stream
-// before an entry point returns, so the stream semantics of the C ABI are unchanged.  XG_NO_OVERLAP=1 disables it.
+// ---- one auxiliary stream per (device, caller stream): weight-gradient / token-side GEMMs that nothing downstream waits
+// for run there, under the latency-bound recurrent kernels of the main chain.  Everything is joined back onto the
+// caller's stream before an entry point returns, so the stream semantics of the C ABI are unchanged, and two callers on
+// two streams (the SCST sampled / greedy rollouts) never share an auxiliary stream.  XG_NO_OVERLAP=1 disables it.
 constexpr int XG_NEV = 16;
 struct XgAux { hipStream_t s = nullptr; hipEvent_t ev[XG_NEV]; bool ok = false; };
-XgAux* aux_for_current_device() {
-    static XgAux table[64];
+XgAux* aux_for(hipStream_t main) {
+    static std::map<std::pair<int, hipStream_t>, XgAux> table;
     static std::mutex mu;
     static const bool disabled = getenv("XG_NO_OVERLAP") != nullptr;
     if (disabled) return nullptr;
     int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
     std::lock_guard<std::mutex> lk(mu);
-    XgAux& a = table[dev];
+    if (table.size() >= 256 && !table.count({dev, main})) return nullptr;     // bounded: no overlap for further streams
+    XgAux& a = table[{dev, main}];
     if (!a.ok) {
         if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
         for (int i = 0; i < XG_NEV; ++i)
@@ -45,7 +49,7 @@ struct Streams {
     int next = 0;
     bool forked = false;
     int dh_split_step = 0, dh_mark = -1;      // heads_bwd -> decoder_bwd_core hand-off (see heads_bwd)
-    explicit Streams(hipStream_t m) : main(m), aux(m), a(aux_for_current_device()) { if (a) aux = a->s; }
+    explicit Streams(hipStream_t m) : main(m), aux(m), a(aux_for(m)) { if (a) aux = a->s; }
     bool overlap() const { return a != nullptr; }
     // aux may start work that depends on everything enqueued on main so far
     int fork() {
@@ -420,6 +424,8 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
             k1b.job[0].seg[0] = seg_nt(s.xt, E, p.l1_i2h_w, E, E); k1b.job[0].bias[0] = p.l1_i2h_b;
             k1b.job[0].seg[1] = seg_nt(s.posg, R, p.l1_a2h_w, R, R); k1b.job[0].bias[1] = p.l1_a2h_b;
             k1b.job[0].seg[2] = seg_nt(s.h1, R, p.l1_h2h_w, R, R); k1b.job[0].bias[2] = p.l1_h2h_b;
+            // (cell 1 and the attention are independent given [p, pos'], but a fork/join pair of stream events per step
+            // costs more than the ~14 us it would hide: measured 64 -> 81 us per step.  One stream.)
             XG_TRY(xgk_skinny(st, k1b));
         }
         XG_TRY(xgk_attn_fwd(st, s.P, vproj, V, p.a2w_w, s.alpha, s.af, B, d.K, R, A));
@@ -777,9 +783,9 @@ extern "C" int xg_step_fwd(void* stream, const XgDims* d, const XgParams* p, con
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, R = d->R, E = d->E;
     const size_t BR = (size_t)B * R;
-    XG_TRY(xgk_embed_gather(st, p->embed_w, E, tokens, B, 1, 0, B, d->V, w.Xe, E));
-    // the step reads the OLD state while cell 1 already writes the new h1 in the same launch: work from a copy
-    if (hipMemcpyAsync(w.state_tmp, state, sizeof(float) * 4 * BR, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
+    // the step reads the OLD state while cell 1 already writes the new h1: work from a copy (same launch as the embedding rows)
+    if ((uintptr_t)state % 16) return XG_EINVAL;
+    XG_TRY(xgk_step_prep(st, p->embed_w, E, tokens, d->V, w.Xe, B, state, w.state_tmp, (int64_t)(4 * BR)));
     StepIO s{};
     s.xt = w.Xe; s.pos = pos_feats; s.gp = w.GP; s.posg = w.POSG; s.pre1 = nullptr; s.mask = xt_mask; s.ldm = 1;
     s.h1 = w.state_tmp; s.c1 = w.state_tmp + BR; s.h2 = w.state_tmp + 2 * BR; s.c2 = w.state_tmp + 3 * BR;

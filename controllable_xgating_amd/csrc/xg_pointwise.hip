@@ -252,6 +252,19 @@ __global__ void embed_gather_kernel(const float* table, int E, const int64_t* to
     const int64_t t = tok_at(tok, i, inner, s_inner, s_outer, V);
     for (int e = threadIdx.x; e < E; e += blockDim.x) out[(size_t)i * ldo + e] = table[(size_t)t * E + e];
 }
+// one launch in front of a stand-alone decoder step: embedding rows of the B tokens + a copy of the recurrent state
+__global__ void step_prep_kernel(const float* table, int E, const int64_t* tok, int V, float* xt, int B,
+                                 const float* state, float* state_copy, int64_t nstate) {
+    if ((int)blockIdx.x < B) {
+        const int i = blockIdx.x;
+        const int64_t t = tok_at(tok, i, B, 1, 0, V);
+        for (int e = threadIdx.x; e < E; e += blockDim.x) xt[(size_t)i * E + e] = table[(size_t)t * E + e];
+    } else {
+        const int64_t i = ((int64_t)(blockIdx.x - B) * blockDim.x + threadIdx.x) * 4;
+        if (i + 3 < nstate) *reinterpret_cast<float4*>(state_copy + i) = *reinterpret_cast<const float4*>(state + i);
+        else for (int64_t j = i; j < nstate; ++j) state_copy[j] = state[j];
+    }
+}
 __global__ void embed_scatter_kernel(float* dtable, int E, const int64_t* tok, int inner, int64_t s_inner,
                                      int64_t s_outer, int V, const float* dX, int ldx) {
     const int i = blockIdx.x;
@@ -379,6 +392,14 @@ int xgk_embed_gather(hipStream_t st, const float* table, int E, const int64_t* t
                      int64_t s_outer, int n, int V, float* out, int ldo) {
     if (n <= 0) return XG_OK;
     hipLaunchKernelGGL(embed_gather_kernel, dim3(n), dim3(128), 0, st, table, E, tok, inner, s_inner, s_outer, V, out, ldo);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_step_prep(hipStream_t st, const float* table, int E, const int64_t* tok, int V, float* xt, int B,
+                  const float* state, float* state_copy, int64_t nstate) {
+    if (((uintptr_t)state % 16) || ((uintptr_t)state_copy % 16)) return XG_EINVAL;
+    const int nb = B + (int)xg_cdiv64(nstate, 4 * 128);
+    hipLaunchKernelGGL(step_prep_kernel, dim3(nb), dim3(128), 0, st, table, E, tok, V, xt, B, state, state_copy, nstate);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }

@@ -22,7 +22,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-constexpr int SKW = 8;            // waves per workgroup (K split)
+#ifndef SK_WAVES
+#define SK_WAVES 8
+#endif
+constexpr int SKW = SK_WAVES;     // waves per workgroup (K split)
 constexpr int SKT = SKW * 64;     // threads
 constexpr int CK = 32;            // k-chunk depth staged per wave
 constexpr int LDR = CK + 4;       // LDS row stride (floats): 9 16-B slots -> conflict-free b128 fragment reads
@@ -66,8 +69,16 @@ __device__ __forceinline__ void st_chunk(float* __restrict__ lds, int lane, cons
         *reinterpret_cast<f32x4*>(lds + (i * 8 + (lane >> 3)) * LDR + ((lane & 7) << 2)) = v[i];
 }
 
+#ifdef SK_TRACE
+__device__ long long sk_trace_buf[4096 * 8];
+#define SK_STAMP(i) do { if (threadIdx.x == 0) sk_trace_buf[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define SK_STAMP(i) do {} while (0)
+#endif
+
 template <bool VEC>
 __global__ void __launch_bounds__(SKT) sk_kernel(SkArgs args) {
+    SK_STAMP(0);
     // wave-private staging (A chunk + B chunk per wave), re-used as the [SKW][32][32] reduction buffer
     __shared__ __attribute__((aligned(16))) float smem[SKW * 2 * OPF];
     float (*red)[32][32] = reinterpret_cast<float (*)[32][32]>(smem);
@@ -156,11 +167,13 @@ __global__ void __launch_bounds__(SKT) sk_kernel(SkArgs args) {
         const int va = ktail - lcol;                         // k-contig: valid floats from the piece start
         const int vb = bn ? ktail - lrow : ktail - lcol;     // n-contig: valid k rows below this piece's row
         f32x4 ra[4], rb[4];
+        if (s == 0) SK_STAMP(1);
         ld_chunk<VEC>(pa, c0, c0 >= nfull, va, 0, ra);
         ld_chunk<VEC>(pb, c0, c0 >= nfull, vb, bn ? 8 : 0, rb);
         for (int c = c0; c < c1; ++c) {
             st_chunk(As, lane, ra);
             st_chunk(Bs, lane, rb);
+            if (s == 0 && c == c0) SK_STAMP(2);
 #ifndef SK_NO_LOAD
             if (c + 1 < c1) {   // next chunk's global loads fly while this chunk's MFMAs run
                 ld_chunk<VEC>(pa, c + 1, c + 1 >= nfull, va, 0, ra);
@@ -190,11 +203,13 @@ __global__ void __launch_bounds__(SKT) sk_kernel(SkArgs args) {
             __builtin_amdgcn_wave_barrier();
         }
     }
+    SK_STAMP(3);
     __syncthreads();   // every wave is done with its staging area before it becomes the reduction buffer
     // ---- reduce the SKW partial tiles through LDS
 #pragma unroll
     for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[r];
     __syncthreads();
+    SK_STAMP(4);
 
     if (job.epi == SK_EPI_STORE) {
 #pragma unroll
@@ -268,6 +283,7 @@ __global__ void __launch_bounds__(SKT) sk_kernel(SkArgs args) {
             job.h_out[(size_t)b * job.ldho + j] = hn;
         }
     }
+    SK_STAMP(5);
 }
 
 }  // namespace

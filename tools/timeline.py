@@ -1,0 +1,68 @@
+#!/usr/bin/env python3
+"""Text timeline of ONE training iteration from a rocprofv3 --kernel-trace csv: which kernels ran on which HIP
+stream (queue), when, and how much of the iteration each stream / the GPU was busy.  Iterations are delimited by
+clip_adam_kernel.   usage: timeline.py <dir with *_kernel_trace.csv> [iteration index from the end, default 1]"""
+import csv
+import glob
+import sys
+
+
+def short(n):
+    return n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:40]
+
+
+def union(iv):
+    iv = sorted(iv)
+    tot, cur_s, cur_e = 0, None, None
+    for s, e in iv:
+        if cur_e is None or s > cur_e:
+            if cur_e is not None:
+                tot += cur_e - cur_s
+            cur_s, cur_e = s, e
+        else:
+            cur_e = max(cur_e, e)
+    if cur_e is not None:
+        tot += cur_e - cur_s
+    return tot
+
+
+def main():
+    d = sys.argv[1]
+    back = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    f = glob.glob(d + "/**/*_kernel_trace.csv", recursive=True)[0]
+    rows = [dict(name=short(r["Kernel_Name"]), q=r.get("Queue_Id", "0"), s=int(r["Start_Timestamp"]), e=int(r["End_Timestamp"]))
+            for r in csv.DictReader(open(f))]
+    rows.sort(key=lambda r: r["s"])
+    adam = [i for i, r in enumerate(rows) if r["name"].startswith("clip_adam")]
+    lo, hi = adam[-back - 1] + 1, adam[-back] + 1
+    it = rows[lo:hi]
+    t0, t1 = it[0]["s"], max(r["e"] for r in it)
+    qs = sorted({r["q"] for r in it}, key=lambda q: -sum(r["e"] - r["s"] for r in it if r["q"] == q))
+    print("iteration span %.3f ms, %d kernels, queues %s" % ((t1 - t0) / 1e6, len(it), qs))
+    for q in qs:
+        iv = [(r["s"], r["e"]) for r in it if r["q"] == q]
+        print("  queue %s: %d kernels, busy %.3f ms" % (q, len(iv), union(iv) / 1e6))
+    print("  GPU busy (union) %.3f ms; both-streams-busy %.3f ms" % (
+        union([(r["s"], r["e"]) for r in it]) / 1e6,
+        (sum(union([(r["s"], r["e"]) for r in it if r["q"] == q]) for q in qs) - union([(r["s"], r["e"]) for r in it])) / 1e6))
+    # merged runs per queue
+    print("\n%9s %9s %5s  %-3s %s" % ("start_us", "dur_us", "n", "q", "kernels"))
+    runs = []
+    for q in qs:
+        cur = None
+        for r in (r for r in it if r["q"] == q):
+            key = r["name"]
+            if cur and (key in cur["names"] or len(cur["names"]) < 6) and r["s"] - cur["e"] < 30000 and cur["n"] < 400 and \
+                    (key in cur["names"] or cur["n"] < 6 * 1):
+                cur["names"].setdefault(key, 0); cur["names"][key] += 1; cur["e"] = max(cur["e"], r["e"]); cur["n"] += 1
+                cur["busy"] += r["e"] - r["s"]
+            else:
+                cur = dict(q=q, s=r["s"], e=r["e"], n=1, names={key: 1}, busy=r["e"] - r["s"])
+                runs.append(cur)
+    for r in sorted(runs, key=lambda r: r["s"]):
+        print("%9.1f %9.1f %5d  %-3s %s" % ((r["s"] - t0) / 1e3, (r["e"] - r["s"]) / 1e3, r["n"], qs.index(r["q"]),
+                                            ", ".join("%s x%d" % kv for kv in r["names"].items())))
+
+
+if __name__ == "__main__":
+    main()

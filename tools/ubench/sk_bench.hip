@@ -11,9 +11,14 @@ static float* dalloc(size_t n, float v) {
 int main() {
     const int B = 128, R = 512, A = 1536;
     float *h1 = dalloc(B * R, 0.01f), *af = dalloc(B * R, 0.02f), *h2 = dalloc(B * R, 0.03f);
-    float *W1 = dalloc(4 * R * R, 0.001f), *W2 = dalloc(4 * R * R, 0.001f), *W3 = dalloc(4 * R * R, 0.001f);
+    // NSET rotating copies of the weights: consecutive launches never find their weights in L2 (as in the model)
+    const int NSET = 8;
+    float *W1s[NSET], *W2s[NSET], *W3s[NSET], *Was[NSET];
+    for (int q = 0; q < NSET; ++q) { W1s[q] = dalloc(4 * R * R, 0.001f); W2s[q] = dalloc(4 * R * R, 0.001f); W3s[q] = dalloc(4 * R * R, 0.001f); Was[q] = dalloc((size_t)A * 2 * R, 0.001f); }
+    float *W1 = W1s[0], *W2 = W2s[0], *W3 = W3s[0];
+    int rot = 0;
     float *b = dalloc(4 * R, 0.f), *c = dalloc(B * R, 0.1f), *co = dalloc(B * R, 0), *ho = dalloc(B * R, 0), *g = dalloc(B * 4 * R, 0);
-    float *Wa = dalloc((size_t)A * 2 * R, 0.001f), *P = dalloc(B * A, 0), *ds = dalloc(B * 4 * R, 0.01f), *dx = dalloc(B * R, 0);
+    float *Wa = Was[0], *P = dalloc(B * A, 0), *ds = dalloc(B * 4 * R, 0.01f), *dx = dalloc(B * R, 0);
     XgRun run{}; run.train = 0;
     auto cell2 = [&]() {
         SkArgs k{}; k.njobs = 1;
@@ -46,11 +51,29 @@ int main() {
     for (int which = 0; which < 3; ++which) {
         for (int it = 0; it < 3; ++it) {
             hipEventRecord(e0);
-            for (int r = 0; r < 1000; ++r) { if (which == 0) cell2(); else if (which == 1) pjob(); else nn(); }
+            for (int r = 0; r < 1000; ++r) { rot = (rot + 1) % NSET; W1 = W1s[rot]; W2 = W2s[rot]; W3 = W3s[rot]; Wa = Was[rot]; if (which == 0) cell2(); else if (which == 1) pjob(); else nn(); }
             hipEventRecord(e1); hipEventSynchronize(e1);
             float ms; hipEventElapsedTime(&ms, e0, e1);
             if (it == 2) printf("%-45s %.2f us/launch\n", names[which], ms * 1e3 / 1000);
         }
     }
+#ifdef SK_TRACE
+    for (int which = 0; which < 3; ++which) {
+        hipDeviceSynchronize();
+        for (int r = 0; r < 5; ++r) { rot = (rot + 1) % NSET; W1 = W1s[rot]; W2 = W2s[rot]; W3 = W3s[rot]; Wa = Was[rot]; if (which == 0) cell2(); else if (which == 1) pjob(); else nn(); }
+        hipDeviceSynchronize();
+        static long long h[4096 * 8];
+        hipMemcpyFromSymbol(h, HIP_SYMBOL(sk_trace_buf), sizeof(h));
+        const int nwg = which == 0 ? 256 : 192;
+        long long t0 = h[0], t5 = 0;
+        for (int w = 0; w < nwg; ++w) { if (h[w * 8] < t0) t0 = h[w * 8]; if (h[w * 8 + 5] > t5) t5 = h[w * 8 + 5]; }
+        printf("%s: span first-entry -> last-exit %.2f us\n", names[which], (t5 - t0) * 0.01);
+        for (int w : {0, 1, 97, nwg - 1}) {
+            printf("   wg %3d: entry +%.2f | prologue %.2f | first chunk %.2f | k loop %.2f | reduce %.2f | epilogue %.2f\n", w, (h[w * 8] - t0) * 0.01,
+                   (h[w * 8 + 1] - h[w * 8]) * 0.01, (h[w * 8 + 2] - h[w * 8 + 1]) * 0.01, (h[w * 8 + 3] - h[w * 8 + 2]) * 0.01,
+                   (h[w * 8 + 4] - h[w * 8 + 3]) * 0.01, (h[w * 8 + 5] - h[w * 8 + 4]) * 0.01);
+        }
+    }
+#endif
     return 0;
 }
