@@ -276,11 +276,26 @@ __global__ void __launch_bounds__(FT) attn_bwd_fast(const float* __restrict__ da
                                                      const float* __restrict__ vproj, const float* __restrict__ V,
                                                      const float* __restrict__ w, const float* __restrict__ alpha,
                                                      float* __restrict__ de, float* __restrict__ dp, int K, int R, int A) {
-    extern __shared__ float sm[];                     // dalpha[K] then de[K]
+    extern __shared__ float sm[];                     // dalpha[K]
+    AT_STAMP(0);
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* qb = vproj + (size_t)b * K * A;
     const float* Vb = V + (size_t)b * K * R;
     const float* dafb = daf + (size_t)b * lddaf;
+    // first needed, first requested: the dalpha operands of this wave's rows (k = wave, wave + 16, ...; R <= 1024 here)
+    constexpr int DR = 2, DC = 4;                     // rows per wave, float4 chunks per row held in registers
+    float4 dv[DC], vv[DR][DC];
+#pragma unroll
+    for (int c = 0; c < DC; ++c) {
+        const int r = lane * 4 + 256 * c;
+        dv[c] = r < R ? *reinterpret_cast<const float4*>(dafb + r) : make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < DR; ++j) {
+            const int k = wave + j * FW;
+            vv[j][c] = (r < R && k < K) ? *reinterpret_cast<const float4*>(Vb + (size_t)k * R + r) : make_float4(0, 0, 0, 0);
+        }
+    }
+    const float al_lane = lane < K ? alpha[(size_t)b * K + lane] : 0.f;
     // thread -> two consecutive attention columns; all K rows of q for them go to registers up front
     const int a0 = tid * 2;
     const bool a_ok = a0 < A;
@@ -289,7 +304,18 @@ __global__ void __launch_bounds__(FT) attn_bwd_fast(const float* __restrict__ da
     for (int k = 0; k < NQ; ++k) q[k] = (a_ok && k < K) ? *reinterpret_cast<const float2*>(qb + (size_t)k * A + a0) : make_float2(0, 0);
     const float2 pa = a_ok ? *reinterpret_cast<const float2*>(p + (size_t)b * A + a0) : make_float2(0, 0);
     const float2 wa = a_ok ? *reinterpret_cast<const float2*>(w + a0) : make_float2(0, 0);
-    for (int k = wave; k < K; k += FW) {
+    AT_STAMP(1);
+#pragma unroll
+    for (int j = 0; j < DR; ++j) {
+        const int k = wave + j * FW;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < DC; ++c)
+            acc += dv[c].x * vv[j][c].x + dv[c].y * vv[j][c].y + dv[c].z * vv[j][c].z + dv[c].w * vv[j][c].w;
+        acc = wave_sum(acc);
+        if (lane == 0 && k < K) sm[k] = acc;
+    }
+    for (int k = wave + DR * FW; k < K; k += FW) {    // K > 32: remaining rows the slow way
         float acc = 0.f;
         for (int r = lane * 4; r < R; r += 256) {
             const float4 d4 = *reinterpret_cast<const float4*>(dafb + r);
@@ -299,22 +325,21 @@ __global__ void __launch_bounds__(FT) attn_bwd_fast(const float* __restrict__ da
         acc = wave_sum(acc);
         if (lane == 0) sm[k] = acc;
     }
+    AT_STAMP(2);
     __syncthreads();
-    float dot = 0.f;
-    for (int k = 0; k < K; ++k) dot += alpha[(size_t)b * K + k] * sm[k];
-    __syncthreads();
-    if (tid < K) {
-        const float d = alpha[(size_t)b * K + tid] * (sm[tid] - dot);
-        sm[tid] = d;
-        de[(size_t)b * K + tid] = d;
-    }
-    __syncthreads();
+    AT_STAMP(3);
+    // softmax backward once per wave, lane k holding row k:  de_k = alpha_k (dalpha_k - sum_j alpha_j dalpha_j)
+    const float da = lane < K ? sm[lane] : 0.f;
+    const float dot = wave_sum(al_lane * da);
+    const float d_lane = al_lane * (da - dot);
+    if (wave == 0 && lane < K) de[(size_t)b * K + lane] = d_lane;
+    AT_STAMP(4);
     if (a_ok) {
         float sx = 0.f, sy = 0.f;
 #pragma unroll
         for (int k = 0; k < NQ; ++k) {
             if (k < K) {
-                const float dk = sm[k];
+                const float dk = xg_readlane(d_lane, k);
                 const float tx = xg_tanh(pa.x + q[k].x), ty = xg_tanh(pa.y + q[k].y);
                 sx += dk * (1.0f - tx * tx);
                 sy += dk * (1.0f - ty * ty);
@@ -322,6 +347,7 @@ __global__ void __launch_bounds__(FT) attn_bwd_fast(const float* __restrict__ da
         }
         *reinterpret_cast<float2*>(dp + (size_t)b * A + a0) = make_float2(sx * wa.x, sy * wa.y);
     }
+    AT_STAMP(5);
 }
 
 }  // namespace
@@ -355,7 +381,7 @@ int xgk_attn_bwd(hipStream_t st, const float* daf, int lddaf, const float* p, co
     if (K > 8192) return XG_EINVAL;
     const bool al16 = ((uintptr_t)p % 16 == 0) && ((uintptr_t)vproj % 16 == 0) && ((uintptr_t)V % 16 == 0) &&
                       ((uintptr_t)w % 16 == 0) && ((uintptr_t)daf % 16 == 0) && ((uintptr_t)dp % 16 == 0);
-    if (al16 && A % 4 == 0 && A <= 2 * FT && R % 4 == 0 && lddaf % 4 == 0 && K <= 48) {
+    if (al16 && A % 4 == 0 && A <= 2 * FT && R % 4 == 0 && R <= 1024 && lddaf % 4 == 0 && K <= 48) {
         const size_t lds = (size_t)K * sizeof(float);
         if (K <= 16) hipLaunchKernelGGL((attn_bwd_fast<16>), dim3(B), dim3(FT), lds, st, daf, lddaf, p, vproj, V, w, alpha, de, dp, K, R, A);
         else if (K <= 32) hipLaunchKernelGGL((attn_bwd_fast<32>), dim3(B), dim3(FT), lds, st, daf, lddaf, p, vproj, V, w, alpha, de, dp, K, R, A);

@@ -30,5 +30,23 @@ int main() {
         printf("  wg %3d: entry +%.2f | issue V/p/w loads %.2f | score rounds %.2f | barrier %.2f | softmax+context %.2f | reduce+store %.2f\n", b,
                (h[b * 8] - t0) * 0.01, (h[b * 8 + 1] - h[b * 8]) * 0.01, (h[b * 8 + 2] - h[b * 8 + 1]) * 0.01, (h[b * 8 + 3] - h[b * 8 + 2]) * 0.01,
                (h[b * 8 + 4] - h[b * 8 + 3]) * 0.01, (h[b * 8 + 5] - h[b * 8 + 4]) * 0.01);
+    float *daf = dalloc(B * R, 0.01f), *de = dalloc(B * K, 0), *dp = dalloc((size_t)B * A, 0);
+    { std::vector<float> ha(B * K, 1.0f / K); (void)hipMemcpy(alpha, ha.data(), ha.size() * 4, hipMemcpyHostToDevice); }
+    for (int it = 0; it < 3; ++it) {
+        (void)hipEventRecord(e0);
+        for (int r = 0; r < 1000; ++r) xgk_attn_bwd(0, daf, R, P[r % NSET], VP[r % NSET], V[r % NSET], w, alpha, de, dp, B, K, R, A);
+        (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+        float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+        if (it == 2) printf("attn_bwd B=128 K=26 A=1536: %.2f us/launch\n", ms);
+    }
+    (void)hipDeviceSynchronize();
+    (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(attn_trace_buf), sizeof(h));
+    t0 = h[0]; t5 = 0;
+    for (int b = 0; b < B; ++b) { if (h[b * 8] < t0) t0 = h[b * 8]; if (h[b * 8 + 5] > t5) t5 = h[b * 8 + 5]; }
+    printf("span first-entry -> last-exit %.2f us\n", (t5 - t0) * 0.01);
+    for (int b : {0, 1, 63, 127})
+        printf("  wg %3d: entry +%.2f | issue loads %.2f | dalpha %.2f | barrier %.2f | softmax bwd %.2f | dp (tanh) %.2f\n", b,
+               (h[b * 8] - t0) * 0.01, (h[b * 8 + 1] - h[b * 8]) * 0.01, (h[b * 8 + 2] - h[b * 8 + 1]) * 0.01, (h[b * 8 + 3] - h[b * 8 + 2]) * 0.01,
+               (h[b * 8 + 4] - h[b * 8 + 3]) * 0.01, (h[b * 8 + 5] - h[b * 8 + 4]) * 0.01);
     return 0;
 }
