@@ -88,7 +88,7 @@ struct Ws {
     // ---- decoder
     float *vbar, *vproj, *Xe, *GP, *POSG, *PRE1, *H1, *C1, *H2, *C2, *G1, *G2, *P, *ALPHA, *AF;
     float *LOGITS, *HC, *CL, *LSE, *LSEC, *sums;   // sums: 8 floats
-    float *DH2OUT, *DHC, *DCL, *DS1, *DS2, *DP, *DE, *DAF, *dst[2][4], *DVPROJ, *DV, *DPOSG, *DGP, *DXe;
+    float *DH2OUT, *DHC, *DCL, *DS1, *DS2, *DP, *DE, *DAF, *dst[2][4], *DVPROJ, *DV, *DPOSG, *DGP, *DXe, *DH1X;
     float *state_tmp;
     // ---- rollout
     int64_t* TOK; float *TOKLP, *UNF; int32_t* alive;
@@ -136,7 +136,7 @@ Ws carve(const XgDims& d, void* base) {
     w.DS1 = c.take<float>(TB * 4 * R); w.DS2 = c.take<float>(TB * 4 * R); w.DP = c.take<float>(TB * A);
     w.DE = c.take<float>(TB * K); w.DAF = c.take<float>(TB * R);
     for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) w.dst[i][j] = c.take<float>(B * R);
-    w.DVPROJ = c.take<float>(N * A); w.DV = c.take<float>(N * R); w.DPOSG = c.take<float>(TB * R);
+    w.DVPROJ = c.take<float>(N * A); w.DV = c.take<float>(N * R); w.DPOSG = c.take<float>(TB * R); w.DH1X = c.take<float>(TB * R);
     w.DGP = c.take<float>(TB * R); w.DXe = c.take<float>(TB * E);
     w.state_tmp = c.take<float>(4 * B * R);
     w.TOK = c.take<int64_t>(TB); w.TOKLP = c.take<float>(TB); w.UNF = c.take<float>(TB);
@@ -530,13 +530,17 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     const int B = d.B, K = d.K, R = d.R, A = d.A, E = d.E, T = d.T, TB = T * B, N = B * K;
     (void)TB;
     const size_t BR = (size_t)B * R;
+    // The reverse-time recurrence splits into two chains.  Chain 2 (cell 2 + attention: dh2, dc2) never reads anything
+    // chain 1 (cell 1: dh1, dc1) produces, and only chain 2's products (dAF, dE) feed the encoder backward: it runs alone
+    // on the main stream, 4 launches per step.  What it hands to cell 1 -- ds2 W_i2h and dp W_h2a[:, :R] -- is batched over
+    // all steps afterwards (two GEMMs), and chain 1 (2 launches per step) runs on the auxiliary stream under the
+    // encoder backward; its results only feed parameter gradients.
     int cur = 0;
     for (int j = 0; j < 4; ++j) ZERO(w.dst[0][j], BR);
     for (int t = T - 1; t >= 0; --t) {
         if (t == ss.dh_split_step - 1) XG_TRY(ss.wait_mark(ss.dh_mark));   // dH of the early steps (auxiliary stream)
-        float *dh1n = w.dst[cur][0], *dc1n = w.dst[cur][1], *dh2n = w.dst[cur][2], *dc2n = w.dst[cur][3];
-        float *dh1p = w.dst[cur ^ 1][0], *dc1p = w.dst[cur ^ 1][1], *dh2p = w.dst[cur ^ 1][2], *dc2p = w.dst[cur ^ 1][3];
-        float* ds1 = w.DS1 + (size_t)t * B * 4 * R;
+        float *dh2n = w.dst[cur][2], *dc2n = w.dst[cur][3];
+        float *dh2p = w.dst[cur ^ 1][2], *dc2p = w.dst[cur ^ 1][3];
         float* ds2 = w.DS2 + (size_t)t * B * 4 * R;
         float* dp = w.DP + (size_t)t * B * A;
         float* daf = w.DAF + t * BR;
@@ -550,48 +554,63 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         a.B = B; a.R = R; a.order = XG_ORDER_IFOG; a.mask_mode = XG_MASK_HOLD;
         a.drop = xg_make_drop(&run, XG_SITE_L2, t);
         XG_TRY(xgk_lstm_bwd(st, a));
-        {   // s2 = h1' Wi + af Wa + h2 Wh : three data gradients, one launch
+        {   // s2 = h1' Wi + af Wa + h2 Wh : the two data gradients chain 2 needs now
             SkArgs sk{};
-            sk.njobs = 3;
-            sk.job[0] = job_store(B, R, dh1n, R, true);  sk.job[0].nseg = 1; sk.job[0].seg[0] = seg_nn(ds2, 4 * R, p.l2_i2h_w, R, 4 * R);
-            sk.job[1] = job_store(B, R, daf, R, false);  sk.job[1].nseg = 1; sk.job[1].seg[0] = seg_nn(ds2, 4 * R, p.l2_a2h_w, R, 4 * R);
-            sk.job[2] = job_store(B, R, dh2p, R, true);  sk.job[2].nseg = 1; sk.job[2].seg[0] = seg_nn(ds2, 4 * R, p.l2_h2h_w, R, 4 * R);
+            sk.njobs = 2;
+            sk.job[0] = job_store(B, R, daf, R, false);  sk.job[0].nseg = 1; sk.job[0].seg[0] = seg_nn(ds2, 4 * R, p.l2_a2h_w, R, 4 * R);
+            sk.job[1] = job_store(B, R, dh2p, R, true);  sk.job[1].nseg = 1; sk.job[1].seg[0] = seg_nn(ds2, 4 * R, p.l2_h2h_w, R, 4 * R);
             XG_TRY(xgk_skinny(st, sk));
         }
         XG_TRY(xgk_attn_bwd(st, daf, R, w.P + (size_t)t * B * A, w.vproj, w.Venc, p.a2w_w, w.ALPHA + (size_t)t * B * K,
                             w.DE + (size_t)t * B * K, dp, B, K, R, A));
-        LstmBwdArgs c{};
-        c.gates = w.G1 + (size_t)t * B * 4 * R; c.ldg = 4 * R;
-        c.c_prev = w.C1 + t * BR; c.ldcp = R; c.c_out = w.C1 + (t + 1) * BR; c.ldco = R;
-        c.mask = mk; c.ldm = ldm; c.dh_out = dh1n; c.lddh = R; c.dc_out = dc1n; c.lddc = R;
-        c.ds = ds1; c.ldds = 4 * R; c.dc_prev = dc1p; c.lddcp = R; c.dh_prev = dh1p; c.lddhp = R;
-        c.B = B; c.R = R; c.order = XG_ORDER_IFOG; c.mask_mode = XG_MASK_HOLD;
-        c.drop = xg_make_drop(&run, XG_SITE_L1, t);
-        XG_TRY(xgk_lstm_bwd(st, c));
-        {   // into step t-1: dh1 += ds1 Wh1 + dp Wh2a[:, :R] ; dh2 += dp Wh2a[:, R:]
+        {   // into step t-1: dh2 += dp Wh2a[:, R:]
             SkArgs sk{};
-            sk.njobs = 2;
-            sk.job[0] = job_store(B, R, dh1p, R, true);
-            sk.job[0].nseg = 2;
-            sk.job[0].seg[0] = seg_nn(ds1, 4 * R, p.l1_h2h_w, R, 4 * R);
-            sk.job[0].seg[1] = seg_nn(dp, A, p.h2a_w, 2 * R, A);
-            sk.job[1] = job_store(B, R, dh2p, R, true);
-            sk.job[1].nseg = 1;
-            sk.job[1].seg[0] = seg_nn(dp, A, p.h2a_w + R, 2 * R, A);
+            sk.njobs = 1;
+            sk.job[0] = job_store(B, R, dh2p, R, true);
+            sk.job[0].nseg = 1;
+            sk.job[0].seg[0] = seg_nn(dp, A, p.h2a_w + R, 2 * R, A);
             XG_TRY(xgk_skinny(st, sk));
         }
         cur ^= 1;
     }
+    const int cur2 = cur;
+    XG_TRY(ss.fork());                        // chain 2 is complete: DS2, DP, DAF, DE
+    hipStream_t sx = ss.aux;
+    // what cell 1's output receives from chain 2, all steps at once:  DH1X[t] = ds2[t] W_i2h2 + dp[t+1] W_h2a[:, :R]
+    XG_TRY(gemm_nn(sx, TB, R, 4 * R, w.DS2, 4 * R, p.l2_i2h_w, R, w.DH1X, R, false));
+    if (T > 1) XG_TRY(gemm_nn(sx, (T - 1) * B, R, A, w.DP + (size_t)B * A, A, p.h2a_w, 2 * R, w.DH1X, R, true));
+    int cur1 = 0;
+    for (int t = T - 1; t >= 0; --t) {
+        float *dh1n = w.dst[cur1][0], *dc1n = w.dst[cur1][1];
+        float *dh1p = w.dst[cur1 ^ 1][0], *dc1p = w.dst[cur1 ^ 1][1];
+        float* ds1 = w.DS1 + (size_t)t * B * 4 * R;
+        LstmBwdArgs c{};
+        c.gates = w.G1 + (size_t)t * B * 4 * R; c.ldg = 4 * R;
+        c.c_prev = w.C1 + t * BR; c.ldcp = R; c.c_out = w.C1 + (t + 1) * BR; c.ldco = R;
+        c.mask = mask + (size_t)t * mask_tstride; c.ldm = ldm;
+        c.dh_out = dh1n; c.lddh = R; c.dh_add = w.DH1X + t * BR; c.lddha = R; c.dc_out = dc1n; c.lddc = R;
+        c.ds = ds1; c.ldds = 4 * R; c.dc_prev = dc1p; c.lddcp = R; c.dh_prev = dh1p; c.lddhp = R;
+        c.B = B; c.R = R; c.order = XG_ORDER_IFOG; c.mask_mode = XG_MASK_HOLD;
+        c.drop = xg_make_drop(&run, XG_SITE_L1, t);
+        XG_TRY(xgk_lstm_bwd(sx, c));
+        SkArgs sk{};
+        sk.njobs = 1;
+        sk.job[0] = job_store(B, R, dh1p, R, true);
+        sk.job[0].nseg = 1;
+        sk.job[0].seg[0] = seg_nn(ds1, 4 * R, p.l1_h2h_w, R, 4 * R);
+        XG_TRY(xgk_skinny(sx, sk));
+        cur1 ^= 1;
+    }
+    // the attention query of step 0 read the INITIAL h1
+    XG_TRY(gemm_nn(sx, B, R, A, w.DP, A, p.h2a_w, 2 * R, w.dst[cur1][0], R, true));
     // ---- after the loop.  Main chain (the encoder backward waits for it): dVproj -> dV.  Everything else is a
     // parameter gradient and goes to the auxiliary stream, under the encoder's recurrent backward.
-    XG_TRY(ss.fork());
-    hipStream_t sx = ss.aux;
     XG_TRY(xgk_attn_bwd_post(st, w.P, w.vproj, p.a2w_w, w.DE, w.DVPROJ, g.a2w_w, T, B, K, A));
     XG_TRY(gemm_nn(st, N, R, A, w.DVPROJ, A, p.v2a_w, R, w.DV, R, false));
     XG_TRY(xgk_attn_dV(st, w.ALPHA, w.DAF, R, (int64_t)BR, w.DV, T, B, K, R, true));
     // gradients wrt the initial state -> img_embed_* (init_hidden; vbar is detached: SAModel.py:59-62)
     {
-        float* gst[4] = {w.dst[cur][0], w.dst[cur][1], w.dst[cur][2], w.dst[cur][3]};
+        float* gst[4] = {w.dst[cur1][0], w.dst[cur1][1], w.dst[cur2][2], w.dst[cur2][3]};
         float* gw[4] = {g.ih1_w, g.ic1_w, g.ih2_w, g.ic2_w};
         float* gb[4] = {g.ih1_b, g.ic1_b, g.ih2_b, g.ic2_b};
         for (int j = 0; j < 4; ++j) {

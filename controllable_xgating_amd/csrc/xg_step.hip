@@ -107,25 +107,28 @@ __global__ void __launch_bounds__(SKT) sk_kernel(SkArgs args) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    // ---- LSTM epilogue operands are requested NOW so their (cold-L2) latency hides under the K loop
-    float e_b[4] = {0.f, 0.f, 0.f, 0.f}, e_cp = 0.f, e_hp = 0.f, e_mk = 1.f;
+    // ---- LSTM epilogue operands are requested NOW so their (cold-L2) latency hides under the K loop.  Every load is
+    // unconditional (absent operands read a valid dummy address and are dropped by a select in the epilogue): a load
+    // under a branch makes the compiler wait for it on the spot, and 19 serialized L2 round trips were 2 us of prologue.
+    float e_b0[4], e_b1[4], e_b2[4], e_ad[4], e_cp = 0.f, e_hp = 0.f, e_mk = 1.f;
     const int em = threadIdx.x >> 3, eu = threadIdx.x & 7;
     const int eb = m0 + em, ej = tn * 8 + eu;
     const bool e_on = lstm && threadIdx.x < 256 && eb < job.M && ej < R;
     if (e_on) {
+        const float* dummy = job.c_prev + (size_t)eb * job.ldcp + ej;
+        const float* mkp = job.mask ? job.mask + (size_t)eb * job.ldm : dummy;
+        const float* hpp = job.mask_mode == XG_MASK_HOLD ? job.h_prev + (size_t)eb * job.ldhp + ej : dummy;
 #pragma unroll
         for (int gi = 0; gi < 4; ++gi) {
             const int col = gi * R + ej;
-            float v = 0.f;
-            if (job.bias[0]) v += job.bias[0][col];
-            if (job.bias[1]) v += job.bias[1][col];
-            if (job.bias[2]) v += job.bias[2][col];
-            if (job.add) v += job.add[(size_t)eb * job.ldadd + col];
-            e_b[gi] = v;
+            e_b0[gi] = *(job.bias[0] ? job.bias[0] + col : dummy);
+            e_b1[gi] = *(job.bias[1] ? job.bias[1] + col : dummy);
+            e_b2[gi] = *(job.bias[2] ? job.bias[2] + col : dummy);
+            e_ad[gi] = *(job.add ? job.add + (size_t)eb * job.ldadd + col : dummy);
         }
-        e_cp = job.c_prev[(size_t)eb * job.ldcp + ej];
-        if (job.mask) e_mk = job.mask[(size_t)eb * job.ldm];
-        if (job.mask_mode == XG_MASK_HOLD) e_hp = job.h_prev[(size_t)eb * job.ldhp + ej];
+        e_cp = *dummy;
+        e_mk = *mkp;
+        e_hp = *hpp;
     }
 
     // ---- K loop: this wave's share of the 32-deep chunks of every segment
@@ -254,7 +257,8 @@ __global__ void __launch_bounds__(SKT) sk_kernel(SkArgs args) {
             float s4[4];
 #pragma unroll
             for (int gi = 0; gi < 4; ++gi) {
-                float v = e_b[gi];
+                float v = (job.bias[0] ? e_b0[gi] : 0.f) + (job.bias[1] ? e_b1[gi] : 0.f) + (job.bias[2] ? e_b2[gi] : 0.f) +
+                          (job.add ? e_ad[gi] : 0.f);
 #pragma unroll
                 for (int w = 0; w < SKW; ++w) v += red[w][em][gi * 8 + eu];
                 s4[gi] = v;
@@ -262,7 +266,7 @@ __global__ void __launch_bounds__(SKT) sk_kernel(SkArgs args) {
             const float so = job.order == XG_ORDER_IFOG ? s4[2] : s4[3];
             const float sg_ = job.order == XG_ORDER_IFOG ? s4[3] : s4[2];
             const float ig = xg_sigmoid(s4[0]), fg = xg_sigmoid(s4[1]), og = xg_sigmoid(so), gg = xg_tanh(sg_);
-            const float cp = e_cp, mk = e_mk;
+            const float cp = e_cp, mk = job.mask ? e_mk : 1.0f;
             float cn = fg * cp + ig * gg, hn;
             if (job.mask_mode == XG_MASK_HOLD) {
                 cn = cn * mk + cp * (1.0f - mk);

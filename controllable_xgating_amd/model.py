@@ -170,6 +170,11 @@ class SAModel(nn.Module):
     def _named(self):
         return dict(self.named_parameters())
 
+    def _param_list(self):
+        """Parameters in the C ABI's order (= state_dict order); one named_parameters() walk per call."""
+        named = self._named()
+        return [named[n] for n in nv.PARAM_NAMES]
+
     def _ensure_flat(self):
         """All parameters live in ONE flat fp32 buffer (one RCCL all-reduce, one Adam launch);
         the nn.Parameters are views into it.  Rebuilt if .cuda()/.to() replaced the storages."""
@@ -285,7 +290,7 @@ class SAModel(nn.Module):
         """SAModel.forward (SAModel.py:67-115): (m,K,F) x2, (m,K), (m,R), (m,T) int64, (m,T) ->
         log-probs (m,T,V) and category log-probs (m,T,C).  ss_prob must be 0 (scheduled sampling is
         SURVEY.md 8f-3, not built yet)."""
-        params = [self._named()[n] for n in nv.PARAM_NAMES]
+        params = self._param_list()
         save = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         if self.training and self.ss_prob > 0.0:                                 # scheduled sampling, SAModel.py:89-99
             T, B = seq.shape[1], seq.shape[0]
@@ -301,7 +306,7 @@ class SAModel(nn.Module):
         """Fused fast path: forward + LanguageModelCriterion (+ weight_class * ClassiferCriterion)
         without materialising the (m,T,V) log-prob tensor or its gradient
         (starttrain.py:125-129).  Returns the scalar loss tensor; .backward() works."""
-        params = [self._named()[n] for n in nv.PARAM_NAMES]
+        params = self._param_list()
         save = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         return _XELossFunction.apply(self, save, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, cap_classes,
                                      class_mask, float(weight_class), *params)
@@ -373,7 +378,7 @@ class SAModel(nn.Module):
         if forced is not None:
             mode = nv.XG_ROLLOUT_REPLAY
         need_grad = torch.is_grad_enabled() and mode != nv.XG_ROLLOUT_GREEDY and any(p.requires_grad for p in self.parameters())
-        params = [self._named()[n] for n in nv.PARAM_NAMES]
+        params = self._param_list()
         uniforms = opt.get("uniforms", None)
         bn_update = bool(opt.get("bn_update", True))
         seq, slp, n = _RolloutFunction.apply(self, feats_rgb, feats_opfl, feat_mask, pos_feats, mode, uniforms, forced,
