@@ -202,7 +202,7 @@ def main():
     def step_scst():
         optim.zero_grad()
         gen, slp, greedy = scst_rollouts(model, x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"],
-                                         overlap=os.environ.get("XG_NO_OVERLAP") is None)
+                                         mode=os.environ.get("XG_SCST_MODE"))
         loss = rl_crit(slp, gen, reward_b.expand(-1, gen.shape[1]))
         loss.backward()
         allreduce_gradients(model)

@@ -229,6 +229,7 @@ struct RollStepArgs {
     float* xt;                // (B,E) out
     float temperature;
     int V, E, t, T, mode;
+    int split;                // rows >= split of a SAMPLE rollout decode greedily and report into maxf[1] (paired SCST rollout)
 };
 
 __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
@@ -243,6 +244,9 @@ __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
         if (tid == 0) { a.tok[b] = 0; a.unf[b] = 1.0f; s_tok = 0; }
     } else {
         const float* x = a.logits + (size_t)b * a.V;
+        const bool second = b >= a.split;
+        const int mode = (second && a.mode == XG_ROLLOUT_SAMPLE) ? XG_ROLLOUT_GREEDY : a.mode;
+        int32_t* maxf = a.maxf + (second ? 1 : 0);
         // pass 1: row max (+ argmax, ties -> lowest index like torch.max) and sum exp for the log-sum-exp
         float best = -INFINITY; int bi = 0x7fffffff;
         for (int v = tid; v < a.V; v += RT) {
@@ -265,9 +269,9 @@ __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
         se = block_sum(se, red);
         const float lse = mx + logf(se);
         int64_t tk;
-        if (a.mode == XG_ROLLOUT_GREEDY) {
+        if (mode == XG_ROLLOUT_GREEDY) {
             tk = bi;
-        } else if (a.mode == XG_ROLLOUT_REPLAY) {
+        } else if (mode == XG_ROLLOUT_REPLAY) {
             tk = a.forced[(size_t)b * a.fstride];
             tk = tk < 0 ? 0 : (tk >= a.V ? a.V - 1 : tk);
         } else {
@@ -308,18 +312,18 @@ __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
             const float lp = x[tk] - lse;
             // unfinished &= it > 0 ; it *= unfinished ; append (:200-210)
             const float u = (a.t == 1 ? 1.0f : a.unf_prev[b]) * (tk > 0 ? 1.0f : 0.0f);
-            if (a.mode != XG_ROLLOUT_REPLAY) {
+            if (mode != XG_ROLLOUT_REPLAY) {
                 const bool was = a.t == 1 ? true : a.unf_prev[b] > 0.f;
-                if (was && u == 0.f) atomicMax(a.maxf, a.t);                 // this row finishes at step t
-                else if (u > 0.f && a.t == a.T - 1) atomicMax(a.maxf, a.T);  // never finished
+                if (was && u == 0.f) atomicMax(maxf, a.t);                 // this row finishes at step t
+                else if (u > 0.f && a.t == a.T - 1) atomicMax(maxf, a.T);  // never finished
             } else if (a.t == a.T - 1) {
-                atomicMax(a.maxf, a.T);
+                atomicMax(maxf, a.T);
             }
             a.unf[b] = u;
             a.lse[b] = lse;
             a.tok[b] = tk;                                                   // xt = embed(it) uses the raw draw (:198)
             a.tok_logp[b] = lp;
-            a.seq[(size_t)b * (a.T - 1) + (a.t - 1)] = a.mode == XG_ROLLOUT_REPLAY ? tk : (u > 0.f ? tk : 0);
+            a.seq[(size_t)b * (a.T - 1) + (a.t - 1)] = mode == XG_ROLLOUT_REPLAY ? tk : (u > 0.f ? tk : 0);
             a.seq_logp[(size_t)b * (a.T - 1) + (a.t - 1)] = lp;
             s_tok = tk;
         }
@@ -328,17 +332,25 @@ __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
     const int64_t tk = s_tok;
     for (int e = tid; e < a.E; e += RT) a.xt[(size_t)b * a.E + e] = a.table[(size_t)tk * a.E + e];
 }
-__global__ void rollout_finalize_kernel(const int32_t* maxf, int32_t* n_steps, int Tm1) {
-    const int m = maxf[0];                        // = max over rows of their finishing step, or T
-    n_steps[0] = m <= 0 ? Tm1 : (m - 1 < Tm1 ? m - 1 : Tm1);
+__global__ void rollout_finalize_kernel(const int32_t* maxf, int32_t* n_steps, int Tm1, int nparts) {
+    for (int i = 0; i < nparts; ++i) {
+        const int m = maxf[i];                    // = max over the part's rows of their finishing step, or T
+        n_steps[i] = m <= 0 ? Tm1 : (m - 1 < Tm1 ? m - 1 : Tm1);
+    }
 }
 // dlogits row b = d * (onehot(tok) - softmax(logits)) from raw logits + lse, in place
 __global__ void __launch_bounds__(RT) rollout_dlogits_lse_kernel(float* __restrict__ logits, const float* lse, const int64_t* tok,
-                                                                   const float* dslp, int64_t dstride, int V) {
-    const int b = blockIdx.x;
-    const float d = dslp[(size_t)b * dstride], l = lse[b];
-    const int64_t tk = tok[b];
-    float* x = logits + (size_t)b * V;
+                                                                   const float* dslp, int64_t dstride, int V, int B) {
+    // grid (B, steps): step y's rows are logits[y*B + b], lse[y*B + b], tok[y*B + b], dslp[b*dstride + y]
+    const int b = blockIdx.x, y = blockIdx.y;
+    const size_t row = (size_t)y * B + b;
+    const float d = dslp[(size_t)b * dstride + y], l = lse[row];
+    const int64_t tk = tok[row];
+    float* x = logits + row * V;
+    if (d == 0.f) {                                   // finished rows (RewardCriterion's mask): nothing to exponentiate
+        for (int v = threadIdx.x; v < V; v += RT) x[v] = 0.f;
+        return;
+    }
     for (int v = threadIdx.x; v < V; v += RT) x[v] = d * ((v == tk ? 1.f : 0.f) - expf(x[v] - l));
 }
 
@@ -453,21 +465,22 @@ int xgk_choose(hipStream_t st, const float* logp, int B, int V, int mode, const 
 int xgk_rollout_step(hipStream_t st, int B, const float* logits, const float* uniforms, const int64_t* forced,
                      int64_t fstride, const float* unf_prev, const float* table, int64_t* tok, float* tok_logp, float* unf,
                      float* lse, int64_t* seq, float* seq_logp, int32_t* maxf, float* xt, float temperature, int V, int E,
-                     int t, int T, int mode) {
+                     int t, int T, int mode, int split) {
     RollStepArgs a{logits, uniforms, forced, fstride, unf_prev, table, tok, tok_logp, unf, lse, seq, seq_logp, maxf, xt,
-                   temperature, V, E, t, T, mode};
+                   temperature, V, E, t, T, mode, split};
     hipLaunchKernelGGL(rollout_step_kernel, dim3(B), dim3(RT), 0, st, a);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
-int xgk_rollout_finalize(hipStream_t st, const int32_t* maxf, int32_t* n_steps, int Tm1) {
-    hipLaunchKernelGGL(rollout_finalize_kernel, dim3(1), dim3(1), 0, st, maxf, n_steps, Tm1);
+int xgk_rollout_finalize(hipStream_t st, const int32_t* maxf, int32_t* n_steps, int Tm1, int nparts) {
+    hipLaunchKernelGGL(rollout_finalize_kernel, dim3(1), dim3(1), 0, st, maxf, n_steps, Tm1, nparts);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
 int xgk_rollout_dlogits_lse(hipStream_t st, float* logits, const float* lse, const int64_t* tok, const float* dslp,
-                            int64_t dstride, int B, int V) {
-    hipLaunchKernelGGL(rollout_dlogits_lse_kernel, dim3(B), dim3(RT), 0, st, logits, lse, tok, dslp, dstride, V);
+                            int64_t dstride, int B, int V, int steps) {
+    if (steps <= 0) return XG_OK;
+    hipLaunchKernelGGL(rollout_dlogits_lse_kernel, dim3(B, steps), dim3(RT), 0, st, logits, lse, tok, dslp, dstride, V, B);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }

@@ -165,10 +165,16 @@ int xgk_choose(hipStream_t st, const float* logp, int B, int V, int mode, const 
 int xgk_rollout_step(hipStream_t st, int B, const float* logits, const float* uniforms, const int64_t* forced,
                      int64_t fstride, const float* unf_prev, const float* table, int64_t* tok, float* tok_logp, float* unf,
                      float* lse, int64_t* seq, float* seq_logp, int32_t* maxf, float* xt, float temperature, int V, int E,
-                     int t, int T, int mode);
-int xgk_rollout_finalize(hipStream_t st, const int32_t* maxf, int32_t* n_steps, int Tm1);
+                     int t, int T, int mode, int split);
+int xgk_rollout_finalize(hipStream_t st, const int32_t* maxf, int32_t* n_steps, int Tm1, int nparts);
+// all steps in one launch: rows (steps, B) of logits / lse / tok, dslp (B, dstride)
 int xgk_rollout_dlogits_lse(hipStream_t st, float* logits, const float* lse, const int64_t* tok, const float* dslp,
-                            int64_t dstride, int B, int V);
+                            int64_t dstride, int B, int V, int steps);
+// gather of row-block prefixes (xg_rollout_compact): entry e copies nblocks blocks of dst_block floats, source pitch src_pitch
+constexpr int XG_COMPACT_MAX = 48;
+struct CompactEntry { float* dst; const float* src; int64_t dst_block, src_pitch, total; };
+struct CompactArgs { int n; int start[XG_COMPACT_MAX + 1]; CompactEntry e[XG_COMPACT_MAX]; };
+int xgk_compact(hipStream_t st, CompactArgs& a);
 // scheduled sampling (SAModel.py:89-99): tok[b] = u_sel[b] < ss_prob ? sampled[b] : seq[b*T + t]
 int xgk_ss_select(hipStream_t st, const int64_t* seq, int T, int t, int B, const float* u_sel, float ss_prob,
                   const int64_t* sampled, int64_t* tok);

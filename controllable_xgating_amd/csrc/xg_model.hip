@@ -978,31 +978,27 @@ extern "C" int xg_xe_loss_bwd(void* stream, const XgDims* d, const XgParams* p, 
     return ss.join();
 }
 
-extern "C" int xg_rollout(void* stream, const XgDims* d, const XgParams* p, const XgBnState* bn, const XgBatch* x,
-                          const XgRun* run, int mode, const float* uniforms, const int64_t* forced, float temperature,
-                          void* ws, size_t ws_bytes, int64_t* seq, float* seq_logp, int32_t* n_steps) {
-    Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
-    if (!p || !x || !run || !seq || !seq_logp || !n_steps || !x->pos_feats || d->T < 2) return XG_EINVAL;
-    if (mode == XG_ROLLOUT_SAMPLE && (!uniforms || !(temperature > 0.f))) return XG_EINVAL;
-    if (mode == XG_ROLLOUT_REPLAY && !forced) return XG_EINVAL;
-    XgGemmModeGuard mode_guard(run->gemm_mode);
-    hipStream_t st = (hipStream_t)stream;
+// One rollout over d.B rows.  split < d.B (SAMPLE mode only): rows [0, split) sample with uniforms (T, split), rows
+// [split, B) decode greedily -- the SCST pair (starttrain.py:131 + myutils.py:45) as ONE batch; n_steps then has two entries.
+static int rollout_impl(hipStream_t st, const XgDims* d, const XgParams* p, const XgBnState* bn, const XgBatch* x,
+                        const XgRun* run, int mode, const float* uniforms, const int64_t* forced, float temperature, Ws& w,
+                        int64_t* seq, float* seq_logp, int32_t* n_steps, int split) {
     const int B = d->B, R = d->R, E = d->E, A = d->A, T = d->T, N = B * d->K;
     const size_t BR = (size_t)B * R;
     XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w));
     XG_TRY(init_hidden(st, *d, *p, w.Venc, x->feat_mask, w, w.H1, w.C1, w.H2, w.C2));
     XG_TRY(xgk_linear(st, N, A, R, w.Venc, R, p->v2a_w, p->v2a_b, w.vproj, A));
-    if (hipMemsetAsync(w.alive, 0, sizeof(int32_t) * 4, st) != hipSuccess) return XG_EHIP;   // alive[0] = running max finishing step
+    if (hipMemsetAsync(w.alive, 0, sizeof(int32_t) * 4, st) != hipSuccess) return XG_EHIP;   // alive[i] = running max finishing step
     for (int t = 0; t < T; ++t) {
         int64_t* tok = w.TOK + (size_t)t * B;
         float* unf = w.UNF + (size_t)t * B;
         float* xt = w.Xe + (size_t)t * B * E;
         // token choice from the previous step's raw logits + bookkeeping + embedding gather: one launch (:183-215)
         XG_TRY(xgk_rollout_step(st, B, t >= 1 ? w.LOGITS + (size_t)(t - 1) * B * d->V : nullptr,
-                                uniforms ? uniforms + (size_t)t * B : nullptr, (forced && t >= 1) ? forced + (t - 1) : nullptr,
+                                uniforms ? uniforms + (size_t)t * split : nullptr, (forced && t >= 1) ? forced + (t - 1) : nullptr,
                                 T - 1, t >= 2 ? unf - B : nullptr, p->embed_w, tok, w.TOKLP + (size_t)t * B, unf,
                                 t >= 1 ? w.LSE + (size_t)(t - 1) * B : nullptr, seq, seq_logp, w.alive, xt, temperature, d->V, E,
-                                t, T, mode));
+                                t, T, mode, split));
         float* gp = w.GP + t * BR;
         float* posg = w.POSG + t * BR;
         StepIO s{};
@@ -1015,7 +1011,73 @@ extern "C" int xg_rollout(void* stream, const XgDims* d, const XgParams* p, cons
         if (t + 1 < T)     // the step at t = L is computed and its logits discarded in the reference (:182,:217)
             XG_TRY(xgk_linear(st, B, d->V, R, s.h2o, R, p->logit_w, p->logit_b, w.LOGITS + (size_t)t * B * d->V, d->V));
     }
-    XG_TRY(xgk_rollout_finalize(st, w.alive, n_steps, T - 1));
+    XG_TRY(xgk_rollout_finalize(st, w.alive, n_steps, T - 1, split < B ? 2 : 1));
+    return XG_OK;
+}
+
+extern "C" int xg_rollout(void* stream, const XgDims* d, const XgParams* p, const XgBnState* bn, const XgBatch* x,
+                          const XgRun* run, int mode, const float* uniforms, const int64_t* forced, float temperature,
+                          void* ws, size_t ws_bytes, int64_t* seq, float* seq_logp, int32_t* n_steps) {
+    Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
+    if (!p || !x || !run || !seq || !seq_logp || !n_steps || !x->pos_feats || d->T < 2) return XG_EINVAL;
+    if (mode == XG_ROLLOUT_SAMPLE && (!uniforms || !(temperature > 0.f))) return XG_EINVAL;
+    if (mode == XG_ROLLOUT_REPLAY && !forced) return XG_EINVAL;
+    XgGemmModeGuard mode_guard(run->gemm_mode);
+    return rollout_impl((hipStream_t)stream, d, p, bn, x, run, mode, uniforms, forced, temperature, w, seq, seq_logp, n_steps, d->B);
+}
+
+extern "C" int xg_rollout_pair(void* stream, const XgDims* d2, const XgParams* p, const XgBnState* bn, const XgBatch* x2,
+                               const XgRun* run, int n_sample, const float* uniforms, float temperature, void* ws2,
+                               size_t ws2_bytes, int64_t* seq, float* seq_logp, int32_t* n_steps) {
+    Ws w; XG_TRY(check(d2, ws2, ws2_bytes, &w));
+    if (!p || !x2 || !run || !seq || !seq_logp || !n_steps || !x2->pos_feats || d2->T < 2) return XG_EINVAL;
+    if (n_sample <= 0 || n_sample >= d2->B || !uniforms || !(temperature > 0.f)) return XG_EINVAL;
+    XgGemmModeGuard mode_guard(run->gemm_mode);
+    return rollout_impl((hipStream_t)stream, d2, p, bn, x2, run, XG_ROLLOUT_SAMPLE, uniforms, nullptr, temperature, w, seq,
+                        seq_logp, n_steps, n_sample);
+}
+
+// Everything xg_rollout_bwd reads, for the FIRST d1->B rows of a rollout that ran over d2->B >= d1->B rows: encoder-side
+// tensors are row prefixes, decoder-side tensors are per-step blocks (pitch B2 -> B1).
+extern "C" int xg_rollout_compact(void* stream, const XgDims* d2, const void* ws2, size_t ws2_bytes, const XgDims* d1,
+                                  void* ws1, size_t ws1_bytes) {
+    Ws a, b;
+    XG_TRY(check(d2, const_cast<void*>(ws2), ws2_bytes, &a));
+    XG_TRY(check(d1, ws1, ws1_bytes, &b));
+    if (d1->B > d2->B || d1->K != d2->K || d1->R != d2->R || d1->A != d2->A || d1->E != d2->E || d1->V != d2->V ||
+        d1->T != d2->T || d1->F1 != d2->F1 || d1->F2 != d2->F2 || d1->C != d2->C || d1->H != d2->H) return XG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t B1 = d1->B, B2 = d2->B, K = d1->K, R = d1->R, A = d1->A, E = d1->E, V = d1->V, T = d1->T, N1 = B1 * K;
+    CompactArgs ca{};
+    auto prefix = [&](void* dst, const void* src, size_t nfloats) -> int {
+        if (ca.n >= XG_COMPACT_MAX) return XG_EINVAL;
+        ca.e[ca.n++] = CompactEntry{static_cast<float*>(dst), static_cast<const float*>(src), (int64_t)nfloats, (int64_t)nfloats, (int64_t)nfloats};
+        return XG_OK;
+    };
+    auto blocks = [&](void* dst, const void* src, size_t width_floats, size_t nblocks) -> int {   // block = B rows x width
+        if (ca.n >= XG_COMPACT_MAX) return XG_EINVAL;
+        ca.e[ca.n++] = CompactEntry{static_cast<float*>(dst), static_cast<const float*>(src), (int64_t)(B1 * width_floats),
+                                    (int64_t)(B2 * width_floats), (int64_t)(B1 * width_floats * nblocks)};
+        return XG_OK;
+    };
+    for (int m = 0; m < 2; ++m) {
+        XG_TRY(prefix(b.Z[m], a.Z[m], N1 * R)); XG_TRY(prefix(b.X[m], a.X[m], N1 * R)); XG_TRY(prefix(b.PRE[m], a.PRE[m], N1 * 4 * R));
+        XG_TRY(prefix(b.Hs[m], a.Hs[m], N1 * R)); XG_TRY(prefix(b.Cs[m], a.Cs[m], N1 * R)); XG_TRY(prefix(b.G[m], a.G[m], N1 * 4 * R));
+        XG_TRY(prefix(b.GG[m], a.GG[m], N1 * R)); XG_TRY(prefix(b.Hprev[m], a.Hprev[m], N1 * R));
+        XG_TRY(prefix(b.bn_mean[m], a.bn_mean[m], R)); XG_TRY(prefix(b.bn_var[m], a.bn_var[m], R));
+    }
+    XG_TRY(prefix(b.Y, a.Y, N1 * 2 * R)); XG_TRY(prefix(b.Venc, a.Venc, N1 * R)); XG_TRY(prefix(b.vbar, a.vbar, B1 * R));
+    XG_TRY(prefix(b.vproj, a.vproj, N1 * A));
+    XG_TRY(blocks(b.Xe, a.Xe, E, T)); XG_TRY(blocks(b.GP, a.GP, R, T)); XG_TRY(blocks(b.POSG, a.POSG, R, T));
+    XG_TRY(blocks(b.H1, a.H1, R, T + 1)); XG_TRY(blocks(b.C1, a.C1, R, T + 1));
+    XG_TRY(blocks(b.H2, a.H2, R, T + 1)); XG_TRY(blocks(b.C2, a.C2, R, T + 1));
+    XG_TRY(blocks(b.G1, a.G1, 4 * R, T)); XG_TRY(blocks(b.G2, a.G2, 4 * R, T));
+    XG_TRY(blocks(b.P, a.P, A, T)); XG_TRY(blocks(b.ALPHA, a.ALPHA, K, T)); XG_TRY(blocks(b.AF, a.AF, R, T));
+    XG_TRY(blocks(b.LOGITS, a.LOGITS, V, T - 1)); XG_TRY(blocks(b.LSE, a.LSE, 1, T));
+    XG_TRY(blocks(b.TOK, a.TOK, 2, T));                       // int64 = 2 floats wide
+    XG_TRY(blocks(b.TOKLP, a.TOKLP, 1, T)); XG_TRY(blocks(b.UNF, a.UNF, 1, T));
+    XG_TRY(xgk_compact(st, ca));
+    ZERO(b.zeroBR, B1 * R);                                   // the encoder's initial state (read by its backward)
     return XG_OK;
 }
 
@@ -1027,10 +1089,8 @@ extern "C" int xg_rollout_bwd(void* stream, const XgDims* d, const XgParams* p, 
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, T = d->T;
     // dlogits of step t-1's output from the token drawn at step t (SAModel.py:195)
-    for (int t = 1; t < T; ++t) {   // LOGITS holds raw logits, LSE their log-sum-exp
-        float* lg = w.LOGITS + (size_t)(t - 1) * B * d->V;
-        XG_TRY(xgk_rollout_dlogits_lse(st, lg, w.LSE + (size_t)(t - 1) * B, w.TOK + (size_t)t * B, dseq_logp + (t - 1), T - 1, B, d->V));
-    }
+    // LOGITS holds raw logits, LSE their log-sum-exp; every step in one launch
+    XG_TRY(xgk_rollout_dlogits_lse(st, w.LOGITS, w.LSE, w.TOK + B, dseq_logp, T - 1, B, d->V, T - 1));
     Streams ss(st);
     XG_TRY(heads_bwd(ss, *d, *p, *g, *run, w, (T - 1) * B, false));
     XG_TRY(decoder_bwd_core(ss, *d, *p, *g, *x, *run, w, w.UNF, 1, B, w.TOK, 1, B));

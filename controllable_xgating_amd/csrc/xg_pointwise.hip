@@ -265,6 +265,33 @@ __global__ void step_prep_kernel(const float* table, int E, const int64_t* tok, 
         else for (int64_t j = i; j < nstate; ++j) state_copy[j] = state[j];
     }
 }
+// xg_rollout_compact: one launch for every tensor.  A workgroup moves 4096 floats of one entry.
+constexpr int CPB = 4096;
+__global__ void __launch_bounds__(256) compact_kernel(CompactArgs a) {
+    int ei = 0;
+    for (int i = 1; i < a.n; ++i) if ((int)blockIdx.x >= a.start[i]) ei = i;
+    const CompactEntry& e = a.e[ei];
+    const int64_t base = (int64_t)(blockIdx.x - a.start[ei]) * CPB;
+    const bool vec = (e.dst_block % 4 == 0) && (e.src_pitch % 4 == 0);
+    if (vec) {
+#pragma unroll
+        for (int u = 0; u < CPB / (256 * 4); ++u) {
+            const int64_t i = base + ((int64_t)u * 256 + threadIdx.x) * 4;
+            if (i < e.total) {
+                const int64_t blk = i / e.dst_block, off = i - blk * e.dst_block;
+                *reinterpret_cast<float4*>(e.dst + i) = *reinterpret_cast<const float4*>(e.src + blk * e.src_pitch + off);
+            }
+        }
+    } else {
+        for (int u = 0; u < CPB / 256; ++u) {
+            const int64_t i = base + (int64_t)u * 256 + threadIdx.x;
+            if (i < e.total) {
+                const int64_t blk = i / e.dst_block, off = i - blk * e.dst_block;
+                e.dst[i] = e.src[blk * e.src_pitch + off];
+            }
+        }
+    }
+}
 __global__ void embed_scatter_kernel(float* dtable, int E, const int64_t* tok, int inner, int64_t s_inner,
                                      int64_t s_outer, int V, const float* dX, int ldx) {
     const int i = blockIdx.x;
@@ -400,6 +427,21 @@ int xgk_step_prep(hipStream_t st, const float* table, int E, const int64_t* tok,
     if (((uintptr_t)state % 16) || ((uintptr_t)state_copy % 16)) return XG_EINVAL;
     const int nb = B + (int)xg_cdiv64(nstate, 4 * 128);
     hipLaunchKernelGGL(step_prep_kernel, dim3(nb), dim3(128), 0, st, table, E, tok, V, xt, B, state, state_copy, nstate);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_compact(hipStream_t st, CompactArgs& a) {
+    if (a.n <= 0 || a.n > XG_COMPACT_MAX) return XG_EINVAL;
+    int blocks = 0;
+    for (int i = 0; i < a.n; ++i) {
+        const CompactEntry& e = a.e[i];
+        if (!e.dst || !e.src || e.dst_block <= 0 || e.total < 0 || ((uintptr_t)e.dst % 16) || ((uintptr_t)e.src % 16)) return XG_EINVAL;
+        a.start[i] = blocks;
+        blocks += (int)xg_cdiv64(e.total, CPB);
+    }
+    a.start[a.n] = blocks;
+    if (blocks == 0) return XG_OK;
+    hipLaunchKernelGGL(compact_kernel, dim3(blocks), dim3(256), 0, st, a);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }

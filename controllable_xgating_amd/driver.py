@@ -55,33 +55,64 @@ def get_self_critical_reward(model, feat1, feat2, feat_mask, pos_feat, gen_resul
     return np.repeat(diff[:, np.newaxis], gen.shape[1], 1)
 
 
-def scst_rollouts(model, feat1, feat2, feat_mask, pos_feat, overlap=True):
+def _second_bn_update(bns, r0):
+    """The reference runs the encoder twice per SCST iteration (two sample() calls), i.e. two momentum updates of the
+    BatchNorm running statistics with the same batch statistics s: with keep = 1 - momentum,
+    r2 = keep r1 + momentum s = (1 + keep) r1 - keep r0."""
+    with torch.no_grad():
+        keep = 1.0 - bns[0].momentum
+        cur = [t for m in bns for t in (m.running_mean, m.running_var)]
+        old = [t for pair in r0 for t in pair]
+        torch._foreach_mul_(cur, 1.0 + keep)                        # two multi-tensor launches for the four buffers
+        torch._foreach_add_(cur, old, alpha=-keep)
+        for m in bns:
+            if m.num_batches_tracked is not None:
+                m.num_batches_tracked += 1
+
+
+def scst_rollouts(model, feat1, feat2, feat_mask, pos_feat, overlap=True, mode=None, uniforms=None):
     """The two rollouts of one SCST iteration (starttrain.py:131 + myutils.py:45-48): the sampled rollout (keeps its
-    activations for the policy-gradient backward) and the greedy baseline.  They are independent given the batch, and each
-    is a latency-bound chain of small launches, so with ``overlap`` the greedy one runs on a side stream UNDER the sampled
-    one (one host sync for both).  Results are those of the sequential reference order: both rollouts see the same batch
-    statistics (BatchNorm's input does not depend on dropout), and the running statistics receive the reference's TWO
-    momentum updates (the second one is reconstructed exactly: r2 = 1.9 r1 - 0.9 r0)."""
-    if not overlap or not model.training:
-        gen, slp = model.sample(feat1, feat2, feat_mask, pos_feat, {"sample_max": 0})
+    activations for the policy-gradient backward) and the greedy baseline.  They are independent given the batch:
+      mode "batched" (default): ONE pass over 2m rows (rows [0,m) sample, rows [m,2m) greedy; SAModel.sample_pair) --
+          every per-step launch streams the decoder weights once for both rollouts;
+      mode "streams": two m-row rollouts on two streams;   mode "sequential": the reference's order.
+    All three give the reference's results: both rollouts see the same batch statistics (BatchNorm's input does not
+    depend on dropout, and statistics of a repeated batch equal those of the batch), and the running statistics receive
+    the reference's TWO momentum updates (the second one is reconstructed exactly)."""
+    if mode is None:
+        mode = "batched" if overlap else "sequential"
+    s_opt = {"sample_max": 0}
+    if uniforms is not None:
+        s_opt["uniforms"] = uniforms
+    if mode == "sequential" or not model.training:
+        gen, slp = model.sample(feat1, feat2, feat_mask, pos_feat, s_opt)
         with torch.no_grad():
             greedy, _ = model.sample(feat1, feat2, feat_mask, pos_feat, {"sample_max": 1})
         return gen, slp, greedy
     bns = [model.two_spatial_encoder.visual_emb_rgb[1], model.two_spatial_encoder.visual_emb_opfl[1]]
     r0 = [(m.running_mean.clone(), m.running_var.clone()) for m in bns]
+    if mode == "batched":
+        gen, slp, greedy, n = model.sample_pair(feat1, feat2, feat_mask, pos_feat, s_opt)
+        # running_var takes the UNBIASED batch variance: the repeated batch has 2N rows, the reference's N
+        rows = feat1.shape[0] * feat1.shape[1]
+        c = (2.0 * rows - 1.0) / (2.0 * rows - 2.0) if rows > 1 else 1.0
+        with torch.no_grad():
+            keep = 1.0 - bns[0].momentum
+            rv, rv0 = [m.running_var for m in bns], [pair[1] for pair in r0]
+            torch._foreach_mul_(rv, c)                              # (rv - keep rv0) c + keep rv0
+            torch._foreach_add_(rv, rv0, alpha=keep * (1.0 - c))
+        _second_bn_update(bns, r0)
+        ns = n.cpu()                                                # ONE host sync for both rollouts
+        n_s, n_g = int(ns[0]), int(ns[1])
+        return gen[:, :n_s], slp[:, :n_s], greedy[:, :n_g]
     main = torch.cuda.current_stream()
     side = torch.cuda.Stream()
     side.wait_stream(main)
     with torch.cuda.stream(side), torch.no_grad():
         g_seq, _, g_n = model.sample(feat1, feat2, feat_mask, pos_feat, {"sample_max": 1, "async": True, "bn_update": False})
-    s_seq, s_slp, s_n = model.sample(feat1, feat2, feat_mask, pos_feat, {"sample_max": 0, "async": True})
+    s_seq, s_slp, s_n = model.sample(feat1, feat2, feat_mask, pos_feat, dict(s_opt, **{"async": True}))
     main.wait_stream(side)
-    with torch.no_grad():                      # the baseline's (second) running-stat update
-        for m, (rm0, rv0) in zip(bns, r0):
-            m.running_mean.mul_(1.9).sub_(0.9 * rm0)
-            m.running_var.mul_(1.9).sub_(0.9 * rv0)
-            if m.num_batches_tracked is not None:
-                m.num_batches_tracked += 1
+    _second_bn_update(bns, r0)                                      # the baseline's (second) running-stat update
     ns = torch.stack([s_n.reshape(()), g_n.reshape(())]).cpu()      # ONE host sync for both rollouts
     n_s, n_g = int(ns[0]), int(ns[1])
     return s_seq[:, :n_s], s_slp[:, :n_s], g_seq[:, :n_g]
@@ -127,7 +158,7 @@ class Trainer:
                 info.update(loss_language=loss_language, loss_classify=loss_classify)
         else:
             gen_result, sample_logprobs, greedy = scst_rollouts(model, b["feat1"], b["feat2"], b["feat_mask"], b["pos_feat"],
-                                                                overlap=getattr(opt, "overlap_rollouts", True))   # :131 + myutils.py:45
+                                                                mode=getattr(opt, "scst_rollout_mode", None))      # :131 + myutils.py:45
             reward = get_self_critical_reward(model, b["feat1"], b["feat2"], b["feat_mask"], b["pos_feat"], gen_result,
                                               self.scorer, greedy_res=greedy)                # :132
             loss = self.rl_crit(sample_logprobs, gen_result,

@@ -311,6 +311,17 @@ class SAModel(nn.Module):
         return _XELossFunction.apply(self, save, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, cap_classes,
                                      class_mask, float(weight_class), *params)
 
+    def sample_pair(self, feats_rgb, feats_opfl, feat_mask, pos_feats, opt={}):
+        """The two rollouts of one SCST iteration in ONE batched pass: ``sample(..., {'sample_max': 0})``
+        (starttrain.py:131) and the greedy baseline ``sample(..., {'sample_max': 1})`` (myutils.py:45-48).
+        Returns (gen (m,L), sample_logprobs (m,L) [differentiable], greedy (m,L), n (2,) int32 device tensor: the
+        reference's early-exit lengths of the two rollouts -- trim with them, one host sync for both)."""
+        temperature = float(opt.get("temperature", 1.0))
+        params = self._param_list()
+        need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        return _RolloutPairFunction.apply(self, feats_rgb, feats_opfl, feat_mask, pos_feats, opt.get("uniforms", None),
+                                          temperature, need_grad, *params)
+
     def init_hidden(self, feat, feat_mask):
         """SAModel.init_hidden (SAModel.py:58-65) -> [(h1,c1),(h2,c2)], each (1,m,R)."""
         B, K, R = feat.shape
@@ -566,6 +577,67 @@ class _RolloutFunction(torch.autograd.Function):
         model._pool.give(d, dev, ctx.ws)
         ctx.ws = None
         return (None,) * 11 + tuple(_grad_views(model, g))
+
+
+class _RolloutPairFunction(torch.autograd.Function):
+    """Sampled rollout + greedy baseline of one SCST iteration as ONE batch of 2m rows (xg_rollout_pair); the sampled
+    half's activations are compacted into an m-row workspace, so backward is xg_rollout_bwd of the sampled rollout alone."""
+
+    @staticmethod
+    def forward(ctx, model, feats_rgb, feats_opfl, feat_mask, pos_feats, uniforms, temperature, need_grad, *params):
+        B, K, _ = feats_rgb.shape
+        T = model.seq_length + 1
+        dev = feats_rgb.device
+        d1, d2 = model._dims(B, K, T), model._dims(2 * B, K, T)
+        ws2 = model._pool.shared(d2, dev)
+        wp2, wn2 = _ws_ptr(ws2)
+        fm = feat_mask
+        if fm.dim() == 1:
+            fm = fm.unsqueeze(0).expand(B, K)
+        b2, keep2 = model._batch(torch.cat([feats_rgb, feats_rgb]), torch.cat([feats_opfl, feats_opfl]), torch.cat([fm, fm]),
+                                 torch.cat([pos_feats, pos_feats]))
+        seq = torch.zeros(2 * B, T - 1, dtype=torch.int64, device=dev)
+        slp = torch.zeros(2 * B, T - 1, dtype=torch.float32, device=dev)
+        n = torch.zeros(2, dtype=torch.int32, device=dev)
+        if uniforms is None:
+            uniforms = torch.rand(T, B, device=dev, dtype=torch.float32)
+        uniforms = uniforms.detach().contiguous().float()
+        ps, bn, run = model._params_struct(), model._bn_struct(), model._run(need_grad)
+        nv.check(nv.lib().xg_rollout_pair(_stream(), C.byref(d2), C.byref(ps), C.byref(bn), C.byref(b2), C.byref(run), B,
+                                          nv.ptr(uniforms), temperature, wp2, wn2, nv.ptr(seq), nv.ptr(slp), nv.ptr(n)),
+                 "xg_rollout_pair")
+        model._bump_bn()
+        ws1 = None
+        if need_grad:
+            ws1 = model._pool.take(d1, dev)
+            wp1, wn1 = _ws_ptr(ws1)
+            nv.check(nv.lib().xg_rollout_compact(_stream(), C.byref(d2), wp2, wn2, C.byref(d1), wp1, wn1), "xg_rollout_compact")
+        ctx.model, ctx.d, ctx.ws, ctx.run, ctx.need_grad = model, d1, ws1, run, need_grad
+        ctx.keep = (feats_rgb, feats_opfl, feat_mask, pos_feats)
+        gen, greedy = seq[:B], seq[B:]
+        slp_s = slp[:B]
+        ctx.mark_non_differentiable(gen, greedy, n)
+        if not need_grad:
+            ctx.mark_non_differentiable(slp_s)
+        return gen, slp_s, greedy, n
+
+    @staticmethod
+    def backward(ctx, dgen, dslp, dgreedy, dn):
+        model, d = ctx.model, ctx.d
+        if not ctx.need_grad:
+            raise nv.XgError("rollout ran without saved activations")
+        dev = ctx.keep[0].device
+        g, gs = _grads_struct(model, dev)
+        b, keep = model._batch(*ctx.keep)
+        wp, wn = _ws_ptr(ctx.ws)
+        ps = model._params_struct()
+        full = torch.zeros(d.B, d.T - 1, dtype=torch.float32, device=dev)
+        full[:, :dslp.shape[1]] = dslp
+        nv.check(nv.lib().xg_rollout_bwd(_stream(), C.byref(d), C.byref(ps), C.byref(gs), C.byref(b), C.byref(ctx.run),
+                                         wp, wn, nv.ptr(full)), "xg_rollout_bwd")
+        model._pool.give(d, dev, ctx.ws)
+        ctx.ws = None
+        return (None,) * 8 + tuple(_grad_views(model, g))
 
 
 # ====================================================================== criteria

@@ -196,6 +196,21 @@ int xg_rollout(void *stream, const XgDims *d, const XgParams *p, const XgBnState
                const XgBatch *x, const XgRun *run, int mode, const float *uniforms,
                const int64_t *forced, float temperature, void *ws, size_t ws_bytes,
                int64_t *seq, float *seq_logp, int32_t *n_steps);
+/* The two rollouts of one SCST iteration -- the sampled one (caption_src/starttrain.py:131) and the greedy
+ * baseline (caption_src/myutils.py:45-48) -- as ONE batch of d2->B = n_sample + n_greedy rows: rows
+ * [0, n_sample) sample with uniforms (T, n_sample), the remaining rows decode greedily; x2 holds the
+ * features of every row (the caller repeats the videos).  seq / seq_logp are (d2->B, T-1); n_steps[0..1]
+ * receive the reference's n of the sampled and of the greedy part.  Rows are independent and BatchNorm
+ * statistics of a repeated batch equal those of the batch, so each part equals its own xg_rollout. */
+int xg_rollout_pair(void *stream, const XgDims *d2, const XgParams *p, const XgBnState *bn,
+                    const XgBatch *x2, const XgRun *run, int n_sample, const float *uniforms,
+                    float temperature, void *ws2, size_t ws2_bytes, int64_t *seq, float *seq_logp,
+                    int32_t *n_steps);
+/* Copies what xg_rollout_bwd reads, for the first d1->B rows of a rollout that ran with d2 (d2->B >= d1->B,
+ * all other extents equal) from workspace ws2 into workspace ws1, so that xg_rollout_bwd(d1, ws1) is the
+ * backward of the sampled part alone. */
+int xg_rollout_compact(void *stream, const XgDims *d2, const void *ws2, size_t ws2_bytes,
+                       const XgDims *d1, void *ws1, size_t ws1_bytes);
 /* Backward of a rollout run with run->save = 1, given d(seq_logp) (B,T-1)
  * (RewardCriterion, caption_src/SAModel.py:259-267; caption_src/starttrain.py:131-134). */
 int xg_rollout_bwd(void *stream, const XgDims *d, const XgParams *p, const XgParams *g,

@@ -12,7 +12,12 @@ SHAPES = [  # name, ta, tb, M, N, K, acc
     ("PRE NT 3328x2048 K=512", 0, 1, 3328, 2048, 512, 0),
     ("vproj NT 3328x1536 K=512", 0, 1, 3328, 1536, 512, 0),
     ("dX NN 3328x512 K=2048", 0, 0, 3328, 512, 2048, 0),
+    ("rollout logits NT 128x20000 K=512", 0, 1, 128, 20000, 512, 0),
+    ("rollout logits NT 64x20000 K=512", 0, 1, 64, 20000, 512, 0),
+    ("dH NN 1920x512 K=20000", 0, 0, 1920, 512, 20000, 0),
 ]
+if os.environ.get("XG_GEMM_SHAPES"):
+    SHAPES = [s for s in SHAPES if any(k in s[0] for k in os.environ["XG_GEMM_SHAPES"].split(","))]
 def run(mode):
     import torch
     from controllable_xgating_amd import _native as nv
@@ -24,7 +29,7 @@ def run(mode):
         def call():
             assert L.xg_gemm_mode(None, mode, ta, tb, M, N, K, nv.ptr(A), A.shape[1], nv.ptr(B), B.shape[1], nv.ptr(Cc), N, None, 0, acc) == 0
         Cc.zero_(); call()
-        sl = slice(0, 256)
+        sl = slice(0, min(256, M))
         ref = ((A.t() if ta else A)[sl].double() @ (B.t() if tb else B).double())
         err = float((Cc[sl].double() - ref).abs().max() / ref.abs().max())
         for _ in range(3): call()
