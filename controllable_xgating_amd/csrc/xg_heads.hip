@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(RT) choose_kernel(const float* __restrict__ lo
                                                       int64_t* tok, float* tok_logp) {
     __shared__ float red[RT / 64];
     __shared__ int redi[RT / 64];
-    __shared__ float chunk_sum[RT];
+    __shared__ double wave_tot[RT / 64];
     const int b = blockIdx.x;
     const float* x = logp + (size_t)b * V;
     if (mode == XG_ROLLOUT_REPLAY) {
@@ -178,27 +178,32 @@ __global__ void __launch_bounds__(RT) choose_kernel(const float* __restrict__ lo
         return;
     }
     // SAMPLE: inverse CDF over w_v = exp(logp_v / temperature) (unnormalised, like torch.multinomial):
-    // each thread owns a contiguous chunk; chunk sums -> serial scan by thread 0 -> owner thread walks its chunk.
+    // each thread owns a contiguous chunk; chunk sums -> block scan -> owner thread walks its chunk.
     const int per = (V + RT - 1) / RT;
     const int v0 = threadIdx.x * per, v1 = min(V, v0 + per);
     const float invt = 1.0f / temperature;
     float s = 0.f;
     for (int v = v0; v < v1; ++v) s += expf(x[v] * invt);
-    chunk_sum[threadIdx.x] = s;
-    __syncthreads();
+    // block-wide inclusive scan of the chunk sums in double, then the first chunk whose running sum passes the target
     __shared__ float target_s; __shared__ int owner; __shared__ float base_s;
-    if (threadIdx.x == 0) {
-        double tot = 0.0;
-        for (int i = 0; i < RT; ++i) tot += chunk_sum[i];
-        const double target = (double)uniforms[b] * tot;
-        double run = 0.0; int ow = RT - 1; double base = 0.0;
-        for (int i = 0; i < RT; ++i) {
-            if (run + chunk_sum[i] > target) { ow = i; base = run; break; }
-            run += chunk_sum[i];
-            base = run;
-        }
-        owner = ow; base_s = (float)base; target_s = (float)target;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    double inc = (double)s;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
     }
+    if (lane == 63) wave_tot[wave] = inc;
+    if (threadIdx.x == 0) owner = RT - 1;
+    __syncthreads();
+    double off = 0.0, tot = 0.0;
+#pragma unroll
+    for (int i = 0; i < RT / 64; ++i) { const double wt = wave_tot[i]; if (i < wave) off += wt; tot += wt; }
+    inc += off;
+    const double target = (double)uniforms[b] * tot;
+    if (inc > target) atomicMin(&owner, (int)threadIdx.x);
+    __syncthreads();
+    if ((int)threadIdx.x == owner) { base_s = (float)(inc - (double)s); target_s = (float)target; }
     __syncthreads();
     if ((int)threadIdx.x == owner) {
         float run = base_s; int pick = min(V, v1) - 1;
@@ -235,7 +240,7 @@ struct RollStepArgs {
 __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
     __shared__ float red[RT / 64];
     __shared__ int redi[RT / 64];
-    __shared__ float chunk_sum[RT];
+    __shared__ double wave_tot[RT / 64];
     __shared__ int64_t s_tok;
     __shared__ float s_bcast[3];
     __shared__ int s_owner;
@@ -281,20 +286,24 @@ __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
             const float invt = 1.0f / a.temperature;
             float cs = 0.f;
             for (int v = v0; v < v1; ++v) cs += expf((x[v] - mx) * invt);
-            chunk_sum[tid] = cs;
-            __syncthreads();
-            if (tid == 0) {
-                double tot = 0.0;
-                for (int i = 0; i < RT; ++i) tot += chunk_sum[i];
-                const double target = (double)a.uniforms[b] * tot;
-                double run = 0.0, base = 0.0; int ow = RT - 1;
-                for (int i = 0; i < RT; ++i) {
-                    if (run + chunk_sum[i] > target) { ow = i; base = run; break; }
-                    run += chunk_sum[i];
-                    base = run;
-                }
-                s_owner = ow; s_bcast[0] = (float)base; s_bcast[1] = (float)target;
+            // block-wide inclusive scan of the RT chunk sums in double (was a 1024-step serial walk by one thread: 50 us)
+            double inc = (double)cs;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const double up = __shfl_up(inc, o, 64);
+                if (lane >= o) inc += up;
             }
+            if (lane == 63) wave_tot[wave] = inc;
+            if (tid == 0) s_owner = RT - 1;
+            __syncthreads();
+            double off = 0.0, tot = 0.0;
+#pragma unroll
+            for (int i = 0; i < RT / 64; ++i) { const double wt = wave_tot[i]; if (i < wave) off += wt; tot += wt; }
+            inc += off;
+            const double target = (double)a.uniforms[b] * tot;
+            if (inc > target) atomicMin(&s_owner, tid);          // first chunk whose running sum passes the target
+            __syncthreads();
+            if (tid == s_owner) { s_bcast[0] = (float)(inc - (double)cs); s_bcast[1] = (float)target; }
             __syncthreads();
             if (tid == s_owner) {
                 float run = s_bcast[0]; int pick = min(a.V, v1) - 1;

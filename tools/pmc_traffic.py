@@ -5,8 +5,8 @@ MI355X_MICROARCH.md section HBM); WRITE_SIZE is taken as reported (uncalibrated)
 usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json>"""
 import collections, csv, glob, json, sys
 
-STEP = {"sk_kernel": 2, "attn_fwd_fast": 1, "gate_fwd_kernel": 1, "embed_gather_kernel": 1, "gemm_kernel": 1,
-        "__amd_rocclr_copyBuffer": 1}
+# launches of one xg_step_fwd: state copy + embedding rows, [p || pos' gate], cell 1, attention, cell 2
+STEP = {"step_prep_kernel": 1, "sk_kernel": 3, "attn_fwd_fast": 1}
 
 
 def per_kernel(d, counter):
