@@ -269,10 +269,15 @@ __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
         for (int i = 1; i < RT / 64; ++i)
             if (red[i] > best || (red[i] == best && redi[i] < bi)) { best = red[i]; bi = redi[i]; }
         const float mx = best;
-        float se = 0.f;
-        for (int v = tid; v < a.V; v += RT) se += expf(x[v] - mx);
-        se = block_sum(se, red);
-        const float lse = mx + logf(se);
+        // log-sum-exp: its own pass, except for a temperature-1 draw whose chunk sums are the same exponentials
+        const bool lse_from_scan = mode == XG_ROLLOUT_SAMPLE && a.temperature == 1.0f;
+        float lse = 0.f;
+        if (!lse_from_scan) {
+            float se = 0.f;
+            for (int v = tid; v < a.V; v += RT) se += expf(x[v] - mx);
+            se = block_sum(se, red);
+            lse = mx + logf(se);
+        }
         int64_t tk;
         if (mode == XG_ROLLOUT_GREEDY) {
             tk = bi;
@@ -300,6 +305,7 @@ __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
 #pragma unroll
             for (int i = 0; i < RT / 64; ++i) { const double wt = wave_tot[i]; if (i < wave) off += wt; tot += wt; }
             inc += off;
+            if (lse_from_scan) lse = mx + logf((float)tot);
             const double target = (double)a.uniforms[b] * tot;
             if (inc > target) atomicMin(&s_owner, tid);          // first chunk whose running sum passes the target
             __syncthreads();
