@@ -153,8 +153,9 @@ def main():
     ap.add_argument("--drop", type=float, default=0.0)
     ap.add_argument("--precision", choices=["fp32", "bf16x3", "bf16"], default="fp32",
                     help="arithmetic of the large GEMMs (XgRun.gemm_mode); the headline number is fp32")
-    ap.add_argument("--workload", choices=["xe", "scst"], default="xe",
-                    help="xe: BASELINE configs[1] (the metric); scst: configs[2] (sample + greedy rollouts + RL backward, B=64, L=30)")
+    ap.add_argument("--workload", choices=["xe", "scst", "xe5"], default="xe",
+                    help="xe: BASELINE configs[1] (the metric); scst: configs[2] (sample + greedy rollouts + RL backward, B=64, L=30); "
+                         "xe5: configs[4] shape (hidden 1024, 40 frames; pair with --precision bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
@@ -184,8 +185,11 @@ def main():
     cfg = dict(B=args.batch, K=26, R=512, A=1536, E=468, V=20000, C=14, L=20, F1=1536, F2=1024)
     if args.workload == "scst":
         cfg.update(B=64 if args.batch == 128 else args.batch, L=30)
+    if args.workload == "xe5":          # BASELINE.json configs[4] shape: hidden 1024, 40 frames (a parity case; measured for DESIGN.md)
+        cfg.update(K=40, R=1024)
     T = cfg["L"] + 1
-    opt = make_opt(None, vocab_size=cfg["V"], seq_length=cfg["L"], drop_prob_lm=args.drop, precision=args.precision)
+    opt = make_opt(None, vocab_size=cfg["V"], seq_length=cfg["L"], drop_prob_lm=args.drop, precision=args.precision,
+                   rnn_size=cfg["R"], att_size=cfg["A"], input_encoding_size=cfg["E"], feat_size=cfg["F1"], feat_size2=cfg["F2"])
     model = SAModel(opt).to(dev)
     model.train()
     broadcast_parameters(model)
@@ -248,17 +252,22 @@ def main():
         value = world * cfg["B"] * T * args.steps / dt * (2 if args.workload == "scst" else 1)
         bytes_step = step_bytes(cfg["B"], cfg["K"], cfg["R"], cfg["A"], cfg["E"], save=False)
         achieved = bytes_step / t_step / 1e9
-        traffic, traffic_src = load_traffic() if cfg["B"] == 128 else (None, None)
+        traffic, traffic_src = load_traffic() if (cfg["B"] == 128 and args.workload == "xe") else (None, None)
+        wl = {"xe": "configs[1]: 1xMI355X batch %d teacher-forced XE train, 26 frames x (1536+1024), hidden 512, "
+                    "att 1536, emb 468, vocab 20000, seq_len 20 (T=21), fp32" % cfg["B"],
+              "scst": "configs[2]: 1xMI355X SCST iteration (sampled rollout + greedy baseline as one 2m-row batch + RL backward + "
+                      "clip + Adam), batch %d, seq_len 30, 26 frames, hidden 512, vocab 20000, CIDEr reward stubbed" % cfg["B"],
+              "xe5": "configs[4] shape: 1xMI355X batch %d teacher-forced XE train, 40 frames x (1536+1024), hidden 1024, att 1536, "
+                     "vocab 20000, seq_len 20" % cfg["B"]}[args.workload]
         out = {
-            "metric": "decoder timesteps/sec (train fwd+bwd) at batch 128, MSRVTT 26x1536+1024" if args.workload == "xe" else
-                      "rollout timesteps/sec, SCST iteration (sample + greedy + RL backward) at batch 64, seq_len 30",
+            "metric": "rollout timesteps/sec, SCST iteration (sample + greedy + RL backward) at batch 64, seq_len 30"
+                      if args.workload == "scst" else "decoder timesteps/sec (train fwd+bwd) at batch 128, MSRVTT 26x1536+1024",
             "value": round(value, 1), "unit": "decoder timesteps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(t_enq * 1e3 / args.steps, 3),
             "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "f32 via split-bf16 (3 planes, 6 MFMAs)", "bf16": "bf16"}[args.precision],
             "data": "synthetic",
-            "config": {"workload": "configs[1]: 1xMI355X batch %d teacher-forced XE train, 26 frames x (1536+1024), hidden 512, "
-                                   "att 1536, emb 468, vocab 20000, seq_len 20 (T=21), fp32" % cfg["B"],
+            "config": {"workload": wl,
                        "global_batch": world * cfg["B"], "per_gpu_batch": cfg["B"], "parallelism": "dp%d" % world,
                        "path": args.path, "drop_prob_lm": args.drop, "gemm_precision": args.precision,
                        "timed_region": "zero_grad + encoder fwd + 21 decoder steps + heads/loss + full backward"

@@ -179,7 +179,7 @@ __device__ long long attn_trace_buf[1024 * 8];
 #define AT_STAMP(i) do {} while (0)
 #endif
 
-template <int NI>
+template <int NI, int VMAX>      // NI: 256-column groups of A per lane; VMAX: V rows held per thread (K <= VMAX * nkp)
 __global__ void __launch_bounds__(FT) attn_fwd_fast(const float* __restrict__ p, const float* __restrict__ vproj,
                                                      const float* __restrict__ V, const float* __restrict__ w,
                                                      float* __restrict__ alpha, float* __restrict__ af, int K, int R, int A) {
@@ -194,7 +194,6 @@ __global__ void __launch_bounds__(FT) attn_fwd_fast(const float* __restrict__ p,
     // context pass mapping: thread -> (4 consecutive r, k-part); its V loads go out first
     const int r4n = R >> 2, nkp = FT / r4n > 0 ? min(FT / r4n, K) : 1;
     const int myr = (tid % r4n) << 2, mykp = tid / r4n;
-    constexpr int VMAX = 8;                           // V rows held per thread (K <= 8 * nkp, checked by the launcher)
     float4 vreg[VMAX];
 #pragma unroll
     for (int j = 0; j < VMAX; ++j) {
@@ -359,14 +358,19 @@ int xgk_attn_fwd(hipStream_t st, const float* p, const float* vproj, const float
     if (al16 && A % 4 == 0 && A <= 2048 && R % 4 == 0 && R <= 4 * FT && R >= 4) {
         const int r4n = R / 4;
         const int nkp = FT / r4n > 0 ? (FT / r4n < K ? FT / r4n : K) : 1;
-        if (K <= 8 * nkp) {
+        if (K <= 16 * nkp) {
             const size_t lds = (size_t)(((K + 3) & ~3) + (size_t)nkp * R) * sizeof(float);
             if (lds <= 60000) {
                 const int ni = (A + 255) / 256;
-                if (ni <= 2) hipLaunchKernelGGL((attn_fwd_fast<2>), dim3(B), dim3(FT), lds, st, p, vproj, V, w, alpha, af, K, R, A);
-                else if (ni <= 4) hipLaunchKernelGGL((attn_fwd_fast<4>), dim3(B), dim3(FT), lds, st, p, vproj, V, w, alpha, af, K, R, A);
-                else if (ni <= 6) hipLaunchKernelGGL((attn_fwd_fast<6>), dim3(B), dim3(FT), lds, st, p, vproj, V, w, alpha, af, K, R, A);
-                else hipLaunchKernelGGL((attn_fwd_fast<8>), dim3(B), dim3(FT), lds, st, p, vproj, V, w, alpha, af, K, R, A);
+#define XG_ATTN_LAUNCH(NI_, VM_) hipLaunchKernelGGL((attn_fwd_fast<NI_, VM_>), dim3(B), dim3(FT), lds, st, p, vproj, V, w, alpha, af, K, R, A)
+                if (K <= 8 * nkp) {
+                    if (ni <= 2) XG_ATTN_LAUNCH(2, 8); else if (ni <= 4) XG_ATTN_LAUNCH(4, 8);
+                    else if (ni <= 6) XG_ATTN_LAUNCH(6, 8); else XG_ATTN_LAUNCH(8, 8);
+                } else {                              // e.g. hidden 1024 (4 row parts) x 40 frames
+                    if (ni <= 2) XG_ATTN_LAUNCH(2, 16); else if (ni <= 4) XG_ATTN_LAUNCH(4, 16);
+                    else if (ni <= 6) XG_ATTN_LAUNCH(6, 16); else XG_ATTN_LAUNCH(8, 16);
+                }
+#undef XG_ATTN_LAUNCH
                 XG_CHECK_LAUNCH();
                 return XG_OK;
             }

@@ -261,6 +261,7 @@ int dispatch(hipStream_t st, GemmArgs g, bool vec) {
 
 static thread_local int tl_gemm_mode = 0;
 void xgk_set_gemm_mode(int mode) { tl_gemm_mode = (mode == 1 || mode == 3) ? mode : 0; }
+int xgk_get_gemm_mode() { return tl_gemm_mode; }
 
 int xgk_gemm(hipStream_t st, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
              const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate) {

@@ -10,6 +10,7 @@ int xgk_gemm_bf16(hipStream_t st, int planes, bool transA, bool transB, int M, i
                   const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate);
 // arithmetic mode of xgk_gemm for the current host thread (set by the C-ABI entry points from XgRun.gemm_mode)
 void xgk_set_gemm_mode(int mode);
+int xgk_get_gemm_mode();
 struct XgGemmModeGuard {
     explicit XgGemmModeGuard(int m) { xgk_set_gemm_mode(m); }
     ~XgGemmModeGuard() { xgk_set_gemm_mode(0); }

@@ -76,7 +76,27 @@ __device__ long long sk_trace_buf[4096 * 8];
 #define SK_STAMP(i) do {} while (0)
 #endif
 
-template <bool VEC>
+// ---- bf16 arithmetic (XgRun.gemm_mode = 1, BASELINE.json configs[4]): the staged chunk is rounded to bf16 on its way
+// into LDS ([32][40] bf16 images: 80-B rows, conflict-free b128 fragments) and the products run on
+// v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate); accumulation, reduction and the cell arithmetic stay fp32.
+typedef short bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int LDH = CK + 8;       // bf16 row stride
+__device__ __forceinline__ unsigned bf16_rne(float x) {
+    unsigned u = __float_as_uint(x);
+    u += 0x7FFFu + ((u >> 16) & 1u);
+    return u >> 16;
+}
+__device__ __forceinline__ void st_chunk_bf16(unsigned short* __restrict__ lds, int lane, const f32x4 (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        uint2 pk;
+        pk.x = bf16_rne(v[i][0]) | (bf16_rne(v[i][1]) << 16);
+        pk.y = bf16_rne(v[i][2]) | (bf16_rne(v[i][3]) << 16);
+        *reinterpret_cast<uint2*>(lds + (i * 8 + (lane >> 3)) * LDH + ((lane & 7) << 2)) = pk;
+    }
+}
+
+template <bool VEC, int PREC>     // PREC 0: fp32 MFMA, 1: bf16 MFMA
 __global__ void __launch_bounds__(SKT) sk_kernel(SkArgs args) {
     SK_STAMP(0);
     // wave-private staging (A chunk + B chunk per wave), re-used as the [SKW][32][32] reduction buffer
@@ -174,8 +194,13 @@ __global__ void __launch_bounds__(SKT) sk_kernel(SkArgs args) {
         ld_chunk<VEC>(pa, c0, c0 >= nfull, va, 0, ra);
         ld_chunk<VEC>(pb, c0, c0 >= nfull, vb, bn ? 8 : 0, rb);
         for (int c = c0; c < c1; ++c) {
-            st_chunk(As, lane, ra);
-            st_chunk(Bs, lane, rb);
+            if (PREC == 1) {
+                st_chunk_bf16(reinterpret_cast<unsigned short*>(As), lane, ra);
+                st_chunk_bf16(reinterpret_cast<unsigned short*>(Bs), lane, rb);
+            } else {
+                st_chunk(As, lane, ra);
+                st_chunk(Bs, lane, rb);
+            }
             if (s == 0 && c == c0) SK_STAMP(2);
 #ifndef SK_NO_LOAD
             if (c + 1 < c1) {   // next chunk's global loads fly while this chunk's MFMAs run
@@ -185,6 +210,23 @@ __global__ void __launch_bounds__(SKT) sk_kernel(SkArgs args) {
 #endif
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if (PREC == 1) {
+                const unsigned short* Ah = reinterpret_cast<const unsigned short*>(As);
+                const unsigned short* Bh = reinterpret_cast<const unsigned short*>(Bs);
+#pragma unroll
+                for (int kb = 0; kb < CK / 16; ++kb) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ah + l31 * LDH + kb * 16 + half * 8);
+                    bf16x8 b;
+                    if (bn) {
+                        const unsigned short* q = Bh + (kb * 16 + half * 8) * LDH + l31;
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) b[i] = (short)q[i * LDH];
+                    } else {
+                        b = *reinterpret_cast<const bf16x8*>(Bh + l31 * LDH + kb * 16 + half * 8);
+                    }
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+                }
+            } else
 #pragma unroll
             for (int kb = 0; kb < CK / 8; ++kb) {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(As + l31 * LDR + kb * 8 + half * 4);
@@ -335,8 +377,11 @@ int xgk_skinny(hipStream_t st, SkArgs& a) {
         for (int j = 0; j < a.njobs; ++j) XG_TRY(skinny_fallback(st, a.job[j]));
         return XG_OK;
     }
-    if (vec) hipLaunchKernelGGL((sk_kernel<true>), dim3(tiles), dim3(SKT), 0, st, a);
-    else hipLaunchKernelGGL((sk_kernel<false>), dim3(tiles), dim3(SKT), 0, st, a);
+    const bool bf16 = xgk_get_gemm_mode() == 1;      // plain-bf16 mode covers the recurrent products too
+    if (vec && bf16) hipLaunchKernelGGL((sk_kernel<true, 1>), dim3(tiles), dim3(SKT), 0, st, a);
+    else if (vec) hipLaunchKernelGGL((sk_kernel<true, 0>), dim3(tiles), dim3(SKT), 0, st, a);
+    else if (bf16) hipLaunchKernelGGL((sk_kernel<false, 1>), dim3(tiles), dim3(SKT), 0, st, a);
+    else hipLaunchKernelGGL((sk_kernel<false, 0>), dim3(tiles), dim3(SKT), 0, st, a);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }

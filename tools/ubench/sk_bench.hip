@@ -3,6 +3,7 @@
 #include "../../controllable_xgating_amd/csrc/xg_step.hip"
 #include <cstdio>
 int xgk_gemm(hipStream_t, bool, bool, int, int, int, const float*, int, const float*, int, float*, int, const float*, bool, bool) { return 0; }
+int xgk_get_gemm_mode() { return getenv("SK_BF16") ? 1 : 0; }
 static float* dalloc(size_t n, float v) {
     float* p; hipMalloc(&p, n * 4);
     std::vector<float> h(n, v); hipMemcpy(p, h.data(), n * 4, hipMemcpyHostToDevice); return p;
