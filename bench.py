@@ -180,7 +180,7 @@ def main():
     if use_dist:
         dist.barrier()
     from controllable_xgating_amd import LanguageModelCriterion, SAModel, make_opt
-    from controllable_xgating_amd.train import ClipAdam, allreduce_gradients, broadcast_parameters
+    from controllable_xgating_amd.train import ClipAdam, GradSync, allreduce_gradients, broadcast_parameters
 
     cfg = dict(B=args.batch, K=26, R=512, A=1536, E=468, V=20000, C=14, L=20, F1=1536, F2=1024)
     if args.workload == "scst":
@@ -195,6 +195,9 @@ def main():
     broadcast_parameters(model)
     x = synth_inputs(cfg["B"], cfg["K"], cfg["L"], cfg["V"], cfg["R"], cfg["F1"], cfg["F2"], cfg["C"], seed=rank, device=dev)
     optim = ClipAdam(model, lr=4e-4, grad_clip=0.1)
+    # data parallel: most of the gradient all-reduce runs under the CG encoder's backward (XG_NO_GRAD_OVERLAP=1: one
+    # all-reduce after the backward)
+    sync = GradSync(model) if (use_dist and os.environ.get("XG_NO_GRAD_OVERLAP") is None) else None
     crit = LanguageModelCriterion()
 
     from controllable_xgating_amd import RewardCriterion
@@ -208,6 +211,8 @@ def main():
         gen, slp, greedy = scst_rollouts(model, x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"],
                                          mode=os.environ.get("XG_SCST_MODE"))
         loss = rl_crit(slp, gen, reward_b.expand(-1, gen.shape[1]))
+        if sync is not None:
+            sync.arm()
         loss.backward()
         allreduce_gradients(model)
         optim.step()
@@ -222,6 +227,8 @@ def main():
         else:
             logp, _ = model(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
             loss = crit(logp, x["seq"], x["seq_mask"])
+        if sync is not None:
+            sync.arm()
         loss.backward()
         allreduce_gradients(model)
         optim.step()

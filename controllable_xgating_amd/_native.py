@@ -84,6 +84,7 @@ def lib():
         "xg_xe_loss_bwd": [vp, PD, PP, PP, PX, vp, vp, f32, vp, PR, vp, C.c_size_t],
         "xg_rollout": [vp, PD, PP, PB, PX, PR, i32, vp, vp, f32, vp, C.c_size_t, vp, vp, vp],
         "xg_rollout_bwd": [vp, PD, PP, PP, PX, PR, vp, C.c_size_t, vp],
+        "xg_set_grad_event": [vp],
         "xg_rollout_pair": [vp, PD, PP, PB, PX, PR, i32, vp, f32, vp, C.c_size_t, vp, vp, vp],
         "xg_rollout_compact": [vp, PD, vp, C.c_size_t, PD, vp, C.c_size_t],
         "xg_nll_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],

@@ -43,6 +43,11 @@ XgAux* aux_for(hipStream_t main) {
     }
     return &a;
 }
+// Optional event recorded (on the auxiliary stream, after it has caught up with the main one) at the point of a backward
+// pass where every gradient except the CG encoder's is final: a data-parallel caller starts the all-reduce of that
+// part of the flat gradient buffer there, under the encoder backward (xg_set_grad_event; per host thread).
+thread_local hipEvent_t tl_grad_event = nullptr;
+
 struct Streams {
     hipStream_t main, aux;
     XgAux* a;
@@ -647,6 +652,8 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     XG_TRY(ss.fork());
     XG_TRY(gemm_tn(sx, N, A, R, w.DVPROJ, A, w.Venc, R, g.v2a_w, R));
     XG_TRY(xgk_colsum(sx, w.DVPROJ, A, N, A, g.v2a_b));
+    // everything but two_spatial_encoder.* is final once the auxiliary stream gets here (it has waited for main above)
+    if (tl_grad_event && hipEventRecord(tl_grad_event, sx) != hipSuccess) return XG_EHIP;
     return XG_OK;
 }
 
@@ -787,6 +794,10 @@ extern "C" int xg_init_hidden(void* stream, const XgDims* d, const XgParams* p, 
     if (!p || !V || !feat_mask || !state) return XG_EINVAL;
     const size_t BR = (size_t)d->B * d->R;
     return init_hidden((hipStream_t)stream, *d, *p, V, feat_mask, w, state, state + BR, state + 2 * BR, state + 3 * BR);
+}
+extern "C" int xg_set_grad_event(void* hip_event) {
+    tl_grad_event = static_cast<hipEvent_t>(hip_event);
+    return XG_OK;
 }
 extern "C" int xg_vproj(void* stream, const XgDims* d, const XgParams* p, const float* V, float* vproj) {
     if (!dims_ok(d) || !p || !V || !vproj) return XG_EINVAL;

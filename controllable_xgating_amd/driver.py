@@ -12,7 +12,7 @@ import numpy as np
 import torch
 
 from .model import ClassiferCriterion, LanguageModelCriterion, RewardCriterion
-from .train import ClipAdam, allreduce_gradients
+from .train import ClipAdam, GradSync, allreduce_gradients
 
 
 def lr_for_epoch(opt, epoch):
@@ -131,6 +131,10 @@ class Trainer:
         self.best_val_score = None
         self.patience = 0
         self.fused = getattr(opt, "fused_xe_loss", False)
+        self.grad_sync = None
+        if torch.distributed.is_available() and torch.distributed.is_initialized() and \
+                torch.distributed.get_world_size() > 1 and next(model.parameters()).is_cuda:
+            self.grad_sync = GradSync(model)        # all-reduce of the non-encoder gradients under the encoder backward
 
     def start_epoch(self, epoch):
         """the update_lr_flag block, starttrain.py:85-107"""
@@ -164,6 +168,8 @@ class Trainer:
             loss = self.rl_crit(sample_logprobs, gen_result,
                                 torch.from_numpy(reward).float().to(sample_logprobs.device))  # :133
             info["avg_reward"] = float(np.mean(reward[:, 0])) if reward.size else 0.0
+        if self.grad_sync is not None:
+            self.grad_sync.arm()
         loss.backward()                                                                      # :134
         allreduce_gradients(model)                                                           # data parallel only
         self.optimizer.step()                                                                # :136-137 (clamp + Adam)

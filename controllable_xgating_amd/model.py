@@ -40,6 +40,24 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+class _grad_event:
+    """Arms the library's "decoder-side gradients are final" event (xg_set_grad_event) around ONE backward call, on
+    the thread that makes the call (autograd runs custom backwards on its own worker thread).  No-op unless a
+    data-parallel helper (train.GradSync) has put an event on the model."""
+
+    def __init__(self, model):
+        self.ev = getattr(model, "_grad_event", None)
+
+    def __enter__(self):
+        if self.ev is not None:
+            nv.check(nv.lib().xg_set_grad_event(C.c_void_p(self.ev.cuda_event)), "xg_set_grad_event")
+
+    def __exit__(self, *exc):
+        if self.ev is not None:
+            nv.lib().xg_set_grad_event(None)
+        return False
+
+
 class _Holder(nn.Module):
     """Bare container so parameter names nest like the reference's sub-modules."""
 
@@ -477,8 +495,9 @@ class _XEFunction(torch.autograd.Function):
         dl = None if dlogp is None else dlogp.contiguous().float()
         dc = None if dcat is None else dcat.contiguous().float()
         fn = nv.lib().xg_backward_ss if ctx.ss else nv.lib().xg_backward_xe
-        nv.check(fn(_stream(), C.byref(d), C.byref(ps), C.byref(gs), C.byref(b), C.byref(ctx.run),
-                    wp, wn, nv.ptr(dl), nv.ptr(dc)), "xg_backward_ss" if ctx.ss else "xg_backward_xe")
+        with _grad_event(model):
+            nv.check(fn(_stream(), C.byref(d), C.byref(ps), C.byref(gs), C.byref(b), C.byref(ctx.run),
+                        wp, wn, nv.ptr(dl), nv.ptr(dc)), "xg_backward_ss" if ctx.ss else "xg_backward_xe")
         model._pool.give(d, dev, ctx.ws)
         ctx.ws = None
         return (None,) * 9 + tuple(_grad_views(model, g))
@@ -515,9 +534,10 @@ class _XELossFunction(torch.autograd.Function):
         b, keep = model._batch(*ctx.keep)
         wp, wn = _ws_ptr(ctx.ws)
         ps = model._params_struct()
-        nv.check(nv.lib().xg_xe_loss_bwd(_stream(), C.byref(d), C.byref(ps), C.byref(gs), C.byref(b), nv.ptr(ctx.cc),
-                                         nv.ptr(ctx.cm), ctx.wc, nv.ptr(dloss.detach().contiguous().float().to(dev)),
-                                         C.byref(ctx.run), wp, wn), "xg_xe_loss_bwd")
+        dl = dloss.detach().contiguous().float().to(dev)
+        with _grad_event(model):
+            nv.check(nv.lib().xg_xe_loss_bwd(_stream(), C.byref(d), C.byref(ps), C.byref(gs), C.byref(b), nv.ptr(ctx.cc),
+                                             nv.ptr(ctx.cm), ctx.wc, nv.ptr(dl), C.byref(ctx.run), wp, wn), "xg_xe_loss_bwd")
         model._pool.give(d, dev, ctx.ws)
         ctx.ws = None
         return (None,) * 11 + tuple(_grad_views(model, g))
@@ -572,8 +592,9 @@ class _RolloutFunction(torch.autograd.Function):
         T = d.T
         full = torch.zeros(d.B, T - 1, dtype=torch.float32, device=dev)
         full[:, :dslp.shape[1]] = dslp
-        nv.check(nv.lib().xg_rollout_bwd(_stream(), C.byref(d), C.byref(ps), C.byref(gs), C.byref(b), C.byref(ctx.run),
-                                         wp, wn, nv.ptr(full)), "xg_rollout_bwd")
+        with _grad_event(model):
+            nv.check(nv.lib().xg_rollout_bwd(_stream(), C.byref(d), C.byref(ps), C.byref(gs), C.byref(b), C.byref(ctx.run),
+                                             wp, wn, nv.ptr(full)), "xg_rollout_bwd")
         model._pool.give(d, dev, ctx.ws)
         ctx.ws = None
         return (None,) * 11 + tuple(_grad_views(model, g))
@@ -633,8 +654,9 @@ class _RolloutPairFunction(torch.autograd.Function):
         ps = model._params_struct()
         full = torch.zeros(d.B, d.T - 1, dtype=torch.float32, device=dev)
         full[:, :dslp.shape[1]] = dslp
-        nv.check(nv.lib().xg_rollout_bwd(_stream(), C.byref(d), C.byref(ps), C.byref(gs), C.byref(b), C.byref(ctx.run),
-                                         wp, wn, nv.ptr(full)), "xg_rollout_bwd")
+        with _grad_event(model):
+            nv.check(nv.lib().xg_rollout_bwd(_stream(), C.byref(d), C.byref(ps), C.byref(gs), C.byref(b), C.byref(ctx.run),
+                                             wp, wn, nv.ptr(full)), "xg_rollout_bwd")
         model._pool.give(d, dev, ctx.ws)
         ctx.ws = None
         return (None,) * 8 + tuple(_grad_views(model, g))

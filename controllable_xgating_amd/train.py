@@ -49,18 +49,71 @@ import os as _os
 _FORCE = _os.environ.get("XG_FORCE_DIST") == "1"      # run the collective even at world size 1 (single-GPU smoke of the path)
 
 
+def _reduce(t, world, group):
+    """sum over ranks / world, in place.  RCCL averages inside the collective; gloo (CPU tests) has no AVG."""
+    import torch.distributed as dist
+    if dist.get_backend(group) == "nccl":
+        dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
+    else:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        t.mul_(1.0 / world)
+
+
 def allreduce_gradients(model, group=None):
-    """Data parallel by video: ONE all-reduce(sum) of the flat gradient buffer,
-    scaled by 1/world, BEFORE the clamp.  No other collective; BatchNorm statistics stay per replica."""
+    """Data parallel by video: all-reduce(sum) / world of the flat gradient buffer BEFORE the clamp.
+    No other collective; BatchNorm statistics stay per replica.  ONE collective -- or, when a GradSync armed this
+    backward, two: the part that was final before the CG encoder's backward has then already been started under it."""
     import torch.distributed as dist
     if not dist.is_available() or not dist.is_initialized():
         return
     world = dist.get_world_size(group)
     if world == 1 and not _FORCE:
         return
-    g = model.flat_grads()
-    dist.all_reduce(g, op=dist.ReduceOp.SUM, group=group)
-    g.mul_(1.0 / world)
+    sync = getattr(model, "_grad_sync", None)
+    if sync is not None and sync.armed:
+        sync.finish(group)
+        return
+    _reduce(model.flat_grads(), world, group)
+
+
+class GradSync:
+    """Overlaps most of the gradient all-reduce with the tail of the backward pass.  The flat gradient buffer is in
+    xg_param_name order: [two_spatial_encoder.* | everything else].  The library records an event
+    (xg_set_grad_event) when "everything else" is final -- the CG encoder's backward is what remains -- and the
+    all-reduce of that suffix (~80 % of the bytes) is issued on a side stream that waits for the event, so RCCL runs
+    under the encoder backward; the encoder prefix follows after the backward.  Same sums, same 1/world, two
+    collectives in a fixed order on every rank.  Usage: sync = GradSync(model); per iteration:
+    sync.arm(); loss.backward(); allreduce_gradients(model); optimizer.step()."""
+
+    def __init__(self, model):
+        model._ensure_flat()
+        self.model = model
+        first_other = next(n for n in nv.PARAM_NAMES if not n.startswith("two_spatial_encoder."))
+        self.split = model._slices[first_other][0]
+        assert all(n.startswith("two_spatial_encoder.") == (model._slices[n][0] < self.split) for n in nv.PARAM_NAMES)
+        self.event = torch.cuda.Event()
+        self.event.record()                      # torch creates the HIP event lazily: make the handle exist
+        self.side = torch.cuda.Stream()
+        self.armed = False
+        model._grad_sync = self
+
+    def arm(self):
+        """Call before loss.backward(): the next backward records the event."""
+        self.model._grad_event = self.event
+        self.armed = True
+
+    def finish(self, group=None):
+        import torch.distributed as dist
+        world = dist.get_world_size(group)
+        g = self.model.flat_grads()
+        main = torch.cuda.current_stream()
+        self.side.wait_event(self.event)         # the backward has been enqueued: this is the record it made
+        with torch.cuda.stream(self.side):
+            _reduce(g[self.split:], world, group)
+        _reduce(g[:self.split], world, group)    # after the whole backward (main stream order)
+        main.wait_stream(self.side)
+        self.model._grad_event = None
+        self.armed = False
 
 
 def broadcast_parameters(model, src=0, group=None):

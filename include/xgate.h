@@ -186,6 +186,12 @@ int xg_xe_loss_bwd(void *stream, const XgDims *d, const XgParams *p, const XgPar
                    const XgBatch *x, const int64_t *cap_classes, const float *class_mask,
                    float weight_class, const float *dloss_dev, const XgRun *run, void *ws, size_t ws_bytes);
 
+/* Data parallel (the reference is single-GPU): register a hipEvent_t that the NEXT backward
+ * entry points called from this host thread record at the moment every gradient except two_spatial_encoder.*
+ * is final (the CG encoder's backward is what remains).  A caller that keeps the gradients in xg_param_name order
+ * can start the RCCL all-reduce of that suffix there, overlapped with the encoder backward.  NULL unregisters. */
+int xg_set_grad_event(void *hip_event);
+
 /* ---- rollouts: SAModel.sample (caption_src/SAModel.py:163-219), beam_size = 1 ----
  * mode GREEDY: argmax (ties -> lowest index, :186); SAMPLE: inverse-CDF draw from
  * exp(logp/temperature) with caller-supplied uniforms (T,B) in [0,1) (:190-194);

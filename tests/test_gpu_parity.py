@@ -2,6 +2,7 @@
 the golden fixtures recorded from the reference.  fp32 tolerances are written at each assert;
 token streams are compared exactly."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -598,3 +599,53 @@ def test_scst_rollout_modes_equal_the_sequential_reference_order():
         for n in a[6]:       # same policy as assert_grads_close (the batched pass runs other GEMM tilings: fp32 round-off)
             err, scale = float(np.abs(a[6][n] - b[6][n]).max()), float(np.abs(a[6][n]).max())
             assert err <= 2e-6 + 2e-3 * scale, (n, err, scale)
+
+
+def test_gradsync_overlapped_allreduce_single_rank():
+    """train.GradSync: the two-part all-reduce started from the library's grad-ready event (xg_set_grad_event) leaves
+    the same gradients as the plain path (single-rank RCCL group: the collective is the identity, the event / stream /
+    slicing mechanics are what is exercised), for the fused XE backward and the rollout backward."""
+    import torch.distributed as dist
+    from controllable_xgating_amd import RewardCriterion
+    from controllable_xgating_amd import train as tr
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29577")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    old_force = tr._FORCE
+    tr._FORCE = True
+    try:
+        d = pg.make_dims(**CFG["mid"])
+        Pn = pg.make_params(d, logit_gain=1.0)
+        x = to_dev(pg.make_inputs(d, seed=0, ragged=True))
+        u = torch.from_numpy(pg.uniform("uni2", (d.L + 1, d.B), 78)).cuda()
+        res = []
+        for use_sync in (False, True):
+            model = make_model(d, P=Pn, train=True)
+            sync = tr.GradSync(model) if use_sync else None
+            out = []
+            for kind in ("xe", "rollout"):
+                model.flat_grads().zero_()
+                if kind == "xe":
+                    loss = model.xe_loss(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+                else:
+                    gen, slp = model.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"],
+                                            {"sample_max": 0, "uniforms": u})
+                    loss = RewardCriterion()(slp, gen, torch.full_like(slp, 0.3))
+                if sync is not None:
+                    sync.arm()
+                loss.backward()
+                tr.allreduce_gradients(model)
+                torch.cuda.synchronize()
+                assert sync is None or not sync.armed
+                out.append(model.flat_grads().detach().cpu().numpy().copy())
+            res.append(out)
+        for a, b in zip(res[0], res[1]):
+            assert np.abs(a).max() > 0
+            np.testing.assert_allclose(a, b, atol=2e-6 + 2e-3 * 0, rtol=2e-3)
+    finally:
+        tr._FORCE = old_force
+        if created:
+            dist.destroy_process_group()
