@@ -610,9 +610,12 @@ def test_gradsync_overlapped_allreduce_single_rank():
     from controllable_xgating_amd import train as tr
     created = False
     if not dist.is_initialized():
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29577")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        import socket
+        with socket.socket() as sk:                     # a free port on the loopback interface
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
         created = True
     old_force = tr._FORCE
     tr._FORCE = True
