@@ -74,6 +74,33 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
     }
 }
 
+// ---- fast path of the vector kernels: per-thread BYTE offsets are computed once (rows clamped into the operand, so every
+// address is valid and nothing is predicated -- rows past the edge only feed output rows / columns that are never stored),
+// and a slab's loads are `uniform base + 32-bit lane offset`: no address arithmetic and no exec masking in the K loop
+// (each non-MFMA VALU instruction there is issue time the matrix pipe does not get back).  A partial last slab takes
+// the predicated loader above.  Requires every offset < 2^31 (checked by the launcher: GemmArgs::fast).
+template <int ROWS, bool KC>
+__device__ __forceinline__ void tile_offsets(int ld, int r0, int nrows, uint32_t (&off)[TileGeom<ROWS, KC>::nvec]) {
+    constexpr int NV = TileGeom<ROWS, KC>::nvec;
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int f = t + 256 * i;
+        if (KC) {
+            const int r = f >> 3, k = (f & 7) << 2;
+            off[i] = (uint32_t)(((size_t)min(r0 + r, nrows - 1) * ld + k) * sizeof(float));
+        } else {
+            const int k = f / (ROWS / 4), r = (f % (ROWS / 4)) << 2;
+            off[i] = (uint32_t)(((size_t)k * ld + min(r0 + r, nrows - 4)) * sizeof(float));
+        }
+    }
+}
+template <int NV>
+__device__ __forceinline__ void load_fast(const char* __restrict__ base, const uint32_t (&off)[NV], f32x4 (&regs)[NV]) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) regs[i] = *reinterpret_cast<const f32x4*>(base + off[i]);
+}
+
 template <int ROWS, bool KC>
 __device__ __forceinline__ void store_tile(float* __restrict__ lds, const f32x4 (&regs)[TileGeom<ROWS, KC>::nvec]) {
     constexpr int NV = TileGeom<ROWS, KC>::nvec;
@@ -112,6 +139,7 @@ struct GemmArgs {
     int M, N, K, lda, ldb, ldc, relu, accumulate;
     int splitk;   // > 1: the K slabs are divided over `splitk` workgroups per tile; partial tiles are added
                   // into C with hardware fp32 atomics (C pre-zeroed by the launcher unless accumulating)
+    int fast;     // vector kernels: offset-based unpredicated loads for the full slabs (all byte offsets < 2^31)
 };
 
 template <int BM, int BN, bool AKC, bool BKC, bool VEC>
@@ -152,6 +180,16 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     const int nslab_all = (g.K + BKS - 1) / BKS;
     const int s_begin = (int)(((long)ks * nslab_all) / g.splitk), s_end = (int)(((long)(ks + 1) * nslab_all) / g.splitk);
     const int nslab = s_end;
+    constexpr int NVA = TileGeom<BM, AKC>::nvec, NVB = TileGeom<BN, BKC>::nvec;
+    uint32_t offA[NVA], offB[NVB];
+    const bool fast = VEC && g.fast;
+    if (fast) {
+        tile_offsets<BM, AKC>(g.lda, m0, g.M, offA);
+        tile_offsets<BN, BKC>(g.ldb, n0, g.N, offB);
+    }
+    const size_t stepA = (AKC ? (size_t)BKS : (size_t)BKS * g.lda) * sizeof(float);   // bytes per slab
+    const size_t stepB = (BKC ? (size_t)BKS : (size_t)BKS * g.ldb) * sizeof(float);
+    const int nfull = g.K / BKS;                 // slabs below nfull are complete
     load_tile<BM, AKC, VEC>(g.A, g.lda, m0, s_begin * BKS, g.M, g.K, ra);
     load_tile<BN, BKC, VEC>(g.B, g.ldb, n0, s_begin * BKS, g.N, g.K, rb);
     store_tile<BM, AKC>(smem, ra);
@@ -161,8 +199,13 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     for (int s = s_begin; s < nslab; ++s) {
         const int cur = (s - s_begin) & 1;
         if (s + 1 < nslab) {
-            load_tile<BM, AKC, VEC>(g.A, g.lda, m0, (s + 1) * BKS, g.M, g.K, ra);
-            load_tile<BN, BKC, VEC>(g.B, g.ldb, n0, (s + 1) * BKS, g.N, g.K, rb);
+            if (fast && s + 1 < nfull) {
+                load_fast<NVA>(reinterpret_cast<const char*>(g.A) + (size_t)(s + 1) * stepA, offA, ra);
+                load_fast<NVB>(reinterpret_cast<const char*>(g.B) + (size_t)(s + 1) * stepB, offB, rb);
+            } else {
+                load_tile<BM, AKC, VEC>(g.A, g.lda, m0, (s + 1) * BKS, g.M, g.K, ra);
+                load_tile<BN, BKC, VEC>(g.B, g.ldb, n0, (s + 1) * BKS, g.N, g.K, rb);
+            }
         }
         const float* as = smem + cur * STAGE;
         const float* bs = as + A_FL;
@@ -270,9 +313,14 @@ int xgk_gemm(hipStream_t st, bool transA, bool transB, int M, int N, int K, cons
     // large products may run on the bf16 matrix cores (split-bf16 or plain bf16); skinny / tiny ones stay fp32
     if (tl_gemm_mode != 0 && M >= 256 && N >= 64 && K >= 64)
         return xgk_gemm_bf16(st, tl_gemm_mode, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate);
-    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1};
+    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1, 0};
     const bool akc = !transA;   // A (M,K) row-major -> k contiguous
     const bool bkc = transB;    // B (N,K) row-major -> k contiguous
+    {   // offset-based loads: the largest byte offset inside either operand must fit 31 bits, and the m/n-contiguous
+        // clamp needs at least 4 rows
+        const size_t ea = akc ? (size_t)M * lda : (size_t)K * lda, eb = bkc ? (size_t)N * ldb : (size_t)K * ldb;
+        g.fast = (ea * 4 < (1u << 31)) && (eb * 4 < (1u << 31)) && M >= 4 && N >= 4;
+    }
     // 16-byte vector loads need aligned bases, ld % 4 == 0 and the vectorised extent % 4 == 0
     bool vec = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && (lda % 4 == 0) && (ldb % 4 == 0);
     vec = vec && ((akc ? K : M) % 4 == 0) && ((bkc ? K : N) % 4 == 0);
