@@ -142,8 +142,14 @@ struct GemmArgs {
     int fast;     // vector kernels: offset-based unpredicated loads for the full slabs (all byte offsets < 2^31)
 };
 
+#ifdef GEMM_CLK
+__device__ long long gemm_clk_buf[4];
+#endif
 template <int BM, int BN, bool AKC, bool BKC, bool VEC>
 __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
+#ifdef GEMM_CLK
+    const long long clk0 = clock64(), wall0 = wall_clock64();
+#endif
     constexpr int WM = BM / 2, WN = BN / 2;      // per-wave tile
     constexpr int MT = WM / 32, NT = WN / 32;    // MFMA tiles per wave
     constexpr int A_FL = TileGeom<BM, AKC>::lds_floats;
@@ -198,6 +204,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
 
     for (int s = s_begin; s < nslab; ++s) {
         const int cur = (s - s_begin) & 1;
+#ifndef GEMM_NO_GLOBAL
         if (s + 1 < nslab) {
             if (fast && s + 1 < nfull) {
                 load_fast<NVA>(reinterpret_cast<const char*>(g.A) + (size_t)(s + 1) * stepA, offA, ra);
@@ -207,6 +214,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
                 load_tile<BN, BKC, VEC>(g.B, g.ldb, n0, (s + 1) * BKS, g.N, g.K, rb);
             }
         }
+#endif
         const float* as = smem + cur * STAGE;
         const float* bs = as + A_FL;
 #pragma unroll
@@ -224,13 +232,20 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
                     for (int j = 0; j < NT; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
         }
+#ifndef GEMM_NO_LDS_STORE
         if (s + 1 < nslab) {
             store_tile<BM, AKC>(smem + (cur ^ 1) * STAGE, ra);
             store_tile<BN, BKC>(smem + (cur ^ 1) * STAGE + A_FL, rb);
         }
+#endif
+#ifndef GEMM_NO_SYNC
         __syncthreads();
+#endif
     }
 
+#ifdef GEMM_CLK
+    if (blockIdx.x == 100 && threadIdx.x == 0) { gemm_clk_buf[0] = clock64() - clk0; gemm_clk_buf[1] = wall_clock64() - wall0; }
+#endif
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int i = 0; i < MT; ++i)
