@@ -96,8 +96,10 @@ __device__ __forceinline__ void st_chunk_bf16(unsigned short* __restrict__ lds, 
     }
 }
 
+// 4 waves per SIMD = two 512-thread workgroups per CU (2 x 74 KB of LDS fit): launches with more than 256 tiles (the
+// encoder's two cells, [p || cell 1]) then run in one round.  Needs <= 128 VGPRs.
 template <bool VEC, int PREC>     // PREC 0: fp32 MFMA, 1: bf16 MFMA
-__global__ void __launch_bounds__(SKT) sk_kernel(SkArgs args) {
+__global__ void __launch_bounds__(SKT) __attribute__((amdgpu_waves_per_eu(4, 4))) sk_kernel(SkArgs args) {
     SK_STAMP(0);
     // wave-private staging (A chunk + B chunk per wave), re-used as the [SKW][32][32] reduction buffer
     __shared__ __attribute__((aligned(16))) float smem[SKW * 2 * OPF];
