@@ -106,7 +106,11 @@ int xgk_fill(hipStream_t st, float* y, float v, int64_t n);
 int xgk_copy2d(hipStream_t st, float* dst, int ldd, const float* src, int lds, int rows, int cols, bool add);
 
 // ---- xg_step.hip : multi-job skinny split-K MFMA GEMM with optional LSTM-cell epilogue
-enum { SK_EPI_STORE = 0, SK_EPI_LSTM = 1, SK_EPI_GATE = 2 };
+enum { SK_EPI_STORE = 0, SK_EPI_LSTM = 1, SK_EPI_GATE = 2,
+       // LSTM cell BACKWARD of the previous time step in the epilogue of the product that completes its dh:
+       //   dh = product (+ C when accumulate) (+ add), then the cell's pointwise backward (xg_pointwise.hip:lstm_bwd_body)
+       //   -> ds (M,4R), dc_prev, and in HOLD mode the (1-m) dh pass-through into dh_hold.  N = R.
+       SK_EPI_LSTMB = 3 };
 constexpr int SK_MAX_JOBS = 4;
 struct SkSeg {
     const float* A; const float* B;   // A (M,K) row-major lda ; B (N,K) row-major ldb, or (K,N) when b_ncontig
@@ -122,6 +126,8 @@ struct SkJob {
     int ldadd, ldcp, ldhp, ldm, ldg, ldco, ldho;
     // GATE epilogue (sub_modules.py:42-47): g = dropout(relu(.)) -> C ; y = g*t + t
     const float* gate_t; float* gate_y; int ldt, ldy;
+    // LSTMB epilogue (reads gates / c_prev / c_out / mask / add from the LSTM fields above)
+    const float* dc_in; float* ds; float* dc_prev; float* dh_hold; int lddci, ldds, lddcp, lddhh;
     int nseg, M, N, ldc, accumulate, relu, epi, R, order, mask_mode, tile0;
     XgDrop drop;
 };

@@ -177,6 +177,18 @@ inline SkJob job_store(int M, int N, float* C, int ldc, bool acc, bool relu = fa
     j.M = M; j.N = N; j.C = C; j.ldc = ldc; j.accumulate = acc ? 1 : 0; j.relu = relu ? 1 : 0; j.epi = SK_EPI_STORE;
     return j;
 }
+// product job whose epilogue runs the pointwise LSTM backward `a` (a.dh_out is ignored: dh = product (+ *acc_from) + a.dh_add)
+inline SkJob job_lstm_bwd(const LstmBwdArgs& a, const float* acc_from, int ldacc) {
+    SkJob j{};
+    j.M = a.B; j.N = a.R; j.R = a.R; j.epi = SK_EPI_LSTMB; j.order = a.order; j.mask_mode = a.mask_mode;
+    j.C = const_cast<float*>(acc_from); j.ldc = ldacc; j.accumulate = acc_from ? 1 : 0;
+    j.add = a.dh_add; j.ldadd = a.lddha;
+    j.gates = const_cast<float*>(a.gates); j.ldg = a.ldg; j.c_prev = a.c_prev; j.ldcp = a.ldcp;
+    j.c_out = const_cast<float*>(a.c_out); j.ldco = a.ldco; j.mask = a.mask; j.ldm = a.ldm;
+    j.dc_in = a.dc_out; j.lddci = a.lddc; j.ds = a.ds; j.ldds = a.ldds; j.dc_prev = a.dc_prev; j.lddcp = a.lddcp;
+    j.dh_hold = a.dh_prev; j.lddhh = a.lddhp; j.drop = a.drop;
+    return j;
+}
 inline SkJob job_lstm(const LstmFwdArgs& a) {
     SkJob j{};
     j.M = a.B; j.N = 4 * a.R; j.R = a.R; j.epi = SK_EPI_LSTM; j.order = a.order; j.mask_mode = a.mask_mode;
@@ -540,25 +552,32 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     // on the main stream, 4 launches per step.  What it hands to cell 1 -- ds2 W_i2h and dp W_h2a[:, :R] -- is batched over
     // all steps afterwards (two GEMMs), and chain 1 (2 launches per step) runs on the auxiliary stream under the
     // encoder backward; its results only feed parameter gradients.
+    // The pointwise LSTM backward of step t-1 runs in the epilogue of the product that completes its dh (the last
+    // launch of step t), so a step of chain 2 is 3 launches and a step of chain 1 is 1.
+    const bool fuse = R % 4 == 0;
     int cur = 0;
     for (int j = 0; j < 4; ++j) ZERO(w.dst[0][j], BR);
-    for (int t = T - 1; t >= 0; --t) {
-        if (t == ss.dh_split_step - 1) XG_TRY(ss.wait_mark(ss.dh_mark));   // dH of the early steps (auxiliary stream)
-        float *dh2n = w.dst[cur][2], *dc2n = w.dst[cur][3];
-        float *dh2p = w.dst[cur ^ 1][2], *dc2p = w.dst[cur ^ 1][3];
-        float* ds2 = w.DS2 + (size_t)t * B * 4 * R;
-        float* dp = w.DP + (size_t)t * B * A;
-        float* daf = w.DAF + t * BR;
-        const float* mk = mask + (size_t)t * mask_tstride;
+    auto cell2_bwd = [&](int t, int c) {          // backward of cell 2 at step t, reading the carried state of parity c
         LstmBwdArgs a{};
         a.gates = w.G2 + (size_t)t * B * 4 * R; a.ldg = 4 * R;
         a.c_prev = w.C2 + t * BR; a.ldcp = R; a.c_out = w.C2 + (t + 1) * BR; a.ldco = R;
-        a.mask = mk; a.ldm = ldm; a.dh_out = dh2n; a.lddh = R; a.dh_add = w.DH2OUT + t * BR; a.lddha = R;
-        a.dc_out = dc2n; a.lddc = R;
-        a.ds = ds2; a.ldds = 4 * R; a.dc_prev = dc2p; a.lddcp = R; a.dh_prev = dh2p; a.lddhp = R;
+        a.mask = mask + (size_t)t * mask_tstride; a.ldm = ldm;
+        a.dh_out = w.dst[c][2]; a.lddh = R; a.dh_add = w.DH2OUT + t * BR; a.lddha = R;
+        a.dc_out = w.dst[c][3]; a.lddc = R;
+        a.ds = w.DS2 + (size_t)t * B * 4 * R; a.ldds = 4 * R;
+        a.dc_prev = w.dst[c ^ 1][3]; a.lddcp = R; a.dh_prev = w.dst[c ^ 1][2]; a.lddhp = R;
         a.B = B; a.R = R; a.order = XG_ORDER_IFOG; a.mask_mode = XG_MASK_HOLD;
         a.drop = xg_make_drop(&run, XG_SITE_L2, t);
-        XG_TRY(xgk_lstm_bwd(st, a));
+        return a;
+    };
+    for (int t = T - 1; t >= 0; --t) {
+        // dH of the early steps comes from the auxiliary stream; fused, step t-1's cell backward runs inside step t
+        if (t == ss.dh_split_step - (fuse ? 0 : 1)) XG_TRY(ss.wait_mark(ss.dh_mark));
+        float* dh2p = w.dst[cur ^ 1][2];
+        float* ds2 = w.DS2 + (size_t)t * B * 4 * R;
+        float* dp = w.DP + (size_t)t * B * A;
+        float* daf = w.DAF + t * BR;
+        if (!fuse || t == T - 1) XG_TRY(xgk_lstm_bwd(st, cell2_bwd(t, cur)));
         {   // s2 = h1' Wi + af Wa + h2 Wh : the two data gradients chain 2 needs now
             SkArgs sk{};
             sk.njobs = 2;
@@ -568,10 +587,11 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         }
         XG_TRY(xgk_attn_bwd(st, daf, R, w.P + (size_t)t * B * A, w.vproj, w.Venc, p.a2w_w, w.ALPHA + (size_t)t * B * K,
                             w.DE + (size_t)t * B * K, dp, B, K, R, A));
-        {   // into step t-1: dh2 += dp Wh2a[:, R:]
+        {   // into step t-1: dh2 += dp Wh2a[:, R:]  (+ cell 2's backward at t-1 on the completed dh2)
             SkArgs sk{};
             sk.njobs = 1;
-            sk.job[0] = job_store(B, R, dh2p, R, true);
+            if (fuse && t > 0) sk.job[0] = job_lstm_bwd(cell2_bwd(t - 1, cur ^ 1), dh2p, R);
+            else sk.job[0] = job_store(B, R, dh2p, R, true);
             sk.job[0].nseg = 1;
             sk.job[0].seg[0] = seg_nn(dp, A, p.h2a_w + R, 2 * R, A);
             XG_TRY(xgk_skinny(st, sk));
@@ -585,22 +605,26 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     XG_TRY(gemm_nn(sx, TB, R, 4 * R, w.DS2, 4 * R, p.l2_i2h_w, R, w.DH1X, R, false));
     if (T > 1) XG_TRY(gemm_nn(sx, (T - 1) * B, R, A, w.DP + (size_t)B * A, A, p.h2a_w, 2 * R, w.DH1X, R, true));
     int cur1 = 0;
+    auto cell1_bwd = [&](int t, int c) {
+        LstmBwdArgs a{};
+        a.gates = w.G1 + (size_t)t * B * 4 * R; a.ldg = 4 * R;
+        a.c_prev = w.C1 + t * BR; a.ldcp = R; a.c_out = w.C1 + (t + 1) * BR; a.ldco = R;
+        a.mask = mask + (size_t)t * mask_tstride; a.ldm = ldm;
+        a.dh_out = w.dst[c][0]; a.lddh = R; a.dh_add = w.DH1X + t * BR; a.lddha = R; a.dc_out = w.dst[c][1]; a.lddc = R;
+        a.ds = w.DS1 + (size_t)t * B * 4 * R; a.ldds = 4 * R;
+        a.dc_prev = w.dst[c ^ 1][1]; a.lddcp = R; a.dh_prev = w.dst[c ^ 1][0]; a.lddhp = R;
+        a.B = B; a.R = R; a.order = XG_ORDER_IFOG; a.mask_mode = XG_MASK_HOLD;
+        a.drop = xg_make_drop(&run, XG_SITE_L1, t);
+        return a;
+    };
     for (int t = T - 1; t >= 0; --t) {
-        float *dh1n = w.dst[cur1][0], *dc1n = w.dst[cur1][1];
-        float *dh1p = w.dst[cur1 ^ 1][0], *dc1p = w.dst[cur1 ^ 1][1];
+        float* dh1p = w.dst[cur1 ^ 1][0];
         float* ds1 = w.DS1 + (size_t)t * B * 4 * R;
-        LstmBwdArgs c{};
-        c.gates = w.G1 + (size_t)t * B * 4 * R; c.ldg = 4 * R;
-        c.c_prev = w.C1 + t * BR; c.ldcp = R; c.c_out = w.C1 + (t + 1) * BR; c.ldco = R;
-        c.mask = mask + (size_t)t * mask_tstride; c.ldm = ldm;
-        c.dh_out = dh1n; c.lddh = R; c.dh_add = w.DH1X + t * BR; c.lddha = R; c.dc_out = dc1n; c.lddc = R;
-        c.ds = ds1; c.ldds = 4 * R; c.dc_prev = dc1p; c.lddcp = R; c.dh_prev = dh1p; c.lddhp = R;
-        c.B = B; c.R = R; c.order = XG_ORDER_IFOG; c.mask_mode = XG_MASK_HOLD;
-        c.drop = xg_make_drop(&run, XG_SITE_L1, t);
-        XG_TRY(xgk_lstm_bwd(sx, c));
+        if (!fuse || t == T - 1) XG_TRY(xgk_lstm_bwd(sx, cell1_bwd(t, cur1)));
         SkArgs sk{};
         sk.njobs = 1;
-        sk.job[0] = job_store(B, R, dh1p, R, true);
+        if (fuse && t > 0) sk.job[0] = job_lstm_bwd(cell1_bwd(t - 1, cur1 ^ 1), dh1p, R);
+        else sk.job[0] = job_store(B, R, dh1p, R, true);
         sk.job[0].nseg = 1;
         sk.job[0].seg[0] = seg_nn(ds1, 4 * R, p.l1_h2h_w, R, 4 * R);
         XG_TRY(xgk_skinny(sx, sk));

@@ -277,6 +277,53 @@ __global__ void __launch_bounds__(SKT) __attribute__((amdgpu_waves_per_eu(4, 4))
                 *dst = v;
             }
         }
+    } else if (job.epi == SK_EPI_LSTMB) {
+        // pointwise LSTM backward of the step whose dh this product completes (same arithmetic as lstm_bwd_body)
+#pragma unroll
+        for (int e = 0; e < 1024 / SKT; ++e) {
+            const int idx = threadIdx.x + SKT * e;
+            const int m = idx >> 5, c = idx & 31;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < SKW; ++w) v += red[w][m][c];
+            const int b = m0 + m, j = n0 + c;
+            if (b < job.M && j < job.N) {
+                if (job.accumulate) v += job.C[(size_t)b * job.ldc + j];
+                if (job.add) v += job.add[(size_t)b * job.ldadd + j];
+                const float* g = job.gates + (size_t)b * job.ldg;
+                const float ig = g[j], fg = g[R + j];
+                const float og = job.order == XG_ORDER_IFOG ? g[2 * R + j] : g[3 * R + j];
+                const float gg = job.order == XG_ORDER_IFOG ? g[3 * R + j] : g[2 * R + j];
+                const float cp = job.c_prev[(size_t)b * job.ldcp + j];
+                const float cn = job.c_out[(size_t)b * job.ldco + j];
+                const float mk = job.mask ? job.mask[(size_t)b * job.ldm] : 1.0f;
+                float dh = v * xg_keep(job.drop, (uint32_t)(b * R + j));
+                float dc = job.dc_in ? job.dc_in[(size_t)b * job.lddci + j] : 0.0f;
+                float dht, dct, dcp;
+                const float tc = xg_tanh(cn);
+                if (job.mask_mode == XG_MASK_HOLD) {
+                    if (job.dh_hold) job.dh_hold[(size_t)b * job.lddhh + j] = (1.0f - mk) * dh;
+                    dht = mk * dh;
+                    dc += dht * og * (1.0f - tc * tc);
+                    dcp = (1.0f - mk) * dc;
+                    dct = mk * dc;
+                } else {
+                    dht = mk * dh;
+                    dct = mk * dc + dht * og * (1.0f - tc * tc);
+                    dcp = 0.0f;
+                }
+                const float d_o = dht * tc;
+                dcp += dct * fg;
+                const float d_f = dct * cp, d_i = dct * gg, d_g = dct * ig;
+                float* ds = job.ds + (size_t)b * job.ldds;
+                ds[j] = d_i * ig * (1.0f - ig);
+                ds[R + j] = d_f * fg * (1.0f - fg);
+                const float dso = d_o * og * (1.0f - og), dsg = d_g * (1.0f - gg * gg);
+                if (job.order == XG_ORDER_IFOG) { ds[2 * R + j] = dso; ds[3 * R + j] = dsg; }
+                else                            { ds[2 * R + j] = dsg; ds[3 * R + j] = dso; }
+                job.dc_prev[(size_t)b * job.lddcp + j] = dcp;
+            }
+        }
     } else if (job.epi == SK_EPI_GATE) {
 #pragma unroll
         for (int e = 0; e < 1024 / SKT; ++e) {
@@ -357,6 +404,8 @@ int xgk_skinny(hipStream_t st, SkArgs& a) {
     for (int j = 0; j < a.njobs; ++j) {
         SkJob& jb = a.job[j];
         if (jb.M <= 0 || jb.N <= 0 || jb.nseg < 1 || jb.nseg > 3) return XG_EINVAL;
+        if (jb.epi == SK_EPI_LSTMB && (jb.N != jb.R || !jb.gates || !jb.c_prev || !jb.c_out || !jb.ds || !jb.dc_prev ||
+                                       (jb.accumulate && !jb.C))) return XG_EINVAL;
         jb.tile0 = tiles; a.tile0[j] = tiles;
         const int ntm = xg_cdiv(jb.M, 32);
         int ntn;
