@@ -24,7 +24,7 @@ namespace {
 // caller's stream before an entry point returns, so the stream semantics of the C ABI are unchanged, and two callers on
 // two streams (the SCST sampled / greedy rollouts) never share an auxiliary stream.  XG_NO_OVERLAP=1 disables it.
 constexpr int XG_NEV = 16;
-struct XgAux { hipStream_t s = nullptr; hipEvent_t ev[XG_NEV]; bool ok = false; };
+struct XgAux { hipStream_t s = nullptr, s2 = nullptr; hipEvent_t ev[XG_NEV]; bool ok = false; };
 XgAux* aux_for(hipStream_t main) {
     static std::map<std::pair<int, hipStream_t>, XgAux> table;
     static std::mutex mu;
@@ -37,6 +37,7 @@ XgAux* aux_for(hipStream_t main) {
     XgAux& a = table[{dev, main}];
     if (!a.ok) {
         if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+        if (hipStreamCreateWithFlags(&a.s2, hipStreamNonBlocking) != hipSuccess) return nullptr;
         for (int i = 0; i < XG_NEV; ++i)
             if (hipEventCreateWithFlags(&a.ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
         a.ok = true;
@@ -49,18 +50,34 @@ XgAux* aux_for(hipStream_t main) {
 thread_local hipEvent_t tl_grad_event = nullptr;
 
 struct Streams {
-    hipStream_t main, aux;
+    hipStream_t main, aux, aux2;              // aux2: a second side chain (the decoder backward's cell-1 recurrence)
     XgAux* a;
     int next = 0;
-    bool forked = false;
+    bool forked = false, forked2 = false;
     int dh_split_step = 0, dh_mark = -1;      // heads_bwd -> decoder_bwd_core hand-off (see heads_bwd)
-    explicit Streams(hipStream_t m) : main(m), aux(m), a(aux_for(m)) { if (a) aux = a->s; }
+    explicit Streams(hipStream_t m) : main(m), aux(m), aux2(m), a(aux_for(m)) { if (a) { aux = a->s; aux2 = a->s2; } }
     bool overlap() const { return a != nullptr; }
     // aux may start work that depends on everything enqueued on main so far
     int fork() {
         if (!a) return XG_OK;
         hipEvent_t e = a->ev[next++ % XG_NEV];
         if (hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(aux, e, 0) != hipSuccess) return XG_EHIP;
+        forked = true;
+        return XG_OK;
+    }
+    // aux2 may start work that depends on everything enqueued on main so far
+    int fork2() {
+        if (!a) return XG_OK;
+        hipEvent_t e = a->ev[next++ % XG_NEV];
+        if (hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(aux2, e, 0) != hipSuccess) return XG_EHIP;
+        forked2 = true;
+        return XG_OK;
+    }
+    // aux waits for everything enqueued on aux2 so far (then a join() of aux covers both)
+    int chain2_into_aux() {
+        if (!a || !forked2) return XG_OK;
+        hipEvent_t e = a->ev[next++ % XG_NEV];
+        if (hipEventRecord(e, aux2) != hipSuccess || hipStreamWaitEvent(aux, e, 0) != hipSuccess) return XG_EHIP;
         forked = true;
         return XG_OK;
     }
@@ -600,10 +617,12 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     }
     const int cur2 = cur;
     XG_TRY(ss.fork());                        // chain 2 is complete: DS2, DP, DAF, DE
-    hipStream_t sx = ss.aux;
+    XG_TRY(ss.fork2());
+    hipStream_t sx = ss.aux;                  // parameter gradients that only need chain 2
+    hipStream_t s1 = ss.aux2;                 // chain 1 and what depends on it
     // what cell 1's output receives from chain 2, all steps at once:  DH1X[t] = ds2[t] W_i2h2 + dp[t+1] W_h2a[:, :R]
-    XG_TRY(gemm_nn(sx, TB, R, 4 * R, w.DS2, 4 * R, p.l2_i2h_w, R, w.DH1X, R, false));
-    if (T > 1) XG_TRY(gemm_nn(sx, (T - 1) * B, R, A, w.DP + (size_t)B * A, A, p.h2a_w, 2 * R, w.DH1X, R, true));
+    XG_TRY(gemm_nn(s1, TB, R, 4 * R, w.DS2, 4 * R, p.l2_i2h_w, R, w.DH1X, R, false));
+    if (T > 1) XG_TRY(gemm_nn(s1, (T - 1) * B, R, A, w.DP + (size_t)B * A, A, p.h2a_w, 2 * R, w.DH1X, R, true));
     int cur1 = 0;
     auto cell1_bwd = [&](int t, int c) {
         LstmBwdArgs a{};
@@ -620,18 +639,18 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     for (int t = T - 1; t >= 0; --t) {
         float* dh1p = w.dst[cur1 ^ 1][0];
         float* ds1 = w.DS1 + (size_t)t * B * 4 * R;
-        if (!fuse || t == T - 1) XG_TRY(xgk_lstm_bwd(sx, cell1_bwd(t, cur1)));
+        if (!fuse || t == T - 1) XG_TRY(xgk_lstm_bwd(s1, cell1_bwd(t, cur1)));
         SkArgs sk{};
         sk.njobs = 1;
         if (fuse && t > 0) sk.job[0] = job_lstm_bwd(cell1_bwd(t - 1, cur1 ^ 1), dh1p, R);
         else sk.job[0] = job_store(B, R, dh1p, R, true);
         sk.job[0].nseg = 1;
         sk.job[0].seg[0] = seg_nn(ds1, 4 * R, p.l1_h2h_w, R, 4 * R);
-        XG_TRY(xgk_skinny(sx, sk));
+        XG_TRY(xgk_skinny(s1, sk));
         cur1 ^= 1;
     }
     // the attention query of step 0 read the INITIAL h1
-    XG_TRY(gemm_nn(sx, B, R, A, w.DP, A, p.h2a_w, 2 * R, w.dst[cur1][0], R, true));
+    XG_TRY(gemm_nn(s1, B, R, A, w.DP, A, p.h2a_w, 2 * R, w.dst[cur1][0], R, true));
     // ---- after the loop.  Main chain (the encoder backward waits for it): dVproj -> dV.  Everything else is a
     // parameter gradient and goes to the auxiliary stream, under the encoder's recurrent backward.
     XG_TRY(xgk_attn_bwd_post(st, w.P, w.vproj, p.a2w_w, w.DE, w.DVPROJ, g.a2w_w, T, B, K, A));
@@ -643,8 +662,9 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         float* gw[4] = {g.ih1_w, g.ic1_w, g.ih2_w, g.ic2_w};
         float* gb[4] = {g.ih1_b, g.ic1_b, g.ih2_b, g.ic2_b};
         for (int j = 0; j < 4; ++j) {
-            XG_TRY(gemm_tn(sx, B, R, R, gst[j], R, w.vbar, R, gw[j], R));
-            XG_TRY(xgk_colsum(sx, gst[j], R, B, R, gb[j]));
+            hipStream_t sj = j < 2 ? s1 : sx;     // h1 / c1 come out of chain 1
+            XG_TRY(gemm_tn(sj, B, R, R, gst[j], R, w.vbar, R, gw[j], R));
+            XG_TRY(xgk_colsum(sj, gst[j], R, B, R, gb[j]));
         }
     }
     // batched weight gradients over all T steps
@@ -654,28 +674,29 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     XG_TRY(xgk_colsum(sx, w.DS2, 4 * R, TB, 4 * R, g.l2_i2h_b));
     XG_TRY(xgk_colsum(sx, w.DS2, 4 * R, TB, 4 * R, g.l2_a2h_b));
     XG_TRY(xgk_colsum(sx, w.DS2, 4 * R, TB, 4 * R, g.l2_h2h_b));
-    XG_TRY(gemm_tn(sx, TB, 4 * R, R, w.DS1, 4 * R, w.H1, R, g.l1_h2h_w, R));
-    XG_TRY(gemm_tn(sx, TB, 4 * R, E, w.DS1, 4 * R, w.Xe, E, g.l1_i2h_w, E));
-    XG_TRY(gemm_tn(sx, TB, 4 * R, R, w.DS1, 4 * R, w.POSG, R, g.l1_a2h_w, R));
-    XG_TRY(xgk_colsum(sx, w.DS1, 4 * R, TB, 4 * R, g.l1_i2h_b));
-    XG_TRY(xgk_colsum(sx, w.DS1, 4 * R, TB, 4 * R, g.l1_a2h_b));
-    XG_TRY(xgk_colsum(sx, w.DS1, 4 * R, TB, 4 * R, g.l1_h2h_b));
+    XG_TRY(gemm_tn(s1, TB, 4 * R, R, w.DS1, 4 * R, w.H1, R, g.l1_h2h_w, R));
+    XG_TRY(gemm_tn(s1, TB, 4 * R, E, w.DS1, 4 * R, w.Xe, E, g.l1_i2h_w, E));
+    XG_TRY(gemm_tn(s1, TB, 4 * R, R, w.DS1, 4 * R, w.POSG, R, g.l1_a2h_w, R));
+    XG_TRY(xgk_colsum(s1, w.DS1, 4 * R, TB, 4 * R, g.l1_i2h_b));
+    XG_TRY(xgk_colsum(s1, w.DS1, 4 * R, TB, 4 * R, g.l1_a2h_b));
+    XG_TRY(xgk_colsum(s1, w.DS1, 4 * R, TB, 4 * R, g.l1_h2h_b));
     XG_TRY(gemm_tn(sx, TB, A, R, w.DP, A, w.H1, R, g.h2a_w, 2 * R));
     XG_TRY(gemm_tn(sx, TB, A, R, w.DP, A, w.H2, R, g.h2a_w + R, 2 * R));
     XG_TRY(xgk_colsum(sx, w.DP, A, TB, A, g.h2a_b));
     // input side of cell 1: pos' gate, embedding
-    XG_TRY(gemm_nn(sx, TB, R, 4 * R, w.DS1, 4 * R, p.l1_a2h_w, R, w.DPOSG, R, false));
-    XG_TRY(gemm_nn(sx, TB, E, 4 * R, w.DS1, 4 * R, p.l1_i2h_w, E, w.DXe, E, false));
-    XG_TRY(xgk_gate_bwd(sx, w.DPOSG, R, w.GP, R, x.pos_feats, R, B, w.DGP, R, nullptr, 0, false, TB, R,
+    XG_TRY(gemm_nn(s1, TB, R, 4 * R, w.DS1, 4 * R, p.l1_a2h_w, R, w.DPOSG, R, false));
+    XG_TRY(gemm_nn(s1, TB, E, 4 * R, w.DS1, 4 * R, p.l1_i2h_w, E, w.DXe, E, false));
+    XG_TRY(xgk_gate_bwd(s1, w.DPOSG, R, w.GP, R, x.pos_feats, R, B, w.DGP, R, nullptr, 0, false, TB, R,
                         xg_make_drop(&run, XG_SITE_DGATE, 0)));
-    XG_TRY(gemm_tn(sx, TB, R, E, w.DGP, R, w.Xe, E, g.dgate_w, E));
-    XG_TRY(xgk_colsum(sx, w.DGP, R, TB, R, g.dgate_b));
-    XG_TRY(gemm_nn(sx, TB, E, R, w.DGP, R, p.dgate_w, E, w.DXe, E, true));
-    XG_TRY(xgk_embed_scatter_add(sx, g.embed_w, E, tok, B, tok_bstride, tok_tstride, TB, d.V, w.DXe, E));
+    XG_TRY(gemm_tn(s1, TB, R, E, w.DGP, R, w.Xe, E, g.dgate_w, E));
+    XG_TRY(xgk_colsum(s1, w.DGP, R, TB, R, g.dgate_b));
+    XG_TRY(gemm_nn(s1, TB, E, R, w.DGP, R, p.dgate_w, E, w.DXe, E, true));
+    XG_TRY(xgk_embed_scatter_add(s1, g.embed_w, E, tok, B, tok_bstride, tok_tstride, TB, d.V, w.DXe, E));
     // the hoisted projection's parameter gradients need dVproj (main stream, above)
     XG_TRY(ss.fork());
     XG_TRY(gemm_tn(sx, N, A, R, w.DVPROJ, A, w.Venc, R, g.v2a_w, R));
     XG_TRY(xgk_colsum(sx, w.DVPROJ, A, N, A, g.v2a_b));
+    XG_TRY(ss.chain2_into_aux());             // aux now also covers the second side chain
     // everything but two_spatial_encoder.* is final once the auxiliary stream gets here (it has waited for main above)
     if (tl_grad_event && hipEventRecord(tl_grad_event, sx) != hipSuccess) return XG_EHIP;
     return XG_OK;
