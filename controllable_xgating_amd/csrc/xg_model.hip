@@ -73,6 +73,13 @@ struct Streams {
         forked2 = true;
         return XG_OK;
     }
+    // main waits for everything enqueued on aux2 so far
+    int join2() {
+        if (!a || !forked2) return XG_OK;
+        hipEvent_t e = a->ev[next++ % XG_NEV];
+        if (hipEventRecord(e, aux2) != hipSuccess || hipStreamWaitEvent(main, e, 0) != hipSuccess) return XG_EHIP;
+        return XG_OK;
+    }
     // aux waits for everything enqueued on aux2 so far (then a join() of aux covers both)
     int chain2_into_aux() {
         if (!a || !forked2) return XG_OK;
@@ -217,7 +224,7 @@ inline SkJob job_lstm(const LstmFwdArgs& a) {
 
 // ================================================================== encoder
 int encoder_fwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgBnState* bn, const XgBatch& x,
-                const XgRun& run, Ws& w) {
+                const XgRun& run, Ws& w, Streams* ss = nullptr) {
     const int B = d.B, K = d.K, R = d.R, N = B * K;
     const float* feats[2] = {x.feats_rgb, x.feats_opfl};
     const int F[2] = {d.F1, d.F2};
@@ -231,7 +238,13 @@ int encoder_fwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgBnSt
     const float* whh[2] = {p.lstm_rgb_whh, p.lstm_opfl_whh};
     const float* bih[2] = {p.lstm_rgb_bih, p.lstm_opfl_bih};
     const float* bhh[2] = {p.lstm_rgb_bhh, p.lstm_opfl_bhh};
+    // the two modalities' embed -> BatchNorm -> W_ih pipelines are independent until the recurrence: the optical-flow one
+    // runs on the second auxiliary stream
+    const bool side = ss && ss->overlap();
+    if (side) XG_TRY(ss->fork2());
+    hipStream_t st_main = st;
     for (int m = 0; m < 2; ++m) {
+        hipStream_t st = (m == 1 && side) ? ss->aux2 : st_main;
         XG_TRY(xgk_linear(st, N, R, F[m], feats[m], F[m], emb_w[m], emb_b[m], w.Z[m], R));          // sub_modules.py:121,126
         if (run.train) {
             XG_TRY(xgk_bn_stats(st, w.Z[m], N, R, w.bn_mean[m], w.bn_var[m], nullptr));
@@ -246,6 +259,7 @@ int encoder_fwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgBnSt
                             run.bn_eps, xg_make_drop(&run, m == 0 ? XG_SITE_EMB_RGB : XG_SITE_EMB_OPFL, 0)));
         XG_TRY(xgk_linear(st, N, 4 * R, R, w.X[m], R, wih[m], bih[m], w.PRE[m], 4 * R));          // hoisted over all K frames
     }
+    if (side) XG_TRY(ss->join2());
     ZERO(w.zeroBR, (size_t)B * R);
     XgRun nodrop = run; nodrop.drop_p = 0.f;
     for (int i = 0; i < K; ++i) {                                                                  // sub_modules.py:132-148
@@ -372,6 +386,10 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
         XG_TRY(gemm_tn(sx, N, 4 * R, R, w.dS[m], 4 * R, w.X[m], R, g_wih[m], R));
         XG_TRY(xgk_colsum(sx, w.dS[m], 4 * R, N, 4 * R, g_bih[m]));
         XG_TRY(xgk_colsum(sx, w.dS[m], 4 * R, N, 4 * R, g_bhh[m]));
+        // the optical-flow modality's input-side backward runs beside the rgb one (second auxiliary stream)
+        if (m == 1 && ss.overlap()) XG_TRY(ss.fork2());
+        hipStream_t st_outer = st;
+        hipStream_t st = (m == 1 && ss.overlap()) ? ss.aux2 : st_outer;
         XG_TRY(gemm_nn(st, N, R, 4 * R, w.dS[m], 4 * R, wih[m], R, w.dX[m], R, false));
         // BatchNorm + ReLU + dropout + mask backward (sub_modules.py:121-123)
         ZERO(w.bn_s1[m], R); ZERO(w.bn_s2[m], R);
@@ -384,7 +402,7 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
         XG_TRY(gemm_tn(st, N, R, F[m], w.dX[m], R, feats[m], F[m], g_emb_w[m], F[m]));
         XG_TRY(xgk_colsum(st, w.dX[m], R, N, R, g_emb_b[m]));
     }
-    return XG_OK;
+    return ss.chain2_into_aux();              // the caller's join() of aux then covers the second side chain too
 }
 
 // ================================================================== decoder pieces
@@ -820,7 +838,8 @@ extern "C" int xg_encoder_fwd(void* stream, const XgDims* d, const XgParams* p, 
     if (!p || !x || !run || !V || !x->feats_rgb || !x->feats_opfl || !x->feat_mask) return XG_EINVAL;
     XgGemmModeGuard mode_guard(run->gemm_mode);
     hipStream_t st = (hipStream_t)stream;
-    XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w));
+    Streams es(st);
+    XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w, &es));
     if (hipMemcpyAsync(V, w.Venc, sizeof(float) * (size_t)d->B * d->K * d->R, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
     return XG_OK;
 }
@@ -885,7 +904,7 @@ extern "C" int xg_forward_xe(void* stream, const XgDims* d, const XgParams* p, c
     int rows_done = 0;
     XG_TRY(ss.fork());
     XG_TRY(decoder_tokens_xe(ss.aux, *d, *p, *x, *run, w));
-    XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w));
+    XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w, &ss));
     XG_TRY(decoder_fwd_xe(ss, *d, *p, *x, *run, w, &rows_done));
     XG_TRY(heads_fwd_logits(ss, *d, *p, *run, w, TB, rows_done));
     XG_TRY(xgk_log_softmax(st, w.LOGITS, d->V, logp, d->V, TB, d->V, d->B, d->T, true));
@@ -929,7 +948,8 @@ extern "C" int xg_forward_ss(void* stream, const XgDims* d, const XgParams* p, c
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, R = d->R, E = d->E, A = d->A, T = d->T, TB = T * B, N = B * d->K;
     const size_t BR = (size_t)B * R;
-    XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w));
+    Streams es(st);
+    XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w, &es));
     XG_TRY(init_hidden(st, *d, *p, w.Venc, x->feat_mask, w, w.H1, w.C1, w.H2, w.C2));
     XG_TRY(xgk_linear(st, N, A, R, w.Venc, R, p->v2a_w, p->v2a_b, w.vproj, A));
     int64_t* sampled = reinterpret_cast<int64_t*>(w.DXe);       // scratch (free until the backward pass)
@@ -999,7 +1019,7 @@ extern "C" int xg_xe_loss_fwd(void* stream, const XgDims* d, const XgParams* p, 
     int rows_done = 0;
     XG_TRY(ss.fork());
     XG_TRY(decoder_tokens_xe(ss.aux, *d, *p, *x, *run, w));
-    XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w));
+    XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w, &ss));
     XG_TRY(decoder_fwd_xe(ss, *d, *p, *x, *run, w, &rows_done));
     XG_TRY(heads_fwd_logits(ss, *d, *p, *run, w, TB, rows_done));
     XG_TRY(xgk_xent_fwd(st, w.LOGITS, d->V, x->seq, x->seq_mask, nullptr, d->B, d->T, d->V, 1, w.LSE, w.sums));
@@ -1041,7 +1061,8 @@ static int rollout_impl(hipStream_t st, const XgDims* d, const XgParams* p, cons
                         int64_t* seq, float* seq_logp, int32_t* n_steps, int split) {
     const int B = d->B, R = d->R, E = d->E, A = d->A, T = d->T, N = B * d->K;
     const size_t BR = (size_t)B * R;
-    XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w));
+    Streams es(st);
+    XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w, &es));
     XG_TRY(init_hidden(st, *d, *p, w.Venc, x->feat_mask, w, w.H1, w.C1, w.H2, w.C2));
     XG_TRY(xgk_linear(st, N, A, R, w.Venc, R, p->v2a_w, p->v2a_b, w.vproj, A));
     if (hipMemsetAsync(w.alive, 0, sizeof(int32_t) * 4, st) != hipSuccess) return XG_EHIP;   // alive[i] = running max finishing step
