@@ -410,11 +410,29 @@ int init_hidden(hipStream_t st, const XgDims& d, const XgParams& p, const float*
                 float* h1, float* c1, float* h2, float* c2) {
     const int B = d.B, R = d.R;
     XG_TRY(xgk_masked_mean(st, V, feat_mask, w.vbar, B, d.K, R));
-    XG_TRY(xgk_linear(st, B, R, R, w.vbar, R, p.ih1_w, p.ih1_b, h1, R));
-    XG_TRY(xgk_linear(st, B, R, R, w.vbar, R, p.ic1_w, p.ic1_b, c1, R));
-    XG_TRY(xgk_linear(st, B, R, R, w.vbar, R, p.ih2_w, p.ih2_b, h2, R));
-    XG_TRY(xgk_linear(st, B, R, R, w.vbar, R, p.ic2_w, p.ic2_b, c2, R));
+    float* out[4] = {h1, c1, h2, c2};
+    const float* wt[4] = {p.ih1_w, p.ic1_w, p.ih2_w, p.ic2_w};
+    const float* bs[4] = {p.ih1_b, p.ic1_b, p.ih2_b, p.ic2_b};
+    if (R % 4 == 0) {                          // the four (B,R)x(R,R) products as four jobs of one skinny launch
+        SkArgs sk{};
+        sk.njobs = 4;
+        for (int j = 0; j < 4; ++j) {
+            sk.job[j] = job_store(B, R, out[j], R, false);
+            sk.job[j].nseg = 1; sk.job[j].seg[0] = seg_nt(w.vbar, R, wt[j], R, R); sk.job[j].bias[0] = bs[j];
+        }
+        return xgk_skinny(st, sk);
+    }
+    for (int j = 0; j < 4; ++j) XG_TRY(xgk_linear(st, B, R, R, w.vbar, R, wt[j], bs[j], out[j], R));
     return XG_OK;
+}
+
+// initial decoder state (main stream) beside the hoisted v2a(V) projection (second auxiliary stream), sub_modules.py:677
+int init_and_vproj(Streams& ss, const XgDims& d, const XgParams& p, const float* feat_mask, Ws& w) {
+    const int N = d.B * d.K;
+    XG_TRY(ss.fork2());
+    XG_TRY(xgk_linear(ss.aux2, N, d.A, d.R, w.Venc, d.R, p.v2a_w, p.v2a_b, w.vproj, d.A));
+    XG_TRY(init_hidden(ss.main, d, p, w.Venc, feat_mask, w, w.H1, w.C1, w.H2, w.C2));
+    return ss.join2();
 }
 
 struct StepIO {
@@ -536,8 +554,7 @@ int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatc
     hipStream_t st = ss.main;
     const int B = d.B, R = d.R, A = d.A, E = d.E, T = d.T, N = B * d.K;
     const size_t BR = (size_t)B * R;
-    XG_TRY(init_hidden(st, d, p, w.Venc, x.feat_mask, w, w.H1, w.C1, w.H2, w.C2));
-    XG_TRY(xgk_linear(st, N, A, R, w.Venc, R, p.v2a_w, p.v2a_b, w.vproj, A));                       // hoisted v2a(V), :677
+    XG_TRY(init_and_vproj(ss, d, p, x.feat_mask, w));
     XG_TRY(ss.join());                                                                              // token-side products
     const int th = (ss.overlap() && T >= 4) ? T / 2 : 0;
     *logit_rows_done = 0;
@@ -950,8 +967,7 @@ extern "C" int xg_forward_ss(void* stream, const XgDims* d, const XgParams* p, c
     const size_t BR = (size_t)B * R;
     Streams es(st);
     XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w, &es));
-    XG_TRY(init_hidden(st, *d, *p, w.Venc, x->feat_mask, w, w.H1, w.C1, w.H2, w.C2));
-    XG_TRY(xgk_linear(st, N, A, R, w.Venc, R, p->v2a_w, p->v2a_b, w.vproj, A));
+    XG_TRY(init_and_vproj(es, *d, *p, x->feat_mask, w));
     int64_t* sampled = reinterpret_cast<int64_t*>(w.DXe);       // scratch (free until the backward pass)
     for (int t = 0; t < T; ++t) {
         int64_t* tok = w.TOK + (size_t)t * B;
@@ -1063,8 +1079,7 @@ static int rollout_impl(hipStream_t st, const XgDims* d, const XgParams* p, cons
     const size_t BR = (size_t)B * R;
     Streams es(st);
     XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w, &es));
-    XG_TRY(init_hidden(st, *d, *p, w.Venc, x->feat_mask, w, w.H1, w.C1, w.H2, w.C2));
-    XG_TRY(xgk_linear(st, N, A, R, w.Venc, R, p->v2a_w, p->v2a_b, w.vproj, A));
+    XG_TRY(init_and_vproj(es, *d, *p, x->feat_mask, w));
     if (hipMemsetAsync(w.alive, 0, sizeof(int32_t) * 4, st) != hipSuccess) return XG_EHIP;   // alive[i] = running max finishing step
     for (int t = 0; t < T; ++t) {
         int64_t* tok = w.TOK + (size_t)t * B;
