@@ -376,6 +376,7 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
             XG_TRY(xgk_skinny(st, sk));
         }
     }
+    XG_TRY(ss.fork2());                          // before modality 0's work is enqueued on the main stream
     for (int m = 0; m < 2; ++m) {
         // Hprev[b,k] = H[b,k-1], zero at k = 0 : one clean TN GEMM for dW_hh
         if (m == 0) XG_TRY(ss.fork());           // dS of both modalities is final after the loop
@@ -386,8 +387,7 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
         XG_TRY(gemm_tn(sx, N, 4 * R, R, w.dS[m], 4 * R, w.X[m], R, g_wih[m], R));
         XG_TRY(xgk_colsum(sx, w.dS[m], 4 * R, N, 4 * R, g_bih[m]));
         XG_TRY(xgk_colsum(sx, w.dS[m], 4 * R, N, 4 * R, g_bhh[m]));
-        // the optical-flow modality's input-side backward runs beside the rgb one (second auxiliary stream)
-        if (m == 1 && ss.overlap()) XG_TRY(ss.fork2());
+        // the optical-flow modality's input-side backward runs beside the rgb one (second auxiliary stream, forked above)
         hipStream_t st_outer = st;
         hipStream_t st = (m == 1 && ss.overlap()) ? ss.aux2 : st_outer;
         XG_TRY(gemm_nn(st, N, R, 4 * R, w.dS[m], 4 * R, wih[m], R, w.dX[m], R, false));
