@@ -652,3 +652,38 @@ def test_gradsync_overlapped_allreduce_single_rank():
         tr._FORCE = old_force
         if created:
             dist.destroy_process_group()
+
+
+def test_repeated_iterations_are_reproducible_across_streams():
+    """The forward / backward passes run on three HIP streams (main + two auxiliary ones).  A missing dependency between
+    them would show up as run-to-run differences far above the fp32-atomic summation noise: the same iteration five
+    times (config-2-like proportions, both the fused XE path and the paired SCST path) must give the same loss and
+    gradients every time."""
+    from controllable_xgating_amd import RewardCriterion
+    d = pg.make_dims(B=32, K=13, R=128, A=192, E=68, V=1200, C=14, L=11, F1=96, F2=64)
+    Pn = pg.make_params(d, logit_gain=1.0)
+    x = to_dev(pg.make_inputs(d, seed=3, ragged=True))
+    u = torch.from_numpy(pg.uniform("uni3", (d.L + 1, d.B), 11)).cuda()
+    model = make_model(d, P=Pn, train=True)
+    ref = {}
+    for rep in range(5):
+        for kind in ("xe", "pair"):
+            model.flat_grads().zero_()
+            if kind == "xe":
+                loss = model.xe_loss(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"],
+                                     x["cap_classes"], x["class_mask"], WEIGHT_CLASS)
+            else:
+                gen, slp, greedy, n = model.sample_pair(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"],
+                                                        {"uniforms": u})
+                loss = RewardCriterion()(slp, gen, torch.full_like(slp, 0.25))
+            loss.backward()
+            torch.cuda.synchronize()
+            g = model.flat_grads().detach().cpu().numpy().copy()
+            lv = float(loss.item())
+            if rep == 0:
+                ref[kind] = (lv, g)
+                assert np.isfinite(g).all() and np.abs(g).max() > 0
+            else:
+                assert abs(lv - ref[kind][0]) <= 1e-6 * max(1.0, abs(ref[kind][0])), (kind, rep, lv, ref[kind][0])
+                err = np.abs(g - ref[kind][1]).max()
+                assert err <= 1e-5 * np.abs(ref[kind][1]).max() + 1e-8, (kind, rep, float(err))
