@@ -345,31 +345,35 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
     XgRun nodrop = run; nodrop.drop_p = 0.f;
     int curc = 0;
     for (int m = 0; m < 2; ++m) { ZERO(w.dHrec[m], (size_t)B * R); ZERO(w.dCrec[m][0], (size_t)B * R); }
+    // cell backward of frame i for modality m, reading / writing the carried dc of parity c.  Stand-alone it takes
+    // dh = dHs[i] + dHrec; fused into the product dS[i+1] Whh (epilogue) it takes dh = product + dHs[i].
+    auto enc_cell_bwd = [&](int m, int i, int c, bool fused) {
+        LstmBwdArgs a{};
+        a.gates = w.G[m] + (size_t)i * 4 * R; a.ldg = K * 4 * R;
+        a.c_prev = i == 0 ? w.zeroBR : w.Cs[m] + (size_t)(i - 1) * R; a.ldcp = i == 0 ? R : K * R;
+        a.c_out = w.Cs[m] + (size_t)i * R; a.ldco = K * R;
+        a.mask = x.feat_mask + i; a.ldm = K;
+        if (fused) { a.dh_out = nullptr; a.lddh = 0; a.dh_add = w.dHs[m] + (size_t)i * R; a.lddha = K * R; }
+        else { a.dh_out = w.dHs[m] + (size_t)i * R; a.lddh = K * R; a.dh_add = w.dHrec[m]; a.lddha = R; }
+        a.dc_out = w.dCrec[m][c]; a.lddc = R;
+        a.ds = w.dS[m] + (size_t)i * 4 * R; a.ldds = K * 4 * R;
+        a.dc_prev = w.dCrec[m][c ^ 1]; a.lddcp = R;
+        a.dh_prev = nullptr; a.lddhp = 0;
+        a.B = B; a.R = R; a.order = XG_ORDER_IFGO; a.mask_mode = XG_MASK_ZERO;
+        a.drop = xg_make_drop(&nodrop, 0, 0);
+        return a;
+    };
+    const bool fuse = R % 4 == 0;
     for (int i = K - 1; i >= 0; --i) {                          // both modalities per launch
-        LstmBwdArgs ab[2];
-        for (int m = 0; m < 2; ++m) {
-            LstmBwdArgs a{};
-            a.gates = w.G[m] + (size_t)i * 4 * R; a.ldg = K * 4 * R;
-            a.c_prev = i == 0 ? w.zeroBR : w.Cs[m] + (size_t)(i - 1) * R; a.ldcp = i == 0 ? R : K * R;
-            a.c_out = w.Cs[m] + (size_t)i * R; a.ldco = K * R;
-            a.mask = x.feat_mask + i; a.ldm = K;
-            a.dh_out = w.dHs[m] + (size_t)i * R; a.lddh = K * R;
-            a.dh_add = w.dHrec[m]; a.lddha = R;
-            a.dc_out = w.dCrec[m][curc]; a.lddc = R;
-            a.ds = w.dS[m] + (size_t)i * 4 * R; a.ldds = K * 4 * R;
-            a.dc_prev = w.dCrec[m][curc ^ 1]; a.lddcp = R;
-            a.dh_prev = nullptr; a.lddhp = 0;
-            a.B = B; a.R = R; a.order = XG_ORDER_IFGO; a.mask_mode = XG_MASK_ZERO;
-            a.drop = xg_make_drop(&nodrop, 0, 0);
-            ab[m] = a;
-        }
-        XG_TRY(xgk_lstm_bwd2(st, ab[0], ab[1]));
+        if (!fuse || i == K - 1) XG_TRY(xgk_lstm_bwd2(st, enc_cell_bwd(0, i, curc, false), enc_cell_bwd(1, i, curc, false)));
         curc ^= 1;
         if (i > 0) {
             SkArgs sk{};
             sk.njobs = 2;
             for (int m = 0; m < 2; ++m) {
-                sk.job[m] = job_store(B, R, w.dHrec[m], R, false);
+                // dh of frame i-1 = dS[i] Whh (+ dHs[i-1]); fused: frame i-1's cell backward in the epilogue
+                if (fuse) sk.job[m] = job_lstm_bwd(enc_cell_bwd(m, i - 1, curc, true), nullptr, 0);
+                else sk.job[m] = job_store(B, R, w.dHrec[m], R, false);
                 sk.job[m].nseg = 1;
                 sk.job[m].seg[0] = seg_nn(w.dS[m] + (size_t)i * 4 * R, K * 4 * R, whh[m], R, 4 * R);
             }
