@@ -54,6 +54,11 @@ def step_bytes(B, K, R, A, E, save):
     return 4 * (w_core + B * (per + s_save))
 
 
+def step_flops(B, K, R, A, E):
+    """fp32 multiply-adds x2 of one decoder step: h2a, POS gate, the two cells' six products, attention scores + context."""
+    return 2.0 * B * (2 * R * A + E * R + (E + 2 * R) * 4 * R + 3 * R * 4 * R + K * A + K * R)
+
+
 def measure_step_group(model, x, reps=200):
     """Average duration of ONE decoder-step launch group (xg_step_fwd) with events on the library's stream."""
     from controllable_xgating_amd import _native as nv
@@ -283,7 +288,12 @@ def main():
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "decoder step launch group (xg_step_fwd: attention + POS gate + lstm_1 + lstm_2)",
-                         "algorithmic_bytes_per_launch": bytes_step, "avg_launch_us": round(t_step * 1e6, 2)},
+                         "algorithmic_bytes_per_launch": bytes_step, "avg_launch_us": round(t_step * 1e6, 2),
+                         # the same launch group against the OTHER roof (exact-fp32 MFMA, 157.3 TF): at B = 128 the step's
+                         # arithmetic intensity (33 FLOP/B) is above the ridge (20), i.e. the MFMA roof is the lower one
+                         "mfma_tflops": round(step_flops(cfg["B"], cfg["K"], cfg["R"], cfg["A"], cfg["E"]) / t_step / 1e12, 2),
+                         "mfma_peak_tflops": 157.3,
+                         "mfma_frac": round(step_flops(cfg["B"], cfg["K"], cfg["R"], cfg["A"], cfg["E"]) / t_step / 157.3e12, 4)},
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_budget)
