@@ -202,7 +202,12 @@ def main():
     optim = ClipAdam(model, lr=4e-4, grad_clip=0.1)
     # data parallel: most of the gradient all-reduce runs under the CG encoder's backward (XG_NO_GRAD_OVERLAP=1: one
     # all-reduce after the backward)
-    sync = GradSync(model) if (use_dist and os.environ.get("XG_NO_GRAD_OVERLAP") is None) else None
+    sync = None
+    if use_dist and os.environ.get("XG_NO_GRAD_OVERLAP") is None:
+        try:
+            sync = GradSync(model)
+        except Exception as e:                   # never lose the run over the overlap: fall back to one all-reduce
+            print("GradSync unavailable (%s): plain all-reduce" % e, file=sys.stderr)
     crit = LanguageModelCriterion()
 
     from controllable_xgating_amd import RewardCriterion
