@@ -237,7 +237,11 @@ struct RollStepArgs {
     int split;                // rows >= split of a SAMPLE rollout decode greedily and report into maxf[1] (paired SCST rollout)
 };
 
+// STAGE: the row's V logits are parked in LDS by the first pass (V * 4 bytes <= 150 KB), so the log-sum-exp / chunk-sum /
+// owner passes read LDS instead of going back to L2 three more times.
+template <bool STAGE>
 __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
+    extern __shared__ float xs[];
     __shared__ float red[RT / 64];
     __shared__ int redi[RT / 64];
     __shared__ double wave_tot[RT / 64];
@@ -256,8 +260,10 @@ __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
         float best = -INFINITY; int bi = 0x7fffffff;
         for (int v = tid; v < a.V; v += RT) {
             const float f = x[v];
+            if (STAGE) xs[v] = f;
             if (f > best || (f == best && v < bi)) { best = f; bi = v; }
         }
+        const float* xr = STAGE ? xs : x;            // valid after the barrier of the reduction below
         for (int o = 32; o > 0; o >>= 1) {
             const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
             if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
@@ -274,7 +280,7 @@ __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
         float lse = 0.f;
         if (!lse_from_scan) {
             float se = 0.f;
-            for (int v = tid; v < a.V; v += RT) se += expf(x[v] - mx);
+            for (int v = tid; v < a.V; v += RT) se += expf(xr[v] - mx);
             se = block_sum(se, red);
             lse = mx + logf(se);
         }
@@ -290,7 +296,7 @@ __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
             const int v0 = tid * per, v1 = min(a.V, v0 + per);
             const float invt = 1.0f / a.temperature;
             float cs = 0.f;
-            for (int v = v0; v < v1; ++v) cs += expf((x[v] - mx) * invt);
+            for (int v = v0; v < v1; ++v) cs += expf((xr[v] - mx) * invt);
             // block-wide inclusive scan of the RT chunk sums in double (was a 1024-step serial walk by one thread: 50 us)
             double inc = (double)cs;
 #pragma unroll
@@ -315,7 +321,7 @@ __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
                 float run = s_bcast[0]; int pick = min(a.V, v1) - 1;
                 if (pick < v0) pick = a.V - 1;
                 for (int v = v0; v < v1; ++v) {
-                    run += expf((x[v] - mx) * invt);
+                    run += expf((xr[v] - mx) * invt);
                     if (run > s_bcast[1]) { pick = v; break; }
                 }
                 s_tok = pick;
@@ -324,7 +330,7 @@ __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
             tk = s_tok;
         }
         if (tid == 0) {
-            const float lp = x[tk] - lse;
+            const float lp = xr[tk] - lse;
             // unfinished &= it > 0 ; it *= unfinished ; append (:200-210)
             const float u = (a.t == 1 ? 1.0f : a.unf_prev[b]) * (tk > 0 ? 1.0f : 0.0f);
             if (mode != XG_ROLLOUT_REPLAY) {
@@ -483,7 +489,18 @@ int xgk_rollout_step(hipStream_t st, int B, const float* logits, const float* un
                      int t, int T, int mode, int split) {
     RollStepArgs a{logits, uniforms, forced, fstride, unf_prev, table, tok, tok_logp, unf, lse, seq, seq_logp, maxf, xt,
                    temperature, V, E, t, T, mode, split};
-    hipLaunchKernelGGL(rollout_step_kernel, dim3(B), dim3(RT), 0, st, a);
+    const size_t lds = (size_t)V * sizeof(float);
+    if (t >= 1 && lds <= 150 * 1024) {
+        static bool attr_done = false;               // > 64 KiB of dynamic LDS is opted into once
+        if (!attr_done) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_step_kernel<true>),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return XG_EHIP;
+            attr_done = true;
+        }
+        hipLaunchKernelGGL((rollout_step_kernel<true>), dim3(B), dim3(RT), lds, st, a);
+    } else {
+        hipLaunchKernelGGL((rollout_step_kernel<false>), dim3(B), dim3(RT), 0, st, a);
+    }
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
