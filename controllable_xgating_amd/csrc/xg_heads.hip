@@ -102,11 +102,21 @@ __global__ void __launch_bounds__(RT) xent_fwd_kernel(const float* __restrict__ 
     const int i = blockIdx.x, t = i / B, b = i % B;
     const float* x = logits + (size_t)i * ld;
     // one pass over the row: online max / sum-exp per thread, merged across the workgroup
+    // (batches of 8 loads are issued before any of them is consumed: the online update is a serial dependency and a
+    //  load-use-load-use loop costs one memory round trip per element)
     float mx = -INFINITY, s = 0.f;
-    for (int v = threadIdx.x; v < V; v += RT) {
-        const float xv = x[v];
-        if (xv > mx) { s = s * expf(mx - xv) + 1.0f; mx = xv; }
-        else s += expf(xv - mx);
+    for (int v0 = threadIdx.x; v0 < V; v0 += 8 * RT) {
+        float xv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const int v = v0 + j * RT; xv[j] = v < V ? x[v] : -INFINITY; }
+        float bm = xv[0];
+#pragma unroll
+        for (int j = 1; j < 8; ++j) bm = fmaxf(bm, xv[j]);
+        if (bm > mx) { s *= expf(mx - bm); mx = bm; }        // bm > -inf here, mx may be -inf (s = 0 then)
+        if (mx > -INFINITY) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += expf(xv[j] - mx);   // exp(-inf) = 0 for the padding
+        }
     }
     const float gmx = block_max(mx, red);
     s = (mx == -INFINITY) ? 0.f : s * expf(mx - gmx);
