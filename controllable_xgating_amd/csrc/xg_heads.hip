@@ -268,10 +268,19 @@ __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
         int32_t* maxf = a.maxf + (second ? 1 : 0);
         // pass 1: row max (+ argmax, ties -> lowest index like torch.max) and sum exp for the log-sum-exp
         float best = -INFINITY; int bi = 0x7fffffff;
-        for (int v = tid; v < a.V; v += RT) {
-            const float f = x[v];
-            if (STAGE) xs[v] = f;
-            if (f > best || (f == best && v < bi)) { best = f; bi = v; }
+        for (int v0 = tid; v0 < a.V; v0 += 8 * RT) {          // 8 loads in flight, then the (branchy) argmax update
+            float f8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const int v = v0 + j * RT; f8[j] = v < a.V ? x[v] : -INFINITY; }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int v = v0 + j * RT;
+                if (v < a.V) {
+                    const float f = f8[j];
+                    if (STAGE) xs[v] = f;
+                    if (f > best || (f == best && v < bi)) { best = f; bi = v; }
+                }
+            }
         }
         const float* xr = STAGE ? xs : x;            // valid after the barrier of the reduction below
         for (int o = 32; o > 0; o >>= 1) {
