@@ -72,6 +72,8 @@ int xgk_relu_drop_bwd(hipStream_t st, float* dy, const float* y, int64_t n, XgDr
 
 // column reductions over rows of X (N,Cn) ld: out[c] += sum_r X[r][c]  (atomic accumulate; caller zeroes)
 int xgk_colsum(hipStream_t st, const float* X, int ld, int N, int Cn, float* out);
+// the same sums added into up to three accumulators (out2 / out3 may be null)
+int xgk_colsum3(hipStream_t st, const float* X, int ld, int N, int Cn, float* out, float* out2, float* out3);
 // out1[c] += sum_r X*Y ; (used for BN dgamma and a2w weight grad)
 int xgk_colsum_prod(hipStream_t st, const float* X, int ldx, const float* Y, int ldy, int N, int Cn, float* out);
 

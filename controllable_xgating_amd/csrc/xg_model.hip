@@ -389,8 +389,7 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
             XG_TRY(xgk_copy2d(sx, w.Hprev[m] + R, K * R, w.Hs[m], K * R, B, (K - 1) * R, false));
         XG_TRY(gemm_tn(sx, N, 4 * R, R, w.dS[m], 4 * R, w.Hprev[m], R, g_whh[m], R));
         XG_TRY(gemm_tn(sx, N, 4 * R, R, w.dS[m], 4 * R, w.X[m], R, g_wih[m], R));
-        XG_TRY(xgk_colsum(sx, w.dS[m], 4 * R, N, 4 * R, g_bih[m]));
-        XG_TRY(xgk_colsum(sx, w.dS[m], 4 * R, N, 4 * R, g_bhh[m]));
+        XG_TRY(xgk_colsum3(sx, w.dS[m], 4 * R, N, 4 * R, g_bih[m], g_bhh[m], nullptr));
         // the optical-flow modality's input-side backward runs beside the rgb one (second auxiliary stream, forked above)
         hipStream_t st_outer = st;
         hipStream_t st = (m == 1 && ss.overlap()) ? ss.aux2 : st_outer;
@@ -710,15 +709,11 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     XG_TRY(gemm_tn(sx, TB, 4 * R, R, w.DS2, 4 * R, w.H1 + BR, R, g.l2_i2h_w, R));
     XG_TRY(gemm_tn(sx, TB, 4 * R, R, w.DS2, 4 * R, w.AF, R, g.l2_a2h_w, R));
     XG_TRY(gemm_tn(sx, TB, 4 * R, R, w.DS2, 4 * R, w.H2, R, g.l2_h2h_w, R));
-    XG_TRY(xgk_colsum(sx, w.DS2, 4 * R, TB, 4 * R, g.l2_i2h_b));
-    XG_TRY(xgk_colsum(sx, w.DS2, 4 * R, TB, 4 * R, g.l2_a2h_b));
-    XG_TRY(xgk_colsum(sx, w.DS2, 4 * R, TB, 4 * R, g.l2_h2h_b));
+    XG_TRY(xgk_colsum3(sx, w.DS2, 4 * R, TB, 4 * R, g.l2_i2h_b, g.l2_a2h_b, g.l2_h2h_b));
     XG_TRY(gemm_tn(s1, TB, 4 * R, R, w.DS1, 4 * R, w.H1, R, g.l1_h2h_w, R));
     XG_TRY(gemm_tn(s1, TB, 4 * R, E, w.DS1, 4 * R, w.Xe, E, g.l1_i2h_w, E));
     XG_TRY(gemm_tn(s1, TB, 4 * R, R, w.DS1, 4 * R, w.POSG, R, g.l1_a2h_w, R));
-    XG_TRY(xgk_colsum(s1, w.DS1, 4 * R, TB, 4 * R, g.l1_i2h_b));
-    XG_TRY(xgk_colsum(s1, w.DS1, 4 * R, TB, 4 * R, g.l1_a2h_b));
-    XG_TRY(xgk_colsum(s1, w.DS1, 4 * R, TB, 4 * R, g.l1_h2h_b));
+    XG_TRY(xgk_colsum3(s1, w.DS1, 4 * R, TB, 4 * R, g.l1_i2h_b, g.l1_a2h_b, g.l1_h2h_b));
     XG_TRY(gemm_tn(sx, TB, A, R, w.DP, A, w.H1, R, g.h2a_w, 2 * R));
     XG_TRY(gemm_tn(sx, TB, A, R, w.DP, A, w.H2, R, g.h2a_w + R, 2 * R));
     XG_TRY(xgk_colsum(sx, w.DP, A, TB, A, g.h2a_b));

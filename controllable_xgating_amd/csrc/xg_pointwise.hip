@@ -138,7 +138,7 @@ __global__ void relu_drop_bwd_kernel(float* dy, const float* y, int64_t n, XgDro
 // block = 64 columns x 4 row lanes; grid.y chunks of rows; atomic accumulate into out.
 template <int MODE>   // 0: sum x ; 1: sum x*y ; 2: sum (x-mean)^2
 __global__ void colreduce_kernel(const float* X, int ldx, const float* Y, int ldy, int N, int Cn, float* out,
-                                 int rows_per_chunk) {
+                                 float* out2, float* out3, int rows_per_chunk) {
     __shared__ float red[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;
@@ -159,15 +159,18 @@ __global__ void colreduce_kernel(const float* X, int ldx, const float* Y, int ld
     if (rl == 0 && c < Cn) {
         const float s = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
         atomicAdd(out + c, s);
+        if (out2) atomicAdd(out2 + c, s);      // the same column sums into up to three accumulators (the three bias
+        if (out3) atomicAdd(out3 + c, s);      // vectors of a two-input LSTM cell share one gradient)
     }
 }
 
 template <int MODE>
-int colreduce(hipStream_t st, const float* X, int ldx, const float* Y, int ldy, int N, int Cn, float* out) {
+int colreduce(hipStream_t st, const float* X, int ldx, const float* Y, int ldy, int N, int Cn, float* out,
+              float* out2 = nullptr, float* out3 = nullptr) {
     if (N <= 0 || Cn <= 0) return XG_OK;
     const int rpc = 64;
     dim3 grid(xg_cdiv(Cn, 64), xg_cdiv(N, rpc));
-    hipLaunchKernelGGL((colreduce_kernel<MODE>), grid, dim3(256), 0, st, X, ldx, Y, ldy, N, Cn, out, rpc);
+    hipLaunchKernelGGL((colreduce_kernel<MODE>), grid, dim3(256), 0, st, X, ldx, Y, ldy, N, Cn, out, out2, out3, rpc);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
@@ -370,6 +373,9 @@ int xgk_relu_drop_bwd(hipStream_t st, float* dy, const float* y, int64_t n, XgDr
 }
 int xgk_colsum(hipStream_t st, const float* X, int ld, int N, int Cn, float* out) {
     return colreduce<0>(st, X, ld, nullptr, 0, N, Cn, out);
+}
+int xgk_colsum3(hipStream_t st, const float* X, int ld, int N, int Cn, float* out, float* out2, float* out3) {
+    return colreduce<0>(st, X, ld, nullptr, 0, N, Cn, out, out2, out3);
 }
 int xgk_colsum_prod(hipStream_t st, const float* X, int ldx, const float* Y, int ldy, int N, int Cn, float* out) {
     return colreduce<1>(st, X, ldx, Y, ldy, N, Cn, out);
