@@ -94,34 +94,62 @@ __global__ void lstm_bwd2_kernel(LstmBwdArgs a, LstmBwdArgs b) {
 }
 
 // ------------------------------------------------------------------ gates
-__global__ void gate_fwd_kernel(float* pre_g, int ldp, const float* t, int ldt, int t_mod, float* y, int ldy, int rows,
-                                int R, XgDrop drop, int s_div, int s_mod, int b_div, int b_mod) {
-    const int64_t idx = (int64_t)blockIdx.x * TPB + threadIdx.x;
+// NV consecutive columns per thread (4 when R and every leading dimension are multiples of 4 and the bases are 16-byte
+// aligned: one 16-byte access per operand instead of four 4-byte ones)
+template <int NV> struct VecT { typedef float type; };
+template <> struct VecT<4> { typedef float4 type; };
+template <int NV> __device__ __forceinline__ void ldv(const float* p, float (&v)[NV]) {
+    if (NV == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else v[0] = p[0];
+}
+template <int NV> __device__ __forceinline__ void stv(float* p, const float (&v)[NV]) {
+    if (NV == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    else p[0] = v[0];
+}
+template <int NV>
+__global__ void gate_fwd_kernel(float* __restrict__ pre_g, int ldp, const float* __restrict__ t, int ldt, int t_mod,
+                                float* __restrict__ y, int ldy, int rows, int R, XgDrop drop, int s_div, int s_mod,
+                                int b_div, int b_mod) {
+    const int64_t idx = ((int64_t)blockIdx.x * TPB + threadIdx.x) * NV;
     if (idx >= (int64_t)rows * R) return;
     const int r = (int)(idx / R), j = (int)(idx % R);
     XgDrop dr = drop;
     dr.step = drop.step + (uint32_t)((r / s_div) % s_mod);
     const uint32_t e = (uint32_t)((r / b_div) % b_mod) * (uint32_t)R + (uint32_t)j;
-    const float g = pre_g[(size_t)r * ldp + j] * xg_keep(dr, e);
-    pre_g[(size_t)r * ldp + j] = g;
+    float g[NV], tv[NV], yv[NV];
+    ldv<NV>(pre_g + (size_t)r * ldp + j, g);
+    if (y) ldv<NV>(t + (size_t)(t_mod > 0 ? r % t_mod : r) * ldt + j, tv);
+#pragma unroll
+    for (int q = 0; q < NV; ++q) g[q] *= xg_keep(dr, e + q);
+    stv<NV>(pre_g + (size_t)r * ldp + j, g);
     if (y) {
-        const float tv = t[(size_t)(t_mod > 0 ? r % t_mod : r) * ldt + j];
-        y[(size_t)r * ldy + j] = g * tv + tv;                // sub_modules.py:45
+#pragma unroll
+        for (int q = 0; q < NV; ++q) yv[q] = g[q] * tv[q] + tv[q];                // sub_modules.py:45
+        stv<NV>(y + (size_t)r * ldy + j, yv);
     }
 }
-__global__ void gate_bwd_kernel(const float* dy, int lddy, const float* g, int ldg, const float* t, int ldt, int t_mod,
-                                float* dpre, int lddp, float* dt, int lddt, int dt_acc, int rows, int R, XgDrop drop) {
-    const int64_t idx = (int64_t)blockIdx.x * TPB + threadIdx.x;
+template <int NV>
+__global__ void gate_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ g, int ldg,
+                                const float* __restrict__ t, int ldt, int t_mod, float* __restrict__ dpre, int lddp,
+                                float* __restrict__ dt, int lddt, int dt_acc, int rows, int R, XgDrop drop) {
+    const int64_t idx = ((int64_t)blockIdx.x * TPB + threadIdx.x) * NV;
     if (idx >= (int64_t)rows * R) return;
     const int r = (int)(idx / R), j = (int)(idx % R);
-    const float d = dy[(size_t)r * lddy + j];
-    const float gv = g[(size_t)r * ldg + j];
-    const float tv = t[(size_t)(t_mod > 0 ? r % t_mod : r) * ldt + j];
-    if (dpre) dpre[(size_t)r * lddp + j] = gv > 0.f ? d * tv * drop.scale : 0.f;   // g>0 <=> relu active & kept
+    float d[NV], gv[NV], tv[NV], o[NV];
+    ldv<NV>(dy + (size_t)r * lddy + j, d);
+    ldv<NV>(g + (size_t)r * ldg + j, gv);
+    ldv<NV>(t + (size_t)(t_mod > 0 ? r % t_mod : r) * ldt + j, tv);
+    if (dpre) {
+#pragma unroll
+        for (int q = 0; q < NV; ++q) o[q] = gv[q] > 0.f ? d[q] * tv[q] * drop.scale : 0.f;   // g>0 <=> relu active & kept
+        stv<NV>(dpre + (size_t)r * lddp + j, o);
+    }
     if (dt) {
-        float* q = dt + (size_t)r * lddt + j;
-        const float v = d * (gv + 1.0f);
-        *q = dt_acc ? *q + v : v;
+        float* qd = dt + (size_t)r * lddt + j;
+        if (dt_acc) ldv<NV>(qd, o);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) o[q] = (dt_acc ? o[q] : 0.f) + d[q] * (gv[q] + 1.0f);
+        stv<NV>(qd, o);
     }
 }
 
@@ -188,21 +216,29 @@ __global__ void bn_running_kernel(const float* mean, const float* var, float* rm
     rmean[i] = (1.f - mom) * rmean[i] + mom * mean[i];
     rvar[i] = (1.f - mom) * rvar[i] + mom * unb;
 }
-__global__ void bn_apply_kernel(const float* Z, const float* mean, const float* var, const float* gamma,
-                                const float* beta, const float* rowmask, float* X, int N, int R, float eps,
+template <int NV>
+__global__ void bn_apply_kernel(const float* __restrict__ Z, const float* __restrict__ mean, const float* __restrict__ var,
+                                const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const float* __restrict__ rowmask, float* __restrict__ X, int N, int R, float eps,
                                 XgDrop drop) {
-    const int64_t idx = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    const int64_t idx = ((int64_t)blockIdx.x * TPB + threadIdx.x) * NV;
     if (idx >= (int64_t)N * R) return;
     const int r = (int)(idx / R), c = (int)(idx % R);
-    const float xh = (Z[idx] - mean[c]) / sqrtf(var[c] + eps);
-    float y = fmaxf(xh * gamma[c] + beta[c], 0.f);
-    y *= xg_keep(drop, (uint32_t)idx);
-    X[idx] = y * rowmask[r];
+    float z[NV], mu[NV], vr[NV], ga[NV], be[NV], o[NV];
+    ldv<NV>(Z + idx, z); ldv<NV>(mean + c, mu); ldv<NV>(var + c, vr); ldv<NV>(gamma + c, ga); ldv<NV>(beta + c, be);
+    const float rm = rowmask[r];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const float xh = (z[q] - mu[q]) / sqrtf(vr[q] + eps);
+        o[q] = fmaxf(xh * ga[q] + be[q], 0.f) * xg_keep(drop, (uint32_t)(idx + q)) * rm;
+    }
+    stv<NV>(X + idx, o);
 }
 // in place dX -> dY (grad wrt BN output), plus column sums of dY and dY*xhat
-__global__ void bn_bwd_reduce_kernel(float* dX, const float* X, const float* Z, const float* mean, const float* var,
-                                     const float* rowmask, int N, int R, float eps, XgDrop drop, float* sum_dy,
-                                     float* sum_dyxhat, int rows_per_chunk) {
+__global__ void bn_bwd_reduce_kernel(float* __restrict__ dX, const float* __restrict__ X, const float* __restrict__ Z,
+                                     const float* __restrict__ mean, const float* __restrict__ var,
+                                     const float* __restrict__ rowmask, int N, int R, float eps, XgDrop drop,
+                                     float* sum_dy, float* sum_dyxhat, int rows_per_chunk) {
     __shared__ float red[2][4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63);
     const int rl = threadIdx.x >> 6;
@@ -211,13 +247,25 @@ __global__ void bn_bwd_reduce_kernel(float* dX, const float* X, const float* Z, 
     float a0 = 0.f, a1 = 0.f;
     if (c < R) {
         const float mu = mean[c], is = 1.0f / sqrtf(var[c] + eps);
-        for (int r = r0 + rl; r < r1; r += 4) {
-            const size_t i = (size_t)r * R + c;
-            // X = relu(.)*keep*rowmask ; X>0 <=> relu active, kept, row unmasked
-            const float dy = X[i] > 0.f ? dX[i] * drop.scale * rowmask[r] : 0.f;
-            dX[i] = dy;
-            a0 += dy;
-            a1 += dy * (Z[i] - mu) * is;
+        for (int rb = r0 + rl; rb < r1; rb += 16) {       // four rows per thread in flight before any is consumed
+            float xv[4], dv[4], zv[4], mk[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = min(rb + 4 * q, r1 - 1);
+                const size_t i = (size_t)r * R + c;
+                xv[q] = X[i]; dv[q] = dX[i]; zv[q] = Z[i]; mk[q] = rowmask[r];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int r = rb + 4 * q;
+                if (r < r1) {
+                    // X = relu(.)*keep*rowmask ; X>0 <=> relu active, kept, row unmasked
+                    const float dy = xv[q] > 0.f ? dv[q] * drop.scale * mk[q] : 0.f;
+                    dX[(size_t)r * R + c] = dy;
+                    a0 += dy;
+                    a1 += dy * (zv[q] - mu) * is;
+                }
+            }
         }
     }
     red[0][rl][threadIdx.x & 63] = a0;
@@ -229,19 +277,28 @@ __global__ void bn_bwd_reduce_kernel(float* dX, const float* X, const float* Z, 
         atomicAdd(sum_dyxhat + c, red[1][0][t] + red[1][1][t] + red[1][2][t] + red[1][3][t]);
     }
 }
-__global__ void bn_bwd_apply_kernel(float* dY, const float* Z, const float* mean, const float* var,
-                                    const float* gamma, const float* sum_dy, const float* sum_dyxhat, int N, int R,
+template <int NV>
+__global__ void bn_bwd_apply_kernel(float* __restrict__ dY, const float* __restrict__ Z, const float* __restrict__ mean,
+                                    const float* __restrict__ var, const float* __restrict__ gamma,
+                                    const float* __restrict__ sum_dy, const float* __restrict__ sum_dyxhat, int N, int R,
                                     float eps, int train) {
-    const int64_t idx = (int64_t)blockIdx.x * TPB + threadIdx.x;
+    const int64_t idx = ((int64_t)blockIdx.x * TPB + threadIdx.x) * NV;
     if (idx >= (int64_t)N * R) return;
     const int c = (int)(idx % R);
-    const float is = 1.0f / sqrtf(var[c] + eps);
-    float d = dY[idx];
-    if (train) {
-        const float xh = (Z[idx] - mean[c]) * is;
-        d = d - sum_dy[c] / (float)N - xh * sum_dyxhat[c] / (float)N;
+    float d[NV], z[NV], mu[NV], vr[NV], ga[NV], s1[NV], s2[NV];
+    ldv<NV>(dY + idx, d); ldv<NV>(Z + idx, z); ldv<NV>(mean + c, mu); ldv<NV>(var + c, vr); ldv<NV>(gamma + c, ga);
+    ldv<NV>(sum_dy + c, s1); ldv<NV>(sum_dyxhat + c, s2);
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const float is = 1.0f / sqrtf(vr[q] + eps);
+        float v = d[q];
+        if (train) {
+            const float xh = (z[q] - mu[q]) * is;
+            v = v - s1[q] / (float)N - xh * s2[q] / (float)N;
+        }
+        d[q] = v * ga[q] * is;
     }
-    dY[idx] = d * gamma[c] * is;
+    stv<NV>(dY + idx, d);
 }
 
 // ------------------------------------------------------------------ embedding, means, misc
@@ -347,15 +404,24 @@ int xgk_lstm_bwd2(hipStream_t st, const LstmBwdArgs& a, const LstmBwdArgs& b) {
 int xgk_gate_fwd(hipStream_t st, float* pre_g, int ldp, const float* t, int ldt, int t_mod, float* y, int ldy,
                  int rows, int R, XgDrop drop, int s_div, int s_mod, int b_div, int b_mod) {
     if (!y && drop.thresh == 0u) return XG_OK;   // pure dropout with p = 0: nothing to do
-    hipLaunchKernelGGL(gate_fwd_kernel, grid1((int64_t)rows * R), dim3(TPB), 0, st, pre_g, ldp, t, ldt, t_mod, y, ldy,
-                       rows, R, drop, s_div, s_mod, b_div, b_mod);
+    const bool v4 = R % 4 == 0 && ldp % 4 == 0 && (!y || (ldt % 4 == 0 && ldy % 4 == 0)) && ((uintptr_t)pre_g % 16 == 0) &&
+                    ((uintptr_t)t % 16 == 0) && ((uintptr_t)y % 16 == 0);
+    if (v4) hipLaunchKernelGGL((gate_fwd_kernel<4>), grid1((int64_t)rows * R / 4), dim3(TPB), 0, st, pre_g, ldp, t, ldt, t_mod, y,
+                               ldy, rows, R, drop, s_div, s_mod, b_div, b_mod);
+    else hipLaunchKernelGGL((gate_fwd_kernel<1>), grid1((int64_t)rows * R), dim3(TPB), 0, st, pre_g, ldp, t, ldt, t_mod, y, ldy,
+                            rows, R, drop, s_div, s_mod, b_div, b_mod);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
 int xgk_gate_bwd(hipStream_t st, const float* dy, int lddy, const float* g, int ldg, const float* t, int ldt, int t_mod,
                  float* dpre, int lddp, float* dt, int lddt, bool dt_accumulate, int rows, int R, XgDrop drop) {
-    hipLaunchKernelGGL(gate_bwd_kernel, grid1((int64_t)rows * R), dim3(TPB), 0, st, dy, lddy, g, ldg, t, ldt, t_mod, dpre,
-                       lddp, dt, lddt, dt_accumulate ? 1 : 0, rows, R, drop);
+    const bool v4 = R % 4 == 0 && lddy % 4 == 0 && ldg % 4 == 0 && ldt % 4 == 0 && (!dpre || lddp % 4 == 0) &&
+                    (!dt || lddt % 4 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)t % 16 == 0) &&
+                    ((uintptr_t)dpre % 16 == 0) && ((uintptr_t)dt % 16 == 0);
+    if (v4) hipLaunchKernelGGL((gate_bwd_kernel<4>), grid1((int64_t)rows * R / 4), dim3(TPB), 0, st, dy, lddy, g, ldg, t, ldt, t_mod,
+                               dpre, lddp, dt, lddt, dt_accumulate ? 1 : 0, rows, R, drop);
+    else hipLaunchKernelGGL((gate_bwd_kernel<1>), grid1((int64_t)rows * R), dim3(TPB), 0, st, dy, lddy, g, ldg, t, ldt, t_mod, dpre,
+                            lddp, dt, lddt, dt_accumulate ? 1 : 0, rows, R, drop);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
@@ -399,8 +465,12 @@ int xgk_bn_running(hipStream_t st, const float* mean, const float* var, float* r
 }
 int xgk_bn_apply(hipStream_t st, const float* Z, const float* mean, const float* var, const float* gamma,
                  const float* beta, const float* rowmask, float* X, int N, int R, float eps, XgDrop drop) {
-    hipLaunchKernelGGL(bn_apply_kernel, grid1((int64_t)N * R), dim3(TPB), 0, st, Z, mean, var, gamma, beta, rowmask, X,
-                       N, R, eps, drop);
+    const bool v4 = R % 4 == 0 && ((uintptr_t)Z % 16 == 0) && ((uintptr_t)X % 16 == 0) && ((uintptr_t)mean % 16 == 0) &&
+                    ((uintptr_t)var % 16 == 0) && ((uintptr_t)gamma % 16 == 0) && ((uintptr_t)beta % 16 == 0);
+    if (v4) hipLaunchKernelGGL((bn_apply_kernel<4>), grid1((int64_t)N * R / 4), dim3(TPB), 0, st, Z, mean, var, gamma, beta,
+                               rowmask, X, N, R, eps, drop);
+    else hipLaunchKernelGGL((bn_apply_kernel<1>), grid1((int64_t)N * R), dim3(TPB), 0, st, Z, mean, var, gamma, beta, rowmask, X,
+                            N, R, eps, drop);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
@@ -416,8 +486,13 @@ int xgk_bn_bwd_reduce(hipStream_t st, float* dX, const float* X, const float* Z,
 int xgk_bn_bwd_apply(hipStream_t st, float* dY, const float* Z, const float* mean, const float* var,
                      const float* gamma, const float* sum_dy, const float* sum_dyxhat, int N, int R, float eps,
                      bool train) {
-    hipLaunchKernelGGL(bn_bwd_apply_kernel, grid1((int64_t)N * R), dim3(TPB), 0, st, dY, Z, mean, var, gamma, sum_dy,
-                       sum_dyxhat, N, R, eps, train ? 1 : 0);
+    const bool v4 = R % 4 == 0 && ((uintptr_t)dY % 16 == 0) && ((uintptr_t)Z % 16 == 0) && ((uintptr_t)mean % 16 == 0) &&
+                    ((uintptr_t)var % 16 == 0) && ((uintptr_t)gamma % 16 == 0) && ((uintptr_t)sum_dy % 16 == 0) &&
+                    ((uintptr_t)sum_dyxhat % 16 == 0);
+    if (v4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), grid1((int64_t)N * R / 4), dim3(TPB), 0, st, dY, Z, mean, var, gamma,
+                               sum_dy, sum_dyxhat, N, R, eps, train ? 1 : 0);
+    else hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), grid1((int64_t)N * R), dim3(TPB), 0, st, dY, Z, mean, var, gamma, sum_dy,
+                            sum_dyxhat, N, R, eps, train ? 1 : 0);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
