@@ -15,6 +15,8 @@ SHAPES = [  # name, ta, tb, M, N, K, acc
     ("rollout logits NT 128x20000 K=512", 0, 1, 128, 20000, 512, 0),
     ("rollout logits NT 64x20000 K=512", 0, 1, 64, 20000, 512, 0),
     ("dH NN 1920x512 K=20000", 0, 0, 1920, 512, 20000, 0),
+    ("dH half NN 1408x512 K=20000", 0, 0, 1408, 512, 20000, 0),
+    ("dH half NN 1280x512 K=20000", 0, 0, 1280, 512, 20000, 0),
 ]
 if os.environ.get("XG_GEMM_SHAPES"):
     SHAPES = [s for s in SHAPES if any(k in s[0] for k in os.environ["XG_GEMM_SHAPES"].split(","))]
