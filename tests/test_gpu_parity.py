@@ -10,7 +10,7 @@ import torch
 
 from oracle import paramgen as pg
 from oracle import xgate_oracle as xo
-from tests.util import CFG, WEIGHT_CLASS, assert_grads_close, load_golden, make_model, oracle_grads, to_dev
+from tests.util import CFG, WEIGHT_CLASS, ZERO_GRAD_PARAMS, assert_grads_close, load_golden, make_model, oracle_grads, to_dev
 
 pytestmark = pytest.mark.gpu
 
@@ -687,3 +687,53 @@ def test_repeated_iterations_are_reproducible_across_streams():
                 assert abs(lv - ref[kind][0]) <= 1e-6 * max(1.0, abs(ref[kind][0])), (kind, rep, lv, ref[kind][0])
                 err = np.abs(g - ref[kind][1]).max()
                 assert err <= 1e-5 * np.abs(ref[kind][1]).max() + 1e-8, (kind, rep, float(err))
+
+
+def _fuzz_dims(i):
+    """Seeded random extents that hit the kernel-selection edges: R % 8 / % 4 (skinny vs generic cells, fused LSTM
+    backward), A % 4 and A > 1024 (attention variants), K > 32 (16 V rows per thread) and K > 64 (serial softmax),
+    E % 4 (vector vs scalar skinny loads), odd V, B = 1."""
+    rng = np.random.RandomState(1000 + i)
+    R = int(rng.choice([8, 16, 24, 40, 64, 72, 12, 20, 128]))
+    A = int(rng.choice([8, 36, 64, 100, 256, 260, 1280]))
+    K = int(rng.choice([1, 2, 7, 26, 33, 40, 70]))
+    E = int(rng.choice([4, 10, 36, 68]))
+    return dict(B=int(rng.choice([1, 2, 5, 9, 33])), K=K, R=R, A=A, E=E, V=int(rng.choice([5, 37, 64, 301])),
+                C=int(rng.choice([2, 14])), L=int(rng.choice([1, 3, 6, 9])), F1=int(rng.choice([4, 20, 48])),
+                F2=int(rng.choice([4, 12, 40])), H=128)
+
+
+@pytest.mark.parametrize("i", range(24))
+def test_fuzzed_extents_xe_and_greedy_vs_oracle(i):
+    cfg = _fuzz_dims(i)
+    d = pg.make_dims(**cfg)
+    ragged = bool(i % 2) and d.L >= 2 and d.K >= 2
+    drop, seed = (0.3, 4242 + i) if i % 3 == 0 else (0.0, None)     # every third case with dropout (hash masks)
+    P, lo, co, lxe_o, lcls_o, running = run_oracle_xe(d, ragged, p=drop, seed=seed or 0)
+    model, lh, ch, lxe_h, lcls_h = run_hip_xe(d, ragged, p=drop, seed=seed)
+    assert abs(lxe_h - lxe_o) < 1e-4, (cfg, lxe_h, lxe_o)
+    assert abs(lcls_h - lcls_o) < 1e-4, cfg
+    np.testing.assert_allclose(lh, lo, atol=3e-4, rtol=0, err_msg=str(cfg))
+    assert_grads_close(model, oracle_grads(P), skip=ZERO_GRAD_PARAMS)
+    # greedy rollout: token for token wherever the oracle's top-2 margin is not at round-off level
+    x = pg.make_inputs(d, seed=0, ragged=ragged)
+    Pt = xo.to_torch_params(pg.make_params(d))
+    xt = xo.to_torch_inputs(x)
+    with torch.no_grad():
+        seq_o, slp_o, logps = xo.sample(Pt, xt["feats_rgb"], xt["feats_opfl"], xt["feat_mask"], xt["pos_feats"], d.L,
+                                        mode="greedy", train=False, running=xo.new_running(d), return_logp=True)
+    model = make_model(d, train=False)            # fresh BatchNorm running statistics, like the oracle's
+    xd = to_dev(x)
+    with torch.no_grad():
+        seq_h, slp_h = model.sample(xd["feats_rgb"], xd["feats_opfl"], xd["feat_mask"], xd["pos_feats"], {"sample_max": 1})
+    seq_o, seq_h = np.asarray(seq_o), seq_h.cpu().numpy()
+    n = min(seq_o.shape[1], seq_h.shape[1])
+    for b in range(d.B):
+        for t in range(n):
+            if seq_h[b, t] != seq_o[b, t]:
+                top2 = np.sort(np.asarray(logps[t])[b])[-2:]
+                assert top2[1] - top2[0] < 1e-3, (cfg, b, t, int(seq_h[b, t]), int(seq_o[b, t]), float(top2[1] - top2[0]))
+                break                                   # the rows diverge after a (legitimate) near-tie
+        else:
+            if n:
+                np.testing.assert_allclose(slp_h.cpu().numpy()[b, :n], np.asarray(slp_o)[b, :n], atol=2e-4, err_msg=str(cfg))

@@ -56,9 +56,16 @@ def oracle_grads(P):
     return {k: (v.grad.numpy() if v.grad is not None else np.zeros(tuple(v.shape), np.float32)) for k, v in P.items()}
 
 
-def assert_grads_close(model, ref, rtol=2e-3, atol=2e-6):
+# parameters whose TRUE gradient is exactly zero (a Linear bias in front of train-mode BatchNorm; a2w.bias, which cancels in
+# the softmax): what is left is round-off of cancelling terms, of no fixed size
+ZERO_GRAD_PARAMS = ("two_spatial_encoder.visual_emb_rgb.0.bias", "two_spatial_encoder.visual_emb_opfl.0.bias", "lstmcore.a2w.bias")
+
+
+def assert_grads_close(model, ref, rtol=2e-3, atol=2e-6, skip=()):
     bad = []
     for name, prm in model.named_parameters():
+        if name in skip:
+            continue
         g = prm.grad
         g = g.detach().cpu().numpy() if g is not None else np.zeros(tuple(prm.shape), np.float32)
         r = ref[name]
