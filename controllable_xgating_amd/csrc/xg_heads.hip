@@ -51,6 +51,54 @@ __global__ void __launch_bounds__(RT) log_softmax_kernel(const float* __restrict
     for (int v = threadIdx.x; v < V; v += RT) y[v] = x[v] - lse;
 }
 
+// Register-resident rows (V <= NPT * 1024): every element is read ONCE (all loads in flight before the first use) and
+// written once; the three-pass kernels above re-read the row from L2 for every pass.
+template <int NPT>
+__global__ void __launch_bounds__(RT) log_softmax_reg_kernel(const float* in, int ldin, float* out, int ldout, int V,
+                                                               int inner, int outer, int permute) {
+    __shared__ float red[RT / 64];
+    const int i = blockIdx.x;
+    const float* x = in + (size_t)i * ldin;
+    float* y = out + (size_t)out_row(i, inner, outer, permute) * ldout;
+    float xv[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) { const int v = threadIdx.x + j * RT; xv[j] = v < V ? x[v] : -INFINITY; }
+    float mx = xv[0];
+#pragma unroll
+    for (int j = 1; j < NPT; ++j) mx = fmaxf(mx, xv[j]);
+    mx = block_max(mx, red);
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) s += expf(xv[j] - mx);          // exp(-inf) = 0 for the padding
+    s = block_sum(s, red);
+    const float lse = mx + logf(s);
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) { const int v = threadIdx.x + j * RT; if (v < V) y[v] = xv[j] - lse; }
+}
+template <int NPT>
+__global__ void __launch_bounds__(RT) log_softmax_bwd_reg_kernel(const float* dlogp, const float* logp, int ldp, float* dlogits,
+                                                                   int ldd, int V, int inner, int outer, int permute) {
+    __shared__ float red[RT / 64];
+    const int i = blockIdx.x;
+    const size_t ro = (size_t)out_row(i, inner, outer, permute != 0) * ldp;
+    const float* dy = dlogp + ro;
+    const float* y = logp + (permute == 2 ? (size_t)i * ldp : ro);
+    float dv[NPT], yv[NPT];
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) {
+        const int v = threadIdx.x + j * RT;
+        dv[j] = v < V ? dy[v] : 0.f;
+        yv[j] = v < V ? y[v] : -INFINITY;
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) s += dv[j];
+    s = block_sum(s, red);
+    float* dx = dlogits + (size_t)i * ldd;
+#pragma unroll
+    for (int j = 0; j < NPT; ++j) { const int v = threadIdx.x + j * RT; if (v < V) dx[v] = dv[j] - expf(yv[j]) * s; }
+}
+
 __global__ void __launch_bounds__(RT) log_softmax_bwd_kernel(const float* __restrict__ dlogp, const float* __restrict__ logp,
                                                                int ldp, float* __restrict__ dlogits, int ldd, int V,
                                                                int inner, int outer, int permute) {
@@ -86,12 +134,12 @@ __global__ void nll_fwd_kernel(const float* logp, const int64_t* target, const f
     if (threadIdx.x == 0) { atomicAdd(out2, a); atomicAdd(out2 + 1, m); }
 }
 __global__ void nll_bwd_kernel(const int64_t* target, const float* mask, const float* mask2, int B, int T, int V,
-                               int roll, const float* sums, float scale, float* dlogp) {
+                               int roll, const float* sums, float scale, const float* scale_dev, float* dlogp) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i >= B * T) return;
     const int b = i / T, t = i % T;
     const float m = mask[i] * (mask2 ? mask2[i] : 1.f);
-    dlogp[(size_t)i * V + tgt_of(target, b, t, T, roll)] = -scale * m / sums[1];
+    dlogp[(size_t)i * V + tgt_of(target, b, t, T, roll)] = -scale * (scale_dev ? scale_dev[0] : 1.f) * m / sums[1];
 }
 
 // ---- fused cross-entropy on time-major logits rows i = t*B + b
@@ -450,16 +498,22 @@ __global__ void __launch_bounds__(RT) rollout_dlogits_kernel(const float* __rest
 int xgk_log_softmax(hipStream_t st, const float* in, int ldin, float* out, int ldout, int rows, int V, int inner,
                     int outer, bool permute) {
     if (rows <= 0) return XG_OK;
-    hipLaunchKernelGGL(log_softmax_kernel, dim3(rows), dim3(RT), 0, st, in, ldin, out, ldout, V, inner, outer,
-                       permute ? 1 : 0);
+    const int npt = xg_cdiv(V, RT), pm = permute ? 1 : 0;
+    if (npt <= 8) hipLaunchKernelGGL((log_softmax_reg_kernel<8>), dim3(rows), dim3(RT), 0, st, in, ldin, out, ldout, V, inner, outer, pm);
+    else if (npt <= 16) hipLaunchKernelGGL((log_softmax_reg_kernel<16>), dim3(rows), dim3(RT), 0, st, in, ldin, out, ldout, V, inner, outer, pm);
+    else if (npt <= 24) hipLaunchKernelGGL((log_softmax_reg_kernel<24>), dim3(rows), dim3(RT), 0, st, in, ldin, out, ldout, V, inner, outer, pm);
+    else hipLaunchKernelGGL(log_softmax_kernel, dim3(rows), dim3(RT), 0, st, in, ldin, out, ldout, V, inner, outer, pm);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
 int xgk_log_softmax_bwd(hipStream_t st, const float* dlogp, const float* logp, int ldp, float* dlogits, int ldd,
                         int rows, int V, int inner, int outer, int permute) {
     if (rows <= 0) return XG_OK;
-    hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3(rows), dim3(RT), 0, st, dlogp, logp, ldp, dlogits, ldd, V, inner,
-                       outer, permute);
+    const int npt = xg_cdiv(V, RT);
+    if (npt <= 8) hipLaunchKernelGGL((log_softmax_bwd_reg_kernel<8>), dim3(rows), dim3(RT), 0, st, dlogp, logp, ldp, dlogits, ldd, V, inner, outer, permute);
+    else if (npt <= 16) hipLaunchKernelGGL((log_softmax_bwd_reg_kernel<16>), dim3(rows), dim3(RT), 0, st, dlogp, logp, ldp, dlogits, ldd, V, inner, outer, permute);
+    else if (npt <= 24) hipLaunchKernelGGL((log_softmax_bwd_reg_kernel<24>), dim3(rows), dim3(RT), 0, st, dlogp, logp, ldp, dlogits, ldd, V, inner, outer, permute);
+    else hipLaunchKernelGGL(log_softmax_bwd_kernel, dim3(rows), dim3(RT), 0, st, dlogp, logp, ldp, dlogits, ldd, V, inner, outer, permute);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
@@ -472,10 +526,10 @@ int xgk_nll_fwd(hipStream_t st, const float* logp, const int64_t* target, const 
     return XG_OK;
 }
 int xgk_nll_bwd(hipStream_t st, const int64_t* target, const float* mask, const float* mask2, int B, int T, int V,
-                int roll, const float* sums, float scale, float* dlogp) {
+                int roll, const float* sums, float scale, const float* scale_dev, float* dlogp) {
     if (hipMemsetAsync(dlogp, 0, sizeof(float) * (size_t)B * T * V, st) != hipSuccess) return XG_EHIP;
     hipLaunchKernelGGL(nll_bwd_kernel, dim3(xg_cdiv(B * T, 256)), dim3(256), 0, st, target, mask, mask2, B, T, V, roll,
-                       sums, scale, dlogp);
+                       sums, scale, scale_dev, dlogp);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
@@ -561,7 +615,7 @@ extern "C" int xg_nll_fwd(void* stream, const float* logp, const int64_t* target
     return xgk_nll_fwd((hipStream_t)stream, logp, target, mask, mask2, B, T, V, roll, out);
 }
 extern "C" int xg_nll_bwd(void* stream, const int64_t* target, const float* mask, const float* mask2, int B, int T,
-                          int V, int roll, const float* sums, float scale, float* dlogp) {
+                          int V, int roll, const float* sums, float scale, const float* scale_dev, float* dlogp) {
     if (!target || !mask || !sums || !dlogp || B <= 0 || T <= 0 || V <= 0) return XG_EINVAL;
-    return xgk_nll_bwd((hipStream_t)stream, target, mask, mask2, B, T, V, roll, sums, scale, dlogp);
+    return xgk_nll_bwd((hipStream_t)stream, target, mask, mask2, B, T, V, roll, sums, scale, scale_dev, dlogp);
 }

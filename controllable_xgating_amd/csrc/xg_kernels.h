@@ -160,7 +160,7 @@ int xgk_log_softmax_bwd(hipStream_t st, const float* dlogp, const float* logp, i
 int xgk_nll_fwd(hipStream_t st, const float* logp, const int64_t* target, const float* mask, const float* mask2,
                 int B, int T, int V, int roll, float* out2);
 int xgk_nll_bwd(hipStream_t st, const int64_t* target, const float* mask, const float* mask2, int B, int T, int V,
-                int roll, const float* sums, float scale, float* dlogp);
+                int roll, const float* sums, float scale, const float* scale_dev, float* dlogp);
 // fused: rows are time-major logits (T*B,V): per-row lse, loss accumulation, and dlogits in place
 int xgk_xent_fwd(hipStream_t st, const float* logits, int ld, const int64_t* seq, const float* mask,
                  const float* mask2, int B, int T, int V, int roll, float* lse, float* sums2);

@@ -681,9 +681,10 @@ class _NLLFunction(torch.autograd.Function):
     def backward(ctx, dloss):
         B, T, V, roll, target, mask, m2, sums = ctx.meta
         dlogp = torch.empty(B, T, V, dtype=torch.float32, device=sums.device)
+        dl = dloss.detach().reshape(1).contiguous().float().to(sums.device)      # device scalar: no sync, no extra pass
         nv.check(nv.lib().xg_nll_bwd(_stream(), nv.ptr(target), nv.ptr(mask), nv.ptr(m2), B, T, V, roll, nv.ptr(sums),
-                                     1.0, nv.ptr(dlogp)), "xg_nll_bwd")
-        return dlogp * dloss, None, None, None, None
+                                     1.0, nv.ptr(dl), nv.ptr(dlogp)), "xg_nll_bwd")
+        return dlogp, None, None, None, None
 
 
 class LanguageModelCriterion(nn.Module):

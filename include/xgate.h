@@ -229,9 +229,11 @@ int xg_rollout_bwd(void *stream, const XgDims *d, const XgParams *p, const XgPar
  * second mask (ClassiferCriterion class_mask :250). */
 int xg_nll_fwd(void *stream, const float *logp, const int64_t *target, const float *mask,
                const float *mask2, int B, int T, int V, int roll, float *out);
-/* dlogp (B,T,V) is OVERWRITTEN with the dense gradient scale * d(loss)/d(logp). */
+/* dlogp (B,T,V) is OVERWRITTEN with the dense gradient scale * scale_dev[0] * d(loss)/d(logp); scale_dev is an
+ * optional DEVICE scalar (the incoming d(objective)/d(loss) of loss.backward(): no host sync, no extra pass). */
 int xg_nll_bwd(void *stream, const int64_t *target, const float *mask, const float *mask2,
-               int B, int T, int V, int roll, const float *sums, float scale, float *dlogp);
+               int B, int T, int V, int roll, const float *sums, float scale, const float *scale_dev,
+               float *dlogp);
 
 /* ---- update: clip_gradient + Adam (caption_src/myutils.py:79-85, caption_src/starttrain.py:76,137) ----
  * Elementwise clamp of g to +-clip (clip <= 0 disables), then torch.optim.Adam semantics
