@@ -102,26 +102,39 @@ def load_traffic():
         return None, None
 
 
-def cpu_baseline(cfg, budget_s=20.0):
+def cpu_baseline(cfg, budget_s=20.0, hip_model=None, hip_x=None):
     """Oracle (port of the reference's CPU path; reference-faithful: v2a(V) recomputed every step).
-    Timed at two thread counts (all host cores, and 8 like SURVEY.md's anchors); the faster one is `value`."""
+    Timed at two thread counts (all host cores, and 8 like SURVEY.md's anchors); the faster one is `value`.
+    With `hip_model` the leg is also the run's parity check: the HIP model takes the oracle's procedural weights and its
+    XE loss on the very same batch is compared with the oracle's (`parity` in the result)."""
+    from oracle import paramgen as pg
+    d = pg.make_dims(B=cfg["B"], K=cfg["K"], R=cfg["R"], A=cfg["A"], E=cfg["E"], V=cfg["V"], C=cfg["C"], L=cfg["L"],
+                     F1=cfg["F1"], F2=cfg["F2"])
+    Pn = pg.make_params(d)
     ncores = torch.get_num_threads()
     res = []
     for nt in sorted({min(8, ncores), ncores}):
         torch.set_num_threads(nt)
-        res.append(_cpu_baseline_once(cfg, budget_s / 2))
+        res.append(_cpu_baseline_once(cfg, d, Pn, budget_s / 2))
     torch.set_num_threads(ncores)
     best = max(res, key=lambda r: r["value"])
     best["sample"] += "; all thread counts tried: " + ", ".join("%d threads -> %.1f/s" % (r["cores"], r["value"]) for r in res)
+    oracle_loss = best.pop("loss")
+    for r in res:
+        r.pop("loss", None)
+    if hip_model is not None:
+        hip_model.load_state_dict({k: torch.from_numpy(v) for k, v in Pn.items()}, strict=False)
+        hip_model.train()
+        with torch.no_grad():
+            hl = hip_model.xe_loss(hip_x["feats_rgb"], hip_x["feats_opfl"], hip_x["feat_mask"], hip_x["pos_feats"], hip_x["seq"],
+                                   hip_x["seq_mask"])
+        best["parity"] = {"oracle_loss": oracle_loss, "hip_loss": float(hl.item()), "delta": abs(float(hl.item()) - oracle_loss)}
     return best
 
 
-def _cpu_baseline_once(cfg, budget_s):
-    from oracle import paramgen as pg
+def _cpu_baseline_once(cfg, d, Pn, budget_s):
     from oracle import xgate_oracle as xo
-    d = pg.make_dims(B=cfg["B"], K=cfg["K"], R=cfg["R"], A=cfg["A"], E=cfg["E"], V=cfg["V"], C=cfg["C"], L=cfg["L"],
-                     F1=cfg["F1"], F2=cfg["F2"])
-    P = xo.to_torch_params(pg.make_params(d), requires_grad=True)
+    P = xo.to_torch_params(Pn, requires_grad=True)
     x = {k: v.cpu() for k, v in synth_inputs(cfg["B"], cfg["K"], cfg["L"], cfg["V"], cfg["R"], cfg["F1"], cfg["F2"], cfg["C"],
                                            0, "cpu").items()}
     running = xo.new_running(d)
@@ -133,7 +146,8 @@ def _cpu_baseline_once(cfg, budget_s):
                                      x["seq_mask"], train=True, running=running, hoist=False)
         loss = xo.lm_criterion(logp, x["seq"], x["seq_mask"])
         loss.backward()
-    t0 = time.time(); it(); warm = time.time() - t0
+        return float(loss.item())
+    t0 = time.time(); loss0 = it(); warm = time.time() - t0
     n, t0 = 0, time.time()
     while True:
         it(); n += 1
@@ -144,7 +158,7 @@ def _cpu_baseline_once(cfg, budget_s):
     return dict(value=round(cfg["B"] * T / dt, 1), unit="decoder timesteps/s", cores=torch.get_num_threads(), kind="port",
                 sample="%d full XE fwd+bwd iterations of the same workload (B=%d, T=%d, V=%d) after 1 warm-up (%.1f s); "
                        "oracle with v2a(V) recomputed per step like the reference" % (n, cfg["B"], T, cfg["V"], warm),
-                ms_per_step=round(dt * 1e3, 1))
+                ms_per_step=round(dt * 1e3, 1), loss=loss0)
 
 
 def main():
@@ -165,10 +179,22 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, RCCL over xGMI) -- never
+        # silently run one GPU and call it N
+        ndev = torch.cuda.device_count()
+        if ndev < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, ndev))
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+                                  "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
@@ -300,9 +326,23 @@ def main():
                          "mfma_peak_tflops": 157.3,
                          "mfma_frac": round(step_flops(cfg["B"], cfg["K"], cfg["R"], cfg["A"], cfg["E"]) / t_step / 157.3e12, 4)},
         }
+        parity_fail = None
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(cfg, args.cpu_budget)
+            check = args.workload in ("xe", "xe5")          # the oracle leg is the XE iteration of the same shape
+            cb = cpu_baseline(cfg, args.cpu_budget, model if check else None, x)
+            par = cb.pop("parity", None)
+            out["cpu_baseline"] = cb
+            if par is not None:
+                # north_star: training loss within 1e-4 of the reference CPU path in fp32 (1e-2 for the bf16 config)
+                tol = 1e-2 if args.precision == "bf16" else 1e-4
+                out["parity_loss_delta"] = round(par["delta"], 7)
+                out["parity"] = {"hip_loss": round(par["hip_loss"], 6), "oracle_loss": round(par["oracle_loss"], 6), "tol": tol,
+                                 "what": "XE loss of this run's HIP model vs the CPU oracle, same procedural weights, same batch"}
+                if not par["delta"] < tol:
+                    parity_fail = "parity: |hip - oracle| = %.3g >= %g" % (par["delta"], tol)
         print(json.dumps(out))
+        if parity_fail:
+            raise SystemExit(parity_fail)
     if use_dist:
         dist.destroy_process_group()
 

@@ -1,0 +1,161 @@
+"""GPU parity at the BENCHMARKED sizes (BASELINE.json configs[1] and configs[2]): the HIP path through the C ABI vs
+the oracle on the same seeded inputs.  These sizes select kernel paths the small cases never reach (4 m-tiles per skinny
+job, 128x128 GEMM tiles with split-K, the 2m = 128-row paired rollout).  About 10 s of CPU oracle per case."""
+import functools
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import paramgen as pg
+from oracle import xgate_oracle as xo
+from tests.util import CFG, ZERO_GRAD_PARAMS, assert_grads_close, make_model, oracle_grads, to_dev
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _need_gpu():
+    assert torch.cuda.is_available(), "-m gpu tests need an MI355X"
+    import __graft_entry__ as ge
+    ge.build()
+    torch.set_num_threads(min(16, torch.get_num_threads()))
+
+
+@functools.lru_cache(maxsize=4)
+def _params(V, gain, bias0):
+    d = pg.make_dims(**dict(CFG["c1"], V=V))
+    P = pg.make_params(d, logit_gain=gain)
+    if bias0:
+        P["logit.bias"] = P["logit.bias"].copy()
+        P["logit.bias"][0] += bias0
+    return P
+
+
+# ------------------------------------------------------------------ configs[1]: B = 128 teacher-forced XE, fp32
+@pytest.mark.parametrize("path,ragged", [("fused", False), ("surface", True)])
+def test_config2_b128_xe_loss_logprobs_and_every_gradient_vs_oracle(path, ragged):
+    from controllable_xgating_amd import LanguageModelCriterion
+    d = pg.make_dims(**dict(CFG["c1"], B=128))
+    Pn = _params(d.V, 8.0, 0.0)
+    xn = pg.make_inputs(d, seed=0, ragged=ragged)
+    P = xo.to_torch_params(Pn, requires_grad=True)
+    xi = xo.to_torch_inputs(xn)
+    running = xo.new_running(d)
+    logp_o, _, _ = xo.forward_xe(P, xi["feats_rgb"], xi["feats_opfl"], xi["feat_mask"], xi["pos_feats"], xi["seq"],
+                                 xi["seq_mask"], train=True, running=running)
+    loss_o = xo.lm_criterion(logp_o, xi["seq"], xi["seq_mask"])
+    loss_o.backward()
+    model = make_model(d, P=Pn)
+    x = to_dev(xn)
+    if path == "fused":          # what bench.py times
+        loss = model.xe_loss(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+        logp = None
+    else:                        # the reference's call sequence (starttrain.py:125-126)
+        logp, _ = model(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+        loss = LanguageModelCriterion()(logp, x["seq"], x["seq_mask"])
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_o.item()) < 1e-4, (loss.item(), loss_o.item())      # north_star: 1e-4 on the training loss
+    if logp is not None:
+        lo = logp_o.detach()
+        np.testing.assert_allclose(logp[:, :, :64].cpu().numpy(), lo[:, :, :64].numpy(), atol=3e-4, rtol=0)
+        tgt = torch.cat([xi["seq"][:, 1:], xi["seq"][:, :1]], 1).unsqueeze(2)
+        np.testing.assert_allclose(logp.detach().cpu().gather(2, tgt).numpy(), lo.gather(2, tgt).numpy(), atol=3e-4, rtol=0)
+        # every row is a normalised distribution
+        np.testing.assert_allclose(torch.logsumexp(logp.detach(), 2).cpu().numpy(), 0.0, atol=1e-4)
+    assert_grads_close(model, oracle_grads(P), skip=ZERO_GRAD_PARAMS)
+    for mod in ("rgb", "opfl"):
+        bn = getattr(model.two_spatial_encoder, f"visual_emb_{mod}")[1]
+        pre = xo.ENC + f"visual_emb_{mod}.1."
+        np.testing.assert_allclose(bn.running_mean.cpu().numpy(), running[pre + "running_mean"].numpy(), atol=1e-5)
+        np.testing.assert_allclose(bn.running_var.cpu().numpy(), running[pre + "running_var"].numpy(), atol=1e-5)
+
+
+# ------------------------------------------------------------------ configs[2]: SCST, B = 64, seq_len 30
+def _scst_case():
+    d = pg.make_dims(**dict(CFG["c1"], B=64, L=30))
+    Pn = _params(d.V, 1.0, 7.0)          # EOS mass ~ 5-10 % per step: rows finish anywhere between t = 1 and t = 30
+    xn = pg.make_inputs(d, seed=0)
+    u = pg.uniform("uni64", (d.L + 1, d.B), 91)
+    reward = np.repeat(pg.uniform("reward64", (d.B, 1), 3, -1.0, 1.0), d.L, 1)      # myutils.py:76
+    return d, Pn, xn, u, reward
+
+
+def _oracle_replay(d, Pn, xn, forced, reward):
+    P = xo.to_torch_params(Pn, requires_grad=True)
+    xi = xo.to_torch_inputs(xn)
+    s, lp = xo.sample(P, xi["feats_rgb"], xi["feats_opfl"], xi["feat_mask"], xi["pos_feats"], d.L, mode="replay",
+                      forced=forced, train=True, running=xo.new_running(d))
+    n = s.shape[1]
+    loss = xo.reward_criterion(lp, s, torch.from_numpy(reward[:, :n]))
+    loss.backward()
+    return P, lp.detach().numpy(), loss.item()
+
+
+def test_config3_scst_b64_l30_replay_of_oracle_sampled_tokens():
+    """model.sample with the oracle's own multinomial draws forced: log-probs, RewardCriterion loss, every gradient."""
+    from controllable_xgating_amd import RewardCriterion
+    d, Pn, xn, u, reward = _scst_case()
+    xi = xo.to_torch_inputs(xn)
+    with torch.no_grad():
+        s_o, _ = xo.sample(xo.to_torch_params(Pn), xi["feats_rgb"], xi["feats_opfl"], xi["feat_mask"], xi["pos_feats"], d.L,
+                           mode="sample", uniforms=u, train=True, running=xo.new_running(d))
+    lens = (s_o.numpy() > 0).sum(1)
+    assert lens.min() < 5 and lens.max() > 20                     # ragged finishing steps
+    P, lp_o, loss_o = _oracle_replay(d, Pn, xn, s_o, reward)
+    model = make_model(d, P=Pn, train=True)
+    x = to_dev(xn)
+    seq, slp = model.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"],
+                            {"sample_max": 0, "forced_tokens": s_o.cuda()})
+    n = s_o.shape[1]
+    assert np.array_equal(seq.cpu().numpy()[:, :n], s_o.numpy())
+    m = np.concatenate([np.ones((d.B, 1), bool), s_o.numpy()[:, :-1] > 0], 1)
+    np.testing.assert_allclose(slp.detach().cpu().numpy()[:, :n][m], lp_o[m], atol=3e-4)
+    loss = RewardCriterion()(slp[:, :n], seq[:, :n], torch.from_numpy(reward[:, :n]).cuda())
+    assert abs(loss.item() - loss_o) < 1e-4, (loss.item(), loss_o)
+    loss.backward()
+    torch.cuda.synchronize()
+    assert_grads_close(model, oracle_grads(P), skip=ZERO_GRAD_PARAMS)
+    # and the HIP sampler itself, from the same uniforms: the oracle's tokens up to CDF-boundary coin flips
+    model2 = make_model(d, P=Pn, train=True)
+    with torch.no_grad():
+        s_h, _ = model2.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"],
+                               {"sample_max": 0, "uniforms": torch.from_numpy(u).cuda()})
+    s_h = s_h.cpu().numpy()
+    rows_diff = sum(1 for b in range(d.B) if s_h.shape != tuple(s_o.shape) or not np.array_equal(s_h[b], s_o.numpy()[b]))
+    assert rows_diff <= 2, rows_diff
+
+
+def test_config3_scst_b64_l30_paired_rollout_vs_oracle():
+    """model.sample_pair (ONE 2m = 128-row pass: sampled rows + greedy baseline): the sampled half's log-probs / loss /
+    gradients equal the oracle's replay of the very tokens it drew, the greedy half equals the oracle's greedy rollout."""
+    from controllable_xgating_amd import RewardCriterion
+    d, Pn, xn, u, reward = _scst_case()
+    model = make_model(d, P=Pn, train=True)
+    x = to_dev(xn)
+    gen, slp, greedy, n = model.sample_pair(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"],
+                                            {"uniforms": torch.from_numpy(u).cuda()})
+    n_s, n_g = (int(v) for v in n.cpu())
+    gen_t, slp_t = gen[:, :n_s], slp[:, :n_s]
+    loss = RewardCriterion()(slp_t, gen_t, torch.from_numpy(reward[:, :n_s]).cuda())
+    loss.backward()
+    torch.cuda.synchronize()
+    forced = gen_t.cpu()
+    P, lp_o, loss_o = _oracle_replay(d, Pn, xn, forced, reward)
+    m = np.concatenate([np.ones((d.B, 1), bool), forced.numpy()[:, :-1] > 0], 1)
+    np.testing.assert_allclose(slp_t.detach().cpu().numpy()[m], lp_o[m], atol=3e-4)
+    assert abs(loss.item() - loss_o) < 1e-4, (loss.item(), loss_o)
+    assert_grads_close(model, oracle_grads(P), skip=ZERO_GRAD_PARAMS)
+    xi = xo.to_torch_inputs(xn)
+    with torch.no_grad():
+        g_o, _, logps = xo.sample(xo.to_torch_params(Pn), xi["feats_rgb"], xi["feats_opfl"], xi["feat_mask"], xi["pos_feats"],
+                                  d.L, mode="greedy", train=True, running=xo.new_running(d), return_logp=True)
+    g_h, g_o = greedy[:, :n_g].cpu().numpy(), g_o.numpy()
+    assert g_h.shape == g_o.shape, (g_h.shape, g_o.shape)
+    for b in range(d.B):
+        for t in range(g_o.shape[1]):
+            if g_h[b, t] != g_o[b, t]:            # only a round-off-level top-2 margin may flip a greedy token
+                top2 = np.sort(logps[t].numpy()[b])[-2:]
+                assert top2[1] - top2[0] < 1e-3, (b, t, int(g_h[b, t]), int(g_o[b, t]))
+                break

@@ -179,3 +179,67 @@ def test_scheduled_sampling_replay_matches_reference():
         gn = np.sqrt((gr.astype(np.float64) ** 2).sum())
         ref_n = float(g["gnorm/" + name])
         assert abs(gn - ref_n) <= 3e-4 * ref_n + 2e-7, (name, gn, ref_n)
+
+
+def test_greedy_with_natural_eos_matches_reference():
+    """Rows finish at steps 3..13 (two never do) and 44 distinct words are emitted: pins `unfinished`, the zeroing of
+    finished rows and the state hold under xt_mask (SAModel.py:200-215) against the reference itself."""
+    from tests.util import EOS_CASE, eos_params
+    g = load("greedy_c1_eos.npz")
+    d = pg.make_dims(**CFG["c1"])
+    P = xo.to_torch_params(eos_params(d))
+    x = xo.to_torch_inputs(pg.make_inputs(d, seed=EOS_CASE["input_seed"]))
+    with torch.no_grad():
+        seq, slp = xo.sample(P, x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], d.L,
+                             mode="greedy", train=False, running=xo.new_running(d))
+    assert g["margin"][g["alive"]].min() >= 1e-3
+    ends = [int(np.flatnonzero(g["seq"][b] == 0)[0]) for b in range(d.B) if (g["seq"][b] == 0).any()]
+    assert len(ends) >= 4 and min(ends) >= 2 and len(np.unique(g["seq"])) > 30
+    assert np.array_equal(seq.numpy(), g["seq"])
+    np.testing.assert_allclose(slp.numpy(), g["seqLogprobs"], atol=3e-5)
+
+
+@pytest.mark.parametrize("tag", ["tiny", "mid"])
+def test_three_iteration_adam_trajectory_matches_reference(tag):
+    """clamp +-0.1 (myutils.py:79-85) + torch.optim.Adam defaults (starttrain.py:76,134-137) on the reference model, three
+    iterations: the oracle's forward/backward + clip_gradient + adam_step follow the same losses and parameters."""
+    from tests.util import ZERO_GRAD_PARAMS
+    g = load(f"traj_{tag}.npz")
+    d, P, x = setup(tag, ragged=True, grad=True)
+    P0 = {k: t.detach().numpy().copy() for k, t in P.items()}
+    m = {k: torch.zeros_like(v) for k, v in P.items()}
+    v = {k: torch.zeros_like(t) for k, t in P.items()}
+    running = xo.new_running(d)
+    losses = []
+    for step in (1, 2, 3):
+        for t in P.values():
+            t.grad = None
+        logp, cat, _ = xo.forward_xe(P, x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"],
+                                     train=True, running=running)
+        loss = xo.lm_criterion(logp, x["seq"], x["seq_mask"]) + WEIGHT_CLASS * xo.cls_criterion(
+            cat, x["cap_classes"], x["seq_mask"], x["class_mask"])
+        loss.backward()
+        losses.append(loss.item())
+        grads = xo.clip_gradient({k: (P[k].grad if P[k].grad is not None else torch.zeros_like(P[k])) for k in P}, 0.1)
+        with torch.no_grad():
+            for k in P:
+                pn, m[k], v[k] = xo.adam_step(P[k].detach(), grads[k], m[k], v[k], step, float(g["lr"]))
+                P[k].copy_(pn)
+    np.testing.assert_allclose(losses, g["losses"], atol=5e-6)
+    assert g["losses"][2] < g["losses"][0]
+    for name in P:
+        if name in ZERO_GRAD_PARAMS:       # true gradient exactly zero: Adam turns round-off noise into +-lr steps
+            continue
+        idx = g["pidx/" + name]
+        got = P[name].detach().numpy().reshape(-1)[idx]
+        np.testing.assert_allclose(got, g["psamp/" + name], atol=2e-6, err_msg=name)
+        # three steps of at most lr each: the DISPLACEMENT itself must agree, not just the value
+        np.testing.assert_allclose(got - P0[name].reshape(-1)[idx], g["dsamp/" + name], atol=2e-6, err_msg=name)
+        assert abs(np.sqrt((P[name].detach().numpy().astype(np.float64) ** 2).sum()) - g["pnorm/" + name]) <= 1e-5 * max(
+            1.0, g["pnorm/" + name]), name
+    for mod in ("rgb", "opfl"):
+        pre = xo.ENC + f"visual_emb_{mod}.1."
+        # the Linear bias in front of BatchNorm has a true gradient of zero: Adam moves it by +-lr per step on round-off
+        # noise, which shifts the batch MEAN (not the output, not the variance) by up to momentum * 3 * lr
+        np.testing.assert_allclose(running[pre + "running_mean"].numpy(), g[f"bn_{mod}_running_mean"], atol=2e-4)
+        np.testing.assert_allclose(running[pre + "running_var"].numpy(), g[f"bn_{mod}_running_var"], atol=1e-5)

@@ -23,6 +23,17 @@ CFG = {
     "mid": dict(B=12, K=9, R=64, A=96, E=36, V=500, C=14, L=7, F1=48, F2=40, H=128),
 }
 WEIGHT_CLASS = 0.5
+# greedy_c1_eos.npz (tools/gen_golden.py:EOS_CASE): embed x15, row 0 of logit.weight x4, inputs of seed 2
+EOS_CASE = dict(embed_gain=15.0, eos_row_gain=4.0, input_seed=2)
+
+
+def eos_params(d):
+    """Weights of the natural-EOS greedy golden (same scaling as tools/gen_golden.py:eos_params)."""
+    P = pg.make_params(d)
+    P["embed.weight"] = P["embed.weight"] * np.float32(EOS_CASE["embed_gain"])
+    P["logit.weight"] = P["logit.weight"].copy()
+    P["logit.weight"][0] *= np.float32(EOS_CASE["eos_row_gain"])
+    return P
 
 
 def load_golden(name):

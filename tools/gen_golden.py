@@ -37,7 +37,13 @@ CFG = {
     "tiny": dict(B=5, K=7, R=24, A=40, E=18, V=61, C=5, L=6, F1=20, F2=12, H=128),
     # BASELINE.json configs[4] shape at small batch (fp32 golden, 1e-2 tol for bf16)
     "c5": dict(B=4, K=40, R=1024, A=1536, E=468, V=20000, C=14, L=6, F1=1536, F2=1024, H=128),
+    # mid-size, everything 16-byte aligned (the vector-load kernel paths)
+    "mid": dict(B=12, K=9, R=64, A=96, E=36, V=500, C=14, L=7, F1=48, F2=40, H=128),
 }
+# greedy golden with natural EOS: a livelier token feedback (embed x15) and a wide-variance EOS logit (row 0 of
+# logit.weight x4) make the rows emit varied words and finish at different steps; chosen so that the reference's own
+# top-1/top-2 margin stays >= 1e-3 on every live step (tests apply the same scaling: tests/util.py:eos_params)
+EOS_CASE = dict(embed_gain=15.0, eos_row_gain=4.0, input_seed=2)
 WEIGHT_CLASS = 0.5
 
 
@@ -168,6 +174,85 @@ def gen_greedy(ref, tag, ragged=False):
     print("wrote", name, "n", seq.shape[1], "min margin", g["margin"][: seq.shape[1]].min())
 
 
+def eos_params(d):
+    P = pg.make_params(d)
+    P["embed.weight"] = P["embed.weight"] * np.float32(EOS_CASE["embed_gain"])
+    P["logit.weight"] = P["logit.weight"].copy()
+    P["logit.weight"][0] *= np.float32(EOS_CASE["eos_row_gain"])
+    return P
+
+
+def gen_greedy_eos(ref):
+    """Greedy decode (SAModel.py:163-219, eval mode) where rows finish naturally at different steps: pins the
+    `unfinished` bookkeeping (:200-215), the zeroing of finished rows (:208) and the state hold under xt_mask."""
+    d = pg.make_dims(**CFG["c1"])
+    P = eos_params(d)
+    x = tt(pg.make_inputs(d, seed=EOS_CASE["input_seed"]))
+    model = build_ref(ref, d, P)
+    model.eval()
+    logps = []
+    hook = model.logit.register_forward_hook(lambda m, i, o: logps.append(torch.log_softmax(o, 1).detach().numpy().copy()))
+    with quiet(), torch.no_grad():
+        seq, slp = model.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"sample_max": 1})
+    hook.remove()
+    s = seq.numpy()
+    lp = np.array(logps)[: s.shape[1]]
+    top2 = -np.sort(-lp, axis=2)[:, :, :2]
+    margin = top2[:, :, 0] - top2[:, :, 1]                     # (n, B): margin of the choice made at step t+1
+    alive = np.ones_like(margin, bool)
+    for b in range(d.B):
+        z = np.flatnonzero(s[b] == 0)
+        if z.size:
+            alive[z[0] + 1:, b] = False
+    g = dict(seq=s, seqLogprobs=slp.numpy(), margin=margin, alive=alive)
+    np.savez_compressed(os.path.join(GOLD, "greedy_c1_eos.npz"), **g)
+    lens = [int(np.flatnonzero(s[b] == 0)[0]) if (s[b] == 0).any() else -1 for b in range(d.B)]
+    print("wrote greedy_c1_eos.npz n", s.shape[1], "distinct tokens", len(np.unique(s)), "EOS at", lens,
+          "min live margin", margin[alive].min())
+    assert margin[alive].min() >= 1e-3 and len(np.unique(s)) > 30 and sum(1 for v in lens if 2 <= v <= 15) >= 4
+
+
+def gen_traj(ref, tag, iters=3):
+    """f-1 / a11: the reference model under the reference's update rule -- optim.Adam(model.parameters(), lr) with torch
+    defaults (starttrain.py:76), loss = L_xe + weight_class * L_cls (:125-129), backward (:134), elementwise clamp of
+    every gradient to +-grad_clip = 0.1 (myutils.py:79-85; py2-only file, its three-line loop is restated here), step
+    (:137) -- three iterations on one batch.  Records the losses and the parameters afterwards."""
+    d = pg.make_dims(**CFG[tag])
+    P = pg.make_params(d)
+    x = tt(pg.make_inputs(d, seed=0, ragged=True))
+    model = build_ref(ref, d, P)
+    model.train()
+    optimizer = torch.optim.Adam(model.parameters(), lr=4e-4, weight_decay=0.0)
+    crit, ccrit = ref.LanguageModelCriterion(), ref.ClassiferCriterion()
+    losses = []
+    for _ in range(iters):
+        optimizer.zero_grad()
+        logp, cat = model(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+        loss = crit(logp, x["seq"], x["seq_mask"]) + WEIGHT_CLASS * ccrit(cat, x["cap_classes"], x["seq_mask"], x["class_mask"])
+        loss.backward()
+        for group in optimizer.param_groups:                       # myutils.clip_gradient
+            for prm in group["params"]:
+                if prm.grad is not None:
+                    prm.grad.data.clamp_(-0.1, 0.1)
+        optimizer.step()
+        losses.append(loss.item())
+    g = dict(losses=np.array(losses, np.float64), lr=np.float64(4e-4), grad_clip=np.float64(0.1))
+    for name, prm in model.named_parameters():
+        v = prm.detach().numpy()
+        g["pnorm/" + name] = np.float64(np.sqrt((v.astype(np.float64) ** 2).sum()))
+        g["pidx/" + name] = sample_idx(name, v.shape, 256)
+        g["psamp/" + name] = v.reshape(-1)[g["pidx/" + name]].copy()
+        g["dsamp/" + name] = (v.reshape(-1)[g["pidx/" + name]] - P[name].reshape(-1)[g["pidx/" + name]]).copy()
+        if tag == "tiny":
+            g["pfull/" + name] = v.copy()
+    for mod in ("rgb", "opfl"):
+        bn = getattr(model.two_spatial_encoder, f"visual_emb_{mod}")[1]
+        g[f"bn_{mod}_running_mean"] = bn.running_mean.numpy().copy()
+        g[f"bn_{mod}_running_var"] = bn.running_var.numpy().copy()
+    np.savez_compressed(os.path.join(GOLD, f"traj_{tag}.npz"), **g)
+    print("wrote", f"traj_{tag}.npz", "losses", losses)
+
+
 def gen_step(ref):
     """G5: one LSTMCore_two_layer_gate step from a random state, B=4, c1 sizes."""
     cfg = dict(CFG["c1"]); cfg["B"] = 4
@@ -277,7 +362,13 @@ def main():
         return 0
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
+    round2_only = "--round2-only" in sys.argv          # (import_reference() resets sys.argv for the reference's argparse)
     ref = import_reference()
+    if round2_only:          # the fixtures added in round 2 (the older ones regenerate bit-identically)
+        gen_greedy_eos(ref)
+        gen_traj(ref, "tiny")
+        gen_traj(ref, "mid")
+        return 0
     gen_xe(ref, "tiny", ragged=False, full=True)
     gen_xe(ref, "tiny", ragged=True, full=True)
     gen_xe(ref, "c1", ragged=False, full=False)
@@ -294,6 +385,9 @@ def main():
     gen_beam(ref, "tiny")
     gen_beam(ref, "c1")
     gen_ss(ref, "tiny")
+    gen_greedy_eos(ref)
+    gen_traj(ref, "tiny")
+    gen_traj(ref, "mid")
     return 0
 
 
