@@ -117,6 +117,12 @@ constexpr int SK_MAX_JOBS = 4;
 struct SkSeg {
     const float* A; const float* B;   // A (M,K) row-major lda ; B (N,K) row-major ldb, or (K,N) when b_ncontig
     int lda, ldb, K, b_ncontig;
+    // packed form of B (xg_pack.hip: 32 x 32 tiles in MFMA-fragment order, nck tiles per 32-column slice) or null: when
+    // every segment of a launch has one, the launch takes the fast kernel (B operand global -> VGPR, no LDS)
+    const float* Bp; int nck;
+    // optional row gather on A: row m of the operand is A + clamp(gather[m * gstride], 0, gather_max) * lda
+    // (embedding lookup folded into the product: caption_src/SAModel.py:105,198)
+    const int64_t* gather; int gstride, gather_max;
 };
 struct SkJob {
     SkSeg seg[3];
@@ -131,10 +137,20 @@ struct SkJob {
     // LSTMB epilogue (reads gates / c_prev / c_out / mask / add from the LSTM fields above)
     const float* dc_in; float* ds; float* dc_prev; float* dh_hold; int lddci, ldds, lddcp, lddhh;
     int nseg, M, N, ldc, accumulate, relu, epi, R, order, mask_mode, tile0;
+    // STORE epilogue over a (M,4R) gate-major pre-activation with the CELL tiling of the weight rows (tile tn = hidden units
+    // 8 tn .. 8 tn + 7 of all four gates, like the LSTM epilogue): a partial cell product another launch finishes
+    int cell_cols;
     XgDrop drop;
 };
 struct SkArgs { int njobs; int tile0[SK_MAX_JOBS]; SkJob job[SK_MAX_JOBS]; };
 int xgk_skinny(hipStream_t st, SkArgs& a);
+
+// ---- xg_pack.hip : weights re-tiled into MFMA-fragment order (caller-owned shadow, XgRun.packed)
+enum { PK_H2A1 = 0, PK_H2A2, PK_DGATE, PK_L1_I2H, PK_L1_A2H, PK_L1_H2H, PK_L2_I2H, PK_L2_A2H, PK_L2_H2H, PK_ENC_RGB, PK_ENC_OPFL,
+       PKB_L2_A2H, PKB_L2_H2H, PKB_H2A2, PKB_L1_H2H, PKB_ENC_RGB, PKB_ENC_OPFL, PK_COUNT };
+struct PackedView { const float* m[PK_COUNT]; int nck[PK_COUNT]; };
+size_t xgk_packed_floats(const XgDims& d);
+bool xgk_packed_view(const XgDims& d, const void* packed, PackedView* v);   // false: no / unusable shadow
 
 // ---- xg_attn.hip
 // per-sample additive attention: e_k = w . tanh(p + q_k), alpha = softmax_k(e), af = sum_k alpha_k V_k

@@ -122,6 +122,8 @@ struct Ws {
     // ---- rollout
     int64_t* TOK; float *TOKLP, *UNF; int32_t* alive;
     size_t bytes;
+    // ---- packed recurrent weights (XgRun.packed; not part of the workspace)
+    PackedView pk; bool packed;
 };
 
 struct Carver {
@@ -194,8 +196,28 @@ inline int gemm_tn(hipStream_t st, int Mrows, int N, int K, const float* dY, int
 }
 
 // ---- skinny-job builders
-inline SkSeg seg_nt(const float* A, int lda, const float* W, int ldw, int K) { return SkSeg{A, W, lda, ldw, K, 0}; }
-inline SkSeg seg_nn(const float* dY, int lddy, const float* W, int ldw, int Kc) { return SkSeg{dY, W, lddy, ldw, Kc, 1}; }
+inline SkSeg seg_nt(const float* A, int lda, const float* W, int ldw, int K) {
+    SkSeg s{}; s.A = A; s.B = W; s.lda = lda; s.ldb = ldw; s.K = K; s.b_ncontig = 0; return s;
+}
+inline SkSeg seg_nn(const float* dY, int lddy, const float* W, int ldw, int Kc) {
+    SkSeg s{}; s.A = dY; s.B = W; s.lda = lddy; s.ldb = ldw; s.K = Kc; s.b_ncontig = 1; return s;
+}
+// the same segments with the packed form of the weight attached when the caller supplied one (XgRun.packed)
+inline SkSeg seg_nt(const Ws& w, int which, const float* A, int lda, const float* W, int ldw, int K) {
+    SkSeg s = seg_nt(A, lda, W, ldw, K);
+    if (w.packed) { s.Bp = w.pk.m[which]; s.nck = w.pk.nck[which]; }
+    return s;
+}
+inline SkSeg seg_nn(const Ws& w, int which, const float* dY, int lddy, const float* W, int ldw, int Kc) {
+    SkSeg s = seg_nn(dY, lddy, W, ldw, Kc);
+    if (w.packed) { s.Bp = w.pk.m[which]; s.nck = w.pk.nck[which]; }
+    return s;
+}
+// (plain-bf16 mode keeps the LDS-staged kernel, which rounds its chunks to bf16 on the way: BASELINE.json configs[4])
+inline void attach_packed(Ws& w, const XgDims& d, const XgRun* run) {
+    static const bool disabled = getenv("XG_NO_PACKED") != nullptr;
+    w.packed = !disabled && run && run->packed && run->gemm_mode != 1 && xgk_packed_view(d, run->packed, &w.pk);
+}
 inline SkJob job_store(int M, int N, float* C, int ldc, bool acc, bool relu = false) {
     SkJob j{};
     j.M = M; j.N = N; j.C = C; j.ldc = ldc; j.accumulate = acc ? 1 : 0; j.relu = relu ? 1 : 0; j.epi = SK_EPI_STORE;
@@ -280,7 +302,8 @@ int encoder_fwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgBnSt
             a.drop = xg_make_drop(&nodrop, 0, 0);
             if (R % 8 == 0) {
                 sk.job[m] = job_lstm(a);
-                sk.job[m].nseg = 1; sk.job[m].seg[0] = seg_nt(hp, ldp, whh[m], R, R); sk.job[m].bias[0] = bhh[m];
+                sk.job[m].nseg = 1; sk.job[m].seg[0] = seg_nt(w, m == 0 ? PK_ENC_RGB : PK_ENC_OPFL, hp, ldp, whh[m], R, R);
+                sk.job[m].bias[0] = bhh[m];
             } else {
                 float* S = m == 0 ? w.S : w.S2;
                 XG_TRY(xgk_linear(st, B, 4 * R, R, hp, ldp, whh[m], bhh[m], S, 4 * R));
@@ -375,7 +398,7 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
                 if (fuse) sk.job[m] = job_lstm_bwd(enc_cell_bwd(m, i - 1, curc, true), nullptr, 0);
                 else sk.job[m] = job_store(B, R, w.dHrec[m], R, false);
                 sk.job[m].nseg = 1;
-                sk.job[m].seg[0] = seg_nn(w.dS[m] + (size_t)i * 4 * R, K * 4 * R, whh[m], R, 4 * R);
+                sk.job[m].seg[0] = seg_nn(w, m == 0 ? PKB_ENC_RGB : PKB_ENC_OPFL, w.dS[m] + (size_t)i * 4 * R, K * 4 * R, whh[m], R, 4 * R);
             }
             XG_TRY(xgk_skinny(st, sk));
         }
@@ -439,20 +462,33 @@ int init_and_vproj(Streams& ss, const XgDims& d, const XgParams& p, const float*
 }
 
 struct StepIO {
-    const float* xt;      // (B,E)
+    const float* xt;      // (B,E) embedding rows of the step's tokens, or null: gathered from `tok` inside the products
+    const int64_t* tok;   // (B) tokens (row gather on embed.weight) when xt == null
     const float* pos;     // (B,R) raw POS feature: the gate runs inside the step when pre1 == null
     float* gp;            // (B,R) gate values g (saved for backward), written when pre1 == null
     float* posg;          // (B,R) gated POS feature (input when pre1 != null, output otherwise)
     const float* pre1;    // (B,4R) hoisted xt/pos' contribution of cell 1, or null (computed here)
     const float* mask; int ldm;
     const float *h1, *c1, *h2, *c2;   // previous state (B,R) contiguous
-    float *h1o, *c1o, *h2o, *c2o;     // new state
+    float *h1o, *c1o, *h2o, *c2o;     // new state (may alias the previous state on the packed path: see core_step)
     float *P, *alpha, *af, *g1, *g2;  // saved per-step tensors (alpha / gates may be scratch)
     int t;
 };
 
-// attention + the two cells for one step (sub_modules.py:677-684): 3 launches
-//   [p = h2a([h1;h2])  ||  cell 1]  ->  attention  ->  cell 2
+// the packed-weight form of the step needs 16-byte rows everywhere (R % 8 covers R; E and A are checked here)
+inline bool step_packed(const Ws& w, const XgDims& d) { return w.packed && d.R % 8 == 0 && d.E % 4 == 0 && d.A % 4 == 0; }
+
+// attention + the two cells for one step (sub_modules.py:677-684).
+//
+// Packed form, 3 launches (4 in the rollout form until the attention joins cell 1's launch):
+//   L1  everything that depends only on the OLD state and the token, as jobs of one skinny launch:
+//         p = h2a([h1;h2]) | S2' = h2 W_h2h2 + b | teacher forcing: cell 1 (h1 W_h2h1 + hoisted token side)
+//                                                | rollout: POS gate, S1' = xt W_i2h1 + h1 W_h2h1 + b
+//   L2  attention (needs p)   [rollout: + cell 1 = pos' W_a2h1 + S1']
+//   L3  cell 2 = h1' W_i2h2 + af W_a2h2 + S2'
+// No launch reads the old state as a matrix operand after L1, and a cell epilogue reads its own (b, j) element of the old
+// h / c before it writes the new one: the state may be updated IN PLACE (xg_step_fwd) with no copy.
+// LDS-staged form (no packed weights): [p || cell 1 / gate] -> (cell 1) -> attention -> cell 2 as in round 1.
 int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& run, Ws& w, const float* V,
               const float* vproj, const StepIO& s) {
     const int B = d.B, R = d.R, A = d.A, E = d.E;
@@ -468,6 +504,74 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
     c.gates = s.g2; c.ldg = 4 * R; c.c_out = s.c2o; c.ldco = R; c.h_out = s.h2o; c.ldho = R;
     c.B = B; c.R = R; c.order = XG_ORDER_IFOG; c.mask_mode = XG_MASK_HOLD;
     c.drop = xg_make_drop(&run, XG_SITE_L2, s.t);
+    if (step_packed(w, d)) {
+        // xt as a matrix operand: the materialised rows, or embed.weight gathered by token
+        auto xt_seg = [&](int which, const float* W) {
+            SkSeg g = seg_nt(w, which, s.xt ? s.xt : p.embed_w, E, W, E, E);
+            if (!s.xt) { g.gather = s.tok; g.gstride = 1; g.gather_max = d.V - 1; }
+            return g;
+        };
+        SkArgs k1{};
+        int nj = 0;
+        {   // p = h2a([h1 ; h2])                                                                         :677
+            SkJob& j = k1.job[nj++];
+            j = job_store(B, A, s.P, A, false);
+            j.nseg = 2;
+            j.seg[0] = seg_nt(w, PK_H2A1, s.h1, R, p.h2a_w, 2 * R, R);
+            j.seg[1] = seg_nt(w, PK_H2A2, s.h2, R, p.h2a_w + R, 2 * R, R);
+            j.bias[0] = p.h2a_b;
+        }
+        if (s.pre1) {   // cell 1: only the recurrent product is left                                     :683
+            SkJob& j = k1.job[nj++];
+            j = job_lstm(a);
+            j.nseg = 1;
+            j.seg[0] = seg_nt(w, PK_L1_H2H, s.h1, R, p.l1_h2h_w, R, R); j.bias[0] = p.l1_h2h_b;
+        } else {        // S1' = xt W_i2h + h1 W_h2h + both biases (gate-major, cell tiling) -> w.S
+            SkJob& j = k1.job[nj++];
+            j = job_store(B, 4 * R, w.S, 4 * R, false);
+            j.cell_cols = 1; j.R = R;
+            j.nseg = 2;
+            j.seg[0] = xt_seg(PK_L1_I2H, p.l1_i2h_w); j.bias[0] = p.l1_i2h_b;
+            j.seg[1] = seg_nt(w, PK_L1_H2H, s.h1, R, p.l1_h2h_w, R, R); j.bias[1] = p.l1_h2h_b;
+        }
+        {   // S2' = h2 W_h2h + b -> w.S2
+            SkJob& j = k1.job[nj++];
+            j = job_store(B, 4 * R, w.S2, 4 * R, false);
+            j.cell_cols = 1; j.R = R;
+            j.nseg = 1;
+            j.seg[0] = seg_nt(w, PK_L2_H2H, s.h2, R, p.l2_h2h_w, R, R); j.bias[0] = p.l2_h2h_b;
+        }
+        if (!s.pre1) {  // POS gate: pos' = dropout(relu(W_g xt + b)) * pos + pos                          :682
+            SkJob& j = k1.job[nj++];
+            j = job_store(B, R, s.gp, R, false);
+            j.epi = SK_EPI_GATE; j.nseg = 1;
+            j.seg[0] = xt_seg(PK_DGATE, p.dgate_w); j.bias[0] = p.dgate_b;
+            j.gate_t = s.pos; j.ldt = R; j.gate_y = s.posg; j.ldy = R;
+            j.drop = xg_make_drop(&run, XG_SITE_DGATE, s.t);
+        }
+        k1.njobs = nj;
+        XG_TRY(xgk_skinny(st, k1));
+        if (!s.pre1) {  // cell 1 = pos' W_a2h + b + S1'
+            SkArgs k1b{};
+            k1b.njobs = 1;
+            a.add = w.S; a.ldadd = 4 * R;
+            k1b.job[0] = job_lstm(a);
+            k1b.job[0].nseg = 1;
+            k1b.job[0].seg[0] = seg_nt(w, PK_L1_A2H, s.posg, R, p.l1_a2h_w, R, R); k1b.job[0].bias[0] = p.l1_a2h_b;
+            XG_TRY(xgk_skinny(st, k1b));
+        }
+        XG_TRY(xgk_attn_fwd(st, s.P, vproj, V, p.a2w_w, s.alpha, s.af, B, d.K, R, A));
+        SkArgs k2{};
+        k2.njobs = 1;
+        c.add = w.S2; c.ldadd = 4 * R;
+        k2.job[0] = job_lstm(c);
+        k2.job[0].nseg = 2;
+        k2.job[0].seg[0] = seg_nt(w, PK_L2_I2H, s.h1o, R, p.l2_i2h_w, R, R); k2.job[0].bias[0] = p.l2_i2h_b;
+        k2.job[0].seg[1] = seg_nt(w, PK_L2_A2H, s.af, R, p.l2_a2h_w, R, R); k2.job[0].bias[1] = p.l2_a2h_b;
+        XG_TRY(xgk_skinny(st, k2));
+        return XG_OK;
+    }
+    if (!s.xt) return XG_EINVAL;                 // the token gather exists on the packed path only
     if (R % 8 == 0) {
         SkArgs k1{};
         k1.njobs = 2;
@@ -497,8 +601,6 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
             k1b.job[0].seg[0] = seg_nt(s.xt, E, p.l1_i2h_w, E, E); k1b.job[0].bias[0] = p.l1_i2h_b;
             k1b.job[0].seg[1] = seg_nt(s.posg, R, p.l1_a2h_w, R, R); k1b.job[0].bias[1] = p.l1_a2h_b;
             k1b.job[0].seg[2] = seg_nt(s.h1, R, p.l1_h2h_w, R, R); k1b.job[0].bias[2] = p.l1_h2h_b;
-            // (cell 1 and the attention are independent given [p, pos'], but a fork/join pair of stream events per step
-            // costs more than the ~14 us it would hide: measured 64 -> 81 us per step.  One stream.)
             XG_TRY(xgk_skinny(st, k1b));
         }
         XG_TRY(xgk_attn_fwd(st, s.P, vproj, V, p.a2w_w, s.alpha, s.af, B, d.K, R, A));
@@ -636,8 +738,8 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         {   // s2 = h1' Wi + af Wa + h2 Wh : the two data gradients chain 2 needs now
             SkArgs sk{};
             sk.njobs = 2;
-            sk.job[0] = job_store(B, R, daf, R, false);  sk.job[0].nseg = 1; sk.job[0].seg[0] = seg_nn(ds2, 4 * R, p.l2_a2h_w, R, 4 * R);
-            sk.job[1] = job_store(B, R, dh2p, R, true);  sk.job[1].nseg = 1; sk.job[1].seg[0] = seg_nn(ds2, 4 * R, p.l2_h2h_w, R, 4 * R);
+            sk.job[0] = job_store(B, R, daf, R, false);  sk.job[0].nseg = 1; sk.job[0].seg[0] = seg_nn(w, PKB_L2_A2H, ds2, 4 * R, p.l2_a2h_w, R, 4 * R);
+            sk.job[1] = job_store(B, R, dh2p, R, true);  sk.job[1].nseg = 1; sk.job[1].seg[0] = seg_nn(w, PKB_L2_H2H, ds2, 4 * R, p.l2_h2h_w, R, 4 * R);
             XG_TRY(xgk_skinny(st, sk));
         }
         XG_TRY(xgk_attn_bwd(st, daf, R, w.P + (size_t)t * B * A, w.vproj, w.Venc, p.a2w_w, w.ALPHA + (size_t)t * B * K,
@@ -648,7 +750,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
             if (fuse && t > 0) sk.job[0] = job_lstm_bwd(cell2_bwd(t - 1, cur ^ 1), dh2p, R);
             else sk.job[0] = job_store(B, R, dh2p, R, true);
             sk.job[0].nseg = 1;
-            sk.job[0].seg[0] = seg_nn(dp, A, p.h2a_w + R, 2 * R, A);
+            sk.job[0].seg[0] = seg_nn(w, PKB_H2A2, dp, A, p.h2a_w + R, 2 * R, A);
             XG_TRY(xgk_skinny(st, sk));
         }
         cur ^= 1;
@@ -683,7 +785,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         if (fuse && t > 0) sk.job[0] = job_lstm_bwd(cell1_bwd(t - 1, cur1 ^ 1), dh1p, R);
         else sk.job[0] = job_store(B, R, dh1p, R, true);
         sk.job[0].nseg = 1;
-        sk.job[0].seg[0] = seg_nn(ds1, 4 * R, p.l1_h2h_w, R, 4 * R);
+        sk.job[0].seg[0] = seg_nn(w, PKB_L1_H2H, ds1, 4 * R, p.l1_h2h_w, R, 4 * R);
         XG_TRY(xgk_skinny(s1, sk));
         cur1 ^= 1;
     }
@@ -853,6 +955,7 @@ extern "C" int xg_encoder_fwd(void* stream, const XgDims* d, const XgParams* p, 
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !x || !run || !V || !x->feats_rgb || !x->feats_opfl || !x->feat_mask) return XG_EINVAL;
     XgGemmModeGuard mode_guard(run->gemm_mode);
+    attach_packed(w, *d, run);
     hipStream_t st = (hipStream_t)stream;
     Streams es(st);
     XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w, &es));
@@ -864,6 +967,7 @@ extern "C" int xg_encoder_bwd(void* stream, const XgDims* d, const XgParams* p, 
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !g || !x || !run || !dV) return XG_EINVAL;
     XgGemmModeGuard mode_guard(run->gemm_mode);
+    attach_packed(w, *d, run);
     Streams ss((hipStream_t)stream);
     XG_TRY(encoder_bwd(ss, *d, *p, *g, *x, *run, w, dV));
     return ss.join();
@@ -893,14 +997,22 @@ extern "C" int xg_step_fwd(void* stream, const XgDims* d, const XgParams* p, con
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, R = d->R, E = d->E;
     const size_t BR = (size_t)B * R;
-    // the step reads the OLD state while cell 1 already writes the new h1: work from a copy (same launch as the embedding rows)
     if ((uintptr_t)state % 16) return XG_EINVAL;
-    XG_TRY(xgk_step_prep(st, p->embed_w, E, tokens, d->V, w.Xe, B, state, w.state_tmp, (int64_t)(4 * BR)));
+    attach_packed(w, *d, run);
     StepIO s{};
-    s.xt = w.Xe; s.pos = pos_feats; s.gp = w.GP; s.posg = w.POSG; s.pre1 = nullptr; s.mask = xt_mask; s.ldm = 1;
-    s.h1 = w.state_tmp; s.c1 = w.state_tmp + BR; s.h2 = w.state_tmp + 2 * BR; s.c2 = w.state_tmp + 3 * BR;
+    s.pos = pos_feats; s.gp = w.GP; s.posg = w.POSG; s.pre1 = nullptr; s.mask = xt_mask; s.ldm = 1;
     s.h1o = state; s.c1o = state + BR; s.h2o = state + 2 * BR; s.c2o = state + 3 * BR;
     s.P = w.P; s.alpha = alpha ? alpha : w.ALPHA; s.af = w.AF; s.g1 = nullptr; s.g2 = nullptr; s.t = step;
+    if (step_packed(w, *d)) {
+        // packed weights: the embedding rows are gathered inside the products and the state is updated in place
+        s.xt = nullptr; s.tok = tokens;
+        s.h1 = state; s.c1 = state + BR; s.h2 = state + 2 * BR; s.c2 = state + 3 * BR;
+    } else {
+        // the step reads the OLD state while cell 1 already writes the new h1: work from a copy (same launch as the embedding rows)
+        XG_TRY(xgk_step_prep(st, p->embed_w, E, tokens, d->V, w.Xe, B, state, w.state_tmp, (int64_t)(4 * BR)));
+        s.xt = w.Xe;
+        s.h1 = w.state_tmp; s.c1 = w.state_tmp + BR; s.h2 = w.state_tmp + 2 * BR; s.c2 = w.state_tmp + 3 * BR;
+    }
     XG_TRY(core_step(st, *d, *p, *run, w, V, vproj, s));
     if (logp) {
         XG_TRY(xgk_linear(st, B, d->V, R, state + 2 * BR, R, p->logit_w, p->logit_b, w.LOGITS, d->V));
@@ -914,6 +1026,7 @@ extern "C" int xg_forward_xe(void* stream, const XgDims* d, const XgParams* p, c
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !x || !run || !logp || !x->seq || !x->seq_mask || !x->pos_feats) return XG_EINVAL;
     XgGemmModeGuard mode_guard(run->gemm_mode);
+    attach_packed(w, *d, run);
     hipStream_t st = (hipStream_t)stream;
     const int TB = d->T * d->B;
     Streams ss(st);
@@ -933,6 +1046,7 @@ extern "C" int xg_backward_xe(void* stream, const XgDims* d, const XgParams* p, 
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !g || !x || !run || !x->seq || !x->seq_mask) return XG_EINVAL;
     XgGemmModeGuard mode_guard(run->gemm_mode);
+    attach_packed(w, *d, run);
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, T = d->T, TB = T * B;
     // log-softmax backward needs logp = logits - lse: recompute lse rows from the saved logits (in place)
@@ -961,6 +1075,7 @@ extern "C" int xg_forward_ss(void* stream, const XgDims* d, const XgParams* p, c
     const bool ss = run->train && ss_prob > 0.f;
     if (ss && (!u_sel || !u_tok)) return XG_EINVAL;
     XgGemmModeGuard mode_guard(run->gemm_mode);
+    attach_packed(w, *d, run);
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, R = d->R, E = d->E, A = d->A, T = d->T, TB = T * B, N = B * d->K;
     const size_t BR = (size_t)B * R;
@@ -1004,6 +1119,7 @@ extern "C" int xg_backward_ss(void* stream, const XgDims* d, const XgParams* p, 
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !g || !x || !run || !x->seq || !x->seq_mask) return XG_EINVAL;
     XgGemmModeGuard mode_guard(run->gemm_mode);
+    attach_packed(w, *d, run);
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, T = d->T, TB = T * B;
     if (dlogp) {   // LOGITS already holds the time-major log-probs
@@ -1028,6 +1144,7 @@ extern "C" int xg_xe_loss_fwd(void* stream, const XgDims* d, const XgParams* p, 
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !x || !run || !losses || !x->seq || !x->seq_mask || !x->pos_feats) return XG_EINVAL;
     XgGemmModeGuard mode_guard(run->gemm_mode);
+    attach_packed(w, *d, run);
     hipStream_t st = (hipStream_t)stream;
     const int TB = d->T * d->B;
     Streams ss(st);
@@ -1053,6 +1170,7 @@ extern "C" int xg_xe_loss_bwd(void* stream, const XgDims* d, const XgParams* p, 
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !g || !x || !run || !x->seq || !x->seq_mask) return XG_EINVAL;
     XgGemmModeGuard mode_guard(run->gemm_mode);
+    attach_packed(w, *d, run);
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, T = d->T, TB = T * B;
     XG_TRY(xgk_xent_bwd(st, w.LOGITS, d->V, x->seq, x->seq_mask, nullptr, B, T, d->V, 1, w.LSE, w.sums, dloss_dev, 1.0f));
@@ -1114,6 +1232,7 @@ extern "C" int xg_rollout(void* stream, const XgDims* d, const XgParams* p, cons
     if (mode == XG_ROLLOUT_SAMPLE && (!uniforms || !(temperature > 0.f))) return XG_EINVAL;
     if (mode == XG_ROLLOUT_REPLAY && !forced) return XG_EINVAL;
     XgGemmModeGuard mode_guard(run->gemm_mode);
+    attach_packed(w, *d, run);
     return rollout_impl((hipStream_t)stream, d, p, bn, x, run, mode, uniforms, forced, temperature, w, seq, seq_logp, n_steps, d->B);
 }
 
@@ -1124,6 +1243,7 @@ extern "C" int xg_rollout_pair(void* stream, const XgDims* d2, const XgParams* p
     if (!p || !x2 || !run || !seq || !seq_logp || !n_steps || !x2->pos_feats || d2->T < 2) return XG_EINVAL;
     if (n_sample <= 0 || n_sample >= d2->B || !uniforms || !(temperature > 0.f)) return XG_EINVAL;
     XgGemmModeGuard mode_guard(run->gemm_mode);
+    attach_packed(w, *d2, run);
     return rollout_impl((hipStream_t)stream, d2, p, bn, x2, run, XG_ROLLOUT_SAMPLE, uniforms, nullptr, temperature, w, seq,
                         seq_logp, n_steps, n_sample);
 }
@@ -1177,6 +1297,7 @@ extern "C" int xg_rollout_bwd(void* stream, const XgDims* d, const XgParams* p, 
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !g || !x || !run || !dseq_logp || d->T < 2) return XG_EINVAL;
     XgGemmModeGuard mode_guard(run->gemm_mode);
+    attach_packed(w, *d, run);
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, T = d->T;
     // dlogits of step t-1's output from the token drawn at step t (SAModel.py:195)

@@ -1,0 +1,141 @@
+// Recurrent weights re-tiled into MFMA-fragment order ("packed weights").
+//
+// The per-timestep products are skinny (M = batch rows <= a few hundred): every workgroup streams a 32-column slice of a
+// weight matrix exactly once per launch.  Staging that slice through LDS costs more LDS-pipe time than the fp32 MFMAs
+// it feeds (measured: the K loop of the LDS-staged kernel runs at 64 % MFMA-busy with NO global loads at all), so the
+// weights are kept a second time in the order the matrix cores consume them: a tile of 32 output columns x 32 k is 1024
+// contiguous floats [i(4)][h(2)][n(32)][4], element (n, k = 16 h + 4 i + q), and the B operand of
+// v_mfma_f32_32x32x2_f32 goes global -> VGPR with four fully coalesced 1 KB wave loads per tile, no LDS, no shuffles.
+// (The MFMA sums over k in any order as long as A uses the same one: lane half h owns k in [16 h, 16 h + 16).)
+//
+// The shadow is caller-owned (xg_packed_bytes / xg_pack_weights), refreshed after every optimizer step
+// (reference update: caption_src/starttrain.py:136-137) and handed to the entry points through XgRun.packed.
+//   NT entries (forward, y = x W^T, W (N,K) row-major):  h2a[:, :R], h2a[:, R:], decoder gate, lstm_1.{i2h,a2h,h2h},
+//       lstm_2.{i2h,a2h,h2h}, encoder W_hh x2.  The 4R-row cell matrices use the cell tiling: tile tn holds hidden units
+//       8 tn .. 8 tn + 7 of all four gates (row r = 8 gate + unit), so one tile carries a unit's whole cell update.
+//   NN entries (backward, dx = dy W, W (Kc,N) row-major): lstm_2.{a2h,h2h}, h2a[:, R:], lstm_1.h2h, encoder W_hh x2.
+#include "xg_common.h"
+#include "xg_kernels.h"
+
+namespace {
+
+struct PackDesc { const float* src; int N, K, sn, sk, cell_R; };   // src(n,k) = src[n*sn + k*sk]; cell_R > 0: cell tiling
+
+void describe(const XgDims& d, const XgParams& p, PackDesc* e) {
+    const int R = d.R, A = d.A, E = d.E;
+    e[PK_H2A1] = {p.h2a_w, A, R, 2 * R, 1, 0};
+    e[PK_H2A2] = {p.h2a_w + R, A, R, 2 * R, 1, 0};
+    e[PK_DGATE] = {p.dgate_w, R, E, E, 1, 0};
+    e[PK_L1_I2H] = {p.l1_i2h_w, 4 * R, E, E, 1, R};
+    e[PK_L1_A2H] = {p.l1_a2h_w, 4 * R, R, R, 1, R};
+    e[PK_L1_H2H] = {p.l1_h2h_w, 4 * R, R, R, 1, R};
+    e[PK_L2_I2H] = {p.l2_i2h_w, 4 * R, R, R, 1, R};
+    e[PK_L2_A2H] = {p.l2_a2h_w, 4 * R, R, R, 1, R};
+    e[PK_L2_H2H] = {p.l2_h2h_w, 4 * R, R, R, 1, R};
+    e[PK_ENC_RGB] = {p.lstm_rgb_whh, 4 * R, R, R, 1, R};
+    e[PK_ENC_OPFL] = {p.lstm_opfl_whh, 4 * R, R, R, 1, R};
+    // data-gradient direction: output column n = input feature, reduction k = weight row
+    e[PKB_L2_A2H] = {p.l2_a2h_w, R, 4 * R, 1, R, 0};
+    e[PKB_L2_H2H] = {p.l2_h2h_w, R, 4 * R, 1, R, 0};
+    e[PKB_H2A2] = {p.h2a_w + R, R, A, 1, 2 * R, 0};
+    e[PKB_L1_H2H] = {p.l1_h2h_w, R, 4 * R, 1, R, 0};
+    e[PKB_ENC_RGB] = {p.lstm_rgb_whh, R, 4 * R, 1, R, 0};
+    e[PKB_ENC_OPFL] = {p.lstm_opfl_whh, R, 4 * R, 1, R, 0};
+}
+
+inline size_t entry_floats(const PackDesc& e) {
+    const size_t ntn = e.cell_R ? (size_t)e.cell_R / 8 : (size_t)xg_cdiv(e.N, 32);
+    return ntn * (size_t)xg_cdiv(e.K, 32) * 1024;
+}
+
+struct PackArgs { PackDesc e[PK_COUNT]; float* dst[PK_COUNT]; int tile0[PK_COUNT + 1]; int first, last; };
+
+// one workgroup (256 threads) per packed tile: reads 32 x 32 source elements (coalesced along the source's unit-stride
+// dimension), writes 4 KB contiguous
+__global__ void __launch_bounds__(256) pack_kernel(PackArgs a) {
+    __shared__ float t[32][33];
+    int ei = a.first;
+    for (int i = a.first + 1; i < a.last; ++i) if ((int)blockIdx.x >= a.tile0[i]) ei = i;
+    const PackDesc e = a.e[ei];
+    const int tile = blockIdx.x - a.tile0[ei];
+    const int nck = (e.K + 31) >> 5;
+    const int tn = tile / nck, kc = tile - tn * nck;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        // (a, b) = (fast, slow) source coordinates: k is unit-stride for NT entries, n for NN entries
+        const int slow = ty + 8 * r, fast = tx;
+        const int nn = e.sk == 1 ? slow : fast, kk = e.sk == 1 ? fast : slow;
+        const int k = kc * 32 + kk;
+        int n;
+        bool ok;
+        if (e.cell_R) { n = (nn >> 3) * e.cell_R + tn * 8 + (nn & 7); ok = true; }
+        else { n = tn * 32 + nn; ok = n < e.N; }
+        float v = 0.f;
+        if (ok && k < e.K) v = e.src[(size_t)n * e.sn + (size_t)k * e.sk];
+        t[nn][kk] = v;
+    }
+    __syncthreads();
+    float* dst = a.dst[ei] + (size_t)tile * 1024;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int o = threadIdx.x + 256 * r;                          // [i(4)][h(2)][n(32)][q(4)]
+        const int q = o & 3, nn = (o >> 2) & 31, h = (o >> 7) & 1, i = o >> 8;
+        dst[o] = t[nn][16 * h + 4 * i + q];
+    }
+}
+
+}  // namespace
+
+size_t xgk_packed_floats(const XgDims& d) {
+    XgParams p{};
+    PackDesc e[PK_COUNT];
+    describe(d, p, e);
+    size_t n = 0;
+    for (int i = 0; i < PK_COUNT; ++i) n += entry_floats(e[i]);
+    return n;
+}
+
+bool xgk_packed_view(const XgDims& d, const void* packed, PackedView* v) {
+    if (!packed || d.R % 8 != 0 || ((uintptr_t)packed % 16) != 0) return false;
+    XgParams p{};
+    PackDesc e[PK_COUNT];
+    describe(d, p, e);
+    const float* base = static_cast<const float*>(packed);
+    size_t off = 0;
+    for (int i = 0; i < PK_COUNT; ++i) {
+        v->m[i] = base + off;
+        v->nck[i] = xg_cdiv(e[i].K, 32);
+        off += entry_floats(e[i]);
+    }
+    return true;
+}
+
+extern "C" size_t xg_packed_bytes(const XgDims* d) {
+    if (!d || d->R <= 0 || d->A <= 0 || d->E <= 0 || d->R % 8 != 0) return 0;
+    return xgk_packed_floats(*d) * sizeof(float);
+}
+
+extern "C" int xg_pack_weights(void* stream, const XgDims* d, const XgParams* p, void* packed, size_t packed_bytes,
+                               int with_backward) {
+    if (!d || !p || !packed || d->R <= 0 || d->A <= 0 || d->E <= 0) return XG_EINVAL;
+    if (d->R % 8 != 0 || ((uintptr_t)packed % 16) != 0) return XG_EINVAL;
+    if (packed_bytes < xgk_packed_floats(*d) * sizeof(float)) return XG_EWORKSPACE;
+    PackArgs a{};
+    describe(*d, *p, a.e);
+    PackedView v;
+    if (!xgk_packed_view(*d, packed, &v)) return XG_EINVAL;
+    a.first = 0;
+    a.last = with_backward ? PK_COUNT : PKB_L2_A2H;
+    int tiles = 0;
+    for (int i = 0; i < a.last; ++i) {
+        if (!a.e[i].src) return XG_EINVAL;
+        a.dst[i] = const_cast<float*>(v.m[i]);
+        a.tile0[i] = tiles;
+        tiles += (int)(entry_floats(a.e[i]) / 1024);
+    }
+    a.tile0[a.last] = tiles;
+    hipLaunchKernelGGL(pack_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}

@@ -16,6 +16,7 @@
 //   op(B): (N,K) row-major "k-contiguous" (nn.Linear weight, forward)  or  (K,N) row-major (data gradient)
 #include "xg_common.h"
 #include "xg_kernels.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -96,6 +97,173 @@ __device__ __forceinline__ void st_chunk_bf16(unsigned short* __restrict__ lds, 
     }
 }
 
+// ---- epilogues shared by the two kernels.  red = [SKW][32][RS] partial tiles in LDS.
+// LSTM cell epilogue operands: every load is unconditional (absent operands read a valid dummy address and are dropped by
+// a select in the epilogue): a load under a branch makes the compiler wait for it on the spot, and 19 serialized L2 round
+// trips were 2 us of prologue.
+struct LstmPre {
+    float b0[4], b1[4], b2[4], ad[4], cp, hp, mk;
+    int eb, ej;
+    bool on;
+};
+__device__ __forceinline__ LstmPre lstm_prefetch(const SkJob& job, int m0, int tn) {
+    LstmPre p;
+    p.cp = 0.f; p.hp = 0.f; p.mk = 1.f;
+    const int em = threadIdx.x >> 3, eu = threadIdx.x & 7;
+    p.eb = m0 + em; p.ej = tn * 8 + eu;
+    p.on = job.epi == SK_EPI_LSTM && threadIdx.x < 256 && p.eb < job.M && p.ej < job.R;
+#pragma unroll
+    for (int gi = 0; gi < 4; ++gi) { p.b0[gi] = 0.f; p.b1[gi] = 0.f; p.b2[gi] = 0.f; p.ad[gi] = 0.f; }
+    if (p.on) {
+        const int R = job.R;
+        const float* dummy = job.c_prev + (size_t)p.eb * job.ldcp + p.ej;
+        const float* mkp = job.mask ? job.mask + (size_t)p.eb * job.ldm : dummy;
+        const float* hpp = job.mask_mode == XG_MASK_HOLD ? job.h_prev + (size_t)p.eb * job.ldhp + p.ej : dummy;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+            const int col = gi * R + p.ej;
+            p.b0[gi] = *(job.bias[0] ? job.bias[0] + col : dummy);
+            p.b1[gi] = *(job.bias[1] ? job.bias[1] + col : dummy);
+            p.b2[gi] = *(job.bias[2] ? job.bias[2] + col : dummy);
+            p.ad[gi] = *(job.add ? job.add + (size_t)p.eb * job.ldadd + col : dummy);
+        }
+        p.cp = *dummy;
+        p.mk = *mkp;
+        p.hp = *hpp;
+    }
+    return p;
+}
+
+template <int RS>
+__device__ __forceinline__ void sk_epilogue(const SkJob& job, const float* __restrict__ redp, int m0, int n0, const LstmPre& pre) {
+    const float (*red)[32][RS] = reinterpret_cast<const float (*)[32][RS]>(redp);
+    const int R = job.R;
+    if (job.epi == SK_EPI_STORE) {
+#pragma unroll
+        for (int e = 0; e < 1024 / SKT; ++e) {
+            const int idx = threadIdx.x + SKT * e;
+            const int m = idx >> 5, c = idx & 31;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < SKW; ++w) v += red[w][m][c];
+            const int row = m0 + m;
+            // n0 = 32 tn; cell tiling: column = gate (c / 8) of hidden unit 8 tn + c % 8
+            const int unit = (n0 >> 2) + (c & 7);
+            const int col = job.cell_cols ? (unit < R ? (c >> 3) * R + unit : job.N) : n0 + c;
+            if (row < job.M && col < job.N) {
+                if (job.bias[0]) v += job.bias[0][col];
+                if (job.bias[1]) v += job.bias[1][col];
+                if (job.bias[2]) v += job.bias[2][col];
+                float* dst = job.C + (size_t)row * job.ldc + col;
+                if (job.accumulate) v += *dst;
+                if (job.relu) v = fmaxf(v, 0.f);
+                *dst = v;
+            }
+        }
+    } else if (job.epi == SK_EPI_LSTMB) {
+        // pointwise LSTM backward of the step whose dh this product completes (same arithmetic as lstm_bwd_body)
+#pragma unroll
+        for (int e = 0; e < 1024 / SKT; ++e) {
+            const int idx = threadIdx.x + SKT * e;
+            const int m = idx >> 5, c = idx & 31;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < SKW; ++w) v += red[w][m][c];
+            const int b = m0 + m, j = n0 + c;
+            if (b < job.M && j < job.N) {
+                if (job.accumulate) v += job.C[(size_t)b * job.ldc + j];
+                if (job.add) v += job.add[(size_t)b * job.ldadd + j];
+                const float* g = job.gates + (size_t)b * job.ldg;
+                const float ig = g[j], fg = g[R + j];
+                const float og = job.order == XG_ORDER_IFOG ? g[2 * R + j] : g[3 * R + j];
+                const float gg = job.order == XG_ORDER_IFOG ? g[3 * R + j] : g[2 * R + j];
+                const float cp = job.c_prev[(size_t)b * job.ldcp + j];
+                const float cn = job.c_out[(size_t)b * job.ldco + j];
+                const float mk = job.mask ? job.mask[(size_t)b * job.ldm] : 1.0f;
+                float dh = v * xg_keep(job.drop, (uint32_t)(b * R + j));
+                float dc = job.dc_in ? job.dc_in[(size_t)b * job.lddci + j] : 0.0f;
+                float dht, dct, dcp;
+                const float tc = xg_tanh(cn);
+                if (job.mask_mode == XG_MASK_HOLD) {
+                    if (job.dh_hold) job.dh_hold[(size_t)b * job.lddhh + j] = (1.0f - mk) * dh;
+                    dht = mk * dh;
+                    dc += dht * og * (1.0f - tc * tc);
+                    dcp = (1.0f - mk) * dc;
+                    dct = mk * dc;
+                } else {
+                    dht = mk * dh;
+                    dct = mk * dc + dht * og * (1.0f - tc * tc);
+                    dcp = 0.0f;
+                }
+                const float d_o = dht * tc;
+                dcp += dct * fg;
+                const float d_f = dct * cp, d_i = dct * gg, d_g = dct * ig;
+                float* ds = job.ds + (size_t)b * job.ldds;
+                ds[j] = d_i * ig * (1.0f - ig);
+                ds[R + j] = d_f * fg * (1.0f - fg);
+                const float dso = d_o * og * (1.0f - og), dsg = d_g * (1.0f - gg * gg);
+                if (job.order == XG_ORDER_IFOG) { ds[2 * R + j] = dso; ds[3 * R + j] = dsg; }
+                else                            { ds[2 * R + j] = dsg; ds[3 * R + j] = dso; }
+                job.dc_prev[(size_t)b * job.lddcp + j] = dcp;
+            }
+        }
+    } else if (job.epi == SK_EPI_GATE) {
+#pragma unroll
+        for (int e = 0; e < 1024 / SKT; ++e) {
+            const int idx = threadIdx.x + SKT * e;
+            const int m = idx >> 5, c = idx & 31;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < SKW; ++w) v += red[w][m][c];
+            const int row = m0 + m, col = n0 + c;
+            if (row < job.M && col < job.N) {
+                if (job.bias[0]) v += job.bias[0][col];
+                const float g = fmaxf(v, 0.f) * xg_keep(job.drop, (uint32_t)(row * job.N + col));
+                job.C[(size_t)row * job.ldc + col] = g;
+                const float tv = job.gate_t[(size_t)row * job.ldt + col];
+                job.gate_y[(size_t)row * job.ldy + col] = g * tv + tv;
+            }
+        }
+    } else {
+        // LSTM cell epilogue: thread -> (row em, unit eu); its four gate pre-activations sit at columns eu + 8*gate
+        const int em_ = threadIdx.x >> 3, eu_ = threadIdx.x & 7;
+        if (pre.on) {
+            const int b = pre.eb, j = pre.ej;
+            float s4[4];
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                float v = (job.bias[0] ? pre.b0[gi] : 0.f) + (job.bias[1] ? pre.b1[gi] : 0.f) + (job.bias[2] ? pre.b2[gi] : 0.f) +
+                          (job.add ? pre.ad[gi] : 0.f);
+#pragma unroll
+                for (int w = 0; w < SKW; ++w) v += red[w][em_][gi * 8 + eu_];
+                s4[gi] = v;
+            }
+            const float so = job.order == XG_ORDER_IFOG ? s4[2] : s4[3];
+            const float sg_ = job.order == XG_ORDER_IFOG ? s4[3] : s4[2];
+            const float ig = xg_sigmoid(s4[0]), fg = xg_sigmoid(s4[1]), og = xg_sigmoid(so), gg = xg_tanh(sg_);
+            const float cp = pre.cp, mk = job.mask ? pre.mk : 1.0f;
+            float cn = fg * cp + ig * gg, hn;
+            if (job.mask_mode == XG_MASK_HOLD) {
+                cn = cn * mk + cp * (1.0f - mk);
+                hn = og * xg_tanh(cn);
+                hn = hn * mk + pre.hp * (1.0f - mk);
+            } else {
+                hn = og * xg_tanh(cn) * mk;
+                cn = cn * mk;
+            }
+            hn *= xg_keep(job.drop, (uint32_t)(b * R + j));
+            if (job.gates) {
+                float* g = job.gates + (size_t)b * job.ldg;
+                g[j] = ig; g[R + j] = fg;
+                if (job.order == XG_ORDER_IFOG) { g[2 * R + j] = og; g[3 * R + j] = gg; }
+                else                            { g[2 * R + j] = gg; g[3 * R + j] = og; }
+            }
+            job.c_out[(size_t)b * job.ldco + j] = cn;
+            job.h_out[(size_t)b * job.ldho + j] = hn;
+        }
+    }
+}
+
 // 4 waves per SIMD = two 512-thread workgroups per CU (2 x 74 KB of LDS fit): launches with more than 256 tiles (the
 // encoder's two cells, [p || cell 1]) then run in one round.  Needs <= 128 VGPRs.
 template <bool VEC, int PREC>     // PREC 0: fp32 MFMA, 1: bf16 MFMA
@@ -120,7 +288,7 @@ __global__ void __launch_bounds__(SKT) __attribute__((amdgpu_waves_per_eu(4, 4))
     const int m0 = tm * 32, n0 = tn * 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
     const int R = job.R;
-    const bool lstm = job.epi == SK_EPI_LSTM;
+    const bool lstm = job.epi == SK_EPI_LSTM || job.cell_cols;      // cell tiling of the weight rows
     float* As = smem + wave * 2 * OPF;
     float* Bs = As + OPF;
     const int lrow = lane >> 3, lcol = (lane & 7) << 2;
@@ -129,29 +297,8 @@ __global__ void __launch_bounds__(SKT) __attribute__((amdgpu_waves_per_eu(4, 4))
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    // ---- LSTM epilogue operands are requested NOW so their (cold-L2) latency hides under the K loop.  Every load is
-    // unconditional (absent operands read a valid dummy address and are dropped by a select in the epilogue): a load
-    // under a branch makes the compiler wait for it on the spot, and 19 serialized L2 round trips were 2 us of prologue.
-    float e_b0[4], e_b1[4], e_b2[4], e_ad[4], e_cp = 0.f, e_hp = 0.f, e_mk = 1.f;
-    const int em = threadIdx.x >> 3, eu = threadIdx.x & 7;
-    const int eb = m0 + em, ej = tn * 8 + eu;
-    const bool e_on = lstm && threadIdx.x < 256 && eb < job.M && ej < R;
-    if (e_on) {
-        const float* dummy = job.c_prev + (size_t)eb * job.ldcp + ej;
-        const float* mkp = job.mask ? job.mask + (size_t)eb * job.ldm : dummy;
-        const float* hpp = job.mask_mode == XG_MASK_HOLD ? job.h_prev + (size_t)eb * job.ldhp + ej : dummy;
-#pragma unroll
-        for (int gi = 0; gi < 4; ++gi) {
-            const int col = gi * R + ej;
-            e_b0[gi] = *(job.bias[0] ? job.bias[0] + col : dummy);
-            e_b1[gi] = *(job.bias[1] ? job.bias[1] + col : dummy);
-            e_b2[gi] = *(job.bias[2] ? job.bias[2] + col : dummy);
-            e_ad[gi] = *(job.add ? job.add + (size_t)eb * job.ldadd + col : dummy);
-        }
-        e_cp = *dummy;
-        e_mk = *mkp;
-        e_hp = *hpp;
-    }
+    // ---- LSTM epilogue operands are requested NOW so their (cold-L2) latency hides under the K loop
+    const LstmPre pre = lstm_prefetch(job, m0, tn);
 
     // ---- K loop: this wave's share of the 32-deep chunks of every segment
     int nc_total = 0;
@@ -258,126 +405,117 @@ __global__ void __launch_bounds__(SKT) __attribute__((amdgpu_waves_per_eu(4, 4))
     __syncthreads();
     SK_STAMP(4);
 
-    if (job.epi == SK_EPI_STORE) {
+    sk_epilogue<32>(job, smem, m0, n0, pre);
+    SK_STAMP(5);
+}
+
+// ================================================================================================
+// Fast kernel: every segment's B operand is a PACKED weight (xg_pack.hip), fp32.
+//   * B goes global -> VGPR: four 1 KB-coalesced wave loads per 32 x 32 tile, used as MFMA operands as they are (no LDS
+//     write, no LDS read, no shuffle).  The LDS-staged kernel above spends more LDS-pipe time per chunk than the 16 MFMAs
+//     it feeds: with no global loads at all its K loop is 64 % MFMA-busy.
+//   * A (the activations: 32 rows of this m-tile) still goes through the wave-private LDS image; the k order inside a
+//     32-deep chunk is the packed one (lane half h owns k in [16 h, 16 h + 16)).  Optional row gather (embedding lookup).
+//   * the job is blockIdx.y: everything the prologue needs comes from ONE round of scalar loads.
+//   * reduction buffer rows are 40 floats apart: conflict-free for the column-wise reads of the cell epilogue.
+constexpr int RSF = 40;
+template <bool HAS_TAIL>
+__device__ __forceinline__ void ldA(const float* const (&ap)[4], int c, int kleft /* K - c*32 - lcol */, f32x4 (&v)[4]) {
 #pragma unroll
-        for (int e = 0; e < 1024 / SKT; ++e) {
-            const int idx = threadIdx.x + SKT * e;
-            const int m = idx >> 5, c = idx & 31;
-            float v = 0.f;
+    for (int i = 0; i < 4; ++i) {
+        const f32x4 t = *reinterpret_cast<const f32x4*>(ap[i] + (size_t)c * CK);
+        if (HAS_TAIL) { const f32x4 z = {0.f, 0.f, 0.f, 0.f}; v[i] = kleft > 0 ? t : z; }
+        else v[i] = t;
+    }
+}
+
+__global__ void __launch_bounds__(SKT) __attribute__((amdgpu_waves_per_eu(4, 4))) skf_kernel(SkArgs args) {
+    SK_STAMP(0);
+    __shared__ __attribute__((aligned(16))) float smem[SKW * 32 * RSF > SKW * OPF ? SKW * 32 * RSF : SKW * OPF];
+    const SkJob& job = args.job[blockIdx.y];
+    const int ntm = (job.M + 31) >> 5;
+    const bool lstm = job.epi == SK_EPI_LSTM || job.cell_cols;      // cell tiling of the weight rows
+    const int ntn = lstm ? job.R >> 3 : (job.N + 31) >> 5;
+    const int ntiles = ntm * ntn;
+    if ((int)blockIdx.x >= ntiles) return;
+    int bid = blockIdx.x;
+    {   // XCD-aware: the m-tiles that share a weight slice stay on one XCD's L2 (gridDim.x is a multiple of 8)
+        const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tm = bid % ntm, tn = bid / ntm;
+    const int m0 = tm * 32, n0 = tn * 32;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+    float* As = smem + wave * OPF;
+    const int lrow = lane >> 3, lcol = (lane & 7) << 2;
+
+    f32x16 acc;
 #pragma unroll
-            for (int w = 0; w < SKW; ++w) v += red[w][m][c];
-            const int row = m0 + m, col = n0 + c;
-            if (row < job.M && col < job.N) {
-                if (job.bias[0]) v += job.bias[0][col];
-                if (job.bias[1]) v += job.bias[1][col];
-                if (job.bias[2]) v += job.bias[2][col];
-                float* dst = job.C + (size_t)row * job.ldc + col;
-                if (job.accumulate) v += *dst;
-                if (job.relu) v = fmaxf(v, 0.f);
-                *dst = v;
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    int nc_total = 0;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) if (s < job.nseg) nc_total += job.seg[s].nck;
+    const int wc0 = (wave * nc_total) / SKW, wc1 = ((wave + 1) * nc_total) / SKW;
+    // the first chunk's loads go out before anything else
+    const LstmPre pre = lstm_prefetch(job, m0, tn);
+    int seg_start = 0;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        if (s >= job.nseg) break;
+        const SkSeg sg = job.seg[s];
+        const int nc = sg.nck;
+        const int c0 = max(wc0, seg_start) - seg_start, c1 = min(wc1, seg_start + nc) - seg_start;
+        seg_start += nc;
+        if (c0 >= c1) continue;
+        const float* bp = sg.Bp + ((size_t)tn * nc) * 1024 + (size_t)(half * 32 + l31) * 4;
+        const float* ap[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            int row = min(m0 + i * 8 + lrow, job.M - 1);
+            if (sg.gather) {
+                const int64_t t = sg.gather[(size_t)row * sg.gstride];
+                row = (int)(t < 0 ? 0 : (t > sg.gather_max ? sg.gather_max : t));
             }
+            ap[i] = sg.A + (size_t)row * sg.lda + lcol;
         }
-    } else if (job.epi == SK_EPI_LSTMB) {
-        // pointwise LSTM backward of the step whose dh this product completes (same arithmetic as lstm_bwd_body)
+        const int nfull = sg.K / CK;                 // chunks >= nfull are the (single) k tail: K % 4 == 0 on this path
+        f32x4 ra[4], rb[4];
+        if (s == 0) SK_STAMP(1);
 #pragma unroll
-        for (int e = 0; e < 1024 / SKT; ++e) {
-            const int idx = threadIdx.x + SKT * e;
-            const int m = idx >> 5, c = idx & 31;
-            float v = 0.f;
+        for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bp + (size_t)c0 * 1024 + i * 256);
+        if (c0 < nfull) ldA<false>(ap, c0, 0, ra); else ldA<true>(ap, c0, sg.K - c0 * CK - lcol, ra);
+        for (int c = c0; c < c1; ++c) {
+            f32x4 fb[4];
 #pragma unroll
-            for (int w = 0; w < SKW; ++w) v += red[w][m][c];
-            const int b = m0 + m, j = n0 + c;
-            if (b < job.M && j < job.N) {
-                if (job.accumulate) v += job.C[(size_t)b * job.ldc + j];
-                if (job.add) v += job.add[(size_t)b * job.ldadd + j];
-                const float* g = job.gates + (size_t)b * job.ldg;
-                const float ig = g[j], fg = g[R + j];
-                const float og = job.order == XG_ORDER_IFOG ? g[2 * R + j] : g[3 * R + j];
-                const float gg = job.order == XG_ORDER_IFOG ? g[3 * R + j] : g[2 * R + j];
-                const float cp = job.c_prev[(size_t)b * job.ldcp + j];
-                const float cn = job.c_out[(size_t)b * job.ldco + j];
-                const float mk = job.mask ? job.mask[(size_t)b * job.ldm] : 1.0f;
-                float dh = v * xg_keep(job.drop, (uint32_t)(b * R + j));
-                float dc = job.dc_in ? job.dc_in[(size_t)b * job.lddci + j] : 0.0f;
-                float dht, dct, dcp;
-                const float tc = xg_tanh(cn);
-                if (job.mask_mode == XG_MASK_HOLD) {
-                    if (job.dh_hold) job.dh_hold[(size_t)b * job.lddhh + j] = (1.0f - mk) * dh;
-                    dht = mk * dh;
-                    dc += dht * og * (1.0f - tc * tc);
-                    dcp = (1.0f - mk) * dc;
-                    dct = mk * dc;
-                } else {
-                    dht = mk * dh;
-                    dct = mk * dc + dht * og * (1.0f - tc * tc);
-                    dcp = 0.0f;
-                }
-                const float d_o = dht * tc;
-                dcp += dct * fg;
-                const float d_f = dct * cp, d_i = dct * gg, d_g = dct * ig;
-                float* ds = job.ds + (size_t)b * job.ldds;
-                ds[j] = d_i * ig * (1.0f - ig);
-                ds[R + j] = d_f * fg * (1.0f - fg);
-                const float dso = d_o * og * (1.0f - og), dsg = d_g * (1.0f - gg * gg);
-                if (job.order == XG_ORDER_IFOG) { ds[2 * R + j] = dso; ds[3 * R + j] = dsg; }
-                else                            { ds[2 * R + j] = dsg; ds[3 * R + j] = dso; }
-                job.dc_prev[(size_t)b * job.lddcp + j] = dcp;
+            for (int i = 0; i < 4; ++i) fb[i] = rb[i];
+            st_chunk(As, lane, ra);
+            if (s == 0 && c == c0) SK_STAMP(2);
+            if (c + 1 < c1) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bp + (size_t)(c + 1) * 1024 + i * 256);
+                if (c + 1 < nfull) ldA<false>(ap, c + 1, 0, ra); else ldA<true>(ap, c + 1, sg.K - (c + 1) * CK - lcol, ra);
             }
-        }
-    } else if (job.epi == SK_EPI_GATE) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-        for (int e = 0; e < 1024 / SKT; ++e) {
-            const int idx = threadIdx.x + SKT * e;
-            const int m = idx >> 5, c = idx & 31;
-            float v = 0.f;
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 a = *reinterpret_cast<const f32x4*>(As + l31 * LDR + half * 16 + i * 4);
 #pragma unroll
-            for (int w = 0; w < SKW; ++w) v += red[w][m][c];
-            const int row = m0 + m, col = n0 + c;
-            if (row < job.M && col < job.N) {
-                if (job.bias[0]) v += job.bias[0][col];
-                const float g = fmaxf(v, 0.f) * xg_keep(job.drop, (uint32_t)(row * job.N + col));
-                job.C[(size_t)row * job.ldc + col] = g;
-                const float tv = job.gate_t[(size_t)row * job.ldt + col];
-                job.gate_y[(size_t)row * job.ldy + col] = g * tv + tv;
+                for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], fb[i][kk], acc, 0, 0, 0);
             }
-        }
-    } else {
-        // LSTM cell epilogue: thread -> (row em, unit eu); its four gate pre-activations sit at columns eu + 8*gate
-        if (e_on) {
-            const int b = eb, j = ej;
-            float s4[4];
-#pragma unroll
-            for (int gi = 0; gi < 4; ++gi) {
-                float v = (job.bias[0] ? e_b0[gi] : 0.f) + (job.bias[1] ? e_b1[gi] : 0.f) + (job.bias[2] ? e_b2[gi] : 0.f) +
-                          (job.add ? e_ad[gi] : 0.f);
-#pragma unroll
-                for (int w = 0; w < SKW; ++w) v += red[w][em][gi * 8 + eu];
-                s4[gi] = v;
-            }
-            const float so = job.order == XG_ORDER_IFOG ? s4[2] : s4[3];
-            const float sg_ = job.order == XG_ORDER_IFOG ? s4[3] : s4[2];
-            const float ig = xg_sigmoid(s4[0]), fg = xg_sigmoid(s4[1]), og = xg_sigmoid(so), gg = xg_tanh(sg_);
-            const float cp = e_cp, mk = job.mask ? e_mk : 1.0f;
-            float cn = fg * cp + ig * gg, hn;
-            if (job.mask_mode == XG_MASK_HOLD) {
-                cn = cn * mk + cp * (1.0f - mk);
-                hn = og * xg_tanh(cn);
-                hn = hn * mk + e_hp * (1.0f - mk);
-            } else {
-                hn = og * xg_tanh(cn) * mk;
-                cn = cn * mk;
-            }
-            hn *= xg_keep(job.drop, (uint32_t)(b * R + j));
-            if (job.gates) {
-                float* g = job.gates + (size_t)b * job.ldg;
-                g[j] = ig; g[R + j] = fg;
-                if (job.order == XG_ORDER_IFOG) { g[2 * R + j] = og; g[3 * R + j] = gg; }
-                else                            { g[2 * R + j] = gg; g[3 * R + j] = og; }
-            }
-            job.c_out[(size_t)b * job.ldco + j] = cn;
-            job.h_out[(size_t)b * job.ldho + j] = hn;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+            __builtin_amdgcn_wave_barrier();
         }
     }
+    SK_STAMP(3);
+    __syncthreads();
+    float (*red)[32][RSF] = reinterpret_cast<float (*)[32][RSF]>(smem);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[r];
+    __syncthreads();
+    SK_STAMP(4);
+    sk_epilogue<RSF>(job, smem, m0, n0, pre);
     SK_STAMP(5);
 }
 
@@ -399,8 +537,8 @@ static int skinny_fallback(hipStream_t st, const SkJob& jb) {
 
 int xgk_skinny(hipStream_t st, SkArgs& a) {
     if (a.njobs <= 0 || a.njobs > SK_MAX_JOBS) return XG_EINVAL;
-    bool vec = true, generic = false;
-    int tiles = 0;
+    bool vec = true, generic = false, packed = true;
+    int tiles = 0, max_tiles = 0;
     for (int j = 0; j < a.njobs; ++j) {
         SkJob& jb = a.job[j];
         if (jb.M <= 0 || jb.N <= 0 || jb.nseg < 1 || jb.nseg > 3) return XG_EINVAL;
@@ -409,16 +547,20 @@ int xgk_skinny(hipStream_t st, SkArgs& a) {
         jb.tile0 = tiles; a.tile0[j] = tiles;
         const int ntm = xg_cdiv(jb.M, 32);
         int ntn;
-        if (jb.epi == SK_EPI_LSTM) {
+        if (jb.cell_cols && jb.epi != SK_EPI_STORE) return XG_EINVAL;
+        if (jb.epi == SK_EPI_LSTM || jb.cell_cols) {
             if (jb.N != 4 * jb.R || jb.R % 8 != 0) return XG_EINVAL;
             ntn = jb.R / 8;
         } else {
             ntn = xg_cdiv(jb.N, 32);
         }
         tiles += ntm * ntn;
+        max_tiles = ntm * ntn > max_tiles ? ntm * ntn : max_tiles;
         for (int s = 0; s < jb.nseg; ++s) {
-            const SkSeg& sg = jb.seg[s];
+            SkSeg& sg = jb.seg[s];
             if (!sg.A || !sg.B || sg.K <= 0) return XG_EINVAL;
+            packed = packed && sg.Bp && sg.nck == xg_cdiv(sg.K, 32);
+            if (sg.gather && !sg.Bp) return XG_EINVAL;        // the row gather exists on the packed path only
             vec = vec && ((uintptr_t)sg.A % 16 == 0) && (sg.lda % 4 == 0) && (sg.K % 4 == 0);
             vec = vec && ((uintptr_t)sg.B % 16 == 0) && (sg.ldb % 4 == 0);
             if (sg.b_ncontig && (jb.N % 4 != 0 || jb.N < 4)) generic = true;
@@ -429,6 +571,14 @@ int xgk_skinny(hipStream_t st, SkArgs& a) {
         return XG_OK;
     }
     const bool bf16 = xgk_get_gemm_mode() == 1;      // plain-bf16 mode covers the recurrent products too
+    static const bool no_packed = getenv("XG_NO_PACKED") != nullptr;
+    if (vec && packed && !bf16 && !no_packed) {
+        hipLaunchKernelGGL(skf_kernel, dim3((max_tiles + 7) & ~7, a.njobs), dim3(SKT), 0, st, a);
+        XG_CHECK_LAUNCH();
+        return XG_OK;
+    }
+    for (int j = 0; j < a.njobs; ++j)
+        for (int s = 0; s < a.job[j].nseg; ++s) if (a.job[j].seg[s].gather) return XG_EINVAL;
     if (vec && bf16) hipLaunchKernelGGL((sk_kernel<true, 1>), dim3(tiles), dim3(SKT), 0, st, a);
     else if (vec) hipLaunchKernelGGL((sk_kernel<true, 0>), dim3(tiles), dim3(SKT), 0, st, a);
     else if (bf16) hipLaunchKernelGGL((sk_kernel<false, 1>), dim3(tiles), dim3(SKT), 0, st, a);

@@ -172,6 +172,9 @@ class SAModel(nn.Module):
         self._pool = _WorkspacePool()
         self._flat = None
         self._call = 0
+        self._packed = None          # recurrent weights in MFMA-fragment order (xg_pack_weights), refreshed lazily
+        self._packed_key = None
+        self._packed_epoch = 0
         # arithmetic of the large GEMMs: 'fp32' (exact fp32 MFMA), 'bf16x3' (split-bf16, fp32-class accuracy, faster),
         # 'bf16' (bf16 operands / fp32 accumulate: BASELINE.json configs[4]).  Recurrent steps are always fp32.
         self.precision = getattr(opt, "precision", "fp32")
@@ -268,6 +271,35 @@ class SAModel(nn.Module):
         d.C, d.H, d.F1, d.F2, d.T = self.category_size, 128, self.feat_size, self.feat_size2, T
         return d
 
+    def mark_params_changed(self):
+        """Tell the model its parameters were rewritten behind torch's back (a HIP kernel on the flat buffer, e.g.
+        train.ClipAdam.step): the packed shadow of the recurrent weights is rebuilt before the next call.  Updates made
+        through torch (optimizers, load_state_dict, copy_) are noticed by themselves (tensor version counters)."""
+        self._packed_epoch += 1
+
+    def _packed_ptr(self):
+        """Device pointer of the packed recurrent weights (include/xgate.h: xg_pack_weights), valid for the current
+        parameter values; None when the shapes do not allow it (rnn_size % 8 != 0)."""
+        self._ensure_flat()
+        key = (self._flat.data_ptr(), self._flat._version, self._packed_epoch,
+               tuple(p._version for p in self.parameters()))
+        if key != self._packed_key:
+            d = self._dims(1, 1, 1)
+            nbytes = nv.lib().xg_packed_bytes(C.byref(d))
+            if nbytes == 0:
+                self._packed = None
+            else:
+                if self._packed is None or self._packed.device != self._flat.device or self._packed.numel() < nbytes + 16:
+                    self._packed = torch.empty(nbytes + 16, dtype=torch.uint8, device=self._flat.device)
+                ptr = (self._packed.data_ptr() + 15) & ~15
+                ps = nv.make_params_struct(self._named())
+                nv.check(nv.lib().xg_pack_weights(_stream(), C.byref(d), C.byref(ps), C.c_void_p(ptr), C.c_size_t(nbytes), 1),
+                         "xg_pack_weights")
+            self._packed_key = key
+        if self._packed is None:
+            return None
+        return (self._packed.data_ptr() + 15) & ~15
+
     def _run(self, save, seed=None):
         r = nv.XgRun()
         r.train = 1 if self.training else 0
@@ -279,6 +311,7 @@ class SAModel(nn.Module):
         r.save = 1 if save else 0
         r.bn_momentum, r.bn_eps = 0.1, 1e-5
         r.gemm_mode = {"fp32": 0, "bf16": 1, "bf16x3": 3}[self.precision]
+        r.packed = self._packed_ptr()
         return r
 
     @staticmethod

@@ -36,6 +36,7 @@ class ClipAdam:
         nv.check(nv.lib().xg_clip_adam(_stream(), flat.numel(), nv.ptr(flat), nv.ptr(g), nv.ptr(self.exp_avg),
                                        nv.ptr(self.exp_avg_sq), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                                        self.step_count, self.clip), "xg_clip_adam")
+        self.model.mark_params_changed()       # the kernel wrote the flat buffer directly: re-pack the recurrent weights
 
     def state_dict(self):
         return dict(exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, step=self.step_count, lr=self.lr)

@@ -99,6 +99,9 @@ typedef struct XgRun {
                              3 = split-bf16 (three bf16 planes, 6 MFMAs, fp32-class accuracy); 1 = bf16 operands,
                              fp32 accumulate (BASELINE.json configs[4], tolerance 1e-2).  The recurrent per-step
                              products, the cells and all reductions are always fp32. */
+    int32_t reserved0;    /* keep 0 */
+    const void *packed;   /* optional: the recurrent weights in MFMA-fragment order (xg_pack_weights), valid for the
+                             CURRENT parameter values; NULL = stream the plain weights through LDS.  Same results. */
 } XgRun;
 
 enum { XG_ROLLOUT_GREEDY = 0, XG_ROLLOUT_SAMPLE = 1, XG_ROLLOUT_REPLAY = 2 };
@@ -234,6 +237,16 @@ int xg_nll_fwd(void *stream, const float *logp, const int64_t *target, const flo
 int xg_nll_bwd(void *stream, const int64_t *target, const float *mask, const float *mask2,
                int B, int T, int V, int roll, const float *sums, float scale, const float *scale_dev,
                float *dlogp);
+
+/* ---- packed recurrent weights (no reference counterpart: a layout shadow of lstmcore.* / lstmcell_*.weight_hh,
+ *      caption_src/sub_modules.py:661-669,104-105) ----
+ * The per-timestep products stream each weight matrix once per step; a second copy of those matrices in the order the
+ * matrix cores consume them (32 x 32 tiles, xg_pack.hip) lets the step kernels load the B operand straight into
+ * registers.  The caller owns the buffer (xg_packed_bytes, 16-byte aligned), refreshes it with xg_pack_weights after
+ * every parameter update (with_backward = 0 skips the data-gradient tiles: inference) and passes it in XgRun.packed. */
+size_t xg_packed_bytes(const XgDims *d);
+int xg_pack_weights(void *stream, const XgDims *d, const XgParams *p, void *packed, size_t packed_bytes,
+                    int with_backward);
 
 /* ---- update: clip_gradient + Adam (caption_src/myutils.py:79-85, caption_src/starttrain.py:76,137) ----
  * Elementwise clamp of g to +-clip (clip <= 0 disables), then torch.optim.Adam semantics

@@ -59,7 +59,7 @@ def test_config2_b128_xe_loss_logprobs_and_every_gradient_vs_oracle(path, ragged
     assert abs(loss.item() - loss_o.item()) < 1e-4, (loss.item(), loss_o.item())      # north_star: 1e-4 on the training loss
     if logp is not None:
         lo = logp_o.detach()
-        np.testing.assert_allclose(logp[:, :, :64].cpu().numpy(), lo[:, :, :64].numpy(), atol=3e-4, rtol=0)
+        np.testing.assert_allclose(logp.detach()[:, :, :64].cpu().numpy(), lo[:, :, :64].numpy(), atol=3e-4, rtol=0)
         tgt = torch.cat([xi["seq"][:, 1:], xi["seq"][:, :1]], 1).unsqueeze(2)
         np.testing.assert_allclose(logp.detach().cpu().gather(2, tgt).numpy(), lo.gather(2, tgt).numpy(), atol=3e-4, rtol=0)
         # every row is a normalised distribution
