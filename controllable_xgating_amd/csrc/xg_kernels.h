@@ -112,7 +112,15 @@ enum { SK_EPI_STORE = 0, SK_EPI_LSTM = 1, SK_EPI_GATE = 2,
        // LSTM cell BACKWARD of the previous time step in the epilogue of the product that completes its dh:
        //   dh = product (+ C when accumulate) (+ add), then the cell's pointwise backward (xg_pointwise.hip:lstm_bwd_body)
        //   -> ds (M,4R), dc_prev, and in HOLD mode the (1-m) dh pass-through into dh_hold.  N = R.
-       SK_EPI_LSTMB = 3 };
+       SK_EPI_LSTMB = 3,
+       // (fast kernel only) zero-fill job: C[0 .. M*N) = 0, one tile per 4096 floats
+       SK_EPI_ZERO = 4,
+       // (fast kernel only) temporal attention of one step, TWO workgroups per video (sub_modules.py:678-680):
+       //   workgroup (b, part) scores its half of the K frames, e_k = w . tanh(p_b + q_bk), and adds its share of the
+       //   UNNORMALISED softmax -- ex_k = exp(e_k - e_0), s = sum ex_k, c = sum ex_k V_bk -- into attn_s[b] / attn_c[b][:]
+       //   (zeroed by a ZERO job of the previous launch; two commutative adds per element, so the sum is deterministic).
+       //   The cell-2 job of the NEXT launch normalises while it stages af (SkSeg.row_scale) -- no merge launch.
+       SK_EPI_ATTN = 5 };
 constexpr int SK_MAX_JOBS = 4;
 struct SkSeg {
     const float* A; const float* B;   // A (M,K) row-major lda ; B (N,K) row-major ldb, or (K,N) when b_ncontig
@@ -123,6 +131,11 @@ struct SkSeg {
     // optional row gather on A: row m of the operand is A + clamp(gather[m * gstride], 0, gather_max) * lda
     // (embedding lookup folded into the product: caption_src/SAModel.py:105,198)
     const int64_t* gather; int gstride, gather_max;
+    // optional per-row scale of A: row m is multiplied by 1 / row_scale[m] while it is staged (the attention context
+    // arrives unnormalised: af = c / s).  scaled_out (lda_out): the scaled rows are written back by the tn == 0 tiles
+    // (the normalised context is a saved tensor); ex / ex_ld / ex_K: those tiles also normalise the (M, ex_K) unnormalised
+    // attention weights in place.
+    const float* row_scale; float* scaled_out; int ld_out; float* ex; int ex_ld, ex_K;
 };
 struct SkJob {
     SkSeg seg[3];
@@ -140,6 +153,9 @@ struct SkJob {
     // STORE epilogue over a (M,4R) gate-major pre-activation with the CELL tiling of the weight rows (tile tn = hidden units
     // 8 tn .. 8 tn + 7 of all four gates, like the LSTM epilogue): a partial cell product another launch finishes
     int cell_cols;
+    // ATTN job: p (M,A) at attn_p, q = v2a(V) (M,K,A) at attn_q, V (M,K,R) at attn_v, w_a (A) at attn_w; outputs
+    // attn_ex (M,K) unnormalised weights, attn_s (M) and attn_c (M,R) accumulated with atomics
+    const float *attn_p, *attn_q, *attn_v, *attn_w; float *attn_ex, *attn_s, *attn_c; int attn_K, attn_A;
     XgDrop drop;
 };
 struct SkArgs { int njobs; int tile0[SK_MAX_JOBS]; SkJob job[SK_MAX_JOBS]; };

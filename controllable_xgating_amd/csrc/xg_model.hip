@@ -119,6 +119,7 @@ struct Ws {
     float *LOGITS, *HC, *CL, *LSE, *LSEC, *sums;   // sums: 8 floats
     float *DH2OUT, *DHC, *DCL, *DS1, *DS2, *DP, *DE, *DAF, *dst[2][4], *DVPROJ, *DV, *DPOSG, *DGP, *DXe, *DH1X;
     float *state_tmp;
+    float *AFU, *ATS;                  // unnormalised attention context (B,R) and softmax denominators (B), contiguous
     // ---- rollout
     int64_t* TOK; float *TOKLP, *UNF; int32_t* alive;
     size_t bytes;
@@ -170,6 +171,7 @@ Ws carve(const XgDims& d, void* base) {
     w.DVPROJ = c.take<float>(N * A); w.DV = c.take<float>(N * R); w.DPOSG = c.take<float>(TB * R); w.DH1X = c.take<float>(TB * R);
     w.DGP = c.take<float>(TB * R); w.DXe = c.take<float>(TB * E);
     w.state_tmp = c.take<float>(4 * B * R);
+    w.AFU = c.take<float>(B * R + ((B + 3) & ~(size_t)3)); w.ATS = w.AFU + B * R;
     w.TOK = c.take<int64_t>(TB); w.TOKLP = c.take<float>(TB); w.UNF = c.take<float>(TB);
     w.alive = c.take<int32_t>(4);
     w.bytes = (c.off + 255) & ~(size_t)255;
@@ -480,12 +482,11 @@ inline bool step_packed(const Ws& w, const XgDims& d) { return w.packed && d.R %
 
 // attention + the two cells for one step (sub_modules.py:677-684).
 //
-// Packed form, 3 launches (4 in the rollout form until the attention joins cell 1's launch):
-//   L1  everything that depends only on the OLD state and the token, as jobs of one skinny launch:
-//         p = h2a([h1;h2]) | S2' = h2 W_h2h2 + b | teacher forcing: cell 1 (h1 W_h2h1 + hoisted token side)
-//                                                | rollout: POS gate, S1' = xt W_i2h1 + h1 W_h2h1 + b
-//   L2  attention (needs p)   [rollout: + cell 1 = pos' W_a2h1 + S1']
-//   L3  cell 2 = h1' W_i2h2 + af W_a2h2 + S2'
+// Packed form, 3 launches, every launch a multi-job skinny launch (xg_step.hip):
+//   L1  what the attention and cell 1 wait for:  p = h2a([h1;h2]) | teacher forcing: cell 1 (h1 W_h2h1 + hoisted token side)
+//                                                                 | rollout: POS gate, S1' = xt W_i2h1 + h1 W_h2h1 + b
+//   L2  attention, two workgroups per video (needs p) | rollout: cell 1 = pos' W_a2h1 + S1' | S2' = h2 W_h2h2 + b
+//   L3  cell 2 = h1' W_i2h2 + (c / s) W_a2h2 + S2'   (normalises the attention context while it stages it)
 // No launch reads the old state as a matrix operand after L1, and a cell epilogue reads its own (b, j) element of the old
 // h / c before it writes the new one: the state may be updated IN PLACE (xg_step_fwd) with no copy.
 // LDS-staged form (no packed weights): [p || cell 1 / gate] -> (cell 1) -> attention -> cell 2 as in round 1.
@@ -511,64 +512,92 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
             if (!s.xt) { g.gather = s.tok; g.gstride = 1; g.gather_max = d.V - 1; }
             return g;
         };
-        SkArgs k1{};
-        int nj = 0;
-        {   // p = h2a([h1 ; h2])                                                                         :677
-            SkJob& j = k1.job[nj++];
-            j = job_store(B, A, s.P, A, false);
-            j.nseg = 2;
-            j.seg[0] = seg_nt(w, PK_H2A1, s.h1, R, p.h2a_w, 2 * R, R);
-            j.seg[1] = seg_nt(w, PK_H2A2, s.h2, R, p.h2a_w + R, 2 * R, R);
-            j.bias[0] = p.h2a_b;
-        }
-        if (s.pre1) {   // cell 1: only the recurrent product is left                                     :683
-            SkJob& j = k1.job[nj++];
-            j = job_lstm(a);
-            j.nseg = 1;
-            j.seg[0] = seg_nt(w, PK_L1_H2H, s.h1, R, p.l1_h2h_w, R, R); j.bias[0] = p.l1_h2h_b;
-        } else {        // S1' = xt W_i2h + h1 W_h2h + both biases (gate-major, cell tiling) -> w.S
-            SkJob& j = k1.job[nj++];
-            j = job_store(B, 4 * R, w.S, 4 * R, false);
-            j.cell_cols = 1; j.R = R;
-            j.nseg = 2;
-            j.seg[0] = xt_seg(PK_L1_I2H, p.l1_i2h_w); j.bias[0] = p.l1_i2h_b;
-            j.seg[1] = seg_nt(w, PK_L1_H2H, s.h1, R, p.l1_h2h_w, R, R); j.bias[1] = p.l1_h2h_b;
-        }
-        {   // S2' = h2 W_h2h + b -> w.S2
-            SkJob& j = k1.job[nj++];
-            j = job_store(B, 4 * R, w.S2, 4 * R, false);
-            j.cell_cols = 1; j.R = R;
-            j.nseg = 1;
-            j.seg[0] = seg_nt(w, PK_L2_H2H, s.h2, R, p.l2_h2h_w, R, R); j.bias[0] = p.l2_h2h_b;
-        }
+        // the attention rides in the second launch as two workgroups per video (SK_EPI_ATTN) when its shapes allow
+        // (rollout form only: there cell 1 and S2' share the launch with it.  Teacher forcing has nothing but S2' to put
+        // beside the attention, and measured better with S2' in launch 1 and the stand-alone attention kernel: 6.85 vs 6.98 ms
+        // per iteration.)
+        static const bool no_fused = getenv("XG_NO_FUSED_ATTN") != nullptr;
+        const bool fused_attn = !s.pre1 && !no_fused && A <= 2048 && d.K <= 128 && ((uintptr_t)V % 8 == 0) &&
+                                ((uintptr_t)vproj % 16 == 0) && ((uintptr_t)p.a2w_w % 16 == 0);
+        const bool s2_first = s.pre1 != nullptr;          // S2' = h2 W_h2h2 + b rides in launch 1 (teacher forcing) or 2
+        SkArgs k1{}, k2{}, k3{};
+        int n1 = 0, n2 = 0;
+        // ---- launch 1 (jobs that gather come first: the index load is one more dependent round trip)
         if (!s.pre1) {  // POS gate: pos' = dropout(relu(W_g xt + b)) * pos + pos                          :682
-            SkJob& j = k1.job[nj++];
+            SkJob& j = k1.job[n1++];
             j = job_store(B, R, s.gp, R, false);
             j.epi = SK_EPI_GATE; j.nseg = 1;
             j.seg[0] = xt_seg(PK_DGATE, p.dgate_w); j.bias[0] = p.dgate_b;
             j.gate_t = s.pos; j.ldt = R; j.gate_y = s.posg; j.ldy = R;
             j.drop = xg_make_drop(&run, XG_SITE_DGATE, s.t);
         }
-        k1.njobs = nj;
-        XG_TRY(xgk_skinny(st, k1));
-        if (!s.pre1) {  // cell 1 = pos' W_a2h + b + S1'
-            SkArgs k1b{};
-            k1b.njobs = 1;
-            a.add = w.S; a.ldadd = 4 * R;
-            k1b.job[0] = job_lstm(a);
-            k1b.job[0].nseg = 1;
-            k1b.job[0].seg[0] = seg_nt(w, PK_L1_A2H, s.posg, R, p.l1_a2h_w, R, R); k1b.job[0].bias[0] = p.l1_a2h_b;
-            XG_TRY(xgk_skinny(st, k1b));
+        if (!s.pre1) {  // S1' = h1 W_h2h + xt W_i2h + both biases (gate-major, cell tiling) -> w.S
+            SkJob& j = k1.job[n1++];
+            j = job_store(B, 4 * R, w.S, 4 * R, false);
+            j.cell_cols = 1; j.R = R;
+            j.nseg = 2;
+            j.seg[0] = seg_nt(w, PK_L1_H2H, s.h1, R, p.l1_h2h_w, R, R); j.bias[0] = p.l1_h2h_b;
+            j.seg[1] = xt_seg(PK_L1_I2H, p.l1_i2h_w); j.bias[1] = p.l1_i2h_b;
         }
-        XG_TRY(xgk_attn_fwd(st, s.P, vproj, V, p.a2w_w, s.alpha, s.af, B, d.K, R, A));
-        SkArgs k2{};
-        k2.njobs = 1;
+        {   // p = h2a([h1 ; h2])                                                                         :677
+            SkJob& j = k1.job[n1++];
+            j = job_store(B, A, s.P, A, false);
+            j.nseg = 2;
+            j.seg[0] = seg_nt(w, PK_H2A1, s.h1, R, p.h2a_w, 2 * R, R);
+            j.seg[1] = seg_nt(w, PK_H2A2, s.h2, R, p.h2a_w + R, 2 * R, R);
+            j.bias[0] = p.h2a_b;
+        }
+        if (s.pre1) {   // teacher forcing: cell 1 is only its recurrent product (token side hoisted)        :683
+            SkJob& j = k1.job[n1++];
+            j = job_lstm(a);
+            j.nseg = 1;
+            j.seg[0] = seg_nt(w, PK_L1_H2H, s.h1, R, p.l1_h2h_w, R, R); j.bias[0] = p.l1_h2h_b;
+        }
+        auto s2_job = [&](SkJob& j) {
+            j = job_store(B, 4 * R, w.S2, 4 * R, false);
+            j.cell_cols = 1; j.R = R;
+            j.nseg = 1;
+            j.seg[0] = seg_nt(w, PK_L2_H2H, s.h2, R, p.l2_h2h_w, R, R); j.bias[0] = p.l2_h2h_b;
+        };
+        if (s2_first) s2_job(k1.job[n1++]);
+        if (fused_attn) {   // the attention's accumulators start from zero
+            SkJob& j = k1.job[n1++];
+            j = SkJob{};
+            j.epi = SK_EPI_ZERO; j.M = 1; j.N = B * R + ((B + 3) & ~3); j.C = w.AFU;
+        }
+        k1.njobs = n1;
+        XG_TRY(xgk_skinny(st, k1));
+        // ---- launch 2: attention || [cell 1] || S2' = h2 W_h2h2 + b
+        if (fused_attn) {
+            SkJob& j = k2.job[n2++];
+            j = SkJob{};
+            j.epi = SK_EPI_ATTN; j.M = B; j.R = R; j.attn_K = d.K; j.attn_A = A;
+            j.attn_p = s.P; j.attn_q = vproj; j.attn_v = V; j.attn_w = p.a2w_w;
+            j.attn_ex = s.alpha; j.attn_s = w.ATS; j.attn_c = w.AFU;
+        }
+        if (!s.pre1) {  // cell 1 = pos' W_a2h + b + S1'
+            SkJob& j = k2.job[n2++];
+            a.add = w.S; a.ldadd = 4 * R;
+            j = job_lstm(a);
+            j.nseg = 1;
+            j.seg[0] = seg_nt(w, PK_L1_A2H, s.posg, R, p.l1_a2h_w, R, R); j.bias[0] = p.l1_a2h_b;
+        }
+        if (!s2_first) s2_job(k2.job[n2++]);
+        k2.njobs = n2;
+        if (n2 > 0) XG_TRY(xgk_skinny(st, k2));
+        if (!fused_attn) XG_TRY(xgk_attn_fwd(st, s.P, vproj, V, p.a2w_w, s.alpha, s.af, B, d.K, R, A));
+        // ---- launch 3: cell 2 = h1' W_i2h + af W_a2h + S2'                                                :684
+        k3.njobs = 1;
         c.add = w.S2; c.ldadd = 4 * R;
-        k2.job[0] = job_lstm(c);
-        k2.job[0].nseg = 2;
-        k2.job[0].seg[0] = seg_nt(w, PK_L2_I2H, s.h1o, R, p.l2_i2h_w, R, R); k2.job[0].bias[0] = p.l2_i2h_b;
-        k2.job[0].seg[1] = seg_nt(w, PK_L2_A2H, s.af, R, p.l2_a2h_w, R, R); k2.job[0].bias[1] = p.l2_a2h_b;
-        XG_TRY(xgk_skinny(st, k2));
+        k3.job[0] = job_lstm(c);
+        k3.job[0].nseg = 2;
+        k3.job[0].seg[0] = seg_nt(w, PK_L2_I2H, s.h1o, R, p.l2_i2h_w, R, R); k3.job[0].bias[0] = p.l2_i2h_b;
+        k3.job[0].seg[1] = seg_nt(w, PK_L2_A2H, fused_attn ? w.AFU : s.af, R, p.l2_a2h_w, R, R); k3.job[0].bias[1] = p.l2_a2h_b;
+        if (fused_attn) {   // af = c / s while it is staged; the tn == 0 tiles store af and normalise alpha
+            SkSeg& g = k3.job[0].seg[1];
+            g.row_scale = w.ATS; g.scaled_out = s.af; g.ld_out = R; g.ex = s.alpha; g.ex_ld = d.K; g.ex_K = d.K;
+        }
+        XG_TRY(xgk_skinny(st, k3));
         return XG_OK;
     }
     if (!s.xt) return XG_EINVAL;                 // the token gather exists on the packed path only

@@ -71,8 +71,11 @@ __device__ __forceinline__ void st_chunk(float* __restrict__ lds, int lane, cons
 }
 
 #ifdef SK_TRACE
+#ifndef SK_TRACE_NJOBS
+#define SK_TRACE_NJOBS 1
+#endif
 __device__ long long sk_trace_buf[4096 * 8];
-#define SK_STAMP(i) do { if (threadIdx.x == 0) sk_trace_buf[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#define SK_STAMP(i) do { if (threadIdx.x == 0 && gridDim.y == SK_TRACE_NJOBS) sk_trace_buf[(blockIdx.x + blockIdx.y * gridDim.x) * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define SK_STAMP(i) do {} while (0)
 #endif
@@ -106,6 +109,7 @@ struct LstmPre {
     int eb, ej;
     bool on;
 };
+template <int NW>
 __device__ __forceinline__ LstmPre lstm_prefetch(const SkJob& job, int m0, int tn) {
     LstmPre p;
     p.cp = 0.f; p.hp = 0.f; p.mk = 1.f;
@@ -134,18 +138,18 @@ __device__ __forceinline__ LstmPre lstm_prefetch(const SkJob& job, int m0, int t
     return p;
 }
 
-template <int RS>
+template <int RS, int NW>
 __device__ __forceinline__ void sk_epilogue(const SkJob& job, const float* __restrict__ redp, int m0, int n0, const LstmPre& pre) {
     const float (*red)[32][RS] = reinterpret_cast<const float (*)[32][RS]>(redp);
     const int R = job.R;
     if (job.epi == SK_EPI_STORE) {
 #pragma unroll
-        for (int e = 0; e < 1024 / SKT; ++e) {
-            const int idx = threadIdx.x + SKT * e;
+        for (int e = 0; e < 1024 / (NW * 64); ++e) {
+            const int idx = threadIdx.x + NW * 64 * e;
             const int m = idx >> 5, c = idx & 31;
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < SKW; ++w) v += red[w][m][c];
+            for (int w = 0; w < NW; ++w) v += red[w][m][c];
             const int row = m0 + m;
             // n0 = 32 tn; cell tiling: column = gate (c / 8) of hidden unit 8 tn + c % 8
             const int unit = (n0 >> 2) + (c & 7);
@@ -163,12 +167,12 @@ __device__ __forceinline__ void sk_epilogue(const SkJob& job, const float* __res
     } else if (job.epi == SK_EPI_LSTMB) {
         // pointwise LSTM backward of the step whose dh this product completes (same arithmetic as lstm_bwd_body)
 #pragma unroll
-        for (int e = 0; e < 1024 / SKT; ++e) {
-            const int idx = threadIdx.x + SKT * e;
+        for (int e = 0; e < 1024 / (NW * 64); ++e) {
+            const int idx = threadIdx.x + NW * 64 * e;
             const int m = idx >> 5, c = idx & 31;
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < SKW; ++w) v += red[w][m][c];
+            for (int w = 0; w < NW; ++w) v += red[w][m][c];
             const int b = m0 + m, j = n0 + c;
             if (b < job.M && j < job.N) {
                 if (job.accumulate) v += job.C[(size_t)b * job.ldc + j];
@@ -209,12 +213,12 @@ __device__ __forceinline__ void sk_epilogue(const SkJob& job, const float* __res
         }
     } else if (job.epi == SK_EPI_GATE) {
 #pragma unroll
-        for (int e = 0; e < 1024 / SKT; ++e) {
-            const int idx = threadIdx.x + SKT * e;
+        for (int e = 0; e < 1024 / (NW * 64); ++e) {
+            const int idx = threadIdx.x + NW * 64 * e;
             const int m = idx >> 5, c = idx & 31;
             float v = 0.f;
 #pragma unroll
-            for (int w = 0; w < SKW; ++w) v += red[w][m][c];
+            for (int w = 0; w < NW; ++w) v += red[w][m][c];
             const int row = m0 + m, col = n0 + c;
             if (row < job.M && col < job.N) {
                 if (job.bias[0]) v += job.bias[0][col];
@@ -235,7 +239,7 @@ __device__ __forceinline__ void sk_epilogue(const SkJob& job, const float* __res
                 float v = (job.bias[0] ? pre.b0[gi] : 0.f) + (job.bias[1] ? pre.b1[gi] : 0.f) + (job.bias[2] ? pre.b2[gi] : 0.f) +
                           (job.add ? pre.ad[gi] : 0.f);
 #pragma unroll
-                for (int w = 0; w < SKW; ++w) v += red[w][em_][gi * 8 + eu_];
+                for (int w = 0; w < NW; ++w) v += red[w][em_][gi * 8 + eu_];
                 s4[gi] = v;
             }
             const float so = job.order == XG_ORDER_IFOG ? s4[2] : s4[3];
@@ -298,7 +302,7 @@ __global__ void __launch_bounds__(SKT) __attribute__((amdgpu_waves_per_eu(4, 4))
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
     // ---- LSTM epilogue operands are requested NOW so their (cold-L2) latency hides under the K loop
-    const LstmPre pre = lstm_prefetch(job, m0, tn);
+    const LstmPre pre = lstm_prefetch<SKW>(job, m0, tn);
 
     // ---- K loop: this wave's share of the 32-deep chunks of every segment
     int nc_total = 0;
@@ -405,8 +409,86 @@ __global__ void __launch_bounds__(SKT) __attribute__((amdgpu_waves_per_eu(4, 4))
     __syncthreads();
     SK_STAMP(4);
 
-    sk_epilogue<32>(job, smem, m0, n0, pre);
+    sk_epilogue<32, SKW>(job, smem, m0, n0, pre);
     SK_STAMP(5);
+}
+
+// ---- ZERO job: one tile = 4096 floats
+template <int NW>
+__device__ __forceinline__ void zero_tile(const SkJob& job, int tile) {
+    const size_t n = (size_t)job.M * job.N;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < 1024 / (NW * 64); ++u) {
+        const size_t i = ((size_t)tile * 1024 + u * (NW * 64) + threadIdx.x) * 4;
+        if (i + 3 < n) *reinterpret_cast<f32x4*>(job.C + i) = z;
+        else for (size_t j = i; j < n; ++j) job.C[j] = 0.f;
+    }
+}
+
+// ---- ATTN job (256-thread workgroups): see SK_EPI_ATTN in xg_kernels.h.  Reference: caption_src/sub_modules.py:678-680.
+//   wave w scores rows k0 + w, k0 + w + 4, ... of this half (whole q rows, lane = 16 B); both halves use e_0 as the
+//   softmax shift (the second half scores frame 0 once more: same arithmetic, same bits), so their unnormalised sums simply
+//   add.  exp argument clamped at 80 (only reachable when a frame outweighs the first by e^80; keeps that finite).
+constexpr int ATT_ROWS = 64;       // rows per half <= 64 (K <= 128)
+template <int NI>                  // float4 groups of A per lane: A <= 256 NI
+__device__ __forceinline__ void attn_part(const SkJob& job, int tile, float* smem) {
+    const int b = tile >> 1, part = tile & 1;
+    const int K = job.attn_K, A = job.attn_A, R = job.R;
+    const int kh = (K + 1) >> 1, k0 = part * kh, k1 = min(K, k0 + kh), nrow = k1 - k0;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* pb = job.attn_p + (size_t)b * A;
+    const float* qb = job.attn_q + (size_t)b * K * A;
+    const float* Vb = job.attn_v + (size_t)b * K * R;
+    float* se = smem;                  // [0, ATT_ROWS): scores of this half; [ATT_ROWS]: e_0; then ex
+    float* sx = smem + ATT_ROWS + 4;
+    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    f32x4 pr[NI], wr[NI], q[NI];
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int a = lane * 4 + 256 * i;
+        pr[i] = a < A ? *reinterpret_cast<const f32x4*>(pb + a) : z;
+        wr[i] = a < A ? *reinterpret_cast<const f32x4*>(job.attn_w + a) : z;
+    }
+    // the second half's reference row (frame 0) rides on its last wave, which has the fewest rows of its own
+    const bool ref_here = part == 1 && wave == 3;
+    const int own = k0 + wave < k1 ? (k1 - k0 - wave + 3) >> 2 : 0;
+    const int cnt = own + (ref_here ? 1 : 0);
+    for (int j = 0; j < cnt; ++j) {
+        const float* qk = qb + (size_t)(j < own ? k0 + wave + 4 * j : 0) * A;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int a = lane * 4 + 256 * i;
+            q[i] = a < A ? *reinterpret_cast<const f32x4*>(qk + a) : z;
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            acc += wr[i][0] * xg_tanh(pr[i][0] + q[i][0]) + wr[i][1] * xg_tanh(pr[i][1] + q[i][1]) +
+                   wr[i][2] * xg_tanh(pr[i][2] + q[i][2]) + wr[i][3] * xg_tanh(pr[i][3] + q[i][3]);
+        acc = wave_sum(acc);
+        if (lane == 0) se[j < own ? wave + 4 * j : ATT_ROWS] = acc;
+    }
+    __syncthreads();
+    const float eref = part == 0 ? se[0] : se[ATT_ROWS];
+    if (wave == 0) {
+        const float ex = lane < nrow ? __expf(fminf(se[lane] - eref, 80.0f)) : 0.f;
+        const float ssum = wave_sum(ex);
+        if (lane < nrow) { sx[lane] = ex; job.attn_ex[(size_t)b * K + k0 + lane] = ex; }
+        if (lane == 0 && nrow > 0) atomicAdd(job.attn_s + b, ssum);
+    }
+    __syncthreads();
+    // unnormalised context of this half: thread -> two adjacent columns
+    for (int c = threadIdx.x * 2; c < R; c += 512) {
+        float ax = 0.f, ay = 0.f;
+#pragma unroll 4
+        for (int r = 0; r < nrow; ++r) {
+            const float2 v = *reinterpret_cast<const float2*>(Vb + (size_t)(k0 + r) * R + c);
+            ax += sx[r] * v.x; ay += sx[r] * v.y;
+        }
+        atomicAdd(job.attn_c + (size_t)b * R + c, ax);
+        atomicAdd(job.attn_c + (size_t)b * R + c + 1, ay);
+    }
 }
 
 // ================================================================================================
@@ -429,10 +511,24 @@ __device__ __forceinline__ void ldA(const float* const (&ap)[4], int c, int klef
     }
 }
 
-__global__ void __launch_bounds__(SKT) __attribute__((amdgpu_waves_per_eu(4, 4))) skf_kernel(SkArgs args) {
+// NW waves split K: 8 for launches of at most two tiles per CU (two waves per SIMD hide each other's LDS / load latency);
+// 4 (256-thread workgroups, four per CU) for launches that carry ATTN jobs or more tiles than that, so that every tile of
+// the launch is resident at once.
+template <int NW>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) skf_kernel(SkArgs args) {
     SK_STAMP(0);
-    __shared__ __attribute__((aligned(16))) float smem[SKW * 32 * RSF > SKW * OPF ? SKW * 32 * RSF : SKW * OPF];
+    __shared__ __attribute__((aligned(16))) float smem[NW * 32 * RSF > NW * OPF ? NW * 32 * RSF : NW * OPF];
     const SkJob& job = args.job[blockIdx.y];
+    if (job.epi == SK_EPI_ZERO) {
+        if ((size_t)blockIdx.x * 4096 < (size_t)job.M * job.N) zero_tile<NW>(job, blockIdx.x);
+        return;
+    }
+    if (job.epi == SK_EPI_ATTN) {
+        if (NW == 4 && (int)blockIdx.x < 2 * job.M) {
+            if (job.attn_A <= 1536) attn_part<6>(job, blockIdx.x, smem); else attn_part<8>(job, blockIdx.x, smem);
+        }
+        return;
+    }
     const int ntm = (job.M + 31) >> 5;
     const bool lstm = job.epi == SK_EPI_LSTM || job.cell_cols;      // cell tiling of the weight rows
     const int ntn = lstm ? job.R >> 3 : (job.N + 31) >> 5;
@@ -453,20 +549,41 @@ __global__ void __launch_bounds__(SKT) __attribute__((amdgpu_waves_per_eu(4, 4))
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    int nc_total = 0;
+    const LstmPre pre = lstm_prefetch<NW>(job, m0, tn);
+    // A scaled operand (the unnormalised attention context): the reciprocal row scales go to LDS behind the staging images;
+    // the workgroup meets at a barrier in front of the first scaled segment, i.e. after every wave has done its share of the
+    // segments before it -- the scale's load latency hides there (registers would be simpler, but four more live values
+    // push the K loop into scratch: measured 47.8 -> 52.9 us per step).  The unnormalised attention weights of this m-tile's
+    // videos are normalised by ALL its n-tiles, a slice each: loads now, multiply + store at the very end.
+    float* rsc_lds = smem + NW * OPF;
+    int scaled_seg = -1;
 #pragma unroll
-    for (int s = 0; s < 3; ++s) if (s < job.nseg) nc_total += job.seg[s].nck;
-    const int wc0 = (wave * nc_total) / SKW, wc1 = ((wave + 1) * nc_total) / SKW;
-    // the first chunk's loads go out before anything else
-    const LstmPre pre = lstm_prefetch(job, m0, tn);
-    int seg_start = 0;
+    for (int s = 0; s < 3; ++s) if (s < job.nseg && job.seg[s].row_scale && scaled_seg < 0) scaled_seg = s;
+    float exv = 0.f, exs = 1.f;
+    float* exp_ = nullptr;
+    if (scaled_seg >= 0) {
+        const SkSeg& sg = job.seg[scaled_seg];
+        if (threadIdx.x < 32) rsc_lds[threadIdx.x] = 1.0f / sg.row_scale[min(m0 + (int)threadIdx.x, job.M - 1)];
+        if (sg.ex) {
+            const int per = (32 * sg.ex_K + ntn - 1) / ntn;              // elements of this tile's slice
+            const int idx = tn * per + (int)threadIdx.x;
+            const int row = m0 + idx / sg.ex_K;
+            if ((int)threadIdx.x < per && idx < 32 * sg.ex_K && row < job.M) {
+                exp_ = sg.ex + (size_t)row * sg.ex_ld + idx % sg.ex_K;
+                exv = *exp_;
+                exs = sg.row_scale[row];
+            }
+        }
+    }
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         if (s >= job.nseg) break;
         const SkSeg sg = job.seg[s];
         const int nc = sg.nck;
-        const int c0 = max(wc0, seg_start) - seg_start, c1 = min(wc1, seg_start + nc) - seg_start;
-        seg_start += nc;
+        if (s == scaled_seg) __syncthreads();               // rsc_lds is complete (uniform: every wave passes here)
+        // every wave takes its share of EVERY segment, in order (a gathered or scaled operand comes last in its job, so the
+        // index / scale loads have the earlier segments to land)
+        const int c0 = (wave * nc) / NW, c1 = ((wave + 1) * nc) / NW;
         if (c0 >= c1) continue;
         const float* bp = sg.Bp + ((size_t)tn * nc) * 1024 + (size_t)(half * 32 + l31) * 4;
         const float* ap[4];
@@ -480,20 +597,31 @@ __global__ void __launch_bounds__(SKT) __attribute__((amdgpu_waves_per_eu(4, 4))
             ap[i] = sg.A + (size_t)row * sg.lda + lcol;
         }
         const int nfull = sg.K / CK;                 // chunks >= nfull are the (single) k tail: K % 4 == 0 on this path
-        f32x4 ra[4], rb[4];
+        // unnormalised attention context as an operand: rows scaled by 1 / s while they are staged; the tn == 0 tiles write
+        // the normalised rows back (scaled_out has A's row pitch: checked by the host)
+        const bool wb_seg = sg.row_scale && sg.scaled_out;      // chunk c of the scaled rows is written back by n-tile c % ntn
+        const ptrdiff_t wb_delta = wb_seg ? sg.scaled_out - sg.A : 0;
+        f32x4 ra[4], rb0[4], rb1[4];
         if (s == 0) SK_STAMP(1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bp + (size_t)c0 * 1024 + i * 256);
+        for (int i = 0; i < 4; ++i) rb0[i] = *reinterpret_cast<const f32x4*>(bp + (size_t)c0 * 1024 + i * 256);
         if (c0 < nfull) ldA<false>(ap, c0, 0, ra); else ldA<true>(ap, c0, sg.K - c0 * CK - lcol, ra);
-        for (int c = c0; c < c1; ++c) {
-            f32x4 fb[4];
+        // one chunk: stage A (scaled / written back when it is the attention context), request the NEXT chunk's operands
+        // (B into the other register set: no copy), then the 16 MFMAs of this chunk
+        auto chunk = [&](int c, const f32x4 (&cur)[4], f32x4 (&nxt)[4]) {
+            if (sg.row_scale) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) fb[i] = rb[i];
+                for (int i = 0; i < 4; ++i) {
+                    ra[i] *= rsc_lds[i * 8 + lrow];
+                    if (wb_seg && c % ntn == tn && m0 + i * 8 + lrow < job.M && c * CK + lcol < sg.K)
+                        *reinterpret_cast<f32x4*>(const_cast<float*>(ap[i]) + wb_delta + (size_t)c * CK) = ra[i];
+                }
+            }
             st_chunk(As, lane, ra);
             if (s == 0 && c == c0) SK_STAMP(2);
             if (c + 1 < c1) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) rb[i] = *reinterpret_cast<const f32x4*>(bp + (size_t)(c + 1) * 1024 + i * 256);
+                for (int i = 0; i < 4; ++i) nxt[i] = *reinterpret_cast<const f32x4*>(bp + (size_t)(c + 1) * 1024 + i * 256);
                 if (c + 1 < nfull) ldA<false>(ap, c + 1, 0, ra); else ldA<true>(ap, c + 1, sg.K - (c + 1) * CK - lcol, ra);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
@@ -502,10 +630,14 @@ __global__ void __launch_bounds__(SKT) __attribute__((amdgpu_waves_per_eu(4, 4))
             for (int i = 0; i < 4; ++i) {
                 const f32x4 a = *reinterpret_cast<const f32x4*>(As + l31 * LDR + half * 16 + i * 4);
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], fb[i][kk], acc, 0, 0, 0);
+                for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], cur[i][kk], acc, 0, 0, 0);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+        };
+        for (int c = c0; c < c1; c += 2) {
+            chunk(c, rb0, rb1);
+            if (c + 1 < c1) chunk(c + 1, rb1, rb0);
         }
     }
     SK_STAMP(3);
@@ -515,7 +647,8 @@ __global__ void __launch_bounds__(SKT) __attribute__((amdgpu_waves_per_eu(4, 4))
     for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[r];
     __syncthreads();
     SK_STAMP(4);
-    sk_epilogue<RSF>(job, smem, m0, n0, pre);
+    sk_epilogue<RSF, NW>(job, smem, m0, n0, pre);
+    if (exp_) *exp_ = exv * (1.0f / exs);
     SK_STAMP(5);
 }
 
@@ -535,16 +668,40 @@ static int skinny_fallback(hipStream_t st, const SkJob& jb) {
     return XG_OK;
 }
 
+#ifdef SK_TRACE
+extern "C" int xg_debug_sk_trace(long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(sk_trace_buf), sizeof(long long) * (size_t)n) == hipSuccess ? 0 : -1;
+}
+#endif
+
 int xgk_skinny(hipStream_t st, SkArgs& a) {
     if (a.njobs <= 0 || a.njobs > SK_MAX_JOBS) return XG_EINVAL;
-    bool vec = true, generic = false, packed = true;
+    bool vec = true, generic = false, packed = true, special = false, has_attn = false;
     int tiles = 0, max_tiles = 0;
     for (int j = 0; j < a.njobs; ++j) {
         SkJob& jb = a.job[j];
-        if (jb.M <= 0 || jb.N <= 0 || jb.nseg < 1 || jb.nseg > 3) return XG_EINVAL;
+        const bool no_segs = jb.epi == SK_EPI_ZERO || jb.epi == SK_EPI_ATTN;
+        if (jb.M <= 0 || (!no_segs && (jb.N <= 0 || jb.nseg < 1 || jb.nseg > 3))) return XG_EINVAL;
         if (jb.epi == SK_EPI_LSTMB && (jb.N != jb.R || !jb.gates || !jb.c_prev || !jb.c_out || !jb.ds || !jb.dc_prev ||
                                        (jb.accumulate && !jb.C))) return XG_EINVAL;
         jb.tile0 = tiles; a.tile0[j] = tiles;
+        if (jb.epi == SK_EPI_ZERO || jb.epi == SK_EPI_ATTN) {       // fast-kernel-only job types, no matrix segments
+            int nt;
+            if (jb.epi == SK_EPI_ZERO) {
+                if (!jb.C || ((uintptr_t)jb.C % 16)) return XG_EINVAL;
+                nt = (int)(((size_t)jb.M * jb.N + 4095) / 4096);
+            } else {
+                if (!jb.attn_p || !jb.attn_q || !jb.attn_v || !jb.attn_w || !jb.attn_ex || !jb.attn_s || !jb.attn_c) return XG_EINVAL;
+                if (jb.attn_A % 4 || jb.attn_A > 256 * 8 || jb.attn_K < 1 || jb.attn_K > 128 || jb.R < 2 || jb.R % 2) return XG_EINVAL;
+                if ((((uintptr_t)jb.attn_p | (uintptr_t)jb.attn_q | (uintptr_t)jb.attn_w) % 16) || ((uintptr_t)jb.attn_v % 8)) return XG_EINVAL;
+                nt = 2 * jb.M;
+                has_attn = true;
+            }
+            special = true;
+            tiles += nt;
+            max_tiles = nt > max_tiles ? nt : max_tiles;
+            continue;
+        }
         const int ntm = xg_cdiv(jb.M, 32);
         int ntn;
         if (jb.cell_cols && jb.epi != SK_EPI_STORE) return XG_EINVAL;
@@ -560,6 +717,7 @@ int xgk_skinny(hipStream_t st, SkArgs& a) {
             SkSeg& sg = jb.seg[s];
             if (!sg.A || !sg.B || sg.K <= 0) return XG_EINVAL;
             packed = packed && sg.Bp && sg.nck == xg_cdiv(sg.K, 32);
+            if (sg.row_scale && (!sg.Bp || sg.gather || (sg.scaled_out && (sg.ld_out != sg.lda || ((uintptr_t)sg.scaled_out % 16))))) return XG_EINVAL;
             if (sg.gather && !sg.Bp) return XG_EINVAL;        // the row gather exists on the packed path only
             vec = vec && ((uintptr_t)sg.A % 16 == 0) && (sg.lda % 4 == 0) && (sg.K % 4 == 0);
             vec = vec && ((uintptr_t)sg.B % 16 == 0) && (sg.ldb % 4 == 0);
@@ -572,8 +730,22 @@ int xgk_skinny(hipStream_t st, SkArgs& a) {
     }
     const bool bf16 = xgk_get_gemm_mode() == 1;      // plain-bf16 mode covers the recurrent products too
     static const bool no_packed = getenv("XG_NO_PACKED") != nullptr;
-    if (vec && packed && !bf16 && !no_packed) {
-        hipLaunchKernelGGL(skf_kernel, dim3((max_tiles + 7) & ~7, a.njobs), dim3(SKT), 0, st, a);
+    const bool fast = vec && packed && !bf16 && !no_packed;
+    if (special && !fast) return XG_EINVAL;            // ZERO / ATTN jobs and scaled operands exist in the fast kernel only
+    static const bool split_jobs = getenv("XG_SPLIT_JOBS") != nullptr;       // diagnosis: one launch per job
+    if (fast && split_jobs && a.njobs > 1 && !special) {
+        for (int j = 0; j < a.njobs; ++j) {
+            SkArgs one{};
+            one.njobs = 1; one.job[0] = a.job[j];
+            XG_TRY(xgk_skinny(st, one));
+        }
+        return XG_OK;
+    }
+    if (fast) {
+        static const int force_nw = getenv("XG_SK_NW") ? atoi(getenv("XG_SK_NW")) : 0;      // diagnosis
+        const bool nw4 = has_attn || (force_nw ? force_nw == 4 : tiles > 2 * 256);
+        if (nw4) hipLaunchKernelGGL((skf_kernel<4>), dim3((max_tiles + 7) & ~7, a.njobs), dim3(256), 0, st, a);
+        else hipLaunchKernelGGL((skf_kernel<8>), dim3((max_tiles + 7) & ~7, a.njobs), dim3(512), 0, st, a);
         XG_CHECK_LAUNCH();
         return XG_OK;
     }
