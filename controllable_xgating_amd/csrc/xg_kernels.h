@@ -156,6 +156,12 @@ struct SkJob {
     // ATTN job: p (M,A) at attn_p, q = v2a(V) (M,K,A) at attn_q, V (M,K,R) at attn_v, w_a (A) at attn_w; outputs
     // attn_ex (M,K) unnormalised weights, attn_s (M) and attn_c (M,R) accumulated with atomics
     const float *attn_p, *attn_q, *attn_v, *attn_w; float *attn_ex, *attn_s, *attn_c; int attn_K, attn_A;
+    // Cross-workgroup split-K (fast kernel; STORE and LSTMB jobs whose result ACCUMULATES into C): ksplit_ok = 1 lets
+    // xgk_skinny spread a tile's reduction over several workgroups when the launch would leave CUs idle (the backward
+    // chains' dh = ds W products are 64-128 tiles, K = 1536-2048 deep).  Each part adds its partial tile into C with fp32
+    // atomics; for LSTMB the last part to arrive (tickets: one zero-initialised int per tile, left at zero again) reads the
+    // completed dh back and runs the pointwise backward.  ksplit is filled in by xgk_skinny.
+    int ksplit_ok, ksplit; int* tickets;
     XgDrop drop;
 };
 struct SkArgs { int njobs; int tile0[SK_MAX_JOBS]; SkJob job[SK_MAX_JOBS]; };

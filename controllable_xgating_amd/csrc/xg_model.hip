@@ -122,6 +122,7 @@ struct Ws {
     float *AFU, *ATS;                  // unnormalised attention context (B,R) and softmax denominators (B), contiguous
     // ---- rollout
     int64_t* TOK; float *TOKLP, *UNF; int32_t* alive;
+    int32_t* tickets;                  // split-K arrival counters (xg_step.hip), SK_MAX_JOBS x 1024, zero between launches
     size_t bytes;
     // ---- packed recurrent weights (XgRun.packed; not part of the workspace)
     PackedView pk; bool packed;
@@ -174,6 +175,7 @@ Ws carve(const XgDims& d, void* base) {
     w.AFU = c.take<float>(B * R + ((B + 3) & ~(size_t)3)); w.ATS = w.AFU + B * R;
     w.TOK = c.take<int64_t>(TB); w.TOKLP = c.take<float>(TB); w.UNF = c.take<float>(TB);
     w.alive = c.take<int32_t>(4);
+    w.tickets = c.take<int32_t>(SK_MAX_JOBS * 1024);
     w.bytes = (c.off + 255) & ~(size_t)255;
     return w;
 }
@@ -216,6 +218,14 @@ inline SkSeg seg_nn(const Ws& w, int which, const float* dY, int lddy, const flo
     return s;
 }
 // (plain-bf16 mode keeps the LDS-staged kernel, which rounds its chunks to bf16 on the way: BASELINE.json configs[4])
+// let xgk_skinny split the reduction of job j across workgroups (its result accumulates into C: see SkJob.ksplit_ok)
+inline void allow_split(SkArgs& sk, int j, const Ws& w) { sk.job[j].ksplit_ok = 1; sk.job[j].tickets = w.tickets + j * 1024; }
+// (the last arriver of every tile leaves its counter at zero; the memsets only make a launch independent of whatever an
+// aborted run left behind.  njobs: how many 1024-counter blocks the caller's launches on THIS stream use -- the decoder
+// backward's cell-1 chain runs on a side stream with block 2 while the encoder backward uses blocks 0-1.)
+inline int zero_tickets(hipStream_t st, const Ws& w, int njobs) {
+    return hipMemsetAsync(w.tickets, 0, sizeof(int32_t) * njobs * 1024, st) == hipSuccess ? XG_OK : XG_EHIP;
+}
 inline void attach_packed(Ws& w, const XgDims& d, const XgRun* run) {
     static const bool disabled = getenv("XG_NO_PACKED") != nullptr;
     w.packed = !disabled && run && run->packed && run->gemm_mode != 1 && xgk_packed_view(d, run->packed, &w.pk);
@@ -370,6 +380,7 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
     XgRun nodrop = run; nodrop.drop_p = 0.f;
     int curc = 0;
     for (int m = 0; m < 2; ++m) { ZERO(w.dHrec[m], (size_t)B * R); ZERO(w.dCrec[m][0], (size_t)B * R); }
+    XG_TRY(zero_tickets(st, w, 2));
     // cell backward of frame i for modality m, reading / writing the carried dc of parity c.  Stand-alone it takes
     // dh = dHs[i] + dHrec; fused into the product dS[i+1] Whh (epilogue) it takes dh = product + dHs[i].
     auto enc_cell_bwd = [&](int m, int i, int c, bool fused) {
@@ -378,7 +389,7 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
         a.c_prev = i == 0 ? w.zeroBR : w.Cs[m] + (size_t)(i - 1) * R; a.ldcp = i == 0 ? R : K * R;
         a.c_out = w.Cs[m] + (size_t)i * R; a.ldco = K * R;
         a.mask = x.feat_mask + i; a.ldm = K;
-        if (fused) { a.dh_out = nullptr; a.lddh = 0; a.dh_add = w.dHs[m] + (size_t)i * R; a.lddha = K * R; }
+        if (fused) { a.dh_out = nullptr; a.lddh = 0; a.dh_add = nullptr; a.lddha = 0; }      // dHs[i] is the job's accumulate operand
         else { a.dh_out = w.dHs[m] + (size_t)i * R; a.lddh = K * R; a.dh_add = w.dHrec[m]; a.lddha = R; }
         a.dc_out = w.dCrec[m][c]; a.lddc = R;
         a.ds = w.dS[m] + (size_t)i * 4 * R; a.ldds = K * 4 * R;
@@ -397,7 +408,8 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
             sk.njobs = 2;
             for (int m = 0; m < 2; ++m) {
                 // dh of frame i-1 = dS[i] Whh (+ dHs[i-1]); fused: frame i-1's cell backward in the epilogue
-                if (fuse) sk.job[m] = job_lstm_bwd(enc_cell_bwd(m, i - 1, curc, true), nullptr, 0);
+                // (the product accumulates into dHs[i-1], which nothing reads afterwards: split-K across workgroups allowed)
+                if (fuse) { sk.job[m] = job_lstm_bwd(enc_cell_bwd(m, i - 1, curc, true), w.dHs[m] + (size_t)(i - 1) * R, K * R); allow_split(sk, m, w); }
                 else sk.job[m] = job_store(B, R, w.dHrec[m], R, false);
                 sk.job[m].nseg = 1;
                 sk.job[m].seg[0] = seg_nn(w, m == 0 ? PKB_ENC_RGB : PKB_ENC_OPFL, w.dS[m] + (size_t)i * 4 * R, K * 4 * R, whh[m], R, 4 * R);
@@ -743,6 +755,8 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     const bool fuse = R % 4 == 0;
     int cur = 0;
     for (int j = 0; j < 4; ++j) ZERO(w.dst[0][j], BR);
+    ZERO(w.DAF, (size_t)T * BR);                 // the dAF products accumulate (split-K across workgroups)
+    XG_TRY(zero_tickets(st, w, SK_MAX_JOBS));
     auto cell2_bwd = [&](int t, int c) {          // backward of cell 2 at step t, reading the carried state of parity c
         LstmBwdArgs a{};
         a.gates = w.G2 + (size_t)t * B * 4 * R; a.ldg = 4 * R;
@@ -767,8 +781,9 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         {   // s2 = h1' Wi + af Wa + h2 Wh : the two data gradients chain 2 needs now
             SkArgs sk{};
             sk.njobs = 2;
-            sk.job[0] = job_store(B, R, daf, R, false);  sk.job[0].nseg = 1; sk.job[0].seg[0] = seg_nn(w, PKB_L2_A2H, ds2, 4 * R, p.l2_a2h_w, R, 4 * R);
+            sk.job[0] = job_store(B, R, daf, R, true);   sk.job[0].nseg = 1; sk.job[0].seg[0] = seg_nn(w, PKB_L2_A2H, ds2, 4 * R, p.l2_a2h_w, R, 4 * R);
             sk.job[1] = job_store(B, R, dh2p, R, true);  sk.job[1].nseg = 1; sk.job[1].seg[0] = seg_nn(w, PKB_L2_H2H, ds2, 4 * R, p.l2_h2h_w, R, 4 * R);
+            allow_split(sk, 0, w); allow_split(sk, 1, w);
             XG_TRY(xgk_skinny(st, sk));
         }
         XG_TRY(xgk_attn_bwd(st, daf, R, w.P + (size_t)t * B * A, w.vproj, w.Venc, p.a2w_w, w.ALPHA + (size_t)t * B * K,
@@ -780,6 +795,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
             else sk.job[0] = job_store(B, R, dh2p, R, true);
             sk.job[0].nseg = 1;
             sk.job[0].seg[0] = seg_nn(w, PKB_H2A2, dp, A, p.h2a_w + R, 2 * R, A);
+            allow_split(sk, 0, w);
             XG_TRY(xgk_skinny(st, sk));
         }
         cur ^= 1;
@@ -815,6 +831,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         else sk.job[0] = job_store(B, R, dh1p, R, true);
         sk.job[0].nseg = 1;
         sk.job[0].seg[0] = seg_nn(w, PKB_L1_H2H, ds1, 4 * R, p.l1_h2h_w, R, 4 * R);
+        allow_split(sk, 0, w); sk.job[0].tickets = w.tickets + 2 * 1024;       // chain 1 runs beside chain 2 / the encoder: own counters
         XG_TRY(xgk_skinny(s1, sk));
         cur1 ^= 1;
     }

@@ -138,6 +138,45 @@ __device__ __forceinline__ LstmPre lstm_prefetch(const SkJob& job, int m0, int t
     return p;
 }
 
+// pointwise LSTM backward of one (row b, unit j) given dh = d(loss)/d(h') before the optional add term (same arithmetic as
+// xg_pointwise.hip:lstm_bwd_body)
+__device__ __forceinline__ void lstmb_point(const SkJob& job, int b, int j, float v) {
+    const int R = job.R;
+    if (job.add) v += job.add[(size_t)b * job.ldadd + j];
+    const float* g = job.gates + (size_t)b * job.ldg;
+    const float ig = g[j], fg = g[R + j];
+    const float og = job.order == XG_ORDER_IFOG ? g[2 * R + j] : g[3 * R + j];
+    const float gg = job.order == XG_ORDER_IFOG ? g[3 * R + j] : g[2 * R + j];
+    const float cp = job.c_prev[(size_t)b * job.ldcp + j];
+    const float cn = job.c_out[(size_t)b * job.ldco + j];
+    const float mk = job.mask ? job.mask[(size_t)b * job.ldm] : 1.0f;
+    float dh = v * xg_keep(job.drop, (uint32_t)(b * R + j));
+    float dc = job.dc_in ? job.dc_in[(size_t)b * job.lddci + j] : 0.0f;
+    float dht, dct, dcp;
+    const float tc = xg_tanh(cn);
+    if (job.mask_mode == XG_MASK_HOLD) {
+        if (job.dh_hold) job.dh_hold[(size_t)b * job.lddhh + j] = (1.0f - mk) * dh;
+        dht = mk * dh;
+        dc += dht * og * (1.0f - tc * tc);
+        dcp = (1.0f - mk) * dc;
+        dct = mk * dc;
+    } else {
+        dht = mk * dh;
+        dct = mk * dc + dht * og * (1.0f - tc * tc);
+        dcp = 0.0f;
+    }
+    const float d_o = dht * tc;
+    dcp += dct * fg;
+    const float d_f = dct * cp, d_i = dct * gg, d_g = dct * ig;
+    float* ds = job.ds + (size_t)b * job.ldds;
+    ds[j] = d_i * ig * (1.0f - ig);
+    ds[R + j] = d_f * fg * (1.0f - fg);
+    const float dso = d_o * og * (1.0f - og), dsg = d_g * (1.0f - gg * gg);
+    if (job.order == XG_ORDER_IFOG) { ds[2 * R + j] = dso; ds[3 * R + j] = dsg; }
+    else                            { ds[2 * R + j] = dsg; ds[3 * R + j] = dso; }
+    job.dc_prev[(size_t)b * job.lddcp + j] = dcp;
+}
+
 template <int RS, int NW>
 __device__ __forceinline__ void sk_epilogue(const SkJob& job, const float* __restrict__ redp, int m0, int n0, const LstmPre& pre) {
     const float (*red)[32][RS] = reinterpret_cast<const float (*)[32][RS]>(redp);
@@ -176,39 +215,7 @@ __device__ __forceinline__ void sk_epilogue(const SkJob& job, const float* __res
             const int b = m0 + m, j = n0 + c;
             if (b < job.M && j < job.N) {
                 if (job.accumulate) v += job.C[(size_t)b * job.ldc + j];
-                if (job.add) v += job.add[(size_t)b * job.ldadd + j];
-                const float* g = job.gates + (size_t)b * job.ldg;
-                const float ig = g[j], fg = g[R + j];
-                const float og = job.order == XG_ORDER_IFOG ? g[2 * R + j] : g[3 * R + j];
-                const float gg = job.order == XG_ORDER_IFOG ? g[3 * R + j] : g[2 * R + j];
-                const float cp = job.c_prev[(size_t)b * job.ldcp + j];
-                const float cn = job.c_out[(size_t)b * job.ldco + j];
-                const float mk = job.mask ? job.mask[(size_t)b * job.ldm] : 1.0f;
-                float dh = v * xg_keep(job.drop, (uint32_t)(b * R + j));
-                float dc = job.dc_in ? job.dc_in[(size_t)b * job.lddci + j] : 0.0f;
-                float dht, dct, dcp;
-                const float tc = xg_tanh(cn);
-                if (job.mask_mode == XG_MASK_HOLD) {
-                    if (job.dh_hold) job.dh_hold[(size_t)b * job.lddhh + j] = (1.0f - mk) * dh;
-                    dht = mk * dh;
-                    dc += dht * og * (1.0f - tc * tc);
-                    dcp = (1.0f - mk) * dc;
-                    dct = mk * dc;
-                } else {
-                    dht = mk * dh;
-                    dct = mk * dc + dht * og * (1.0f - tc * tc);
-                    dcp = 0.0f;
-                }
-                const float d_o = dht * tc;
-                dcp += dct * fg;
-                const float d_f = dct * cp, d_i = dct * gg, d_g = dct * ig;
-                float* ds = job.ds + (size_t)b * job.ldds;
-                ds[j] = d_i * ig * (1.0f - ig);
-                ds[R + j] = d_f * fg * (1.0f - fg);
-                const float dso = d_o * og * (1.0f - og), dsg = d_g * (1.0f - gg * gg);
-                if (job.order == XG_ORDER_IFOG) { ds[2 * R + j] = dso; ds[3 * R + j] = dsg; }
-                else                            { ds[2 * R + j] = dsg; ds[3 * R + j] = dso; }
-                job.dc_prev[(size_t)b * job.lddcp + j] = dcp;
+                lstmb_point(job, b, j, v);
             }
         }
     } else if (job.epi == SK_EPI_GATE) {
@@ -265,6 +272,47 @@ __device__ __forceinline__ void sk_epilogue(const SkJob& job, const float* __res
             job.c_out[(size_t)b * job.ldco + j] = cn;
             job.h_out[(size_t)b * job.ldho + j] = hn;
         }
+    }
+}
+
+// Split-K epilogue (see SkJob.ksplit_ok): this part's tile goes into C with atomics; LSTMB: last arriver finishes.
+template <int RS, int NW>
+__device__ __forceinline__ void sk_epilogue_split(const SkJob& job, float* __restrict__ smem, int m0, int n0, int kp, int tile_id) {
+    const float (*red)[32][RS] = reinterpret_cast<const float (*)[32][RS]>(smem);
+#pragma unroll
+    for (int e = 0; e < 1024 / (NW * 64); ++e) {
+        const int idx = threadIdx.x + NW * 64 * e;
+        const int m = idx >> 5, c = idx & 31;
+        float v = 0.f;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) v += red[w][m][c];
+        const int row = m0 + m, col = n0 + c;
+        if (row < job.M && col < job.N) {
+            if (kp == 0 && job.epi == SK_EPI_STORE) {
+                if (job.bias[0]) v += job.bias[0][col];
+                if (job.bias[1]) v += job.bias[1][col];
+                if (job.bias[2]) v += job.bias[2][col];
+            }
+            atomicAdd(job.C + (size_t)row * job.ldc + col, v);
+        }
+    }
+    if (job.epi != SK_EPI_LSTMB) return;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's adds have been performed
+    __syncthreads();
+    int* flag = reinterpret_cast<int*>(smem);                  // (the partial tiles are dead after the barrier)
+    if (threadIdx.x == 0) {
+        const int t = atomicAdd(job.tickets + tile_id, 1);
+        if (t == job.ksplit - 1) job.tickets[tile_id] = 0;     // every part has passed: ready for the next launch
+        *flag = t;
+    }
+    __syncthreads();
+    if (*flag != job.ksplit - 1) return;
+#pragma unroll
+    for (int e = 0; e < 1024 / (NW * 64); ++e) {
+        const int idx = threadIdx.x + NW * 64 * e;
+        const int b = m0 + (idx >> 5), j = n0 + (idx & 31);
+        if (b < job.M && j < job.N)     // device-scope load: the other parts' atomics were performed at that scope
+            lstmb_point(job, b, j, __hip_atomic_load(job.C + (size_t)b * job.ldc + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
 }
 
@@ -532,14 +580,15 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
     const int ntm = (job.M + 31) >> 5;
     const bool lstm = job.epi == SK_EPI_LSTM || job.cell_cols;      // cell tiling of the weight rows
     const int ntn = lstm ? job.R >> 3 : (job.N + 31) >> 5;
-    const int ntiles = ntm * ntn;
+    const int ks = job.ksplit > 1 ? job.ksplit : 1;             // cross-workgroup split of the reduction
+    const int ntiles = ntm * ntn * ks;
     if ((int)blockIdx.x >= ntiles) return;
     int bid = blockIdx.x;
     {   // XCD-aware: the m-tiles that share a weight slice stay on one XCD's L2 (gridDim.x is a multiple of 8)
         const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid % ntm, tn = bid / ntm;
+    const int tm = bid % ntm, kp = (bid / ntm) % ks, tn = bid / (ntm * ks);
     const int m0 = tm * 32, n0 = tn * 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
     float* As = smem + wave * OPF;
@@ -583,7 +632,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
         if (s == scaled_seg) __syncthreads();               // rsc_lds is complete (uniform: every wave passes here)
         // every wave takes its share of EVERY segment, in order (a gathered or scaled operand comes last in its job, so the
         // index / scale loads have the earlier segments to land)
-        const int c0 = (wave * nc) / NW, c1 = ((wave + 1) * nc) / NW;
+        const int p0 = (kp * nc) / ks, pn = ((kp + 1) * nc) / ks - p0;      // this workgroup's part of the segment
+        const int c0 = p0 + (wave * pn) / NW, c1 = p0 + ((wave + 1) * pn) / NW;
         if (c0 >= c1) continue;
         const float* bp = sg.Bp + ((size_t)tn * nc) * 1024 + (size_t)(half * 32 + l31) * 4;
         const float* ap[4];
@@ -647,7 +697,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
     for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[r];
     __syncthreads();
     SK_STAMP(4);
-    sk_epilogue<RSF, NW>(job, smem, m0, n0, pre);
+    if (ks > 1) sk_epilogue_split<RSF, NW>(job, smem, m0, n0, kp, tm + ntm * tn);
+    else sk_epilogue<RSF, NW>(job, smem, m0, n0, pre);
     if (exp_) *exp_ = exv * (1.0f / exs);
     SK_STAMP(5);
 }
@@ -731,6 +782,22 @@ int xgk_skinny(hipStream_t st, SkArgs& a) {
     const bool bf16 = xgk_get_gemm_mode() == 1;      // plain-bf16 mode covers the recurrent products too
     static const bool no_packed = getenv("XG_NO_PACKED") != nullptr;
     const bool fast = vec && packed && !bf16 && !no_packed;
+    // cross-workgroup split-K for launches that would leave most CUs idle (every job must allow it)
+    int ks = 1;
+    {
+        static const bool no_split = getenv("XG_NO_SPLITK") != nullptr;
+        bool ok = fast && !special && !no_split;
+        int min_chunks = 1 << 30;
+        for (int j = 0; j < a.njobs && ok; ++j) {
+            const SkJob& jb = a.job[j];
+            ok = jb.ksplit_ok && jb.C && jb.accumulate && !jb.relu && (jb.epi == SK_EPI_STORE || (jb.epi == SK_EPI_LSTMB && jb.tickets)) &&
+                 xg_cdiv(jb.M, 32) * xg_cdiv(jb.N, 32) <= 1024;
+            for (int s = 0; s < jb.nseg; ++s) min_chunks = jb.seg[s].nck < min_chunks ? jb.seg[s].nck : min_chunks;
+        }
+        if (ok) while (ks < 8 && tiles * ks * 2 <= 512 && min_chunks / (ks * 2) >= 4) ks *= 2;
+        for (int j = 0; j < a.njobs; ++j) a.job[j].ksplit = ks;
+        tiles *= ks; max_tiles *= ks;
+    }
     if (special && !fast) return XG_EINVAL;            // ZERO / ATTN jobs and scaled operands exist in the fast kernel only
     static const bool split_jobs = getenv("XG_SPLIT_JOBS") != nullptr;       // diagnosis: one launch per job
     if (fast && split_jobs && a.njobs > 1 && !special) {
@@ -743,7 +810,7 @@ int xgk_skinny(hipStream_t st, SkArgs& a) {
     }
     if (fast) {
         static const int force_nw = getenv("XG_SK_NW") ? atoi(getenv("XG_SK_NW")) : 0;      // diagnosis
-        const bool nw4 = has_attn || (force_nw ? force_nw == 4 : tiles > 2 * 256);
+        const bool nw4 = has_attn || ks > 1 || (force_nw ? force_nw == 4 : tiles > 2 * 256);
         if (nw4) hipLaunchKernelGGL((skf_kernel<4>), dim3((max_tiles + 7) & ~7, a.njobs), dim3(256), 0, st, a);
         else hipLaunchKernelGGL((skf_kernel<8>), dim3((max_tiles + 7) & ~7, a.njobs), dim3(512), 0, st, a);
         XG_CHECK_LAUNCH();
