@@ -71,7 +71,7 @@ def measure_step_group(model, x, reps=200):
         d = model._dims(B, K, 1)
         ps, run = model._params_struct(), model._run(False)
         vproj = torch.empty(B, K, model.att_size, device=V.device)
-        nv.check(nv.lib().xg_vproj(_stream(), C.byref(d), C.byref(ps), nv.ptr(V), nv.ptr(vproj)), "xg_vproj")
+        nv.check(nv.lib().xg_vproj(_stream(), C.byref(d), C.byref(ps), nv.ptr(V), nv.ptr(vproj), C.byref(run)), "xg_vproj")
         ws = model._pool.shared(d, V.device)
         wp, wn = _ws_ptr(ws)
         tok = x["seq"][:, 1].contiguous()

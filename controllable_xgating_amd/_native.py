@@ -29,7 +29,7 @@ class XgBatch(C.Structure):
 class XgRun(C.Structure):
     _fields_ = [("train", C.c_int32), ("drop_p", C.c_float), ("seed", C.c_uint32), ("save", C.c_int32),
                 ("bn_momentum", C.c_float), ("bn_eps", C.c_float), ("gemm_mode", C.c_int32), ("reserved0", C.c_int32),
-                ("packed", C.c_void_p)]
+                ("packed", C.c_void_p), ("aux", C.c_void_p), ("grad_event", C.c_void_p)]
 
 
 class XgError(RuntimeError):
@@ -77,7 +77,7 @@ def lib():
         "xg_encoder_fwd": [vp, PD, PP, PB, PX, PR, vp, C.c_size_t, vp],
         "xg_encoder_bwd": [vp, PD, PP, PP, PX, PR, vp, C.c_size_t, vp],
         "xg_init_hidden": [vp, PD, PP, vp, vp, vp, C.c_size_t, vp],
-        "xg_vproj": [vp, PD, PP, vp, vp],
+        "xg_vproj": [vp, PD, PP, vp, vp, PR],
         "xg_step_fwd": [vp, PD, PP, vp, vp, vp, vp, vp, PR, i32, vp, C.c_size_t, vp, vp, vp],
         "xg_forward_xe": [vp, PD, PP, PB, PX, PR, vp, C.c_size_t, vp, vp],
         "xg_backward_xe": [vp, PD, PP, PP, PX, PR, vp, C.c_size_t, vp, vp],
@@ -87,7 +87,8 @@ def lib():
         "xg_xe_loss_bwd": [vp, PD, PP, PP, PX, vp, vp, f32, vp, PR, vp, C.c_size_t],
         "xg_rollout": [vp, PD, PP, PB, PX, PR, i32, vp, vp, f32, vp, C.c_size_t, vp, vp, vp],
         "xg_rollout_bwd": [vp, PD, PP, PP, PX, PR, vp, C.c_size_t, vp],
-        "xg_set_grad_event": [vp],
+        "xg_aux_create": [C.POINTER(C.c_void_p)],
+        "xg_aux_destroy": [vp],
         "xg_rollout_pair": [vp, PD, PP, PB, PX, PR, i32, vp, f32, vp, C.c_size_t, vp, vp, vp],
         "xg_rollout_compact": [vp, PD, vp, C.c_size_t, PD, vp, C.c_size_t],
         "xg_nll_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 #include "../../include/xgate.h"
 
 #define XG_CHECK_LAUNCH()                                  \
@@ -92,6 +93,18 @@ __device__ __forceinline__ float wave_max(float v) {
     v = fmaxf(v, xg_dpp<0x141>(v));
     v = fmaxf(v, xg_dpp<0x140>(v));
     return fmaxf(fmaxf(xg_readlane(v, 0), xg_readlane(v, 16)), fmaxf(xg_readlane(v, 32), xg_readlane(v, 48)));
+}
+
+// Kernels that use more than 64 KiB of dynamic LDS must opt in once per kernel AND per device (hipFuncSetAttribute is
+// per device).  `done` is a per-kernel bit set, one bit per device; thread-safe; devices >= 32 opt in on every launch.
+static inline int xg_lds_optin(std::atomic<unsigned>& done, const void* kernel, int bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return XG_EHIP;
+    const unsigned bit = dev >= 0 && dev < 32 ? 1u << dev : 0u;
+    if (bit && (done.load(std::memory_order_acquire) & bit)) return XG_OK;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return XG_EHIP;
+    done.fetch_or(bit, std::memory_order_release);
+    return XG_OK;
 }
 
 static inline int xg_cdiv(int a, int b) { return (a + b - 1) / b; }

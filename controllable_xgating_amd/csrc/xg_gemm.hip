@@ -277,11 +277,9 @@ int launch(hipStream_t st, const GemmArgs& g) {
         else if (hipMemset2DAsync(g.C, sizeof(float) * g.ldc, 0, sizeof(float) * g.N, g.M, st) != hipSuccess) return XG_EHIP;
     }
     const size_t lds = 2 * (TileGeom<BM, AKC>::lds_floats + TileGeom<BN, BKC>::lds_floats) * sizeof(float);
-    static bool attr_done = false;   // > 64 KiB of dynamic LDS must be opted into once per kernel
-    if (!attr_done && lds > 65536) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AKC, BKC, VEC>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XG_EHIP;
-        attr_done = true;
+    if (lds > 65536) {
+        static std::atomic<unsigned> optin{0};
+        XG_TRY(xg_lds_optin(optin, reinterpret_cast<const void*>(&gemm_kernel<BM, BN, AKC, BKC, VEC>), (int)lds));
     }
     hipLaunchKernelGGL((gemm_kernel<BM, BN, AKC, BKC, VEC>), dim3(ntm * ntn * g.splitk), dim3(256), lds, st, g);
     XG_CHECK_LAUNCH();
@@ -317,17 +315,13 @@ int dispatch(hipStream_t st, GemmArgs g, bool vec) {
 
 }  // namespace
 
-static thread_local int tl_gemm_mode = 0;
-void xgk_set_gemm_mode(int mode) { tl_gemm_mode = (mode == 1 || mode == 3) ? mode : 0; }
-int xgk_get_gemm_mode() { return tl_gemm_mode; }
-
-int xgk_gemm(hipStream_t st, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
+int xgk_gemm(hipStream_t st, int mode, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
              const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate) {
     if (M <= 0 || N <= 0) return XG_OK;
     if (K < 0 || !A || !B || !C) return XG_EINVAL;
     // large products may run on the bf16 matrix cores (split-bf16 or plain bf16); skinny / tiny ones stay fp32
-    if (tl_gemm_mode != 0 && M >= 256 && N >= 64 && K >= 64)
-        return xgk_gemm_bf16(st, tl_gemm_mode, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate);
+    if ((mode == 1 || mode == 3) && M >= 256 && N >= 64 && K >= 64)
+        return xgk_gemm_bf16(st, mode, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate);
     GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1, 0};
     const bool akc = !transA;   // A (M,K) row-major -> k contiguous
     const bool bkc = transB;    // B (N,K) row-major -> k contiguous
@@ -349,7 +343,7 @@ extern "C" int xg_gemm_mode(void* stream, int mode, int transA, int transB, int 
                             const float* B, int ldb, float* C, int ldc, const float* bias, int relu, int accumulate) {
     if (mode != 0 && mode != 1 && mode != 3) return XG_EINVAL;
     if (mode == 0 || M <= 0 || N <= 0)
-        return xgk_gemm((hipStream_t)stream, transA != 0, transB != 0, M, N, K, A, lda, B, ldb, C, ldc, bias, relu != 0, accumulate != 0);
+        return xgk_gemm((hipStream_t)stream, 0, transA != 0, transB != 0, M, N, K, A, lda, B, ldb, C, ldc, bias, relu != 0, accumulate != 0);
     if (K < 0 || !A || !B || !C) return XG_EINVAL;
     return xgk_gemm_bf16((hipStream_t)stream, mode, transA != 0, transB != 0, M, N, K, A, lda, B, ldb, C, ldc, bias,
                          relu != 0, accumulate != 0);
@@ -357,6 +351,6 @@ extern "C" int xg_gemm_mode(void* stream, int mode, int transA, int transB, int 
 
 extern "C" int xg_gemm(void* stream, int transA, int transB, int M, int N, int K, const float* A, int lda,
                        const float* B, int ldb, float* C, int ldc, const float* bias, int relu, int accumulate) {
-    return xgk_gemm((hipStream_t)stream, transA != 0, transB != 0, M, N, K, A, lda, B, ldb, C, ldc, bias,
+    return xgk_gemm((hipStream_t)stream, 0, transA != 0, transB != 0, M, N, K, A, lda, B, ldb, C, ldc, bias,
                     relu != 0, accumulate != 0);
 }

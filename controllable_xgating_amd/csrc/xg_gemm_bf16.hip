@@ -229,11 +229,9 @@ int launch(hipStream_t st, const BArgs& g) {
         else if (hipMemset2DAsync(g.C, sizeof(float) * g.ldc, 0, sizeof(float) * g.N, g.M, st) != hipSuccess) return XG_EHIP;
     }
     const size_t lds = (size_t)NP * (plane_elems<AKC>() + plane_elems<BKC>()) * sizeof(unsigned short);
-    static bool attr_done = false;
-    if (!attr_done && lds > 65536) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bs_kernel<NP, AKC, BKC, VEC>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return XG_EHIP;
-        attr_done = true;
+    if (lds > 65536) {
+        static std::atomic<unsigned> optin{0};
+        XG_TRY(xg_lds_optin(optin, reinterpret_cast<const void*>(&gemm_bs_kernel<NP, AKC, BKC, VEC>), (int)lds));
     }
     hipLaunchKernelGGL((gemm_bs_kernel<NP, AKC, BKC, VEC>), dim3(ntm * ntn * g.splitk), dim3(256), lds, st, g);
     XG_CHECK_LAUNCH();

@@ -564,12 +564,8 @@ int xgk_rollout_step(hipStream_t st, int B, const float* logits, const float* un
                    temperature, V, E, t, T, mode, split};
     const size_t lds = (size_t)V * sizeof(float);
     if (t >= 1 && lds <= 150 * 1024) {
-        static bool attr_done = false;               // > 64 KiB of dynamic LDS is opted into once
-        if (!attr_done) {
-            if (hipFuncSetAttribute(reinterpret_cast<const void*>(&rollout_step_kernel<true>),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) return XG_EHIP;
-            attr_done = true;
-        }
+        static std::atomic<unsigned> optin{0};        // > 64 KiB of dynamic LDS is opted into once per device
+        XG_TRY(xg_lds_optin(optin, reinterpret_cast<const void*>(&rollout_step_kernel<true>), 150 * 1024));
         hipLaunchKernelGGL((rollout_step_kernel<true>), dim3(B), dim3(RT), lds, st, a);
     } else {
         hipLaunchKernelGGL((rollout_step_kernel<false>), dim3(B), dim3(RT), 0, st, a);

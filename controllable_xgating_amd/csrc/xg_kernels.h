@@ -3,22 +3,17 @@
 #include "xg_common.h"
 
 // ---- xg_gemm.hip
-int xgk_gemm(hipStream_t st, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
+// `mode` = arithmetic of the product (XgRun.gemm_mode): 0 exact fp32 MFMA, 3 split-bf16, 1 bf16 operands; modes 1 / 3 apply
+// to LARGE products only (M >= 256, N >= 64, K >= 64), everything else is fp32.  An explicit argument: no per-thread state.
+int xgk_gemm(hipStream_t st, int mode, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
              const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate);
 // xg_gemm_bf16.hip: split-bf16 / bf16 arithmetic for large products (planes = 3 or 1)
 int xgk_gemm_bf16(hipStream_t st, int planes, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
                   const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate);
-// arithmetic mode of xgk_gemm for the current host thread (set by the C-ABI entry points from XgRun.gemm_mode)
-void xgk_set_gemm_mode(int mode);
-int xgk_get_gemm_mode();
-struct XgGemmModeGuard {
-    explicit XgGemmModeGuard(int m) { xgk_set_gemm_mode(m); }
-    ~XgGemmModeGuard() { xgk_set_gemm_mode(0); }
-};
 // Y[M,N] (+)= X[M,K] W[N,K]^T + bias   (nn.Linear forward)
-static inline int xgk_linear(hipStream_t st, int M, int N, int K, const float* X, int ldx, const float* W,
+static inline int xgk_linear(hipStream_t st, int mode, int M, int N, int K, const float* X, int ldx, const float* W,
                              const float* bias, float* Y, int ldy, bool relu = false, bool acc = false) {
-    return xgk_gemm(st, false, true, M, N, K, X, ldx, W, K, Y, ldy, bias, relu, acc);
+    return xgk_gemm(st, mode, false, true, M, N, K, X, ldx, W, K, Y, ldy, bias, relu, acc);
 }
 
 // ---- xg_pointwise.hip
@@ -165,7 +160,8 @@ struct SkJob {
     XgDrop drop;
 };
 struct SkArgs { int njobs; int tile0[SK_MAX_JOBS]; SkJob job[SK_MAX_JOBS]; };
-int xgk_skinny(hipStream_t st, SkArgs& a);
+// gemm_mode 1 (plain bf16) rounds the staged chunks to bf16 (LDS-staged kernel); 0 / 3: exact fp32
+int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode);
 
 // ---- xg_pack.hip : weights re-tiled into MFMA-fragment order (caller-owned shadow, XgRun.packed)
 enum { PK_H2A1 = 0, PK_H2A2, PK_DGATE, PK_L1_I2H, PK_L1_A2H, PK_L1_H2H, PK_L2_I2H, PK_L2_A2H, PK_L2_H2H, PK_ENC_RGB, PK_ENC_OPFL,

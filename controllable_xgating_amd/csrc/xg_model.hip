@@ -12,42 +12,28 @@
 #include "xg_common.h"
 #include "xg_kernels.h"
 
-#include <map>
-#include <mutex>
-#include <utility>
+#include <new>
 #include <cstdlib>
 
 namespace {
 
-// ---- one auxiliary stream per (device, caller stream): weight-gradient / token-side GEMMs that nothing downstream waits
-// for run there, under the latency-bound recurrent kernels of the main chain.  Everything is joined back onto the
-// caller's stream before an entry point returns, so the stream semantics of the C ABI are unchanged, and two callers on
-// two streams (the SCST sampled / greedy rollouts) never share an auxiliary stream.  XG_NO_OVERLAP=1 disables it.
+// ---- auxiliary streams: weight-gradient / token-side GEMMs that nothing downstream waits for run there, under the
+// latency-bound recurrent kernels of the main chain.  The two streams and their events belong to an EXPLICIT handle the
+// caller creates (xg_aux_create), passes in XgRun.aux and destroys (xg_aux_destroy): no library-global state.  One handle
+// serves one caller stream at a time (two callers on two streams -- the SCST sampled / greedy rollouts -- use two
+// handles).  Everything is joined back onto the caller's stream before an entry point returns, so the stream semantics of
+// the C ABI are unchanged.  XgRun.aux == NULL (or XG_NO_OVERLAP=1): everything runs on the caller's stream.
 constexpr int XG_NEV = 16;
-struct XgAux { hipStream_t s = nullptr, s2 = nullptr; hipEvent_t ev[XG_NEV]; bool ok = false; };
-XgAux* aux_for(hipStream_t main) {
-    static std::map<std::pair<int, hipStream_t>, XgAux> table;
-    static std::mutex mu;
+struct XgAux { uint32_t magic; int device; hipStream_t s = nullptr, s2 = nullptr; hipEvent_t ev[XG_NEV]; };
+constexpr uint32_t XG_AUX_MAGIC = 0x58474158u;
+XgAux* aux_of(const XgRun* run) {
     static const bool disabled = getenv("XG_NO_OVERLAP") != nullptr;
-    if (disabled) return nullptr;
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess) return nullptr;
-    std::lock_guard<std::mutex> lk(mu);
-    if (table.size() >= 256 && !table.count({dev, main})) return nullptr;     // bounded: no overlap for further streams
-    XgAux& a = table[{dev, main}];
-    if (!a.ok) {
-        if (hipStreamCreateWithFlags(&a.s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        if (hipStreamCreateWithFlags(&a.s2, hipStreamNonBlocking) != hipSuccess) return nullptr;
-        for (int i = 0; i < XG_NEV; ++i)
-            if (hipEventCreateWithFlags(&a.ev[i], hipEventDisableTiming) != hipSuccess) return nullptr;
-        a.ok = true;
-    }
-    return &a;
+    if (disabled || !run || !run->aux) return nullptr;
+    XgAux* a = static_cast<XgAux*>(run->aux);
+    int dev = -1;
+    if (a->magic != XG_AUX_MAGIC || hipGetDevice(&dev) != hipSuccess || dev != a->device) return nullptr;
+    return a;
 }
-// Optional event recorded (on the auxiliary stream, after it has caught up with the main one) at the point of a backward
-// pass where every gradient except the CG encoder's is final: a data-parallel caller starts the all-reduce of that
-// part of the flat gradient buffer there, under the encoder backward (xg_set_grad_event; per host thread).
-thread_local hipEvent_t tl_grad_event = nullptr;
 
 struct Streams {
     hipStream_t main, aux, aux2;              // aux2: a second side chain (the decoder backward's cell-1 recurrence)
@@ -55,7 +41,11 @@ struct Streams {
     int next = 0;
     bool forked = false, forked2 = false;
     int dh_split_step = 0, dh_mark = -1;      // heads_bwd -> decoder_bwd_core hand-off (see heads_bwd)
-    explicit Streams(hipStream_t m) : main(m), aux(m), aux2(m), a(aux_for(m)) { if (a) { aux = a->s; aux2 = a->s2; } }
+    hipEvent_t grad_event = nullptr;          // XgRun.grad_event: recorded when every gradient but the encoder's is final
+    Streams(hipStream_t m, const XgRun* run) : main(m), aux(m), aux2(m), a(aux_of(run)) {
+        if (a) { aux = a->s; aux2 = a->s2; }
+        if (run) grad_event = static_cast<hipEvent_t>(run->grad_event);
+    }
     bool overlap() const { return a != nullptr; }
     // aux may start work that depends on everything enqueued on main so far
     int fork() {
@@ -126,6 +116,7 @@ struct Ws {
     size_t bytes;
     // ---- packed recurrent weights (XgRun.packed; not part of the workspace)
     PackedView pk; bool packed;
+    int gm;                            // XgRun.gemm_mode of this call (0 / 1 / 3), handed to every product explicitly
 };
 
 struct Carver {
@@ -189,14 +180,14 @@ bool dims_ok(const XgDims* d) {
     do { if (hipMemsetAsync((ptr), 0, sizeof(float) * (size_t)(nfloats), st) != hipSuccess) return XG_EHIP; } while (0)
 
 // NN data-gradient GEMM: dX[M,N] (+)= dY[M,Kc] * W[Kc,N]   (W row-major, ldw)
-inline int gemm_nn(hipStream_t st, int M, int N, int Kc, const float* dY, int lddy, const float* W, int ldw,
+inline int gemm_nn(hipStream_t st, int mode, int M, int N, int Kc, const float* dY, int lddy, const float* W, int ldw,
                    float* dX, int lddx, bool acc) {
-    return xgk_gemm(st, false, false, M, N, Kc, dY, lddy, W, ldw, dX, lddx, nullptr, false, acc);
+    return xgk_gemm(st, mode, false, false, M, N, Kc, dY, lddy, W, ldw, dX, lddx, nullptr, false, acc);
 }
 // TN weight-gradient GEMM: dW[N,K] += dY[M,N]^T * X[M,K]
-inline int gemm_tn(hipStream_t st, int Mrows, int N, int K, const float* dY, int lddy, const float* X, int ldx,
+inline int gemm_tn(hipStream_t st, int mode, int Mrows, int N, int K, const float* dY, int lddy, const float* X, int ldx,
                    float* dW, int lddw) {
-    return xgk_gemm(st, true, false, N, K, Mrows, dY, lddy, X, ldx, dW, lddw, nullptr, false, true);
+    return xgk_gemm(st, mode, true, false, N, K, Mrows, dY, lddy, X, ldx, dW, lddw, nullptr, false, true);
 }
 
 // ---- skinny-job builders
@@ -279,7 +270,7 @@ int encoder_fwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgBnSt
     hipStream_t st_main = st;
     for (int m = 0; m < 2; ++m) {
         hipStream_t st = (m == 1 && side) ? ss->aux2 : st_main;
-        XG_TRY(xgk_linear(st, N, R, F[m], feats[m], F[m], emb_w[m], emb_b[m], w.Z[m], R));          // sub_modules.py:121,126
+        XG_TRY(xgk_linear(st, w.gm, N, R, F[m], feats[m], F[m], emb_w[m], emb_b[m], w.Z[m], R));          // sub_modules.py:121,126
         if (run.train) {
             XG_TRY(xgk_bn_stats(st, w.Z[m], N, R, w.bn_mean[m], w.bn_var[m], nullptr));
             if (rmean[m] && rvar[m])
@@ -291,7 +282,7 @@ int encoder_fwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgBnSt
         }
         XG_TRY(xgk_bn_apply(st, w.Z[m], w.bn_mean[m], w.bn_var[m], bn_g[m], bn_b[m], x.feat_mask, w.X[m], N, R,
                             run.bn_eps, xg_make_drop(&run, m == 0 ? XG_SITE_EMB_RGB : XG_SITE_EMB_OPFL, 0)));
-        XG_TRY(xgk_linear(st, N, 4 * R, R, w.X[m], R, wih[m], bih[m], w.PRE[m], 4 * R));          // hoisted over all K frames
+        XG_TRY(xgk_linear(st, w.gm, N, 4 * R, R, w.X[m], R, wih[m], bih[m], w.PRE[m], 4 * R));          // hoisted over all K frames
     }
     if (side) XG_TRY(ss->join2());
     ZERO(w.zeroBR, (size_t)B * R);
@@ -318,22 +309,22 @@ int encoder_fwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgBnSt
                 sk.job[m].bias[0] = bhh[m];
             } else {
                 float* S = m == 0 ? w.S : w.S2;
-                XG_TRY(xgk_linear(st, B, 4 * R, R, hp, ldp, whh[m], bhh[m], S, 4 * R));
+                XG_TRY(xgk_linear(st, w.gm, B, 4 * R, R, hp, ldp, whh[m], bhh[m], S, 4 * R));
                 a.s = S; a.lds_ = 4 * R;
                 XG_TRY(xgk_lstm_fwd(st, a));
             }
         }
-        if (R % 8 == 0) XG_TRY(xgk_skinny(st, sk));
+        if (R % 8 == 0) XG_TRY(xgk_skinny(st, sk, w.gm));
     }
     // cross gates, all frames at once (gated values are not fed back): sub_modules.py:151-152
-    XG_TRY(xgk_linear(st, N, R, R, w.Hs[1], R, p.gate_rgb_w, p.gate_rgb_b, w.GG[0], R, true));
-    XG_TRY(xgk_linear(st, N, R, R, w.Hs[0], R, p.gate_opfl_w, p.gate_opfl_b, w.GG[1], R, true));
+    XG_TRY(xgk_linear(st, w.gm, N, R, R, w.Hs[1], R, p.gate_rgb_w, p.gate_rgb_b, w.GG[0], R, true));
+    XG_TRY(xgk_linear(st, w.gm, N, R, R, w.Hs[0], R, p.gate_opfl_w, p.gate_opfl_b, w.GG[1], R, true));
     for (int m = 0; m < 2; ++m) {
         XgDrop dr = xg_make_drop(&run, m == 0 ? XG_SITE_GATE_RGB : XG_SITE_GATE_OPFL, 0);
         XG_TRY(xgk_gate_fwd(st, w.GG[m], R, w.Hs[m], R, 0, w.Y + (size_t)m * R, 2 * R, N, R, dr, /*step=row%K*/ 1, K,
                             /*b=row/K*/ K, 1 << 30));
     }
-    XG_TRY(xgk_linear(st, N, R, 2 * R, w.Y, 2 * R, p.fusion_w, p.fusion_b, w.Venc, R, true));       // :69-70
+    XG_TRY(xgk_linear(st, w.gm, N, R, 2 * R, w.Y, 2 * R, p.fusion_w, p.fusion_b, w.Venc, R, true));       // :69-70
     XG_TRY(xgk_relu_drop_fwd(st, w.Venc, (int64_t)N * R, xg_make_drop(&run, XG_SITE_FUSION, 0)));
     return XG_OK;
 }
@@ -362,9 +353,9 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
     if (hipMemcpyAsync(w.dVw, dV_in, sizeof(float) * (size_t)N * R, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
     XG_TRY(xgk_relu_drop_bwd(st, w.dVw, w.Venc, (int64_t)N * R, xg_make_drop(&run, XG_SITE_FUSION, 0)));
     XG_TRY(ss.fork());
-    XG_TRY(gemm_tn(sx, N, R, 2 * R, w.dVw, R, w.Y, 2 * R, g.fusion_w, 2 * R));
+    XG_TRY(gemm_tn(sx, w.gm, N, R, 2 * R, w.dVw, R, w.Y, 2 * R, g.fusion_w, 2 * R));
     XG_TRY(xgk_colsum(sx, w.dVw, R, N, R, g.fusion_b));
-    XG_TRY(gemm_nn(st, N, 2 * R, R, w.dVw, R, p.fusion_w, 2 * R, w.dY, 2 * R, false));
+    XG_TRY(gemm_nn(st, w.gm, N, 2 * R, R, w.dVw, R, p.fusion_w, 2 * R, w.dY, 2 * R, false));
     for (int m = 0; m < 2; ++m) {   // y = g*h + h : dpre -> dGG, dh -> dHs (overwrite)
         XgDrop dr = xg_make_drop(&run, m == 0 ? XG_SITE_GATE_RGB : XG_SITE_GATE_OPFL, 0);
         XG_TRY(xgk_gate_bwd(st, w.dY + (size_t)m * R, 2 * R, w.GG[m], R, w.Hs[m], R, 0, w.dGG[m], R, w.dHs[m], R, false,
@@ -373,9 +364,9 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
     XG_TRY(ss.fork());
     for (int m = 0; m < 2; ++m) {   // gate m takes source = hidden of the OTHER modality
         const int o = 1 - m;
-        XG_TRY(gemm_tn(sx, N, R, R, w.dGG[m], R, w.Hs[o], R, g_gate_w[m], R));
+        XG_TRY(gemm_tn(sx, w.gm, N, R, R, w.dGG[m], R, w.Hs[o], R, g_gate_w[m], R));
         XG_TRY(xgk_colsum(sx, w.dGG[m], R, N, R, g_gate_b[m]));
-        XG_TRY(gemm_nn(st, N, R, R, w.dGG[m], R, gate_w[m], R, w.dHs[o], R, true));
+        XG_TRY(gemm_nn(st, w.gm, N, R, R, w.dGG[m], R, gate_w[m], R, w.dHs[o], R, true));
     }
     XgRun nodrop = run; nodrop.drop_p = 0.f;
     int curc = 0;
@@ -414,7 +405,7 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
                 sk.job[m].nseg = 1;
                 sk.job[m].seg[0] = seg_nn(w, m == 0 ? PKB_ENC_RGB : PKB_ENC_OPFL, w.dS[m] + (size_t)i * 4 * R, K * 4 * R, whh[m], R, 4 * R);
             }
-            XG_TRY(xgk_skinny(st, sk));
+            XG_TRY(xgk_skinny(st, sk, w.gm));
         }
     }
     XG_TRY(ss.fork2());                          // before modality 0's work is enqueued on the main stream
@@ -424,13 +415,13 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
         if (hipMemsetAsync(w.Hprev[m], 0, sizeof(float) * (size_t)N * R, sx) != hipSuccess) return XG_EHIP;
         if (K > 1)   // one strided 2-D copy covers all videos: rows = B, cols = (K-1)*R
             XG_TRY(xgk_copy2d(sx, w.Hprev[m] + R, K * R, w.Hs[m], K * R, B, (K - 1) * R, false));
-        XG_TRY(gemm_tn(sx, N, 4 * R, R, w.dS[m], 4 * R, w.Hprev[m], R, g_whh[m], R));
-        XG_TRY(gemm_tn(sx, N, 4 * R, R, w.dS[m], 4 * R, w.X[m], R, g_wih[m], R));
+        XG_TRY(gemm_tn(sx, w.gm, N, 4 * R, R, w.dS[m], 4 * R, w.Hprev[m], R, g_whh[m], R));
+        XG_TRY(gemm_tn(sx, w.gm, N, 4 * R, R, w.dS[m], 4 * R, w.X[m], R, g_wih[m], R));
         XG_TRY(xgk_colsum3(sx, w.dS[m], 4 * R, N, 4 * R, g_bih[m], g_bhh[m], nullptr));
         // the optical-flow modality's input-side backward runs beside the rgb one (second auxiliary stream, forked above)
         hipStream_t st_outer = st;
         hipStream_t st = (m == 1 && ss.overlap()) ? ss.aux2 : st_outer;
-        XG_TRY(gemm_nn(st, N, R, 4 * R, w.dS[m], 4 * R, wih[m], R, w.dX[m], R, false));
+        XG_TRY(gemm_nn(st, w.gm, N, R, 4 * R, w.dS[m], 4 * R, wih[m], R, w.dX[m], R, false));
         // BatchNorm + ReLU + dropout + mask backward (sub_modules.py:121-123)
         ZERO(w.bn_s1[m], R); ZERO(w.bn_s2[m], R);
         XG_TRY(xgk_bn_bwd_reduce(st, w.dX[m], w.X[m], w.Z[m], w.bn_mean[m], w.bn_var[m], x.feat_mask, N, R, run.bn_eps,
@@ -439,7 +430,7 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
         XG_TRY(xgk_axpy(st, g_bn_g[m], w.bn_s2[m], 1.f, R));
         XG_TRY(xgk_bn_bwd_apply(st, w.dX[m], w.Z[m], w.bn_mean[m], w.bn_var[m], bn_g[m], w.bn_s1[m], w.bn_s2[m], N, R,
                                 run.bn_eps, run.train != 0));
-        XG_TRY(gemm_tn(st, N, R, F[m], w.dX[m], R, feats[m], F[m], g_emb_w[m], F[m]));
+        XG_TRY(gemm_tn(st, w.gm, N, R, F[m], w.dX[m], R, feats[m], F[m], g_emb_w[m], F[m]));
         XG_TRY(xgk_colsum(st, w.dX[m], R, N, R, g_emb_b[m]));
     }
     return ss.chain2_into_aux();              // the caller's join() of aux then covers the second side chain too
@@ -460,9 +451,9 @@ int init_hidden(hipStream_t st, const XgDims& d, const XgParams& p, const float*
             sk.job[j] = job_store(B, R, out[j], R, false);
             sk.job[j].nseg = 1; sk.job[j].seg[0] = seg_nt(w.vbar, R, wt[j], R, R); sk.job[j].bias[0] = bs[j];
         }
-        return xgk_skinny(st, sk);
+        return xgk_skinny(st, sk, w.gm);
     }
-    for (int j = 0; j < 4; ++j) XG_TRY(xgk_linear(st, B, R, R, w.vbar, R, wt[j], bs[j], out[j], R));
+    for (int j = 0; j < 4; ++j) XG_TRY(xgk_linear(st, w.gm, B, R, R, w.vbar, R, wt[j], bs[j], out[j], R));
     return XG_OK;
 }
 
@@ -470,7 +461,7 @@ int init_hidden(hipStream_t st, const XgDims& d, const XgParams& p, const float*
 int init_and_vproj(Streams& ss, const XgDims& d, const XgParams& p, const float* feat_mask, Ws& w) {
     const int N = d.B * d.K;
     XG_TRY(ss.fork2());
-    XG_TRY(xgk_linear(ss.aux2, N, d.A, d.R, w.Venc, d.R, p.v2a_w, p.v2a_b, w.vproj, d.A));
+    XG_TRY(xgk_linear(ss.aux2, w.gm, N, d.A, d.R, w.Venc, d.R, p.v2a_w, p.v2a_b, w.vproj, d.A));
     XG_TRY(init_hidden(ss.main, d, p, w.Venc, feat_mask, w, w.H1, w.C1, w.H2, w.C2));
     return ss.join2();
 }
@@ -578,7 +569,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
             j.epi = SK_EPI_ZERO; j.M = 1; j.N = B * R + ((B + 3) & ~3); j.C = w.AFU;
         }
         k1.njobs = n1;
-        XG_TRY(xgk_skinny(st, k1));
+        XG_TRY(xgk_skinny(st, k1, w.gm));
         // ---- launch 2: attention || [cell 1] || S2' = h2 W_h2h2 + b
         if (fused_attn) {
             SkJob& j = k2.job[n2++];
@@ -596,7 +587,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         }
         if (!s2_first) s2_job(k2.job[n2++]);
         k2.njobs = n2;
-        if (n2 > 0) XG_TRY(xgk_skinny(st, k2));
+        if (n2 > 0) XG_TRY(xgk_skinny(st, k2, w.gm));
         if (!fused_attn) XG_TRY(xgk_attn_fwd(st, s.P, vproj, V, p.a2w_w, s.alpha, s.af, B, d.K, R, A));
         // ---- launch 3: cell 2 = h1' W_i2h + af W_a2h + S2'                                                :684
         k3.njobs = 1;
@@ -609,7 +600,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
             SkSeg& g = k3.job[0].seg[1];
             g.row_scale = w.ATS; g.scaled_out = s.af; g.ld_out = R; g.ex = s.alpha; g.ex_ld = d.K; g.ex_K = d.K;
         }
-        XG_TRY(xgk_skinny(st, k3));
+        XG_TRY(xgk_skinny(st, k3, w.gm));
         return XG_OK;
     }
     if (!s.xt) return XG_EINVAL;                 // the token gather exists on the packed path only
@@ -625,7 +616,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         if (s.pre1) {
             k1.job[1].nseg = 1;
             k1.job[1].seg[0] = seg_nt(s.h1, R, p.l1_h2h_w, R, R); k1.job[1].bias[0] = p.l1_h2h_b;
-            XG_TRY(xgk_skinny(st, k1));
+            XG_TRY(xgk_skinny(st, k1, w.gm));
         } else {
             // rollout form: [p || POS gate] first (the gate feeds cell 1), then cell 1 with all three products
             SkJob cell1 = k1.job[1];
@@ -634,7 +625,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
             k1.job[1].seg[0] = seg_nt(s.xt, E, p.dgate_w, E, E); k1.job[1].bias[0] = p.dgate_b;
             k1.job[1].gate_t = s.pos; k1.job[1].ldt = R; k1.job[1].gate_y = s.posg; k1.job[1].ldy = R;
             k1.job[1].drop = xg_make_drop(&run, XG_SITE_DGATE, s.t);
-            XG_TRY(xgk_skinny(st, k1));
+            XG_TRY(xgk_skinny(st, k1, w.gm));
             SkArgs k1b{};
             k1b.njobs = 1;
             k1b.job[0] = cell1;
@@ -642,7 +633,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
             k1b.job[0].seg[0] = seg_nt(s.xt, E, p.l1_i2h_w, E, E); k1b.job[0].bias[0] = p.l1_i2h_b;
             k1b.job[0].seg[1] = seg_nt(s.posg, R, p.l1_a2h_w, R, R); k1b.job[0].bias[1] = p.l1_a2h_b;
             k1b.job[0].seg[2] = seg_nt(s.h1, R, p.l1_h2h_w, R, R); k1b.job[0].bias[2] = p.l1_h2h_b;
-            XG_TRY(xgk_skinny(st, k1b));
+            XG_TRY(xgk_skinny(st, k1b, w.gm));
         }
         XG_TRY(xgk_attn_fwd(st, s.P, vproj, V, p.a2w_w, s.alpha, s.af, B, d.K, R, A));
         SkArgs k2{};
@@ -652,27 +643,27 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         k2.job[0].seg[0] = seg_nt(s.h1o, R, p.l2_i2h_w, R, R); k2.job[0].bias[0] = p.l2_i2h_b;
         k2.job[0].seg[1] = seg_nt(s.af, R, p.l2_a2h_w, R, R); k2.job[0].bias[1] = p.l2_a2h_b;
         k2.job[0].seg[2] = seg_nt(s.h2, R, p.l2_h2h_w, R, R); k2.job[0].bias[2] = p.l2_h2h_b;
-        XG_TRY(xgk_skinny(st, k2));
+        XG_TRY(xgk_skinny(st, k2, w.gm));
         return XG_OK;
     }
     // generic path (R not a multiple of 8): plain GEMMs + pointwise cell kernels
     if (!s.pre1) {
-        XG_TRY(xgk_linear(st, B, R, E, s.xt, E, p.dgate_w, p.dgate_b, s.gp, R, true));
+        XG_TRY(xgk_linear(st, w.gm, B, R, E, s.xt, E, p.dgate_w, p.dgate_b, s.gp, R, true));
         XG_TRY(xgk_gate_fwd(st, s.gp, R, s.pos, R, 0, s.posg, R, B, R, xg_make_drop(&run, XG_SITE_DGATE, s.t), B, 1 << 30, 1, B));
     }
-    XG_TRY(xgk_gemm(st, false, true, B, A, R, s.h1, R, p.h2a_w, 2 * R, s.P, A, p.h2a_b, false, false));
-    XG_TRY(xgk_gemm(st, false, true, B, A, R, s.h2, R, p.h2a_w + R, 2 * R, s.P, A, nullptr, false, true));
+    XG_TRY(xgk_gemm(st, w.gm, false, true, B, A, R, s.h1, R, p.h2a_w, 2 * R, s.P, A, p.h2a_b, false, false));
+    XG_TRY(xgk_gemm(st, w.gm, false, true, B, A, R, s.h2, R, p.h2a_w + R, 2 * R, s.P, A, nullptr, false, true));
     XG_TRY(xgk_attn_fwd(st, s.P, vproj, V, p.a2w_w, s.alpha, s.af, B, d.K, R, A));
-    XG_TRY(xgk_linear(st, B, 4 * R, R, s.h1, R, p.l1_h2h_w, p.l1_h2h_b, w.S, 4 * R));
+    XG_TRY(xgk_linear(st, w.gm, B, 4 * R, R, s.h1, R, p.l1_h2h_w, p.l1_h2h_b, w.S, 4 * R));
     if (!s.pre1) {
-        XG_TRY(xgk_linear(st, B, 4 * R, E, s.xt, E, p.l1_i2h_w, p.l1_i2h_b, w.S, 4 * R, false, true));
-        XG_TRY(xgk_linear(st, B, 4 * R, R, s.posg, R, p.l1_a2h_w, p.l1_a2h_b, w.S, 4 * R, false, true));
+        XG_TRY(xgk_linear(st, w.gm, B, 4 * R, E, s.xt, E, p.l1_i2h_w, p.l1_i2h_b, w.S, 4 * R, false, true));
+        XG_TRY(xgk_linear(st, w.gm, B, 4 * R, R, s.posg, R, p.l1_a2h_w, p.l1_a2h_b, w.S, 4 * R, false, true));
     }
     a.s = w.S; a.lds_ = 4 * R;
     XG_TRY(xgk_lstm_fwd(st, a));
-    XG_TRY(xgk_linear(st, B, 4 * R, R, s.h1o, R, p.l2_i2h_w, p.l2_i2h_b, w.S2, 4 * R));
-    XG_TRY(xgk_linear(st, B, 4 * R, R, s.af, R, p.l2_a2h_w, p.l2_a2h_b, w.S2, 4 * R, false, true));
-    XG_TRY(xgk_linear(st, B, 4 * R, R, s.h2, R, p.l2_h2h_w, p.l2_h2h_b, w.S2, 4 * R, false, true));
+    XG_TRY(xgk_linear(st, w.gm, B, 4 * R, R, s.h1o, R, p.l2_i2h_w, p.l2_i2h_b, w.S2, 4 * R));
+    XG_TRY(xgk_linear(st, w.gm, B, 4 * R, R, s.af, R, p.l2_a2h_w, p.l2_a2h_b, w.S2, 4 * R, false, true));
+    XG_TRY(xgk_linear(st, w.gm, B, 4 * R, R, s.h2, R, p.l2_h2h_w, p.l2_h2h_b, w.S2, 4 * R, false, true));
     c.s = w.S2; c.lds_ = 4 * R;
     XG_TRY(xgk_lstm_fwd(st, c));
     return XG_OK;
@@ -684,11 +675,11 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
 int decoder_tokens_xe(hipStream_t sx, const XgDims& d, const XgParams& p, const XgBatch& x, const XgRun& run, Ws& w) {
     const int B = d.B, R = d.R, E = d.E, T = d.T, TB = T * B;
     XG_TRY(xgk_embed_gather(sx, p.embed_w, E, x.seq, /*inner=*/B, /*s_inner=*/T, /*s_outer=*/1, TB, d.V, w.Xe, E));
-    XG_TRY(xgk_linear(sx, TB, R, E, w.Xe, E, p.dgate_w, p.dgate_b, w.GP, R, true));                 // :682 gate, all steps
+    XG_TRY(xgk_linear(sx, w.gm, TB, R, E, w.Xe, E, p.dgate_w, p.dgate_b, w.GP, R, true));                 // :682 gate, all steps
     XG_TRY(xgk_gate_fwd(sx, w.GP, R, x.pos_feats, R, B, w.POSG, R, TB, R, xg_make_drop(&run, XG_SITE_DGATE, 0),
                         /*step=row/B*/ B, 1 << 30, /*b=row%B*/ 1, B));
-    XG_TRY(xgk_linear(sx, TB, 4 * R, E, w.Xe, E, p.l1_i2h_w, p.l1_i2h_b, w.PRE1, 4 * R));
-    XG_TRY(xgk_linear(sx, TB, 4 * R, R, w.POSG, R, p.l1_a2h_w, p.l1_a2h_b, w.PRE1, 4 * R, false, true));
+    XG_TRY(xgk_linear(sx, w.gm, TB, 4 * R, E, w.Xe, E, p.l1_i2h_w, p.l1_i2h_b, w.PRE1, 4 * R));
+    XG_TRY(xgk_linear(sx, w.gm, TB, 4 * R, R, w.POSG, R, p.l1_a2h_w, p.l1_a2h_b, w.PRE1, 4 * R, false, true));
     return XG_OK;
 }
 
@@ -715,7 +706,7 @@ int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatc
         XG_TRY(core_step(st, d, p, run, w, w.Venc, w.vproj, s));
         if (th > 0 && t == th - 1) {
             XG_TRY(ss.fork());
-            XG_TRY(xgk_linear(ss.aux, th * B, d.V, R, w.H2 + BR, R, p.logit_w, p.logit_b, w.LOGITS, d.V));
+            XG_TRY(xgk_linear(ss.aux, w.gm, th * B, d.V, R, w.H2 + BR, R, p.logit_w, p.logit_b, w.LOGITS, d.V));
             *logit_rows_done = th * B;
         }
     }
@@ -727,12 +718,12 @@ int heads_fwd_logits(Streams& ss, const XgDims& d, const XgParams& p, const XgRu
     hipStream_t st = ss.main;
     const int B = d.B, R = d.R;
     const float* Hout = w.H2 + (size_t)B * R;
-    XG_TRY(xgk_linear(st, rows - rows_done, d.V, R, Hout + (size_t)rows_done * R, R, p.logit_w, p.logit_b,
+    XG_TRY(xgk_linear(st, w.gm, rows - rows_done, d.V, R, Hout + (size_t)rows_done * R, R, p.logit_w, p.logit_b,
                       w.LOGITS + (size_t)rows_done * d.V, d.V));
-    XG_TRY(xgk_linear(st, rows, d.H, R, Hout, R, p.cls0_w, p.cls0_b, w.HC, d.H, true));
+    XG_TRY(xgk_linear(st, w.gm, rows, d.H, R, Hout, R, p.cls0_w, p.cls0_b, w.HC, d.H, true));
     XG_TRY(xgk_gate_fwd(st, w.HC, d.H, nullptr, 0, 0, nullptr, 0, rows, d.H, xg_make_drop(&run, XG_SITE_CLS, 0), B, 1 << 30,
                         1, B));
-    XG_TRY(xgk_linear(st, rows, d.C, d.H, w.HC, d.H, p.cls3_w, p.cls3_b, w.CL, d.C));
+    XG_TRY(xgk_linear(st, w.gm, rows, d.C, d.H, w.HC, d.H, p.cls3_w, p.cls3_b, w.CL, d.C));
     return ss.join();                         // first-half logits from the auxiliary stream
 }
 
@@ -784,7 +775,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
             sk.job[0] = job_store(B, R, daf, R, true);   sk.job[0].nseg = 1; sk.job[0].seg[0] = seg_nn(w, PKB_L2_A2H, ds2, 4 * R, p.l2_a2h_w, R, 4 * R);
             sk.job[1] = job_store(B, R, dh2p, R, true);  sk.job[1].nseg = 1; sk.job[1].seg[0] = seg_nn(w, PKB_L2_H2H, ds2, 4 * R, p.l2_h2h_w, R, 4 * R);
             allow_split(sk, 0, w); allow_split(sk, 1, w);
-            XG_TRY(xgk_skinny(st, sk));
+            XG_TRY(xgk_skinny(st, sk, w.gm));
         }
         XG_TRY(xgk_attn_bwd(st, daf, R, w.P + (size_t)t * B * A, w.vproj, w.Venc, p.a2w_w, w.ALPHA + (size_t)t * B * K,
                             w.DE + (size_t)t * B * K, dp, B, K, R, A));
@@ -796,7 +787,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
             sk.job[0].nseg = 1;
             sk.job[0].seg[0] = seg_nn(w, PKB_H2A2, dp, A, p.h2a_w + R, 2 * R, A);
             allow_split(sk, 0, w);
-            XG_TRY(xgk_skinny(st, sk));
+            XG_TRY(xgk_skinny(st, sk, w.gm));
         }
         cur ^= 1;
     }
@@ -806,8 +797,8 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     hipStream_t sx = ss.aux;                  // parameter gradients that only need chain 2
     hipStream_t s1 = ss.aux2;                 // chain 1 and what depends on it
     // what cell 1's output receives from chain 2, all steps at once:  DH1X[t] = ds2[t] W_i2h2 + dp[t+1] W_h2a[:, :R]
-    XG_TRY(gemm_nn(s1, TB, R, 4 * R, w.DS2, 4 * R, p.l2_i2h_w, R, w.DH1X, R, false));
-    if (T > 1) XG_TRY(gemm_nn(s1, (T - 1) * B, R, A, w.DP + (size_t)B * A, A, p.h2a_w, 2 * R, w.DH1X, R, true));
+    XG_TRY(gemm_nn(s1, w.gm, TB, R, 4 * R, w.DS2, 4 * R, p.l2_i2h_w, R, w.DH1X, R, false));
+    if (T > 1) XG_TRY(gemm_nn(s1, w.gm, (T - 1) * B, R, A, w.DP + (size_t)B * A, A, p.h2a_w, 2 * R, w.DH1X, R, true));
     int cur1 = 0;
     auto cell1_bwd = [&](int t, int c) {
         LstmBwdArgs a{};
@@ -832,15 +823,15 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         sk.job[0].nseg = 1;
         sk.job[0].seg[0] = seg_nn(w, PKB_L1_H2H, ds1, 4 * R, p.l1_h2h_w, R, 4 * R);
         allow_split(sk, 0, w); sk.job[0].tickets = w.tickets + 2 * 1024;       // chain 1 runs beside chain 2 / the encoder: own counters
-        XG_TRY(xgk_skinny(s1, sk));
+        XG_TRY(xgk_skinny(s1, sk, w.gm));
         cur1 ^= 1;
     }
     // the attention query of step 0 read the INITIAL h1
-    XG_TRY(gemm_nn(s1, B, R, A, w.DP, A, p.h2a_w, 2 * R, w.dst[cur1][0], R, true));
+    XG_TRY(gemm_nn(s1, w.gm, B, R, A, w.DP, A, p.h2a_w, 2 * R, w.dst[cur1][0], R, true));
     // ---- after the loop.  Main chain (the encoder backward waits for it): dVproj -> dV.  Everything else is a
     // parameter gradient and goes to the auxiliary stream, under the encoder's recurrent backward.
     XG_TRY(xgk_attn_bwd_post(st, w.P, w.vproj, p.a2w_w, w.DE, w.DVPROJ, g.a2w_w, T, B, K, A));
-    XG_TRY(gemm_nn(st, N, R, A, w.DVPROJ, A, p.v2a_w, R, w.DV, R, false));
+    XG_TRY(gemm_nn(st, w.gm, N, R, A, w.DVPROJ, A, p.v2a_w, R, w.DV, R, false));
     XG_TRY(xgk_attn_dV(st, w.ALPHA, w.DAF, R, (int64_t)BR, w.DV, T, B, K, R, true));
     // gradients wrt the initial state -> img_embed_* (init_hidden; vbar is detached: SAModel.py:59-62)
     {
@@ -849,38 +840,38 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         float* gb[4] = {g.ih1_b, g.ic1_b, g.ih2_b, g.ic2_b};
         for (int j = 0; j < 4; ++j) {
             hipStream_t sj = j < 2 ? s1 : sx;     // h1 / c1 come out of chain 1
-            XG_TRY(gemm_tn(sj, B, R, R, gst[j], R, w.vbar, R, gw[j], R));
+            XG_TRY(gemm_tn(sj, w.gm, B, R, R, gst[j], R, w.vbar, R, gw[j], R));
             XG_TRY(xgk_colsum(sj, gst[j], R, B, R, gb[j]));
         }
     }
     // batched weight gradients over all T steps
-    XG_TRY(gemm_tn(sx, TB, 4 * R, R, w.DS2, 4 * R, w.H1 + BR, R, g.l2_i2h_w, R));
-    XG_TRY(gemm_tn(sx, TB, 4 * R, R, w.DS2, 4 * R, w.AF, R, g.l2_a2h_w, R));
-    XG_TRY(gemm_tn(sx, TB, 4 * R, R, w.DS2, 4 * R, w.H2, R, g.l2_h2h_w, R));
+    XG_TRY(gemm_tn(sx, w.gm, TB, 4 * R, R, w.DS2, 4 * R, w.H1 + BR, R, g.l2_i2h_w, R));
+    XG_TRY(gemm_tn(sx, w.gm, TB, 4 * R, R, w.DS2, 4 * R, w.AF, R, g.l2_a2h_w, R));
+    XG_TRY(gemm_tn(sx, w.gm, TB, 4 * R, R, w.DS2, 4 * R, w.H2, R, g.l2_h2h_w, R));
     XG_TRY(xgk_colsum3(sx, w.DS2, 4 * R, TB, 4 * R, g.l2_i2h_b, g.l2_a2h_b, g.l2_h2h_b));
-    XG_TRY(gemm_tn(s1, TB, 4 * R, R, w.DS1, 4 * R, w.H1, R, g.l1_h2h_w, R));
-    XG_TRY(gemm_tn(s1, TB, 4 * R, E, w.DS1, 4 * R, w.Xe, E, g.l1_i2h_w, E));
-    XG_TRY(gemm_tn(s1, TB, 4 * R, R, w.DS1, 4 * R, w.POSG, R, g.l1_a2h_w, R));
+    XG_TRY(gemm_tn(s1, w.gm, TB, 4 * R, R, w.DS1, 4 * R, w.H1, R, g.l1_h2h_w, R));
+    XG_TRY(gemm_tn(s1, w.gm, TB, 4 * R, E, w.DS1, 4 * R, w.Xe, E, g.l1_i2h_w, E));
+    XG_TRY(gemm_tn(s1, w.gm, TB, 4 * R, R, w.DS1, 4 * R, w.POSG, R, g.l1_a2h_w, R));
     XG_TRY(xgk_colsum3(s1, w.DS1, 4 * R, TB, 4 * R, g.l1_i2h_b, g.l1_a2h_b, g.l1_h2h_b));
-    XG_TRY(gemm_tn(sx, TB, A, R, w.DP, A, w.H1, R, g.h2a_w, 2 * R));
-    XG_TRY(gemm_tn(sx, TB, A, R, w.DP, A, w.H2, R, g.h2a_w + R, 2 * R));
+    XG_TRY(gemm_tn(sx, w.gm, TB, A, R, w.DP, A, w.H1, R, g.h2a_w, 2 * R));
+    XG_TRY(gemm_tn(sx, w.gm, TB, A, R, w.DP, A, w.H2, R, g.h2a_w + R, 2 * R));
     XG_TRY(xgk_colsum(sx, w.DP, A, TB, A, g.h2a_b));
     // input side of cell 1: pos' gate, embedding
-    XG_TRY(gemm_nn(s1, TB, R, 4 * R, w.DS1, 4 * R, p.l1_a2h_w, R, w.DPOSG, R, false));
-    XG_TRY(gemm_nn(s1, TB, E, 4 * R, w.DS1, 4 * R, p.l1_i2h_w, E, w.DXe, E, false));
+    XG_TRY(gemm_nn(s1, w.gm, TB, R, 4 * R, w.DS1, 4 * R, p.l1_a2h_w, R, w.DPOSG, R, false));
+    XG_TRY(gemm_nn(s1, w.gm, TB, E, 4 * R, w.DS1, 4 * R, p.l1_i2h_w, E, w.DXe, E, false));
     XG_TRY(xgk_gate_bwd(s1, w.DPOSG, R, w.GP, R, x.pos_feats, R, B, w.DGP, R, nullptr, 0, false, TB, R,
                         xg_make_drop(&run, XG_SITE_DGATE, 0)));
-    XG_TRY(gemm_tn(s1, TB, R, E, w.DGP, R, w.Xe, E, g.dgate_w, E));
+    XG_TRY(gemm_tn(s1, w.gm, TB, R, E, w.DGP, R, w.Xe, E, g.dgate_w, E));
     XG_TRY(xgk_colsum(s1, w.DGP, R, TB, R, g.dgate_b));
-    XG_TRY(gemm_nn(s1, TB, E, R, w.DGP, R, p.dgate_w, E, w.DXe, E, true));
+    XG_TRY(gemm_nn(s1, w.gm, TB, E, R, w.DGP, R, p.dgate_w, E, w.DXe, E, true));
     XG_TRY(xgk_embed_scatter_add(s1, g.embed_w, E, tok, B, tok_bstride, tok_tstride, TB, d.V, w.DXe, E));
     // the hoisted projection's parameter gradients need dVproj (main stream, above)
     XG_TRY(ss.fork());
-    XG_TRY(gemm_tn(sx, N, A, R, w.DVPROJ, A, w.Venc, R, g.v2a_w, R));
+    XG_TRY(gemm_tn(sx, w.gm, N, A, R, w.DVPROJ, A, w.Venc, R, g.v2a_w, R));
     XG_TRY(xgk_colsum(sx, w.DVPROJ, A, N, A, g.v2a_b));
     XG_TRY(ss.chain2_into_aux());             // aux now also covers the second side chain
     // everything but two_spatial_encoder.* is final once the auxiliary stream gets here (it has waited for main above)
-    if (tl_grad_event && hipEventRecord(tl_grad_event, sx) != hipSuccess) return XG_EHIP;
+    if (ss.grad_event && hipEventRecord(ss.grad_event, sx) != hipSuccess) return XG_EHIP;
     return XG_OK;
 }
 
@@ -898,22 +889,22 @@ int heads_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams& g
     const int r0 = th * B;
     ss.dh_split_step = th; ss.dh_mark = -1;
     if (th > 0) {
-        XG_TRY(gemm_nn(ss.aux, r0, R, d.V, w.LOGITS, d.V, p.logit_w, R, w.DH2OUT, R, false));
+        XG_TRY(gemm_nn(ss.aux, w.gm, r0, R, d.V, w.LOGITS, d.V, p.logit_w, R, w.DH2OUT, R, false));
         ss.dh_mark = ss.mark();
         if (ss.dh_mark == -2) return XG_EHIP;
     }
     // dW_logit / db: parameter gradients, under the loop as well
-    XG_TRY(gemm_tn(ss.aux, rows, d.V, R, w.LOGITS, d.V, Hout, R, g.logit_w, R));
+    XG_TRY(gemm_tn(ss.aux, w.gm, rows, d.V, R, w.LOGITS, d.V, Hout, R, g.logit_w, R));
     XG_TRY(xgk_colsum(ss.aux, w.LOGITS, d.V, rows, d.V, g.logit_b));
-    XG_TRY(gemm_nn(st, rows - r0, R, d.V, w.LOGITS + (size_t)r0 * d.V, d.V, p.logit_w, R, w.DH2OUT + (size_t)r0 * R, R, false));
+    XG_TRY(gemm_nn(st, w.gm, rows - r0, R, d.V, w.LOGITS + (size_t)r0 * d.V, d.V, p.logit_w, R, w.DH2OUT + (size_t)r0 * R, R, false));
     if (have_cls) {
-        XG_TRY(gemm_tn(st, rows, d.C, d.H, w.DCL, d.C, w.HC, d.H, g.cls3_w, d.H));
+        XG_TRY(gemm_tn(st, w.gm, rows, d.C, d.H, w.DCL, d.C, w.HC, d.H, g.cls3_w, d.H));
         XG_TRY(xgk_colsum(st, w.DCL, d.C, rows, d.C, g.cls3_b));
-        XG_TRY(gemm_nn(st, rows, d.H, d.C, w.DCL, d.C, p.cls3_w, d.H, w.DHC, d.H, false));
+        XG_TRY(gemm_nn(st, w.gm, rows, d.H, d.C, w.DCL, d.C, p.cls3_w, d.H, w.DHC, d.H, false));
         XG_TRY(xgk_relu_drop_bwd(st, w.DHC, w.HC, (int64_t)rows * d.H, xg_make_drop(&run, XG_SITE_CLS, 0)));
-        XG_TRY(gemm_tn(st, rows, d.H, R, w.DHC, d.H, Hout, R, g.cls0_w, R));
+        XG_TRY(gemm_tn(st, w.gm, rows, d.H, R, w.DHC, d.H, Hout, R, g.cls0_w, R));
         XG_TRY(xgk_colsum(st, w.DHC, d.H, rows, d.H, g.cls0_b));
-        XG_TRY(gemm_nn(st, rows, R, d.H, w.DHC, d.H, p.cls0_w, R, w.DH2OUT, R, true));
+        XG_TRY(gemm_nn(st, w.gm, rows, R, d.H, w.DHC, d.H, p.cls0_w, R, w.DH2OUT, R, true));
     }
     return XG_OK;
 }
@@ -1000,10 +991,10 @@ extern "C" int xg_encoder_fwd(void* stream, const XgDims* d, const XgParams* p, 
                               const XgRun* run, void* ws, size_t ws_bytes, float* V) {
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !x || !run || !V || !x->feats_rgb || !x->feats_opfl || !x->feat_mask) return XG_EINVAL;
-    XgGemmModeGuard mode_guard(run->gemm_mode);
+    w.gm = (run->gemm_mode == 1 || run->gemm_mode == 3) ? run->gemm_mode : 0;
     attach_packed(w, *d, run);
     hipStream_t st = (hipStream_t)stream;
-    Streams es(st);
+    Streams es(st, run);
     XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w, &es));
     if (hipMemcpyAsync(V, w.Venc, sizeof(float) * (size_t)d->B * d->K * d->R, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
     return XG_OK;
@@ -1012,9 +1003,9 @@ extern "C" int xg_encoder_bwd(void* stream, const XgDims* d, const XgParams* p, 
                               const XgRun* run, void* ws, size_t ws_bytes, const float* dV) {
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !g || !x || !run || !dV) return XG_EINVAL;
-    XgGemmModeGuard mode_guard(run->gemm_mode);
+    w.gm = (run->gemm_mode == 1 || run->gemm_mode == 3) ? run->gemm_mode : 0;
     attach_packed(w, *d, run);
-    Streams ss((hipStream_t)stream);
+    Streams ss((hipStream_t)stream, run);
     XG_TRY(encoder_bwd(ss, *d, *p, *g, *x, *run, w, dV));
     return ss.join();
 }
@@ -1025,13 +1016,36 @@ extern "C" int xg_init_hidden(void* stream, const XgDims* d, const XgParams* p, 
     const size_t BR = (size_t)d->B * d->R;
     return init_hidden((hipStream_t)stream, *d, *p, V, feat_mask, w, state, state + BR, state + 2 * BR, state + 3 * BR);
 }
-extern "C" int xg_set_grad_event(void* hip_event) {
-    tl_grad_event = static_cast<hipEvent_t>(hip_event);
+extern "C" int xg_aux_destroy(void* aux) {
+    XgAux* a = static_cast<XgAux*>(aux);
+    if (!a) return XG_OK;
+    if (a->magic != XG_AUX_MAGIC) return XG_EINVAL;
+    for (int i = 0; i < XG_NEV; ++i) if (a->ev[i]) (void)hipEventDestroy(a->ev[i]);
+    if (a->s) (void)hipStreamDestroy(a->s);
+    if (a->s2) (void)hipStreamDestroy(a->s2);
+    a->magic = 0;
+    delete a;
     return XG_OK;
 }
-extern "C" int xg_vproj(void* stream, const XgDims* d, const XgParams* p, const float* V, float* vproj) {
+extern "C" int xg_aux_create(void** aux) {
+    if (!aux) return XG_EINVAL;
+    *aux = nullptr;
+    XgAux* a = new (std::nothrow) XgAux();
+    if (!a) return XG_EHIP;
+    a->magic = XG_AUX_MAGIC;
+    for (int i = 0; i < XG_NEV; ++i) a->ev[i] = nullptr;
+    bool ok = hipGetDevice(&a->device) == hipSuccess &&
+              hipStreamCreateWithFlags(&a->s, hipStreamNonBlocking) == hipSuccess &&
+              hipStreamCreateWithFlags(&a->s2, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; ok && i < XG_NEV; ++i) ok = hipEventCreateWithFlags(&a->ev[i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { xg_aux_destroy(a); return XG_EHIP; }
+    *aux = a;
+    return XG_OK;
+}
+extern "C" int xg_vproj(void* stream, const XgDims* d, const XgParams* p, const float* V, float* vproj, const XgRun* run) {
     if (!dims_ok(d) || !p || !V || !vproj) return XG_EINVAL;
-    return xgk_linear((hipStream_t)stream, d->B * d->K, d->A, d->R, V, d->R, p->v2a_w, p->v2a_b, vproj, d->A);
+    const int mode = run && (run->gemm_mode == 1 || run->gemm_mode == 3) ? run->gemm_mode : 0;     // same arithmetic as the rollouts' own v2a(V)
+    return xgk_linear((hipStream_t)stream, mode, d->B * d->K, d->A, d->R, V, d->R, p->v2a_w, p->v2a_b, vproj, d->A);
 }
 
 extern "C" int xg_step_fwd(void* stream, const XgDims* d, const XgParams* p, const int64_t* tokens, const float* xt_mask,
@@ -1039,7 +1053,7 @@ extern "C" int xg_step_fwd(void* stream, const XgDims* d, const XgParams* p, con
                            void* ws, size_t ws_bytes, float* state, float* logp, float* alpha) {
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !tokens || !V || !vproj || !pos_feats || !run || !state) return XG_EINVAL;
-    XgGemmModeGuard mode_guard(run->gemm_mode);
+    w.gm = (run->gemm_mode == 1 || run->gemm_mode == 3) ? run->gemm_mode : 0;
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, R = d->R, E = d->E;
     const size_t BR = (size_t)B * R;
@@ -1061,7 +1075,7 @@ extern "C" int xg_step_fwd(void* stream, const XgDims* d, const XgParams* p, con
     }
     XG_TRY(core_step(st, *d, *p, *run, w, V, vproj, s));
     if (logp) {
-        XG_TRY(xgk_linear(st, B, d->V, R, state + 2 * BR, R, p->logit_w, p->logit_b, w.LOGITS, d->V));
+        XG_TRY(xgk_linear(st, w.gm, B, d->V, R, state + 2 * BR, R, p->logit_w, p->logit_b, w.LOGITS, d->V));
         XG_TRY(xgk_log_softmax(st, w.LOGITS, d->V, logp, d->V, B, d->V, 1, 1, false));
     }
     return XG_OK;
@@ -1071,11 +1085,11 @@ extern "C" int xg_forward_xe(void* stream, const XgDims* d, const XgParams* p, c
                              const XgRun* run, void* ws, size_t ws_bytes, float* logp, float* cat_logp) {
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !x || !run || !logp || !x->seq || !x->seq_mask || !x->pos_feats) return XG_EINVAL;
-    XgGemmModeGuard mode_guard(run->gemm_mode);
+    w.gm = (run->gemm_mode == 1 || run->gemm_mode == 3) ? run->gemm_mode : 0;
     attach_packed(w, *d, run);
     hipStream_t st = (hipStream_t)stream;
     const int TB = d->T * d->B;
-    Streams ss(st);
+    Streams ss(st, run);
     int rows_done = 0;
     XG_TRY(ss.fork());
     XG_TRY(decoder_tokens_xe(ss.aux, *d, *p, *x, *run, w));
@@ -1091,7 +1105,7 @@ extern "C" int xg_backward_xe(void* stream, const XgDims* d, const XgParams* p, 
                               const XgRun* run, void* ws, size_t ws_bytes, const float* dlogp, const float* dcat_logp) {
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !g || !x || !run || !x->seq || !x->seq_mask) return XG_EINVAL;
-    XgGemmModeGuard mode_guard(run->gemm_mode);
+    w.gm = (run->gemm_mode == 1 || run->gemm_mode == 3) ? run->gemm_mode : 0;
     attach_packed(w, *d, run);
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, T = d->T, TB = T * B;
@@ -1106,7 +1120,7 @@ extern "C" int xg_backward_xe(void* stream, const XgDims* d, const XgParams* p, 
         XG_TRY(xgk_log_softmax(st, w.CL, d->C, w.CL, d->C, TB, d->C, 1, 1, false));
         XG_TRY(xgk_log_softmax_bwd(st, dcat_logp, w.CL, d->C, w.DCL, d->C, TB, d->C, B, T, 2));
     }
-    Streams ss(st);
+    Streams ss(st, run);
     XG_TRY(heads_bwd(ss, *d, *p, *g, *run, w, TB, dcat_logp != nullptr));
     XG_TRY(decoder_bwd_core(ss, *d, *p, *g, *x, *run, w, x->seq_mask, T, 1, x->seq, T, 1));
     XG_TRY(encoder_bwd(ss, *d, *p, *g, *x, *run, w, w.DV));
@@ -1120,12 +1134,12 @@ extern "C" int xg_forward_ss(void* stream, const XgDims* d, const XgParams* p, c
     if (!p || !x || !run || !logp || !x->seq || !x->seq_mask || !x->pos_feats) return XG_EINVAL;
     const bool ss = run->train && ss_prob > 0.f;
     if (ss && (!u_sel || !u_tok)) return XG_EINVAL;
-    XgGemmModeGuard mode_guard(run->gemm_mode);
+    w.gm = (run->gemm_mode == 1 || run->gemm_mode == 3) ? run->gemm_mode : 0;
     attach_packed(w, *d, run);
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, R = d->R, E = d->E, A = d->A, T = d->T, TB = T * B, N = B * d->K;
     const size_t BR = (size_t)B * R;
-    Streams es(st);
+    Streams es(st, run);
     XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w, &es));
     XG_TRY(init_and_vproj(es, *d, *p, x->feat_mask, w));
     int64_t* sampled = reinterpret_cast<int64_t*>(w.DXe);       // scratch (free until the backward pass)
@@ -1147,15 +1161,15 @@ extern "C" int xg_forward_ss(void* stream, const XgDims* d, const XgParams* p, c
         s.g1 = w.G1 + (size_t)t * B * 4 * R; s.g2 = w.G2 + (size_t)t * B * 4 * R; s.t = t;
         XG_TRY(core_step(st, *d, *p, *run, w, w.Venc, w.vproj, s));
         float* lg = w.LOGITS + (size_t)t * B * d->V;
-        XG_TRY(xgk_linear(st, B, d->V, R, s.h2o, R, p->logit_w, p->logit_b, lg, d->V));
+        XG_TRY(xgk_linear(st, w.gm, B, d->V, R, s.h2o, R, p->logit_w, p->logit_b, lg, d->V));
         XG_TRY(xgk_log_softmax(st, lg, d->V, lg, d->V, B, d->V, 1, 1, false));        // LOGITS now holds log-probs (time-major)
     }
     // (T*B,V) time-major log-probs -> (B,T,V); classifier head batched over T as in xg_forward_xe
     XG_TRY(xgk_log_softmax(st, w.LOGITS, d->V, logp, d->V, TB, d->V, B, T, true));    // log_softmax of log-probs = identity
     const float* Hout = w.H2 + BR;
-    XG_TRY(xgk_linear(st, TB, d->H, R, Hout, R, p->cls0_w, p->cls0_b, w.HC, d->H, true));
+    XG_TRY(xgk_linear(st, w.gm, TB, d->H, R, Hout, R, p->cls0_w, p->cls0_b, w.HC, d->H, true));
     XG_TRY(xgk_gate_fwd(st, w.HC, d->H, nullptr, 0, 0, nullptr, 0, TB, d->H, xg_make_drop(run, XG_SITE_CLS, 0), B, 1 << 30, 1, B));
-    XG_TRY(xgk_linear(st, TB, d->C, d->H, w.HC, d->H, p->cls3_w, p->cls3_b, w.CL, d->C));
+    XG_TRY(xgk_linear(st, w.gm, TB, d->C, d->H, w.HC, d->H, p->cls3_w, p->cls3_b, w.CL, d->C));
     if (cat_logp) XG_TRY(xgk_log_softmax(st, w.CL, d->C, cat_logp, d->C, TB, d->C, B, T, true));
     return XG_OK;
 }
@@ -1164,7 +1178,7 @@ extern "C" int xg_backward_ss(void* stream, const XgDims* d, const XgParams* p, 
                               const XgRun* run, void* ws, size_t ws_bytes, const float* dlogp, const float* dcat_logp) {
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !g || !x || !run || !x->seq || !x->seq_mask) return XG_EINVAL;
-    XgGemmModeGuard mode_guard(run->gemm_mode);
+    w.gm = (run->gemm_mode == 1 || run->gemm_mode == 3) ? run->gemm_mode : 0;
     attach_packed(w, *d, run);
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, T = d->T, TB = T * B;
@@ -1177,7 +1191,7 @@ extern "C" int xg_backward_ss(void* stream, const XgDims* d, const XgParams* p, 
         XG_TRY(xgk_log_softmax(st, w.CL, d->C, w.CL, d->C, TB, d->C, 1, 1, false));
         XG_TRY(xgk_log_softmax_bwd(st, dcat_logp, w.CL, d->C, w.DCL, d->C, TB, d->C, B, T, 2));
     }
-    Streams ss(st);
+    Streams ss(st, run);
     XG_TRY(heads_bwd(ss, *d, *p, *g, *run, w, TB, dcat_logp != nullptr));
     XG_TRY(decoder_bwd_core(ss, *d, *p, *g, *x, *run, w, x->seq_mask, T, 1, w.TOK, 1, B));
     XG_TRY(encoder_bwd(ss, *d, *p, *g, *x, *run, w, w.DV));
@@ -1189,11 +1203,11 @@ extern "C" int xg_xe_loss_fwd(void* stream, const XgDims* d, const XgParams* p, 
                               void* ws, size_t ws_bytes, float* losses) {
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !x || !run || !losses || !x->seq || !x->seq_mask || !x->pos_feats) return XG_EINVAL;
-    XgGemmModeGuard mode_guard(run->gemm_mode);
+    w.gm = (run->gemm_mode == 1 || run->gemm_mode == 3) ? run->gemm_mode : 0;
     attach_packed(w, *d, run);
     hipStream_t st = (hipStream_t)stream;
     const int TB = d->T * d->B;
-    Streams ss(st);
+    Streams ss(st, run);
     int rows_done = 0;
     XG_TRY(ss.fork());
     XG_TRY(decoder_tokens_xe(ss.aux, *d, *p, *x, *run, w));
@@ -1215,7 +1229,7 @@ extern "C" int xg_xe_loss_bwd(void* stream, const XgDims* d, const XgParams* p, 
                               const float* dloss_dev, const XgRun* run, void* ws, size_t ws_bytes) {
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !g || !x || !run || !x->seq || !x->seq_mask) return XG_EINVAL;
-    XgGemmModeGuard mode_guard(run->gemm_mode);
+    w.gm = (run->gemm_mode == 1 || run->gemm_mode == 3) ? run->gemm_mode : 0;
     attach_packed(w, *d, run);
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, T = d->T, TB = T * B;
@@ -1226,7 +1240,7 @@ extern "C" int xg_xe_loss_bwd(void* stream, const XgDims* d, const XgParams* p, 
         XG_TRY(xgk_xent_bwd(st, w.DCL, d->C, cap_classes, x->seq_mask, class_mask, B, T, d->C, 0, w.LSEC, w.sums + 2,
                             dloss_dev, weight_class));
     }
-    Streams ss(st);
+    Streams ss(st, run);
     XG_TRY(heads_bwd(ss, *d, *p, *g, *run, w, TB, cls));
     XG_TRY(decoder_bwd_core(ss, *d, *p, *g, *x, *run, w, x->seq_mask, T, 1, x->seq, T, 1));
     XG_TRY(encoder_bwd(ss, *d, *p, *g, *x, *run, w, w.DV));
@@ -1240,7 +1254,7 @@ static int rollout_impl(hipStream_t st, const XgDims* d, const XgParams* p, cons
                         int64_t* seq, float* seq_logp, int32_t* n_steps, int split) {
     const int B = d->B, R = d->R, E = d->E, A = d->A, T = d->T, N = B * d->K;
     const size_t BR = (size_t)B * R;
-    Streams es(st);
+    Streams es(st, run);
     XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w, &es));
     XG_TRY(init_and_vproj(es, *d, *p, x->feat_mask, w));
     if (hipMemsetAsync(w.alive, 0, sizeof(int32_t) * 4, st) != hipSuccess) return XG_EHIP;   // alive[i] = running max finishing step
@@ -1264,7 +1278,7 @@ static int rollout_impl(hipStream_t st, const XgDims* d, const XgParams* p, cons
         s.g1 = w.G1 + (size_t)t * B * 4 * R; s.g2 = w.G2 + (size_t)t * B * 4 * R; s.t = t;
         XG_TRY(core_step(st, *d, *p, *run, w, w.Venc, w.vproj, s));
         if (t + 1 < T)     // the step at t = L is computed and its logits discarded in the reference (:182,:217)
-            XG_TRY(xgk_linear(st, B, d->V, R, s.h2o, R, p->logit_w, p->logit_b, w.LOGITS + (size_t)t * B * d->V, d->V));
+            XG_TRY(xgk_linear(st, w.gm, B, d->V, R, s.h2o, R, p->logit_w, p->logit_b, w.LOGITS + (size_t)t * B * d->V, d->V));
     }
     XG_TRY(xgk_rollout_finalize(st, w.alive, n_steps, T - 1, split < B ? 2 : 1));
     return XG_OK;
@@ -1277,7 +1291,7 @@ extern "C" int xg_rollout(void* stream, const XgDims* d, const XgParams* p, cons
     if (!p || !x || !run || !seq || !seq_logp || !n_steps || !x->pos_feats || d->T < 2) return XG_EINVAL;
     if (mode == XG_ROLLOUT_SAMPLE && (!uniforms || !(temperature > 0.f))) return XG_EINVAL;
     if (mode == XG_ROLLOUT_REPLAY && !forced) return XG_EINVAL;
-    XgGemmModeGuard mode_guard(run->gemm_mode);
+    w.gm = (run->gemm_mode == 1 || run->gemm_mode == 3) ? run->gemm_mode : 0;
     attach_packed(w, *d, run);
     return rollout_impl((hipStream_t)stream, d, p, bn, x, run, mode, uniforms, forced, temperature, w, seq, seq_logp, n_steps, d->B);
 }
@@ -1288,7 +1302,7 @@ extern "C" int xg_rollout_pair(void* stream, const XgDims* d2, const XgParams* p
     Ws w; XG_TRY(check(d2, ws2, ws2_bytes, &w));
     if (!p || !x2 || !run || !seq || !seq_logp || !n_steps || !x2->pos_feats || d2->T < 2) return XG_EINVAL;
     if (n_sample <= 0 || n_sample >= d2->B || !uniforms || !(temperature > 0.f)) return XG_EINVAL;
-    XgGemmModeGuard mode_guard(run->gemm_mode);
+    w.gm = (run->gemm_mode == 1 || run->gemm_mode == 3) ? run->gemm_mode : 0;
     attach_packed(w, *d2, run);
     return rollout_impl((hipStream_t)stream, d2, p, bn, x2, run, XG_ROLLOUT_SAMPLE, uniforms, nullptr, temperature, w, seq,
                         seq_logp, n_steps, n_sample);
@@ -1342,14 +1356,14 @@ extern "C" int xg_rollout_bwd(void* stream, const XgDims* d, const XgParams* p, 
                               const XgRun* run, void* ws, size_t ws_bytes, const float* dseq_logp) {
     Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
     if (!p || !g || !x || !run || !dseq_logp || d->T < 2) return XG_EINVAL;
-    XgGemmModeGuard mode_guard(run->gemm_mode);
+    w.gm = (run->gemm_mode == 1 || run->gemm_mode == 3) ? run->gemm_mode : 0;
     attach_packed(w, *d, run);
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, T = d->T;
     // dlogits of step t-1's output from the token drawn at step t (SAModel.py:195)
     // LOGITS holds raw logits, LSE their log-sum-exp; every step in one launch
     XG_TRY(xgk_rollout_dlogits_lse(st, w.LOGITS, w.LSE, w.TOK + B, dseq_logp, T - 1, B, d->V, T - 1));
-    Streams ss(st);
+    Streams ss(st, run);
     XG_TRY(heads_bwd(ss, *d, *p, *g, *run, w, (T - 1) * B, false));
     XG_TRY(decoder_bwd_core(ss, *d, *p, *g, *x, *run, w, w.UNF, 1, B, w.TOK, 1, B));
     XG_TRY(encoder_bwd(ss, *d, *p, *g, *x, *run, w, w.DV));

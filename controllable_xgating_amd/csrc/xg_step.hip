@@ -706,12 +706,12 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
 }  // namespace
 
 // Generic route for shapes the tile layout cannot take (n-contiguous B with N % 4 != 0): plain tiled GEMMs.
-static int skinny_fallback(hipStream_t st, const SkJob& jb) {
+static int skinny_fallback(hipStream_t st, const SkJob& jb, int gemm_mode) {
     if (jb.epi != SK_EPI_STORE) return XG_EINVAL;     // LSTM / GATE jobs never use an n-contiguous B
     for (int s = 0; s < jb.nseg; ++s) {
         const SkSeg& sg = jb.seg[s];
         const bool last = s == jb.nseg - 1;
-        XG_TRY(xgk_gemm(st, false, !sg.b_ncontig, jb.M, jb.N, sg.K, sg.A, sg.lda, sg.B, sg.ldb, jb.C, jb.ldc,
+        XG_TRY(xgk_gemm(st, gemm_mode, false, !sg.b_ncontig, jb.M, jb.N, sg.K, sg.A, sg.lda, sg.B, sg.ldb, jb.C, jb.ldc,
                         s == 0 ? jb.bias[0] : nullptr, last && jb.relu && !jb.bias[1] && !jb.bias[2],
                         s > 0 || jb.accumulate));
     }
@@ -725,7 +725,7 @@ extern "C" int xg_debug_sk_trace(long long* out, int n) {
 }
 #endif
 
-int xgk_skinny(hipStream_t st, SkArgs& a) {
+int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
     if (a.njobs <= 0 || a.njobs > SK_MAX_JOBS) return XG_EINVAL;
     bool vec = true, generic = false, packed = true, special = false, has_attn = false;
     int tiles = 0, max_tiles = 0;
@@ -776,10 +776,10 @@ int xgk_skinny(hipStream_t st, SkArgs& a) {
         }
     }
     if (generic) {
-        for (int j = 0; j < a.njobs; ++j) XG_TRY(skinny_fallback(st, a.job[j]));
+        for (int j = 0; j < a.njobs; ++j) XG_TRY(skinny_fallback(st, a.job[j], gemm_mode));
         return XG_OK;
     }
-    const bool bf16 = xgk_get_gemm_mode() == 1;      // plain-bf16 mode covers the recurrent products too
+    const bool bf16 = gemm_mode == 1;      // plain-bf16 mode covers the recurrent products too
     static const bool no_packed = getenv("XG_NO_PACKED") != nullptr;
     const bool fast = vec && packed && !bf16 && !no_packed;
     // cross-workgroup split-K for launches that would leave most CUs idle (every job must allow it)
@@ -804,7 +804,7 @@ int xgk_skinny(hipStream_t st, SkArgs& a) {
         for (int j = 0; j < a.njobs; ++j) {
             SkArgs one{};
             one.njobs = 1; one.job[0] = a.job[j];
-            XG_TRY(xgk_skinny(st, one));
+            XG_TRY(xgk_skinny(st, one, gemm_mode));
         }
         return XG_OK;
     }

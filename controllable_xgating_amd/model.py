@@ -40,22 +40,16 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
-class _grad_event:
-    """Arms the library's "decoder-side gradients are final" event (xg_set_grad_event) around ONE backward call, on
-    the thread that makes the call (autograd runs custom backwards on its own worker thread).  No-op unless a
-    data-parallel helper (train.GradSync) has put an event on the model."""
-
-    def __init__(self, model):
-        self.ev = getattr(model, "_grad_event", None)
-
-    def __enter__(self):
-        if self.ev is not None:
-            nv.check(nv.lib().xg_set_grad_event(C.c_void_p(self.ev.cuda_event)), "xg_set_grad_event")
-
-    def __exit__(self, *exc):
-        if self.ev is not None:
-            nv.lib().xg_set_grad_event(None)
-        return False
+def _with_grad_event(model, run):
+    """XgRun for ONE backward call: carries the "decoder-side gradients are final" event (XgRun.grad_event) when a
+    data-parallel helper (train.GradSync) has armed one on the model; otherwise the forward's XgRun as it is."""
+    ev = getattr(model, "_grad_event", None)
+    if ev is None:
+        return run
+    r = nv.XgRun()
+    C.memmove(C.byref(r), C.byref(run), C.sizeof(nv.XgRun))
+    r.grad_event = ev.cuda_event
+    return r
 
 
 class _Holder(nn.Module):
@@ -172,6 +166,7 @@ class SAModel(nn.Module):
         self._pool = _WorkspacePool()
         self._flat = None
         self._call = 0
+        self._aux = {}               # (device, stream) -> xg_aux_create handle (side streams of the entry points)
         self._packed = None          # recurrent weights in MFMA-fragment order (xg_pack_weights), refreshed lazily
         self._packed_key = None
         self._packed_epoch = 0
@@ -277,6 +272,24 @@ class SAModel(nn.Module):
         through torch (optimizers, load_state_dict, copy_) are noticed by themselves (tensor version counters)."""
         self._packed_epoch += 1
 
+    def _aux_handle(self):
+        """Side-stream handle (include/xgate.h: xg_aux_create) for the current device and stream, created on first use."""
+        st = torch.cuda.current_stream()
+        key = (st.device.index, st.cuda_stream)
+        h = self._aux.get(key)
+        if h is None:
+            out = C.c_void_p()
+            nv.check(nv.lib().xg_aux_create(C.byref(out)), "xg_aux_create")
+            h = self._aux[key] = out.value
+        return h
+
+    def __del__(self):
+        try:
+            for h in getattr(self, "_aux", {}).values():
+                nv.lib().xg_aux_destroy(C.c_void_p(h))
+        except Exception:
+            pass
+
     def _packed_ptr(self):
         """Device pointer of the packed recurrent weights (include/xgate.h: xg_pack_weights), valid for the current
         parameter values; None when the shapes do not allow it (rnn_size % 8 != 0)."""
@@ -312,6 +325,7 @@ class SAModel(nn.Module):
         r.bn_momentum, r.bn_eps = 0.1, 1e-5
         r.gemm_mode = {"fp32": 0, "bf16": 1, "bf16x3": 3}[self.precision]
         r.packed = self._packed_ptr()
+        r.aux = self._aux_handle()
         return r
 
     @staticmethod
@@ -410,11 +424,13 @@ class SAModel(nn.Module):
         wp, wn = _ws_ptr(ws)
         feats = feats.detach().contiguous().float()
         st = torch.cat([state[0][0], state[0][1], state[1][0], state[1][1]], 0).contiguous().float()
-        key = (feats.data_ptr(), feats._version, B, K)
+        v2a = self.lstmcore.v2a
+        key = (feats.data_ptr(), feats._version, B, K, v2a.weight._version, v2a.bias._version, self._packed_epoch, self.precision)
         if getattr(self, "_vproj_key", None) != key:
             self._vproj_cache = torch.empty(B, K, self.att_size, dtype=torch.float32, device=feats.device)
-            ps = self._params_struct()
-            nv.check(nv.lib().xg_vproj(_stream(), C.byref(d), C.byref(ps), nv.ptr(feats), nv.ptr(self._vproj_cache)), "xg_vproj")
+            ps, run0 = self._params_struct(), self._run(False)
+            nv.check(nv.lib().xg_vproj(_stream(), C.byref(d), C.byref(ps), nv.ptr(feats), nv.ptr(self._vproj_cache), C.byref(run0)),
+                     "xg_vproj")
             self._vproj_key = key
             self._vproj_feats = feats
         logp = torch.empty(B, self.vocab_size, dtype=torch.float32, device=feats.device)
@@ -528,9 +544,9 @@ class _XEFunction(torch.autograd.Function):
         dl = None if dlogp is None else dlogp.contiguous().float()
         dc = None if dcat is None else dcat.contiguous().float()
         fn = nv.lib().xg_backward_ss if ctx.ss else nv.lib().xg_backward_xe
-        with _grad_event(model):
-            nv.check(fn(_stream(), C.byref(d), C.byref(ps), C.byref(gs), C.byref(b), C.byref(ctx.run),
-                        wp, wn, nv.ptr(dl), nv.ptr(dc)), "xg_backward_ss" if ctx.ss else "xg_backward_xe")
+        run = _with_grad_event(model, ctx.run)
+        nv.check(fn(_stream(), C.byref(d), C.byref(ps), C.byref(gs), C.byref(b), C.byref(run),
+                    wp, wn, nv.ptr(dl), nv.ptr(dc)), "xg_backward_ss" if ctx.ss else "xg_backward_xe")
         model._pool.give(d, dev, ctx.ws)
         ctx.ws = None
         return (None,) * 9 + tuple(_grad_views(model, g))
@@ -568,9 +584,9 @@ class _XELossFunction(torch.autograd.Function):
         wp, wn = _ws_ptr(ctx.ws)
         ps = model._params_struct()
         dl = dloss.detach().contiguous().float().to(dev)
-        with _grad_event(model):
-            nv.check(nv.lib().xg_xe_loss_bwd(_stream(), C.byref(d), C.byref(ps), C.byref(gs), C.byref(b), nv.ptr(ctx.cc),
-                                             nv.ptr(ctx.cm), ctx.wc, nv.ptr(dl), C.byref(ctx.run), wp, wn), "xg_xe_loss_bwd")
+        run = _with_grad_event(model, ctx.run)
+        nv.check(nv.lib().xg_xe_loss_bwd(_stream(), C.byref(d), C.byref(ps), C.byref(gs), C.byref(b), nv.ptr(ctx.cc),
+                                         nv.ptr(ctx.cm), ctx.wc, nv.ptr(dl), C.byref(run), wp, wn), "xg_xe_loss_bwd")
         model._pool.give(d, dev, ctx.ws)
         ctx.ws = None
         return (None,) * 11 + tuple(_grad_views(model, g))
@@ -625,9 +641,9 @@ class _RolloutFunction(torch.autograd.Function):
         T = d.T
         full = torch.zeros(d.B, T - 1, dtype=torch.float32, device=dev)
         full[:, :dslp.shape[1]] = dslp
-        with _grad_event(model):
-            nv.check(nv.lib().xg_rollout_bwd(_stream(), C.byref(d), C.byref(ps), C.byref(gs), C.byref(b), C.byref(ctx.run),
-                                             wp, wn, nv.ptr(full)), "xg_rollout_bwd")
+        run = _with_grad_event(model, ctx.run)
+        nv.check(nv.lib().xg_rollout_bwd(_stream(), C.byref(d), C.byref(ps), C.byref(gs), C.byref(b), C.byref(run),
+                                         wp, wn, nv.ptr(full)), "xg_rollout_bwd")
         model._pool.give(d, dev, ctx.ws)
         ctx.ws = None
         return (None,) * 11 + tuple(_grad_views(model, g))
@@ -687,9 +703,9 @@ class _RolloutPairFunction(torch.autograd.Function):
         ps = model._params_struct()
         full = torch.zeros(d.B, d.T - 1, dtype=torch.float32, device=dev)
         full[:, :dslp.shape[1]] = dslp
-        with _grad_event(model):
-            nv.check(nv.lib().xg_rollout_bwd(_stream(), C.byref(d), C.byref(ps), C.byref(gs), C.byref(b), C.byref(ctx.run),
-                                             wp, wn, nv.ptr(full)), "xg_rollout_bwd")
+        run = _with_grad_event(model, ctx.run)
+        nv.check(nv.lib().xg_rollout_bwd(_stream(), C.byref(d), C.byref(ps), C.byref(gs), C.byref(b), C.byref(run),
+                                         wp, wn, nv.ptr(full)), "xg_rollout_bwd")
         model._pool.give(d, dev, ctx.ws)
         ctx.ws = None
         return (None,) * 8 + tuple(_grad_views(model, g))

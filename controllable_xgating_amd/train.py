@@ -80,7 +80,7 @@ def allreduce_gradients(model, group=None):
 class GradSync:
     """Overlaps most of the gradient all-reduce with the tail of the backward pass.  The flat gradient buffer is in
     xg_param_name order: [two_spatial_encoder.* | everything else].  The library records an event
-    (xg_set_grad_event) when "everything else" is final -- the CG encoder's backward is what remains -- and the
+    (XgRun.grad_event) when "everything else" is final -- the CG encoder's backward is what remains -- and the
     all-reduce of that suffix (~80 % of the bytes) is issued on a side stream that waits for the event, so RCCL runs
     under the encoder backward; the encoder prefix follows after the backward.  Same sums, same 1/world, two
     collectives in a fixed order on every rank.  Usage: sync = GradSync(model); per iteration:

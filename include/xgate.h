@@ -95,13 +95,21 @@ typedef struct XgRun {
     int32_t save;         /* 1: keep activations in the workspace for a following *_bwd */
     float bn_momentum;    /* 0.1 */
     float bn_eps;         /* 1e-5 */
-    int32_t gemm_mode;    /* arithmetic of the LARGE products (tiled GEMMs): 0 = fp32 MFMA, exact fp32 (default);
-                             3 = split-bf16 (three bf16 planes, 6 MFMAs, fp32-class accuracy); 1 = bf16 operands,
-                             fp32 accumulate (BASELINE.json configs[4], tolerance 1e-2).  The recurrent per-step
-                             products, the cells and all reductions are always fp32. */
+    int32_t gemm_mode;    /* arithmetic of the products: 0 = fp32 MFMA, exact fp32 (default); 3 = split-bf16 for the LARGE
+                             products (three bf16 planes, 6 MFMAs, fp32-class accuracy), per-step products fp32;
+                             1 = bf16 operands, fp32 accumulate, for the large AND the per-step products
+                             (BASELINE.json configs[4], tolerance 1e-2).  Accumulation, the cell arithmetic, the
+                             attention and every reduction are fp32 in all modes. */
     int32_t reserved0;    /* keep 0 */
     const void *packed;   /* optional: the recurrent weights in MFMA-fragment order (xg_pack_weights), valid for the
                              CURRENT parameter values; NULL = stream the plain weights through LDS.  Same results. */
+    void *aux;            /* optional: handle from xg_aux_create -- side streams on which the entry points overlap work that
+                             nothing downstream waits for; everything is joined back onto `stream` before the call
+                             returns.  NULL = one stream.  One handle per caller stream in use at a time. */
+    void *grad_event;     /* optional hipEvent_t (data parallel): backward entry points record it at the moment
+                             every gradient except two_spatial_encoder.* is final, so that a caller who keeps the gradients
+                             in xg_param_name order can start the RCCL all-reduce of that suffix under the CG encoder's
+                             backward.  NULL = not recorded. */
 } XgRun;
 
 enum { XG_ROLLOUT_GREEDY = 0, XG_ROLLOUT_SAMPLE = 1, XG_ROLLOUT_REPLAY = 2 };
@@ -142,7 +150,8 @@ int xg_init_hidden(void *stream, const XgDims *d, const XgParams *p, const float
                    const float *feat_mask, void *ws, size_t ws_bytes, float *state);
 
 /* ---- hoisted attention projection: lstmcore.v2a(V) (caption_src/sub_modules.py:677) ---- */
-int xg_vproj(void *stream, const XgDims *d, const XgParams *p, const float *V, float *vproj /* (B,K,A) */);
+int xg_vproj(void *stream, const XgDims *d, const XgParams *p, const float *V, float *vproj /* (B,K,A) */,
+             const XgRun *run /* gemm_mode only; NULL = fp32 */);
 
 /* ---- one decoder step: LSTMCore_two_layer_gate.forward + logit/log_softmax
  *      (caption_src/sub_modules.py:671-687, caption_src/SAModel.py:117-127 get_logprobs_state).
@@ -189,11 +198,10 @@ int xg_xe_loss_bwd(void *stream, const XgDims *d, const XgParams *p, const XgPar
                    const XgBatch *x, const int64_t *cap_classes, const float *class_mask,
                    float weight_class, const float *dloss_dev, const XgRun *run, void *ws, size_t ws_bytes);
 
-/* Data parallel (the reference is single-GPU): register a hipEvent_t that the NEXT backward
- * entry points called from this host thread record at the moment every gradient except two_spatial_encoder.*
- * is final (the CG encoder's backward is what remains).  A caller that keeps the gradients in xg_param_name order
- * can start the RCCL all-reduce of that suffix there, overlapped with the encoder backward.  NULL unregisters. */
-int xg_set_grad_event(void *hip_event);
+/* ---- side streams (see XgRun.aux).  The handle owns two HIP streams and a few events on the CURRENT device; create it
+ *      once per caller stream, destroy it when done.  The library keeps no global state. */
+int xg_aux_create(void **aux);
+int xg_aux_destroy(void *aux);
 
 /* ---- rollouts: SAModel.sample (caption_src/SAModel.py:163-219), beam_size = 1 ----
  * mode GREEDY: argmax (ties -> lowest index, :186); SAMPLE: inverse-CDF draw from

@@ -59,7 +59,7 @@ def test_bad_arguments_return_error_codes_without_a_gpu(built):
     assert L.xg_clip_adam(None, 10, None, None, None, None, 1e-3, 0.9, 0.999, 1e-8, 0.0, 0, 0.1) == -1
     d = pg.make_dims(**CFG["tiny"])
     dims = nv.XgDims(d.B, d.K, d.R, d.A, d.E, d.V, d.C, d.H, d.F1, d.F2, d.L + 1)
-    assert L.xg_vproj(None, ctypes.byref(dims), None, None, None) == -1
+    assert L.xg_vproj(None, ctypes.byref(dims), None, None, None, None) == -1
 
 
 def test_state_dict_contract_matches_reference_names_and_shapes(built):

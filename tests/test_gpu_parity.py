@@ -602,7 +602,7 @@ def test_scst_rollout_modes_equal_the_sequential_reference_order():
 
 
 def test_gradsync_overlapped_allreduce_single_rank():
-    """train.GradSync: the two-part all-reduce started from the library's grad-ready event (xg_set_grad_event) leaves
+    """train.GradSync: the two-part all-reduce started from the library's grad-ready event (XgRun.grad_event) leaves
     the same gradients as the plain path (single-rank RCCL group: the collective is the identity, the event / stream /
     slicing mechanics are what is exercised), for the fused XE backward and the rollout backward."""
     import torch.distributed as dist
@@ -779,7 +779,7 @@ def test_raw_step_fwd_with_mask_and_alpha_vs_reference_golden():
     ps, run = model._params_struct(), model._run(False)
     vproj = torch.empty(B, K, d.A, device="cuda")
     L = nv.lib()
-    nv.check(L.xg_vproj(_stream(), C.byref(dd), C.byref(ps), nv.ptr(V), nv.ptr(vproj)), "xg_vproj")
+    nv.check(L.xg_vproj(_stream(), C.byref(dd), C.byref(ps), nv.ptr(V), nv.ptr(vproj), C.byref(run)), "xg_vproj")
     ws = model._pool.shared(dd, V.device)
     wp, wn = _ws_ptr(ws)
     state = st0.clone()
