@@ -142,6 +142,40 @@ __global__ void nll_bwd_kernel(const int64_t* target, const float* mask, const f
     dlogp[(size_t)i * V + tgt_of(target, b, t, T, roll)] = -scale * (scale_dev ? scale_dev[0] : 1.f) * m / sums[1];
 }
 
+// ---- RewardCriterion (caption_src/SAModel.py:259-267): loss = -sum(slp * reward * mask) / sum(mask) with
+// mask[:, 0] = 1, mask[:, t] = (seq[:, t-1] > 0).  n_dev (device int32, may be null) is the reference's early-exit width:
+// columns t >= n do not exist there, so they carry no mask here -- the caller keeps full-width (m, L) tensors and never
+// has to bring n to the host.  reward element (b, t) at reward[b * rs_b + t * rs_t] (rs_t = 0: one value per video,
+// caption_src/myutils.py:75-76).
+__device__ __forceinline__ float reward_mask(const int64_t* seq, int ld_seq, int b, int t, int n) {
+    if (t >= n) return 0.f;
+    return (t == 0 || seq[(size_t)b * ld_seq + t - 1] > 0) ? 1.f : 0.f;
+}
+__global__ void reward_fwd_kernel(const float* slp, int ld_slp, const int64_t* seq, int ld_seq, const float* reward, int rs_b,
+                                  int rs_t, const int32_t* n_dev, int m, int L, float* out2) {
+    __shared__ float red[256 / 64];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int n = n_dev ? min(max(*n_dev, 0), L) : L;
+    float a = 0.f, k = 0.f;
+    if (i < m * L) {
+        const int b = i / L, t = i % L;
+        k = reward_mask(seq, ld_seq, b, t, n);
+        if (k != 0.f) a = -slp[(size_t)b * ld_slp + t] * reward[(size_t)b * rs_b + (size_t)t * rs_t];
+    }
+    a = block_sum(a, red);
+    k = block_sum(k, red);
+    if (threadIdx.x == 0) { atomicAdd(out2, a); atomicAdd(out2 + 1, k); }
+}
+__global__ void reward_bwd_kernel(const int64_t* seq, int ld_seq, const float* reward, int rs_b, int rs_t, const int32_t* n_dev,
+                                  int m, int L, const float* sums, const float* scale_dev, float* dslp, int ld_d) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= m * L) return;
+    const int n = n_dev ? min(max(*n_dev, 0), L) : L;
+    const int b = i / L, t = i % L;
+    const float k = reward_mask(seq, ld_seq, b, t, n);
+    dslp[(size_t)b * ld_d + t] = k != 0.f ? -(scale_dev ? scale_dev[0] : 1.f) * reward[(size_t)b * rs_b + (size_t)t * rs_t] / sums[1] : 0.f;
+}
+
 // ---- fused cross-entropy on time-major logits rows i = t*B + b
 __global__ void __launch_bounds__(RT) xent_fwd_kernel(const float* __restrict__ logits, int ld, const int64_t* seq,
                                                         const float* mask, const float* mask2, int B, int T, int V,
@@ -614,4 +648,23 @@ extern "C" int xg_nll_bwd(void* stream, const int64_t* target, const float* mask
                           int V, int roll, const float* sums, float scale, const float* scale_dev, float* dlogp) {
     if (!target || !mask || !sums || !dlogp || B <= 0 || T <= 0 || V <= 0) return XG_EINVAL;
     return xgk_nll_bwd((hipStream_t)stream, target, mask, mask2, B, T, V, roll, sums, scale, scale_dev, dlogp);
+}
+
+extern "C" int xg_reward_fwd(void* stream, const float* slp, int ld_slp, const int64_t* seq, int ld_seq, const float* reward,
+                             int rs_b, int rs_t, const int32_t* n_dev, int m, int L, float* out) {
+    if (!slp || !seq || !reward || !out || m <= 0 || L <= 0 || ld_slp < L || ld_seq < L) return XG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(out, 0, 2 * sizeof(float), st) != hipSuccess) return XG_EHIP;
+    hipLaunchKernelGGL(reward_fwd_kernel, dim3(xg_cdiv(m * L, 256)), dim3(256), 0, st, slp, ld_slp, seq, ld_seq, reward, rs_b, rs_t,
+                       n_dev, m, L, out);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+extern "C" int xg_reward_bwd(void* stream, const int64_t* seq, int ld_seq, const float* reward, int rs_b, int rs_t,
+                             const int32_t* n_dev, int m, int L, const float* sums, const float* scale_dev, float* dslp, int ld_d) {
+    if (!seq || !reward || !sums || !dslp || m <= 0 || L <= 0 || ld_seq < L || ld_d < L) return XG_EINVAL;
+    hipLaunchKernelGGL(reward_bwd_kernel, dim3(xg_cdiv(m * L, 256)), dim3(256), 0, (hipStream_t)stream, seq, ld_seq, reward, rs_b,
+                       rs_t, n_dev, m, L, sums, scale_dev, dslp, ld_d);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
 }

@@ -70,12 +70,14 @@ def _second_bn_update(bns, r0):
                 m.num_batches_tracked += 1
 
 
-def scst_rollouts(model, feat1, feat2, feat_mask, pos_feat, overlap=True, mode=None, uniforms=None):
+def scst_rollouts(model, feat1, feat2, feat_mask, pos_feat, overlap=True, mode=None, uniforms=None, trim=True):
     """The two rollouts of one SCST iteration (starttrain.py:131 + myutils.py:45-48): the sampled rollout (keeps its
     activations for the policy-gradient backward) and the greedy baseline.  They are independent given the batch:
       mode "batched" (default): ONE pass over 2m rows (rows [0,m) sample, rows [m,2m) greedy; SAModel.sample_pair) --
           every per-step launch streams the decoder weights once for both rollouts;
       mode "streams": two m-row rollouts on two streams;   mode "sequential": the reference's order.
+    trim=False (batched mode): returns (gen (m,L), slp (m,L), greedy (m,L), n (2,) device int32) with NO host sync -- feed
+    them to RewardCriterion(..., n=n[0]); the reference's trimmed views are gen[:, :n[0]] etc.
     All three give the reference's results: both rollouts see the same batch statistics (BatchNorm's input does not
     depend on dropout, and statistics of a repeated batch equal those of the batch), and the running statistics receive
     the reference's TWO momentum updates (the second one is reconstructed exactly)."""
@@ -90,21 +92,14 @@ def scst_rollouts(model, feat1, feat2, feat_mask, pos_feat, overlap=True, mode=N
             greedy, _ = model.sample(feat1, feat2, feat_mask, pos_feat, {"sample_max": 1})
         return gen, slp, greedy
     bns = [model.two_spatial_encoder.visual_emb_rgb[1], model.two_spatial_encoder.visual_emb_opfl[1]]
-    r0 = [(m.running_mean.clone(), m.running_var.clone()) for m in bns]
-    if mode == "batched":
+    if mode == "batched":                                           # (the BatchNorm bookkeeping of the pair is sample_pair's)
         gen, slp, greedy, n = model.sample_pair(feat1, feat2, feat_mask, pos_feat, s_opt)
-        # running_var takes the UNBIASED batch variance: the repeated batch has 2N rows, the reference's N
-        rows = feat1.shape[0] * feat1.shape[1]
-        c = (2.0 * rows - 1.0) / (2.0 * rows - 2.0) if rows > 1 else 1.0
-        with torch.no_grad():
-            keep = 1.0 - bns[0].momentum
-            rv, rv0 = [m.running_var for m in bns], [pair[1] for pair in r0]
-            torch._foreach_mul_(rv, c)                              # (rv - keep rv0) c + keep rv0
-            torch._foreach_add_(rv, rv0, alpha=keep * (1.0 - c))
-        _second_bn_update(bns, r0)
+        if not trim:                                                # no host sync at all: full-width tensors + device-side n
+            return gen, slp, greedy, n
         ns = n.cpu()                                                # ONE host sync for both rollouts
         n_s, n_g = int(ns[0]), int(ns[1])
         return gen[:, :n_s], slp[:, :n_s], greedy[:, :n_g]
+    r0 = [(m.running_mean.clone(), m.running_var.clone()) for m in bns]
     main = torch.cuda.current_stream()
     side = torch.cuda.Stream()
     side.wait_stream(main)
@@ -112,6 +107,8 @@ def scst_rollouts(model, feat1, feat2, feat_mask, pos_feat, overlap=True, mode=N
         g_seq, _, g_n = model.sample(feat1, feat2, feat_mask, pos_feat, {"sample_max": 1, "async": True, "bn_update": False})
     s_seq, s_slp, s_n = model.sample(feat1, feat2, feat_mask, pos_feat, dict(s_opt, **{"async": True}))
     main.wait_stream(side)
+    for t in (g_seq, g_n):                                          # allocated under the side stream, consumed on main
+        t.record_stream(main)
     _second_bn_update(bns, r0)                                      # the baseline's (second) running-stat update
     ns = torch.stack([s_n.reshape(()), g_n.reshape(())]).cpu()      # ONE host sync for both rollouts
     n_s, n_g = int(ns[0]), int(ns[1])

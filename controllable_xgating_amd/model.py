@@ -165,6 +165,9 @@ class SAModel(nn.Module):
             raise ValueError("only fusion_activity='ReLU' (the shipped recipe) is implemented in HIP")
         self._pool = _WorkspacePool()
         self._flat = None
+        self._ps_cache = None
+        self._gs_cache = None
+        self._offsets = []
         self._call = 0
         self._aux = {}               # (device, stream) -> xg_aux_create handle (side streams of the entry points)
         self._packed = None          # recurrent weights in MFMA-fragment order (xg_pack_weights), refreshed lazily
@@ -186,36 +189,43 @@ class SAModel(nn.Module):
     def _named(self):
         return dict(self.named_parameters())
 
+    def _plist(self):
+        """The nn.Parameter objects in the C ABI's order (= state_dict order).  The objects themselves are stable for the
+        life of the module (.cuda()/.to()/load_state_dict replace their DATA), so the walk over named_parameters() is
+        done once."""
+        pl = self.__dict__.get("_plist_cache")
+        if pl is None:
+            named = self._named()
+            pl = [named[n] for n in nv.PARAM_NAMES]
+            self.__dict__["_plist_cache"] = pl
+        return pl
+
     def _param_list(self):
-        """Parameters in the C ABI's order (= state_dict order); one named_parameters() walk per call."""
-        named = self._named()
-        return [named[n] for n in nv.PARAM_NAMES]
+        return self._plist()
 
     def _ensure_flat(self):
         """All parameters live in ONE flat fp32 buffer (one RCCL all-reduce, one Adam launch);
         the nn.Parameters are views into it.  Rebuilt if .cuda()/.to() replaced the storages."""
-        named = self._named()
         names = nv.PARAM_NAMES
-        first = named[names[0]]
+        plist = self._plist()
+        first = plist[0]
         if self._flat is not None and self._flat.device == first.device:
-            off, ok = 0, True
-            for n in names:
-                p = named[n]
-                if p.data_ptr() != self._flat.data_ptr() + 4 * off:
+            base, ok = self._flat.data_ptr(), True
+            for p, off in zip(plist, self._offsets):
+                if p.data_ptr() != base + 4 * off:
                     ok = False
                     break
-                off += (p.numel() + 63) // 64 * 64
             if ok:
                 return
         if not first.is_cuda:
             raise nv.XgError("SAModel runs on an MI355X only: call model.cuda() first (no CPU path)")
-        total = sum((named[n].numel() + 63) // 64 * 64 for n in names)
+        total = sum((p.numel() + 63) // 64 * 64 for p in plist)
         flat = torch.zeros(total, dtype=torch.float32, device=first.device)
         gflat = torch.zeros(total, dtype=torch.float32, device=first.device)
         off = 0
         self._slices = {}
-        for n in names:
-            p = named[n]
+        self._offsets = []
+        for n, p in zip(names, plist):
             if p.dtype != torch.float32:
                 raise nv.XgError("fp32 parameters only")
             k = p.numel()
@@ -227,8 +237,11 @@ class SAModel(nn.Module):
             p.data = v
             p.grad = gflat[off:off + k].view_as(p) if had_grad else None
             self._slices[n] = (off, k)
+            self._offsets.append(off)
             off += (k + 63) // 64 * 64
         self._flat, self._gflat = flat, gflat
+        self._ps_cache = None
+        self._gs_cache = None
 
     def flat_parameters(self):
         self._ensure_flat()
@@ -237,11 +250,10 @@ class SAModel(nn.Module):
     def flat_grads(self):
         """Flat gradient buffer; binds every p.grad to its slice (zeroing is the caller's zero_grad)."""
         self._ensure_flat()
-        named = self._named()
-        for n, (off, k) in self._slices.items():
-            p = named[n]
-            if p.grad is None or p.grad.data_ptr() != self._gflat.data_ptr() + 4 * off:
-                v = self._gflat[off:off + k].view_as(p)
+        base = self._gflat.data_ptr()
+        for p, off in zip(self._plist(), self._offsets):
+            if p.grad is None or p.grad.data_ptr() != base + 4 * off:
+                v = self._gflat[off:off + p.numel()].view_as(p)
                 if p.grad is not None:
                     v.copy_(p.grad)
                 else:
@@ -250,8 +262,15 @@ class SAModel(nn.Module):
         return self._gflat
 
     def _params_struct(self):
+        """XgParams of the flat buffer's slices (cached until the buffer is rebuilt)."""
         self._ensure_flat()
-        return nv.make_params_struct(self._named())
+        if self._ps_cache is None:
+            ps = nv.XgParams()
+            base = self._flat.data_ptr()
+            for i, off in enumerate(self._offsets):
+                setattr(ps, "p%d" % i, base + 4 * off)
+            self._ps_cache = ps
+        return self._ps_cache
 
     def _bn_struct(self):
         e = self.two_spatial_encoder
@@ -295,7 +314,7 @@ class SAModel(nn.Module):
         parameter values; None when the shapes do not allow it (rnn_size % 8 != 0)."""
         self._ensure_flat()
         key = (self._flat.data_ptr(), self._flat._version, self._packed_epoch,
-               tuple(p._version for p in self.parameters()))
+               tuple(p._version for p in self._plist()))
         if key != self._packed_key:
             d = self._dims(1, 1, 1)
             nbytes = nv.lib().xg_packed_bytes(C.byref(d))
@@ -305,7 +324,7 @@ class SAModel(nn.Module):
                 if self._packed is None or self._packed.device != self._flat.device or self._packed.numel() < nbytes + 16:
                     self._packed = torch.empty(nbytes + 16, dtype=torch.uint8, device=self._flat.device)
                 ptr = (self._packed.data_ptr() + 15) & ~15
-                ps = nv.make_params_struct(self._named())
+                ps = self._params_struct()
                 nv.check(nv.lib().xg_pack_weights(_stream(), C.byref(d), C.byref(ps), C.c_void_p(ptr), C.c_size_t(nbytes), 1),
                          "xg_pack_weights")
             self._packed_key = key
@@ -380,12 +399,36 @@ class SAModel(nn.Module):
         """The two rollouts of one SCST iteration in ONE batched pass: ``sample(..., {'sample_max': 0})``
         (starttrain.py:131) and the greedy baseline ``sample(..., {'sample_max': 1})`` (myutils.py:45-48).
         Returns (gen (m,L), sample_logprobs (m,L) [differentiable], greedy (m,L), n (2,) int32 device tensor: the
-        reference's early-exit lengths of the two rollouts -- trim with them, one host sync for both)."""
+        reference's early-exit lengths of the two rollouts -- trim with them, or hand n[:1] to RewardCriterion).
+        In train mode the BatchNorm running statistics end up exactly where the reference's TWO sample() calls leave
+        them (two momentum updates with the unbiased N/(N-1) variance of the un-repeated batch)."""
         temperature = float(opt.get("temperature", 1.0))
         params = self._param_list()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        return _RolloutPairFunction.apply(self, feats_rgb, feats_opfl, feat_mask, pos_feats, opt.get("uniforms", None),
-                                          temperature, need_grad, *params)
+        bns = [self.two_spatial_encoder.visual_emb_rgb[1], self.two_spatial_encoder.visual_emb_opfl[1]]
+        r0 = [(m.running_mean.clone(), m.running_var.clone()) for m in bns] if self.training else None
+        out = _RolloutPairFunction.apply(self, feats_rgb, feats_opfl, feat_mask, pos_feats, opt.get("uniforms", None),
+                                         temperature, need_grad, *params)
+        if r0 is not None:
+            # the library saw ONE batch of 2N repeated rows: same mean and biased variance as the N-row batch, but its
+            # running_var took the unbiased factor 2N/(2N-1) instead of N/(N-1), and only one momentum update was made
+            rows = feats_rgb.shape[0] * feats_rgb.shape[1]
+            with torch.no_grad():
+                keep = 1.0 - bns[0].momentum
+                if rows > 1:
+                    c = (2.0 * rows - 1.0) / (2.0 * rows - 2.0)
+                    rv, rv0 = [m.running_var for m in bns], [pair[1] for pair in r0]
+                    torch._foreach_mul_(rv, c)                              # (rv - keep rv0) c + keep rv0
+                    torch._foreach_add_(rv, rv0, alpha=keep * (1.0 - c))
+                # second update with the same batch statistics s:  r2 = keep r1 + momentum s = (1 + keep) r1 - keep r0
+                cur = [t for m in bns for t in (m.running_mean, m.running_var)]
+                old = [t for pair in r0 for t in pair]
+                torch._foreach_mul_(cur, 1.0 + keep)
+                torch._foreach_add_(cur, old, alpha=-keep)
+                for m in bns:
+                    if m.num_batches_tracked is not None:
+                        m.num_batches_tracked += 1
+        return out
 
     def init_hidden(self, feat, feat_mask):
         """SAModel.init_hidden (SAModel.py:58-65) -> [(h1,c1),(h2,c2)], each (1,m,R)."""
@@ -473,10 +516,9 @@ class SAModel(nn.Module):
 
 # ====================================================================== autograd glue
 def _grads_bound(model):
-    named = model._named()
     base = model._gflat.data_ptr()
-    for n, (off, k) in model._slices.items():
-        g = named[n].grad
+    for p, off in zip(model._plist(), model._offsets):
+        g = p.grad
         if g is None or g.data_ptr() != base + 4 * off:
             return False
     return True
@@ -487,24 +529,25 @@ def _grads_struct(model, device):
     already bound to the model's flat gradient buffer (model.flat_grads()), accumulate there directly
     and hand autograd nothing; otherwise use a fresh zero buffer and return views for autograd."""
     model._ensure_flat()
-    g = None if _grads_bound(model) else torch.zeros_like(model._flat)
-    base = model._gflat if g is None else g
+    if _grads_bound(model):
+        if model._gs_cache is None:
+            s = nv.XgParams()
+            base = model._gflat.data_ptr()
+            for i, off in enumerate(model._offsets):
+                setattr(s, "p%d" % i, base + 4 * off)
+            model._gs_cache = s
+        return None, model._gs_cache
+    g = torch.zeros_like(model._flat)
     s = nv.XgParams()
-    for i, n in enumerate(nv.PARAM_NAMES):
-        off, k = model._slices[n]
-        setattr(s, "p%d" % i, base.data_ptr() + 4 * off)
+    for i, off in enumerate(model._offsets):
+        setattr(s, "p%d" % i, g.data_ptr() + 4 * off)
     return g, s
 
 
 def _grad_views(model, g):
     if g is None:
         return [None] * len(nv.PARAM_NAMES)
-    named = model._named()
-    out = []
-    for n in nv.PARAM_NAMES:
-        off, k = model._slices[n]
-        out.append(g[off:off + k].view_as(named[n]))
-    return out
+    return [g[off:off + p.numel()].view_as(p) for p, off in zip(model._plist(), model._offsets)]
 
 
 class _XEFunction(torch.autograd.Function):
@@ -750,13 +793,47 @@ class ClassiferCriterion(nn.Module):
         return _NLLFunction.apply(input, target, mask, class_mask, 0)
 
 
-class RewardCriterion(nn.Module):
-    """reference caption_src/SAModel.py:255-267 (policy-gradient loss on (m,n) tensors; a few KB of
-    element-wise work, left to the tensor runtime)."""
+class _RewardFunction(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, slp, seq, reward, n):
+        m, L = slp.shape
+        slp_c = slp if slp.stride(1) == 1 else slp.contiguous()
+        seq = seq.detach()
+        seq = seq if (seq.stride(1) == 1 and seq.dtype == torch.int64) else seq.contiguous().long()
+        reward = reward.detach()
+        if reward.dim() == 1:
+            reward = reward.unsqueeze(1)
+        reward = reward.float() if reward.dtype != torch.float32 else reward
+        if reward.shape[1] == 1:
+            rs_b, rs_t = reward.stride(0), 0
+        else:
+            if reward.shape[1] < L:
+                raise nv.XgError("reward has fewer columns than the log-probs")
+            rs_b, rs_t = reward.stride(0), reward.stride(1)
+        nd = None if n is None else n.detach().reshape(-1)[:1].to(torch.int32)
+        sums = torch.empty(2, dtype=torch.float32, device=slp.device)
+        nv.check(nv.lib().xg_reward_fwd(_stream(), nv.ptr(slp_c), slp_c.stride(0), nv.ptr(seq), seq.stride(0), nv.ptr(reward),
+                                        rs_b, rs_t, nv.ptr(nd), m, L, nv.ptr(sums)), "xg_reward_fwd")
+        ctx.meta = (m, L, seq, reward, rs_b, rs_t, nd, sums)
+        return sums[0] / sums[1]
 
-    def forward(self, input, seq, reward):
-        mask = (seq > 0).float()
-        mask = torch.cat([mask.new_ones(mask.size(0), 1), mask[:, :-1]], 1)
+    @staticmethod
+    def backward(ctx, dloss):
+        m, L, seq, reward, rs_b, rs_t, nd, sums = ctx.meta
+        dslp = torch.empty(m, L, dtype=torch.float32, device=sums.device)
+        dl = dloss.detach().reshape(1).contiguous().float().to(sums.device)
+        nv.check(nv.lib().xg_reward_bwd(_stream(), nv.ptr(seq), seq.stride(0), nv.ptr(reward), rs_b, rs_t, nv.ptr(nd), m, L,
+                                        nv.ptr(sums), nv.ptr(dl), nv.ptr(dslp), L), "xg_reward_bwd")
+        return dslp, None, None, None
+
+
+class RewardCriterion(nn.Module):
+    """reference caption_src/SAModel.py:255-267: policy-gradient loss -sum(input * reward * mask) / sum(mask) with
+    mask[:, 0] = 1, mask[:, t] = seq[:, t-1] > 0, as ONE HIP launch forward and one backward (xg_reward_fwd/bwd).
+    ``n`` (optional device int tensor: the rollout's early-exit width, e.g. from ``model.sample(..., {'async': True})`` or
+    ``scst_rollouts(..., trim=False)``) lets the caller pass full-width (m, L) rollout outputs without ever syncing on n;
+    ``reward`` may be (m, n') or one value per video, (m,) / (m, 1)."""
+
+    def forward(self, input, seq, reward, n=None):
         reward = torch.as_tensor(reward, dtype=torch.float32, device=input.device)
-        out = -input * reward * mask
-        return out.sum() / mask.sum()
+        return _RewardFunction.apply(input, seq, reward, n)

@@ -246,6 +246,16 @@ int xg_nll_bwd(void *stream, const int64_t *target, const float *mask, const flo
                int B, int T, int V, int roll, const float *sums, float scale, const float *scale_dev,
                float *dlogp);
 
+/* RewardCriterion (caption_src/SAModel.py:255-267; caption_src/starttrain.py:133): out = {sum(-slp * reward * mask),
+ * sum(mask)} with mask[:, 0] = 1, mask[:, t] = seq[:, t-1] > 0; loss = out[0] / out[1].  slp / seq are (m, L) with row
+ * pitches ld_*; reward element (b, t) at reward[b * rs_b + t * rs_t] (rs_t = 0: one reward per video).  n_dev: optional
+ * DEVICE int32 = the rollout's early-exit width n (xg_rollout's n_steps): columns t >= n are ignored, so full-width
+ * rollout outputs can be fed without a host round trip.  xg_reward_bwd writes d(loss)/d(slp) * scale_dev[0] into dslp. */
+int xg_reward_fwd(void *stream, const float *slp, int ld_slp, const int64_t *seq, int ld_seq, const float *reward,
+                  int rs_b, int rs_t, const int32_t *n_dev, int m, int L, float *out);
+int xg_reward_bwd(void *stream, const int64_t *seq, int ld_seq, const float *reward, int rs_b, int rs_t,
+                  const int32_t *n_dev, int m, int L, const float *sums, const float *scale_dev, float *dslp, int ld_d);
+
 /* ---- packed recurrent weights (no reference counterpart: a layout shadow of lstmcore.* / lstmcell_*.weight_hh,
  *      caption_src/sub_modules.py:661-669,104-105) ----
  * The per-timestep products stream each weight matrix once per step; a second copy of those matrices in the order the

@@ -832,3 +832,61 @@ def test_three_iteration_trajectory_vs_reference_adam_golden(tag):
         np.testing.assert_allclose(got, g["psamp/" + name], atol=3.1 * float(g["lr"]), err_msg=name)
         disp_err = np.abs((got - P0[name].reshape(-1)[idx]) - g["dsamp/" + name])
         assert (disp_err > 4e-5).mean() <= 0.02, (name, float(disp_err.max()), float((disp_err > 4e-5).mean()))
+
+
+def test_reward_criterion_hip_kernel_full_width_equals_trimmed_reference_form():
+    """RewardCriterion (SAModel.py:259-267) as one HIP launch: (a) trimmed (m, n) inputs == the oracle's restatement, value
+    and gradient; (b) full-width (m, L) inputs + the device-side early-exit width n == (a), with no host sync on n; (c) one
+    reward per video (myutils.py:75-76) == the broadcast matrix."""
+    from controllable_xgating_amd import RewardCriterion
+    g = torch.Generator().manual_seed(11)
+    m, L, n = 9, 14, 10
+    seq = torch.randint(1, 50, (m, L), generator=g)
+    for b in range(m):                                   # rows finish at different steps; nothing after column n-1
+        end = 2 + (b * 3) % (n - 1)
+        seq[b, end:] = 0
+    seq[0, :n] = torch.randint(1, 50, (n,), generator=g)     # one row is alive through column n-1
+    seq[:, n:] = 0
+    slp = -torch.rand(m, L, generator=g) * 5
+    rew_b = torch.randn(m, 1, generator=g)
+    rew = rew_b.expand(-1, n).contiguous()
+    crit = RewardCriterion()
+    # (a) trimmed vs oracle
+    s_o = slp[:, :n].clone().requires_grad_(True)
+    lo = xo.reward_criterion(s_o, seq[:, :n], rew)
+    lo.backward()
+    s_a = slp[:, :n].clone().cuda().requires_grad_(True)
+    la = crit(s_a, seq[:, :n].cuda(), rew.cuda())
+    la.backward()
+    assert abs(la.item() - lo.item()) < 1e-6
+    np.testing.assert_allclose(s_a.grad.cpu().numpy(), s_o.grad.numpy(), atol=1e-7)
+    # (b) full width + device n, (c) per-video reward
+    s_b = slp.clone().cuda().requires_grad_(True)
+    lb = crit(s_b, seq.cuda(), rew_b.cuda(), n=torch.tensor([n], dtype=torch.int32, device="cuda"))
+    (2.0 * lb).backward()
+    assert abs(lb.item() - lo.item()) < 1e-6
+    np.testing.assert_allclose(s_b.grad.cpu().numpy()[:, :n], 2.0 * s_o.grad.numpy(), atol=1e-7)
+    assert float(s_b.grad[:, n:].abs().max()) == 0.0
+
+
+def test_sample_pair_leaves_reference_batchnorm_statistics():
+    """SAModel.sample_pair called DIRECTLY (not through driver.scst_rollouts): running_mean / running_var /
+    num_batches_tracked equal those after the reference's two sequential sample() calls (two momentum updates, unbiased
+    variance of the N-row batch, not of the 2N repeated rows)."""
+    d = pg.make_dims(**CFG["mid"])
+    Pn = pg.make_params(d, logit_gain=1.0)
+    x = to_dev(pg.make_inputs(d, seed=0))
+    u = torch.from_numpy(pg.uniform("uni2", (d.L + 1, d.B), 78)).cuda()
+    ma = make_model(d, P=Pn, train=True)
+    ma.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"sample_max": 0, "uniforms": u})
+    with torch.no_grad():
+        ma.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"sample_max": 1})
+    mb = make_model(d, P=Pn, train=True)
+    mb.sample_pair(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"uniforms": u})
+    torch.cuda.synchronize()
+    for mod in ("rgb", "opfl"):
+        a = getattr(ma.two_spatial_encoder, f"visual_emb_{mod}")[1]
+        b = getattr(mb.two_spatial_encoder, f"visual_emb_{mod}")[1]
+        np.testing.assert_allclose(b.running_mean.cpu().numpy(), a.running_mean.cpu().numpy(), atol=1e-6)
+        np.testing.assert_allclose(b.running_var.cpu().numpy(), a.running_var.cpu().numpy(), atol=1e-6)
+        assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == 2
