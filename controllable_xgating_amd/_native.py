@@ -28,7 +28,7 @@ class XgBatch(C.Structure):
 
 class XgRun(C.Structure):
     _fields_ = [("train", C.c_int32), ("drop_p", C.c_float), ("seed", C.c_uint32), ("save", C.c_int32),
-                ("bn_momentum", C.c_float), ("bn_eps", C.c_float), ("gemm_mode", C.c_int32), ("reserved0", C.c_int32),
+                ("bn_momentum", C.c_float), ("bn_eps", C.c_float), ("gemm_mode", C.c_int32), ("packed_dtype", C.c_int32),
                 ("packed", C.c_void_p), ("aux", C.c_void_p), ("grad_event", C.c_void_p)]
 
 
@@ -61,7 +61,7 @@ def lib():
     L.xg_workspace_bytes.restype = C.c_size_t
     L.xg_workspace_bytes.argtypes = [C.POINTER(XgDims)]
     L.xg_packed_bytes.restype = C.c_size_t
-    L.xg_packed_bytes.argtypes = [C.POINTER(XgDims)]
+    L.xg_packed_bytes.argtypes = [C.POINTER(XgDims), C.c_int]
     n = L.xg_param_count()
     PARAM_NAMES = [L.xg_param_name(i).decode() for i in range(n)]
 
@@ -94,7 +94,7 @@ def lib():
         "xg_nll_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
         "xg_nll_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp, f32, vp, vp],
         "xg_clip_adam": [vp, i64, vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, f32],
-        "xg_pack_weights": [vp, PD, PP, vp, C.c_size_t, i32],
+        "xg_pack_weights": [vp, PD, PP, vp, C.c_size_t, i32, i32],
         "xg_reward_fwd": [vp, vp, i32, vp, i32, vp, i32, i32, vp, i32, i32, vp],
         "xg_reward_bwd": [vp, vp, i32, vp, i32, i32, vp, i32, i32, vp, vp, vp, i32],
     }

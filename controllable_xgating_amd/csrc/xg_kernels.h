@@ -122,7 +122,7 @@ struct SkSeg {
     int lda, ldb, K, b_ncontig;
     // packed form of B (xg_pack.hip: 32 x 32 tiles in MFMA-fragment order, nck tiles per 32-column slice) or null: when
     // every segment of a launch has one, the launch takes the fast kernel (B operand global -> VGPR, no LDS)
-    const float* Bp; int nck;
+    const float* Bp; int nck;          // (bf16 tiles when the launch runs with gemm_mode 1: xgk_skinny's argument)
     // optional row gather on A: row m of the operand is A + clamp(gather[m * gstride], 0, gather_max) * lda
     // (embedding lookup folded into the product: caption_src/SAModel.py:105,198)
     const int64_t* gather; int gstride, gather_max;
@@ -166,9 +166,9 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode);
 // ---- xg_pack.hip : weights re-tiled into MFMA-fragment order (caller-owned shadow, XgRun.packed)
 enum { PK_H2A1 = 0, PK_H2A2, PK_DGATE, PK_L1_I2H, PK_L1_A2H, PK_L1_H2H, PK_L2_I2H, PK_L2_A2H, PK_L2_H2H, PK_ENC_RGB, PK_ENC_OPFL,
        PKB_L2_A2H, PKB_L2_H2H, PKB_H2A2, PKB_L1_H2H, PKB_ENC_RGB, PKB_ENC_OPFL, PK_COUNT };
-struct PackedView { const float* m[PK_COUNT]; int nck[PK_COUNT]; };
+struct PackedView { const float* m[PK_COUNT]; int nck[PK_COUNT]; int dtype; };    // dtype 0: fp32 tiles (4 KB), 1: bf16 tiles (2 KB)
 size_t xgk_packed_floats(const XgDims& d);
-bool xgk_packed_view(const XgDims& d, const void* packed, PackedView* v);   // false: no / unusable shadow
+bool xgk_packed_view(const XgDims& d, const void* packed, int dtype, PackedView* v);   // false: no / unusable shadow
 
 // ---- xg_attn.hip
 // per-sample additive attention: e_k = w . tanh(p + q_k), alpha = softmax_k(e), af = sum_k alpha_k V_k

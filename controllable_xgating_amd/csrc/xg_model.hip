@@ -208,7 +208,6 @@ inline SkSeg seg_nn(const Ws& w, int which, const float* dY, int lddy, const flo
     if (w.packed) { s.Bp = w.pk.m[which]; s.nck = w.pk.nck[which]; }
     return s;
 }
-// (plain-bf16 mode keeps the LDS-staged kernel, which rounds its chunks to bf16 on the way: BASELINE.json configs[4])
 // let xgk_skinny split the reduction of job j across workgroups (its result accumulates into C: see SkJob.ksplit_ok)
 inline void allow_split(SkArgs& sk, int j, const Ws& w) { sk.job[j].ksplit_ok = 1; sk.job[j].tickets = w.tickets + j * 1024; }
 // (the last arriver of every tile leaves its counter at zero; the memsets only make a launch independent of whatever an
@@ -217,9 +216,11 @@ inline void allow_split(SkArgs& sk, int j, const Ws& w) { sk.job[j].ksplit_ok = 
 inline int zero_tickets(hipStream_t st, const Ws& w, int njobs) {
     return hipMemsetAsync(w.tickets, 0, sizeof(int32_t) * njobs * 1024, st) == hipSuccess ? XG_OK : XG_EHIP;
 }
+// (the tile element type must fit the arithmetic: bf16 tiles for gemm_mode 1, fp32 tiles otherwise)
 inline void attach_packed(Ws& w, const XgDims& d, const XgRun* run) {
     static const bool disabled = getenv("XG_NO_PACKED") != nullptr;
-    w.packed = !disabled && run && run->packed && run->gemm_mode != 1 && xgk_packed_view(d, run->packed, &w.pk);
+    w.packed = !disabled && run && run->packed && (run->gemm_mode == 1) == (run->packed_dtype == 1) &&
+               xgk_packed_view(d, run->packed, run->packed_dtype, &w.pk);
 }
 inline SkJob job_store(int M, int N, float* C, int ldc, bool acc, bool relu = false) {
     SkJob j{};

@@ -8,6 +8,10 @@
 // v_mfma_f32_32x32x2_f32 goes global -> VGPR with four fully coalesced 1 KB wave loads per tile, no LDS, no shuffles.
 // (The MFMA sums over k in any order as long as A uses the same one: lane half h owns k in [16 h, 16 h + 16).)
 //
+// dtype 1 = bf16 tiles (XgRun.gemm_mode 1, BASELINE.json configs[4]): the same 32 x 32 tiles, rounded to bf16 ONCE here
+// (round-to-nearest-even) instead of on every pass of every step, as [i(2)][h(2)][n(32)][8]: element (n, k = 16 i + 8 h + q),
+// the B operand of v_mfma_f32_32x32x16_bf16, two 1 KB wave loads per tile; half the weight bytes per step.
+//
 // The shadow is caller-owned (xg_packed_bytes / xg_pack_weights), refreshed after every optimizer step
 // (reference update: caption_src/starttrain.py:136-137) and handed to the entry points through XgRun.packed.
 //   NT entries (forward, y = x W^T, W (N,K) row-major):  h2a[:, :R], h2a[:, R:], decoder gate, lstm_1.{i2h,a2h,h2h},
@@ -48,7 +52,7 @@ inline size_t entry_floats(const PackDesc& e) {
     return ntn * (size_t)xg_cdiv(e.K, 32) * 1024;
 }
 
-struct PackArgs { PackDesc e[PK_COUNT]; float* dst[PK_COUNT]; int tile0[PK_COUNT + 1]; int first, last; };
+struct PackArgs { PackDesc e[PK_COUNT]; float* dst[PK_COUNT]; int tile0[PK_COUNT + 1]; int first, last, bf16; };
 
 // one workgroup (256 threads) per packed tile: reads 32 x 32 source elements (coalesced along the source's unit-stride
 // dimension), writes 4 KB contiguous
@@ -76,6 +80,18 @@ __global__ void __launch_bounds__(256) pack_kernel(PackArgs a) {
         t[nn][kk] = v;
     }
     __syncthreads();
+    if (a.bf16) {
+        unsigned short* dst = reinterpret_cast<unsigned short*>(a.dst[ei]) + (size_t)tile * 1024;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = threadIdx.x + 256 * r;                      // [i(2)][h(2)][n(32)][q(8)]
+            const int q = o & 7, nn = (o >> 3) & 31, h = (o >> 8) & 1, i = o >> 9;
+            unsigned u = __float_as_uint(t[nn][16 * i + 8 * h + q]);
+            u += 0x7FFFu + ((u >> 16) & 1u);                          // round to nearest even
+            dst[o] = (unsigned short)(u >> 16);
+        }
+        return;
+    }
     float* dst = a.dst[ei] + (size_t)tile * 1024;
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -96,37 +112,40 @@ size_t xgk_packed_floats(const XgDims& d) {
     return n;
 }
 
-bool xgk_packed_view(const XgDims& d, const void* packed, PackedView* v) {
-    if (!packed || d.R % 8 != 0 || ((uintptr_t)packed % 16) != 0) return false;
+bool xgk_packed_view(const XgDims& d, const void* packed, int dtype, PackedView* v) {
+    if (!packed || d.R % 8 != 0 || ((uintptr_t)packed % 16) != 0 || (dtype != 0 && dtype != 1)) return false;
     XgParams p{};
     PackDesc e[PK_COUNT];
     describe(d, p, e);
-    const float* base = static_cast<const float*>(packed);
+    const char* base = static_cast<const char*>(packed);
+    const size_t esz = dtype == 1 ? 2 : 4;
     size_t off = 0;
     for (int i = 0; i < PK_COUNT; ++i) {
-        v->m[i] = base + off;
+        v->m[i] = reinterpret_cast<const float*>(base + off);
         v->nck[i] = xg_cdiv(e[i].K, 32);
-        off += entry_floats(e[i]);
+        off += entry_floats(e[i]) * esz;
     }
+    v->dtype = dtype;
     return true;
 }
 
-extern "C" size_t xg_packed_bytes(const XgDims* d) {
-    if (!d || d->R <= 0 || d->A <= 0 || d->E <= 0 || d->R % 8 != 0) return 0;
-    return xgk_packed_floats(*d) * sizeof(float);
+extern "C" size_t xg_packed_bytes(const XgDims* d, int dtype) {
+    if (!d || d->R <= 0 || d->A <= 0 || d->E <= 0 || d->R % 8 != 0 || (dtype != 0 && dtype != 1)) return 0;
+    return xgk_packed_floats(*d) * (dtype == 1 ? 2 : 4);
 }
 
 extern "C" int xg_pack_weights(void* stream, const XgDims* d, const XgParams* p, void* packed, size_t packed_bytes,
-                               int with_backward) {
+                               int dtype, int with_backward) {
     if (!d || !p || !packed || d->R <= 0 || d->A <= 0 || d->E <= 0) return XG_EINVAL;
-    if (d->R % 8 != 0 || ((uintptr_t)packed % 16) != 0) return XG_EINVAL;
-    if (packed_bytes < xgk_packed_floats(*d) * sizeof(float)) return XG_EWORKSPACE;
+    if (d->R % 8 != 0 || ((uintptr_t)packed % 16) != 0 || (dtype != 0 && dtype != 1)) return XG_EINVAL;
+    if (packed_bytes < xgk_packed_floats(*d) * (dtype == 1 ? 2 : 4)) return XG_EWORKSPACE;
     PackArgs a{};
     describe(*d, *p, a.e);
     PackedView v;
-    if (!xgk_packed_view(*d, packed, &v)) return XG_EINVAL;
+    if (!xgk_packed_view(*d, packed, dtype, &v)) return XG_EINVAL;
     a.first = 0;
     a.last = with_backward ? PK_COUNT : PKB_L2_A2H;
+    a.bf16 = dtype == 1;
     int tiles = 0;
     for (int i = 0; i < a.last; ++i) {
         if (!a.e[i].src) return XG_EINVAL;

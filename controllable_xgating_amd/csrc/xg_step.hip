@@ -562,7 +562,9 @@ __device__ __forceinline__ void ldA(const float* const (&ap)[4], int c, int klef
 // NW waves split K: 8 for launches of at most two tiles per CU (two waves per SIMD hide each other's LDS / load latency);
 // 4 (256-thread workgroups, four per CU) for launches that carry ATTN jobs or more tiles than that, so that every tile of
 // the launch is resident at once.
-template <int NW>
+// PREC 1 (XgRun.gemm_mode 1): the packed tiles are bf16 ([i(2)][h(2)][n(32)][8], two 1 KB wave loads), the A chunk is
+// rounded to bf16 on its way into LDS and a 32-deep chunk is two v_mfma_f32_32x32x16_bf16; accumulation / epilogues fp32.
+template <int NW, int PREC>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) skf_kernel(SkArgs args) {
     SK_STAMP(0);
     __shared__ __attribute__((aligned(16))) float smem[NW * 32 * RSF > NW * OPF ? NW * 32 * RSF : NW * OPF];
@@ -635,7 +637,10 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
         const int p0 = (kp * nc) / ks, pn = ((kp + 1) * nc) / ks - p0;      // this workgroup's part of the segment
         const int c0 = p0 + (wave * pn) / NW, c1 = p0 + ((wave + 1) * pn) / NW;
         if (c0 >= c1) continue;
-        const float* bp = sg.Bp + ((size_t)tn * nc) * 1024 + (size_t)(half * 32 + l31) * 4;
+        // this lane's 16-byte piece of B tile (tn, chunk c), sub-piece i: bp + c * TILE + i * 256   (float units; a bf16
+        // tile is 512 float-sized words: 2 pieces of 256, an fp32 tile 1024: 4 pieces)
+        constexpr int TILE = PREC == 1 ? 512 : 1024, NPB = PREC == 1 ? 2 : 4;
+        const float* bp = sg.Bp + ((size_t)tn * nc) * TILE + (size_t)(half * 32 + l31) * 4;
         const float* ap[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -651,14 +656,14 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
         // the normalised rows back (scaled_out has A's row pitch: checked by the host)
         const bool wb_seg = sg.row_scale && sg.scaled_out;      // chunk c of the scaled rows is written back by n-tile c % ntn
         const ptrdiff_t wb_delta = wb_seg ? sg.scaled_out - sg.A : 0;
-        f32x4 ra[4], rb0[4], rb1[4];
+        f32x4 ra[4], rb0[NPB], rb1[NPB];
         if (s == 0) SK_STAMP(1);
 #pragma unroll
-        for (int i = 0; i < 4; ++i) rb0[i] = *reinterpret_cast<const f32x4*>(bp + (size_t)c0 * 1024 + i * 256);
+        for (int i = 0; i < NPB; ++i) rb0[i] = *reinterpret_cast<const f32x4*>(bp + (size_t)c0 * TILE + i * 256);
         if (c0 < nfull) ldA<false>(ap, c0, 0, ra); else ldA<true>(ap, c0, sg.K - c0 * CK - lcol, ra);
         // one chunk: stage A (scaled / written back when it is the attention context), request the NEXT chunk's operands
         // (B into the other register set: no copy), then the 16 MFMAs of this chunk
-        auto chunk = [&](int c, const f32x4 (&cur)[4], f32x4 (&nxt)[4]) {
+        auto chunk = [&](int c, const f32x4 (&cur)[NPB], f32x4 (&nxt)[NPB]) {
             if (sg.row_scale) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -667,20 +672,30 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
                         *reinterpret_cast<f32x4*>(const_cast<float*>(ap[i]) + wb_delta + (size_t)c * CK) = ra[i];
                 }
             }
-            st_chunk(As, lane, ra);
+            if (PREC == 1) st_chunk_bf16(reinterpret_cast<unsigned short*>(As), lane, ra);
+            else st_chunk(As, lane, ra);
             if (s == 0 && c == c0) SK_STAMP(2);
             if (c + 1 < c1) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) nxt[i] = *reinterpret_cast<const f32x4*>(bp + (size_t)(c + 1) * 1024 + i * 256);
+                for (int i = 0; i < NPB; ++i) nxt[i] = *reinterpret_cast<const f32x4*>(bp + (size_t)(c + 1) * TILE + i * 256);
                 if (c + 1 < nfull) ldA<false>(ap, c + 1, 0, ra); else ldA<true>(ap, c + 1, sg.K - (c + 1) * CK - lcol, ra);
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
+            if (PREC == 1) {
+                const unsigned short* Ah = reinterpret_cast<const unsigned short*>(As);
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const f32x4 a = *reinterpret_cast<const f32x4*>(As + l31 * LDR + half * 16 + i * 4);
+                for (int i = 0; i < 2; ++i) {
+                    const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ah + l31 * LDH + i * 16 + half * 8);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, cur[i]), acc, 0, 0, 0);
+                }
+            } else {
 #pragma unroll
-                for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], cur[i][kk], acc, 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                    const f32x4 a = *reinterpret_cast<const f32x4*>(As + l31 * LDR + half * 16 + i * 4);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], cur[i][kk], acc, 0, 0, 0);
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -781,7 +796,7 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
     }
     const bool bf16 = gemm_mode == 1;      // plain-bf16 mode covers the recurrent products too
     static const bool no_packed = getenv("XG_NO_PACKED") != nullptr;
-    const bool fast = vec && packed && !bf16 && !no_packed;
+    const bool fast = vec && packed && !no_packed;       // (the caller attaches bf16 tiles iff gemm_mode is 1: attach_packed)
     // cross-workgroup split-K for launches that would leave most CUs idle (every job must allow it)
     int ks = 1;
     {
@@ -811,8 +826,14 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
     if (fast) {
         static const int force_nw = getenv("XG_SK_NW") ? atoi(getenv("XG_SK_NW")) : 0;      // diagnosis
         const bool nw4 = has_attn || ks > 1 || (force_nw ? force_nw == 4 : tiles > 2 * 256);
-        if (nw4) hipLaunchKernelGGL((skf_kernel<4>), dim3((max_tiles + 7) & ~7, a.njobs), dim3(256), 0, st, a);
-        else hipLaunchKernelGGL((skf_kernel<8>), dim3((max_tiles + 7) & ~7, a.njobs), dim3(512), 0, st, a);
+        const dim3 grid((max_tiles + 7) & ~7, a.njobs);
+        if (bf16) {
+            if (nw4) hipLaunchKernelGGL((skf_kernel<4, 1>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((skf_kernel<8, 1>), grid, dim3(512), 0, st, a);
+        } else {
+            if (nw4) hipLaunchKernelGGL((skf_kernel<4, 0>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((skf_kernel<8, 0>), grid, dim3(512), 0, st, a);
+        }
         XG_CHECK_LAUNCH();
         return XG_OK;
     }

@@ -313,11 +313,12 @@ class SAModel(nn.Module):
         """Device pointer of the packed recurrent weights (include/xgate.h: xg_pack_weights), valid for the current
         parameter values; None when the shapes do not allow it (rnn_size % 8 != 0)."""
         self._ensure_flat()
-        key = (self._flat.data_ptr(), self._flat._version, self._packed_epoch,
+        dtype = 1 if self.precision == "bf16" else 0
+        key = (self._flat.data_ptr(), self._flat._version, self._packed_epoch, dtype,
                tuple(p._version for p in self._plist()))
         if key != self._packed_key:
             d = self._dims(1, 1, 1)
-            nbytes = nv.lib().xg_packed_bytes(C.byref(d))
+            nbytes = nv.lib().xg_packed_bytes(C.byref(d), dtype)
             if nbytes == 0:
                 self._packed = None
             else:
@@ -325,7 +326,7 @@ class SAModel(nn.Module):
                     self._packed = torch.empty(nbytes + 16, dtype=torch.uint8, device=self._flat.device)
                 ptr = (self._packed.data_ptr() + 15) & ~15
                 ps = self._params_struct()
-                nv.check(nv.lib().xg_pack_weights(_stream(), C.byref(d), C.byref(ps), C.c_void_p(ptr), C.c_size_t(nbytes), 1),
+                nv.check(nv.lib().xg_pack_weights(_stream(), C.byref(d), C.byref(ps), C.c_void_p(ptr), C.c_size_t(nbytes), dtype, 1),
                          "xg_pack_weights")
             self._packed_key = key
         if self._packed is None:
@@ -344,6 +345,7 @@ class SAModel(nn.Module):
         r.bn_momentum, r.bn_eps = 0.1, 1e-5
         r.gemm_mode = {"fp32": 0, "bf16": 1, "bf16x3": 3}[self.precision]
         r.packed = self._packed_ptr()
+        r.packed_dtype = 1 if self.precision == "bf16" else 0
         r.aux = self._aux_handle()
         return r
 

@@ -100,9 +100,10 @@ typedef struct XgRun {
                              1 = bf16 operands, fp32 accumulate, for the large AND the per-step products
                              (BASELINE.json configs[4], tolerance 1e-2).  Accumulation, the cell arithmetic, the
                              attention and every reduction are fp32 in all modes. */
-    int32_t reserved0;    /* keep 0 */
+    int32_t packed_dtype; /* element type of `packed`: 0 = fp32 tiles (gemm_mode 0 / 3), 1 = bf16 tiles (gemm_mode 1) */
     const void *packed;   /* optional: the recurrent weights in MFMA-fragment order (xg_pack_weights), valid for the
-                             CURRENT parameter values; NULL = stream the plain weights through LDS.  Same results. */
+                             CURRENT parameter values; NULL (or a dtype that does not fit gemm_mode) = stream the plain
+                             weights through LDS.  Same results (bf16: the same rounding, done once instead of per pass). */
     void *aux;            /* optional: handle from xg_aux_create -- side streams on which the entry points overlap work that
                              nothing downstream waits for; everything is joined back onto `stream` before the call
                              returns.  NULL = one stream.  One handle per caller stream in use at a time. */
@@ -261,10 +262,11 @@ int xg_reward_bwd(void *stream, const int64_t *seq, int ld_seq, const float *rew
  * The per-timestep products stream each weight matrix once per step; a second copy of those matrices in the order the
  * matrix cores consume them (32 x 32 tiles, xg_pack.hip) lets the step kernels load the B operand straight into
  * registers.  The caller owns the buffer (xg_packed_bytes, 16-byte aligned), refreshes it with xg_pack_weights after
- * every parameter update (with_backward = 0 skips the data-gradient tiles: inference) and passes it in XgRun.packed. */
-size_t xg_packed_bytes(const XgDims *d);
+ * every parameter update (with_backward = 0 skips the data-gradient tiles: inference) and passes it in XgRun.packed
+ * with XgRun.packed_dtype.  dtype 0: fp32 tiles; dtype 1: bf16 tiles for gemm_mode 1 (weights rounded once, half the bytes). */
+size_t xg_packed_bytes(const XgDims *d, int dtype);
 int xg_pack_weights(void *stream, const XgDims *d, const XgParams *p, void *packed, size_t packed_bytes,
-                    int with_backward);
+                    int dtype, int with_backward);
 
 /* ---- update: clip_gradient + Adam (caption_src/myutils.py:79-85, caption_src/starttrain.py:76,137) ----
  * Elementwise clamp of g to +-clip (clip <= 0 disables), then torch.optim.Adam semantics
