@@ -293,10 +293,18 @@ int dispatch(hipStream_t st, GemmArgs g, bool vec) {
     const int nslab = xg_cdiv(g.K, BKS);
     g.splitk = 1;
     bool big = false;
-    // measured on MI355X (tools/ubench/gemm_bench.py): 128x128 wins only with >= ~400 tiles (x2 split when the
-    // reduction is deep); below that 64x64 tiles with enough K splits to put ~1000-1500 workgroups in flight.
+    // measured on MI355X (tools/ubench/gemm_bench.py): 128x128 wins with >= ~400 tiles (x2 split when the reduction is
+    // deep), and for FEW tiles under a very deep reduction (dH = dlogits W: 84 tiles, K = 20000) when split-K fills exactly
+    // one round of 512 workgroups (87.6 -> 104 TF); otherwise 64x64 tiles with enough K splits to put ~1000-1500
+    // workgroups in flight.  (A per-shape cost model over rounds x depth was tried and lost on the mid-size shapes.)
     if (t128 >= 1024) big = true;
     else if (t128 >= 384) { big = true; if (!g.relu && nslab >= 32) g.splitk = 2; }
+    else if (!g.relu && t128 >= 32 && nslab >= 256 && 512 / t128 >= 2) {
+        big = true;
+        long sk = 512 / t128;
+        if (sk > nslab / 16) sk = nslab / 16;
+        g.splitk = (int)sk;
+    }
     else if (!g.relu && t64 >= 4) {
         const long target = (AKC && BKC) ? 768 : 1536;
         long sk = target / t64;
