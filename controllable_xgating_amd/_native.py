@@ -79,6 +79,7 @@ def lib():
         "xg_init_hidden": [vp, PD, PP, vp, vp, vp, C.c_size_t, vp],
         "xg_vproj": [vp, PD, PP, vp, vp, PR],
         "xg_step_fwd": [vp, PD, PP, vp, vp, vp, vp, vp, PR, i32, vp, C.c_size_t, vp, vp, vp],
+        "xg_step_bwd": [vp, PD, PP, PP, vp, vp, vp, vp, vp, PR, i32, vp, C.c_size_t, vp, vp, vp, vp, vp, vp],
         "xg_forward_xe": [vp, PD, PP, PB, PX, PR, vp, C.c_size_t, vp, vp],
         "xg_backward_xe": [vp, PD, PP, PP, PX, PR, vp, C.c_size_t, vp, vp],
         "xg_forward_ss": [vp, PD, PP, PB, PX, PR, f32, vp, vp, vp, C.c_size_t, vp, vp],

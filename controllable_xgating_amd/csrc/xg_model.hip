@@ -1064,6 +1064,14 @@ extern "C" int xg_step_fwd(void* stream, const XgDims* d, const XgParams* p, con
     s.pos = pos_feats; s.gp = w.GP; s.posg = w.POSG; s.pre1 = nullptr; s.mask = xt_mask; s.ldm = 1;
     s.h1o = state; s.c1o = state + BR; s.h2o = state + 2 * BR; s.c2o = state + 3 * BR;
     s.P = w.P; s.alpha = alpha ? alpha : w.ALPHA; s.af = w.AF; s.g1 = nullptr; s.g2 = nullptr; s.t = step;
+    if (run->save) {
+        // a following xg_step_bwd needs the OLD state (the step overwrites it in place), the activated gates and alpha
+        if (hipMemcpyAsync(w.H1, state, sizeof(float) * BR, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(w.C1, state + BR, sizeof(float) * BR, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(w.H2, state + 2 * BR, sizeof(float) * BR, hipMemcpyDeviceToDevice, st) != hipSuccess ||
+            hipMemcpyAsync(w.C2, state + 3 * BR, sizeof(float) * BR, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
+        s.g1 = w.G1; s.g2 = w.G2; s.alpha = w.ALPHA;
+    }
     if (step_packed(w, *d)) {
         // packed weights: the embedding rows are gathered inside the products and the state is updated in place
         s.xt = nullptr; s.tok = tokens;
@@ -1075,10 +1083,84 @@ extern "C" int xg_step_fwd(void* stream, const XgDims* d, const XgParams* p, con
         s.h1 = w.state_tmp; s.c1 = w.state_tmp + BR; s.h2 = w.state_tmp + 2 * BR; s.c2 = w.state_tmp + 3 * BR;
     }
     XG_TRY(core_step(st, *d, *p, *run, w, V, vproj, s));
+    if (run->save && alpha &&
+        hipMemcpyAsync(alpha, w.ALPHA, sizeof(float) * (size_t)B * d->K, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
     if (logp) {
         XG_TRY(xgk_linear(st, w.gm, B, d->V, R, state + 2 * BR, R, p->logit_w, p->logit_b, w.LOGITS, d->V));
         XG_TRY(xgk_log_softmax(st, w.LOGITS, d->V, logp, d->V, B, d->V, 1, 1, false));
     }
+    return XG_OK;
+}
+
+// Backward of ONE decoder step (LSTMCore_two_layer_gate.forward, caption_src/sub_modules.py:671-687 with the cell :750-770
+// and the gate :42-47), the counterpart of xg_step_fwd run with XgRun.save = 1 on the same workspace.  Plain launches
+// (pointwise kernels + GEMMs): this is the single-step building block, not the benchmarked path -- whole sequences go
+// through xg_backward_xe / xg_rollout_bwd, which batch the weight gradients over all steps.
+extern "C" int xg_step_bwd(void* stream, const XgDims* d, const XgParams* p, const XgParams* g, const int64_t* tokens,
+                           const float* xt_mask, const float* V, const float* vproj, const float* pos_feats, const XgRun* run,
+                           int step, void* ws, size_t ws_bytes, const float* state_new, const float* dstate_new,
+                           float* dstate, float* dV, float* dvproj, float* dpos) {
+    Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
+    if (!p || !g || !tokens || !V || !vproj || !pos_feats || !run || !state_new || !dstate_new || !dstate) return XG_EINVAL;
+    w.gm = 0;                                   // single-step products are small: exact fp32
+    hipStream_t st = (hipStream_t)stream;
+    const int B = d->B, K = d->K, R = d->R, A = d->A, E = d->E;
+    const size_t BR = (size_t)B * R;
+    const float* h1n = state_new;               // new state (after the step)
+    const float* c1n = state_new + BR;
+    const float* c2n = state_new + 3 * BR;
+    const float *h1o = w.H1, *c1o = w.C1, *h2o = w.H2, *c2o = w.C2;      // old state saved by xg_step_fwd
+    float *dh1 = dstate, *dc1 = dstate + BR, *dh2 = dstate + 2 * BR, *dc2 = dstate + 3 * BR;
+    float* dh1n = w.dst[0][0];                  // total gradient wrt h1' = incoming + what cell 2 sends down
+    float* daf = w.DAF;
+    XG_TRY(xgk_embed_gather(st, p->embed_w, E, tokens, B, 1, 0, B, d->V, w.Xe, E));
+    // ---- cell 2                                                                                          :684
+    LstmBwdArgs c2{};
+    c2.gates = w.G2; c2.ldg = 4 * R; c2.c_prev = c2o; c2.ldcp = R; c2.c_out = c2n; c2.ldco = R;
+    c2.mask = xt_mask; c2.ldm = 1;
+    c2.dh_out = dstate_new + 2 * BR; c2.lddh = R; c2.dh_add = nullptr; c2.dc_out = dstate_new + 3 * BR; c2.lddc = R;
+    c2.ds = w.DS2; c2.ldds = 4 * R; c2.dc_prev = dc2; c2.lddcp = R; c2.dh_prev = dh2; c2.lddhp = R;
+    c2.B = B; c2.R = R; c2.order = XG_ORDER_IFOG; c2.mask_mode = XG_MASK_HOLD; c2.drop = xg_make_drop(run, XG_SITE_L2, step);
+    XG_TRY(xgk_lstm_bwd(st, c2));
+    if (hipMemcpyAsync(dh1n, dstate_new, sizeof(float) * BR, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
+    XG_TRY(gemm_nn(st, 0, B, R, 4 * R, w.DS2, 4 * R, p->l2_i2h_w, R, dh1n, R, true));
+    XG_TRY(gemm_nn(st, 0, B, R, 4 * R, w.DS2, 4 * R, p->l2_a2h_w, R, daf, R, false));
+    XG_TRY(gemm_nn(st, 0, B, R, 4 * R, w.DS2, 4 * R, p->l2_h2h_w, R, dh2, R, true));
+    XG_TRY(gemm_tn(st, 0, B, 4 * R, R, w.DS2, 4 * R, h1n, R, g->l2_i2h_w, R));
+    XG_TRY(gemm_tn(st, 0, B, 4 * R, R, w.DS2, 4 * R, w.AF, R, g->l2_a2h_w, R));
+    XG_TRY(gemm_tn(st, 0, B, 4 * R, R, w.DS2, 4 * R, h2o, R, g->l2_h2h_w, R));
+    XG_TRY(xgk_colsum3(st, w.DS2, 4 * R, B, 4 * R, g->l2_i2h_b, g->l2_a2h_b, g->l2_h2h_b));
+    // ---- attention                                                                                       :677-680
+    XG_TRY(xgk_attn_bwd(st, daf, R, w.P, vproj, V, p->a2w_w, w.ALPHA, w.DE, w.DP, B, K, R, A));
+    XG_TRY(xgk_attn_bwd_post(st, w.P, vproj, p->a2w_w, w.DE, w.DVPROJ, g->a2w_w, 1, B, K, A));
+    if (dvproj) XG_TRY(xgk_axpy(st, dvproj, w.DVPROJ, 1.0f, (int64_t)B * K * A));
+    if (dV) XG_TRY(xgk_attn_dV(st, w.ALPHA, daf, R, (int64_t)BR, dV, 1, B, K, R, true));
+    XG_TRY(gemm_nn(st, 0, B, R, A, w.DP, A, p->h2a_w + R, 2 * R, dh2, R, true));
+    XG_TRY(gemm_tn(st, 0, B, A, R, w.DP, A, h1o, R, g->h2a_w, 2 * R));
+    XG_TRY(gemm_tn(st, 0, B, A, R, w.DP, A, h2o, R, g->h2a_w + R, 2 * R));
+    XG_TRY(xgk_colsum(st, w.DP, A, B, A, g->h2a_b));
+    // ---- cell 1                                                                                          :683
+    LstmBwdArgs c1{};
+    c1.gates = w.G1; c1.ldg = 4 * R; c1.c_prev = c1o; c1.ldcp = R; c1.c_out = c1n; c1.ldco = R;
+    c1.mask = xt_mask; c1.ldm = 1;
+    c1.dh_out = dh1n; c1.lddh = R; c1.dh_add = nullptr; c1.dc_out = dstate_new + BR; c1.lddc = R;
+    c1.ds = w.DS1; c1.ldds = 4 * R; c1.dc_prev = dc1; c1.lddcp = R; c1.dh_prev = dh1; c1.lddhp = R;
+    c1.B = B; c1.R = R; c1.order = XG_ORDER_IFOG; c1.mask_mode = XG_MASK_HOLD; c1.drop = xg_make_drop(run, XG_SITE_L1, step);
+    XG_TRY(xgk_lstm_bwd(st, c1));
+    XG_TRY(gemm_nn(st, 0, B, R, 4 * R, w.DS1, 4 * R, p->l1_h2h_w, R, dh1, R, true));
+    XG_TRY(gemm_nn(st, 0, B, R, A, w.DP, A, p->h2a_w, 2 * R, dh1, R, true));          // the attention query read the old h1
+    XG_TRY(gemm_tn(st, 0, B, 4 * R, R, w.DS1, 4 * R, h1o, R, g->l1_h2h_w, R));
+    XG_TRY(gemm_tn(st, 0, B, 4 * R, E, w.DS1, 4 * R, w.Xe, E, g->l1_i2h_w, E));
+    XG_TRY(gemm_tn(st, 0, B, 4 * R, R, w.DS1, 4 * R, w.POSG, R, g->l1_a2h_w, R));
+    XG_TRY(xgk_colsum3(st, w.DS1, 4 * R, B, 4 * R, g->l1_i2h_b, g->l1_a2h_b, g->l1_h2h_b));
+    // ---- POS gate and the token side                                                                      :682, SAModel.py:105
+    XG_TRY(gemm_nn(st, 0, B, R, 4 * R, w.DS1, 4 * R, p->l1_a2h_w, R, w.DPOSG, R, false));
+    XG_TRY(gemm_nn(st, 0, B, E, 4 * R, w.DS1, 4 * R, p->l1_i2h_w, E, w.DXe, E, false));
+    XG_TRY(xgk_gate_bwd(st, w.DPOSG, R, w.GP, R, pos_feats, R, 0, w.DGP, R, dpos, R, true, B, R, xg_make_drop(run, XG_SITE_DGATE, step)));
+    XG_TRY(gemm_tn(st, 0, B, R, E, w.DGP, R, w.Xe, E, g->dgate_w, E));
+    XG_TRY(xgk_colsum(st, w.DGP, R, B, R, g->dgate_b));
+    XG_TRY(gemm_nn(st, 0, B, E, R, w.DGP, R, p->dgate_w, E, w.DXe, E, true));
+    XG_TRY(xgk_embed_scatter_add(st, g->embed_w, E, tokens, B, 1, 0, B, d->V, w.DXe, E));
     return XG_OK;
 }
 

@@ -163,6 +163,16 @@ int xg_step_fwd(void *stream, const XgDims *d, const XgParams *p, const int64_t 
                 const XgRun *run, int step, void *ws, size_t ws_bytes,
                 float *state, float *logp, float *alpha);
 
+/* Backward of one step: xg_step_fwd must have run with run->save = 1 on the same workspace (it then keeps the old state,
+ * the activated gates, p, alpha, af and the gate values there).  state_new: the (4,B,R) state AFTER the step;
+ * dstate_new: gradient wrt it (the step's output is h2' = state_new[2]: add its gradient there); dstate (out, overwritten):
+ * gradient wrt the state BEFORE the step.  dV (B,K,R), dvproj (B,K,A), dpos (B,R): optional, ACCUMULATED.  Parameter
+ * gradients (lstmcore.*, embed.weight) are accumulated into g.  The logit head is not part of it (xg_gemm / xg_nll_*). */
+int xg_step_bwd(void *stream, const XgDims *d, const XgParams *p, const XgParams *g, const int64_t *tokens,
+                const float *xt_mask, const float *V, const float *vproj, const float *pos_feats,
+                const XgRun *run, int step, void *ws, size_t ws_bytes, const float *state_new,
+                const float *dstate_new, float *dstate, float *dV, float *dvproj, float *dpos);
+
 /* ---- teacher-forced forward: SAModel.forward (caption_src/SAModel.py:67-115), ss_prob = 0 ----
  * Runs encoder, init_hidden, T decoder steps and both heads.
  * logp (B,T,V), cat_logp (B,T,C) out. */

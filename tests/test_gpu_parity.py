@@ -890,3 +890,71 @@ def test_sample_pair_leaves_reference_batchnorm_statistics():
         np.testing.assert_allclose(b.running_mean.cpu().numpy(), a.running_mean.cpu().numpy(), atol=1e-6)
         np.testing.assert_allclose(b.running_var.cpu().numpy(), a.running_var.cpu().numpy(), atol=1e-6)
         assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == 2
+
+
+def test_single_step_backward_vs_oracle_autograd():
+    """xg_step_bwd (SURVEY.md 8b export list): gradients of one LSTMCore_two_layer_gate step (sub_modules.py:671-687) wrt
+    the old state, V, v2a(V), pos and every lstmcore / embed parameter == autograd over the oracle's core_step, with a held
+    row (xt_mask = 0) in the batch."""
+    from controllable_xgating_amd import _native as nv
+    from controllable_xgating_amd.model import _grads_struct, _stream, _ws_ptr
+    d = pg.make_dims(**CFG["mid"])
+    Pn = pg.make_params(d)
+    B, K, R, E, A = d.B, d.K, d.R, d.E, d.A
+    Vn = pg.uniform("sb.V", (B, K, R), 7, 0.0, 1.0)
+    posn = pg.uniform("sb.pos", (B, R), 7, -1.0, 1.0)
+    stn = pg.uniform("sb.st", (4, B, R), 7, -0.5, 0.5)
+    wn = pg.uniform("sb.w", (4, B, R), 7, -1.0, 1.0)                  # d(loss)/d(new state)
+    tok = pg.randint("sb.tok", (B,), 7, 2, d.V)
+    mk = np.ones((B,), np.float32); mk[2] = 0.0; mk[7] = 0.0
+    # ---- oracle
+    P = xo.to_torch_params(Pn, requires_grad=True)
+    Vt = torch.from_numpy(Vn).requires_grad_(True)
+    vp = (Vt.detach() @ P["lstmcore.v2a.weight"].detach().t() + P["lstmcore.v2a.bias"].detach()).requires_grad_(True)
+    post = torch.from_numpy(posn).requires_grad_(True)
+    st = [torch.from_numpy(stn[i].copy()).requires_grad_(True) for i in range(4)]
+    xt = P["embed.weight"][torch.from_numpy(tok)]
+    out, ns, alpha_o = xo.core_step(P, xt, torch.from_numpy(mk).unsqueeze(1), Vt, post, [(st[0], st[1]), (st[2], st[3])], vproj=vp)
+    wt = torch.from_numpy(wn)
+    loss = (ns[0][0] * wt[0]).sum() + (ns[0][1] * wt[1]).sum() + (ns[1][0] * wt[2]).sum() + (ns[1][1] * wt[3]).sum()
+    loss.backward()
+    # ---- HIP
+    model = make_model(d, P=Pn, train=True)
+    model.flat_grads().zero_()
+    dd = model._dims(B, K, 1)
+    ps = model._params_struct()
+    run = model._run(True)
+    g, gs = _grads_struct(model, "cuda")
+    assert g is None                                                    # grads accumulate into the bound flat buffer
+    L = nv.lib()
+    Vd, posd = torch.from_numpy(Vn).cuda(), torch.from_numpy(posn).cuda()
+    vpd = vp.detach().cuda().contiguous()
+    tokd, mkd = torch.from_numpy(tok).cuda(), torch.from_numpy(mk).cuda()
+    state = torch.from_numpy(stn).cuda().contiguous()
+    ws = model._pool.shared(dd, Vd.device)
+    wp, wnb = _ws_ptr(ws)
+    alpha = torch.zeros(B, K, device="cuda")
+    nv.check(L.xg_step_fwd(_stream(), C.byref(dd), C.byref(ps), nv.ptr(tokd), nv.ptr(mkd), nv.ptr(Vd), nv.ptr(vpd), nv.ptr(posd),
+                           C.byref(run), 3, wp, wnb, nv.ptr(state), None, nv.ptr(alpha)), "xg_step_fwd")
+    np.testing.assert_allclose(state[2].cpu().numpy(), out.detach().numpy(), atol=2e-5)
+    np.testing.assert_allclose(alpha.cpu().numpy(), alpha_o.detach().numpy(), atol=2e-6)
+    dst_new = torch.from_numpy(wn).cuda().contiguous()
+    dst = torch.full((4, B, R), 7.0, device="cuda")                     # overwritten
+    dV = torch.zeros(B, K, R, device="cuda"); dvp = torch.zeros(B, K, A, device="cuda"); dpos = torch.zeros(B, R, device="cuda")
+    nv.check(L.xg_step_bwd(_stream(), C.byref(dd), C.byref(ps), C.byref(gs), nv.ptr(tokd), nv.ptr(mkd), nv.ptr(Vd), nv.ptr(vpd),
+                           nv.ptr(posd), C.byref(run), 3, wp, wnb, nv.ptr(state), nv.ptr(dst_new), nv.ptr(dst), nv.ptr(dV),
+                           nv.ptr(dvp), nv.ptr(dpos)), "xg_step_bwd")
+    torch.cuda.synchronize()
+
+    def close(got, want, name):
+        want = want.numpy()
+        err = np.abs(got.cpu().numpy() - want).max()
+        assert err <= 2e-6 + 2e-3 * np.abs(want).max(), (name, float(err), float(np.abs(want).max()))
+    for i in range(4):
+        close(dst[i], st[i].grad, "dstate[%d]" % i)
+    close(dV, Vt.grad, "dV"); close(dvp, vp.grad, "dvproj"); close(dpos, post.grad, "dpos")
+    for name, prm in model.named_parameters():
+        if not (name.startswith("lstmcore.") or name == "embed.weight") or name in ("lstmcore.a2w.bias", "lstmcore.v2a.weight", "lstmcore.v2a.bias"):
+            continue
+        want = P[name].grad if P[name].grad is not None else torch.zeros_like(P[name])
+        close(prm.grad, want, name)
