@@ -29,7 +29,7 @@ class XgBatch(C.Structure):
 class XgRun(C.Structure):
     _fields_ = [("train", C.c_int32), ("drop_p", C.c_float), ("seed", C.c_uint32), ("save", C.c_int32),
                 ("bn_momentum", C.c_float), ("bn_eps", C.c_float), ("gemm_mode", C.c_int32), ("packed_dtype", C.c_int32),
-                ("packed", C.c_void_p), ("aux", C.c_void_p), ("grad_event", C.c_void_p)]
+                ("packed", C.c_void_p), ("aux", C.c_void_p), ("grad_event", C.c_void_p), ("grad_event_head", C.c_void_p)]
 
 
 class XgError(RuntimeError):

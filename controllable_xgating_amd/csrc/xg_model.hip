@@ -42,9 +42,10 @@ struct Streams {
     bool forked = false, forked2 = false;
     int dh_split_step = 0, dh_mark = -1;      // heads_bwd -> decoder_bwd_core hand-off (see heads_bwd)
     hipEvent_t grad_event = nullptr;          // XgRun.grad_event: recorded when every gradient but the encoder's is final
+    hipEvent_t grad_event_head = nullptr;     // XgRun.grad_event_head: recorded when the logit.* gradients are final
     Streams(hipStream_t m, const XgRun* run) : main(m), aux(m), aux2(m), a(aux_of(run)) {
         if (a) { aux = a->s; aux2 = a->s2; }
-        if (run) grad_event = static_cast<hipEvent_t>(run->grad_event);
+        if (run) { grad_event = static_cast<hipEvent_t>(run->grad_event); grad_event_head = static_cast<hipEvent_t>(run->grad_event_head); }
     }
     bool overlap() const { return a != nullptr; }
     // aux may start work that depends on everything enqueued on main so far
@@ -897,6 +898,8 @@ int heads_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams& g
     // dW_logit / db: parameter gradients, under the loop as well
     XG_TRY(gemm_tn(ss.aux, w.gm, rows, d.V, R, w.LOGITS, d.V, Hout, R, g.logit_w, R));
     XG_TRY(xgk_colsum(ss.aux, w.LOGITS, d.V, rows, d.V, g.logit_b));
+    // data parallel: the vocabulary head's gradients are final here, long before anything else (XgRun.grad_event_head)
+    if (ss.grad_event_head && hipEventRecord(ss.grad_event_head, ss.aux) != hipSuccess) return XG_EHIP;
     XG_TRY(gemm_nn(st, w.gm, rows - r0, R, d.V, w.LOGITS + (size_t)r0 * d.V, d.V, p.logit_w, R, w.DH2OUT + (size_t)r0 * R, R, false));
     if (have_cls) {
         XG_TRY(gemm_tn(st, w.gm, rows, d.C, d.H, w.DCL, d.C, w.HC, d.H, g.cls3_w, d.H));

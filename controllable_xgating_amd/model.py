@@ -49,6 +49,9 @@ def _with_grad_event(model, run):
     r = nv.XgRun()
     C.memmove(C.byref(r), C.byref(run), C.sizeof(nv.XgRun))
     r.grad_event = ev.cuda_event
+    ev_head = getattr(model, "_grad_event_head", None)
+    if ev_head is not None:
+        r.grad_event_head = ev_head.cuda_event
     return r
 
 

@@ -111,6 +111,8 @@ typedef struct XgRun {
                              every gradient except two_spatial_encoder.* is final, so that a caller who keeps the gradients
                              in xg_param_name order can start the RCCL all-reduce of that suffix under the CG encoder's
                              backward.  NULL = not recorded. */
+    void *grad_event_head;/* optional hipEvent_t: recorded earlier still, when logit.weight / logit.bias gradients (a third of
+                             all gradient bytes at V = 20000) are final -- before the reverse-time decoder loop starts. */
 } XgRun;
 
 enum { XG_ROLLOUT_GREEDY = 0, XG_ROLLOUT_SAMPLE = 1, XG_ROLLOUT_REPLAY = 2 };
