@@ -92,6 +92,41 @@ def measure_step_group(model, x, reps=200):
         return e0.elapsed_time(e1) * 1e-3 / reps
 
 
+def measure_traffic(timeout_s=150):
+    """HBM bytes per decoder-step launch group measured NOW: two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE -- separate
+    passes, no tracing, as MI355X_MICROARCH.md's HBM section prescribes) over tools/step_group_run.py, FETCH_SIZE doubled
+    (gfx950 counts a wide coalesced read at half its bytes), WRITE_SIZE as reported.  Returns (bytes, source) or (None, why)."""
+    import shutil, subprocess, tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import pmc_traffic
+        tmp = tempfile.mkdtemp(prefix="xg_pmc_", dir="/tmp")
+        env = dict(os.environ, TMPDIR="/tmp")
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+            env.pop(k, None)
+        dirs = {}
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            dirs[counter] = os.path.join(tmp, counter)
+            r = subprocess.run(["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", dirs[counter], "--",
+                                sys.executable, os.path.join(ROOT, "tools", "step_group_run.py"), "40"],
+                               cwd="/tmp", env=env, capture_output=True, text=True, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, "rocprofv3 --pmc %s failed: %s" % (counter, (r.stderr or r.stdout)[-300:])
+        fetch, n1 = pmc_traffic.per_kernel(dirs["FETCH_SIZE"], "FETCH_SIZE")
+        write, _ = pmc_traffic.per_kernel(dirs["WRITE_SIZE"], "WRITE_SIZE")
+        tot = 0.0
+        for k, mult in pmc_traffic.STEP.items():
+            if k not in fetch or k not in write:
+                return None, "no %s dispatches in the PMC pass" % k
+            tot += (fetch[k] * 2.0 + write[k]) * 1024 * mult
+        shutil.rmtree(tmp, ignore_errors=True)
+        return int(round(tot)), "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this run (FETCH x2 gfx950 correction; %d dispatches)" % sum(n1.values())
+    except Exception as e:                                   # never lose the bench line over the counters
+        return None, "PMC passes failed: %r" % (e,)
+
+
 def load_traffic():
     """HBM bytes per decoder-step launch group from the committed PMC passes (tools/pmc_traffic.py)."""
     try:
@@ -176,6 +211,7 @@ def main():
                     help="xe: BASELINE configs[1] (the metric); scst: configs[2] (sample + greedy rollouts + RL backward, B=64, L=30); "
                          "xe5: configs[4] shape (hidden 1024, 40 frames; pair with --precision bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -309,7 +345,15 @@ def main():
         value = world * cfg["B"] * T * args.steps / dt * (2 if args.workload == "scst" else 1)
         bytes_step = step_bytes(cfg["B"], cfg["K"], cfg["R"], cfg["A"], cfg["E"], save=False)
         achieved = bytes_step / t_step / 1e9
-        traffic, traffic_src = load_traffic() if (cfg["B"] == 128 and args.workload == "xe") else (None, None)
+        traffic, traffic_src = (None, None)
+        if cfg["B"] == 128 and args.workload == "xe" and args.precision == "fp32":
+            if not args.no_pmc:
+                traffic, traffic_src = measure_traffic()
+            if traffic is None:                              # fall back to the committed passes, and say so
+                why = traffic_src
+                traffic, traffic_src = load_traffic()
+                if traffic_src:
+                    traffic_src += " (committed earlier: live PMC pass unavailable -- %s)" % why
         wl = {"xe": "configs[1]: 1xMI355X batch %d teacher-forced XE train, 26 frames x (1536+1024), hidden 512, "
                     "att 1536, emb 468, vocab 20000, seq_len 20 (T=21), fp32" % cfg["B"],
               "scst": "configs[2]: 1xMI355X SCST iteration (sampled rollout + greedy baseline as one 2m-row batch + RL backward + "

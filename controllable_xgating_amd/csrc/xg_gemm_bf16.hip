@@ -104,10 +104,24 @@ __device__ __forceinline__ void store_tile(unsigned short* __restrict__ lds, con
                 v[j] = ok ? v[j] : 0.f;
             }
         }
+        const int off = KC ? r * LDKC + k : k * LDMC + r;
+        if constexpr (NP == 1) {
+            // plain bf16: the hardware's packed round-to-nearest-even convert (v_cvt_pk_bf16_f32), one instruction per pair
+            // instead of ~4 integer operations per element (269 -> 294 TF on the vocabulary products).  (A 64-deep,
+            // double-buffered variant of this kernel was measured SLOWER, 267 TF: at bf16 rates a slab is 0.2 us of MFMA
+            // against ~1.5 us of load latency, so what is missing is depth of prefetch -- an LDS-DMA ring fed from bf16
+            // operand copies -- not fewer barriers.)
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            bf16x2_t lo, hi;
+            lo[0] = (__bf16)v[0]; lo[1] = (__bf16)v[1]; hi[0] = (__bf16)v[2]; hi[1] = (__bf16)v[3];
+            uint2 w;
+            w.x = __builtin_bit_cast(unsigned, lo); w.y = __builtin_bit_cast(unsigned, hi);
+            *reinterpret_cast<uint2*>(lds + off) = w;
+            continue;
+        }
         unsigned short h[4][NP];
 #pragma unroll
         for (int j = 0; j < 4; ++j) split<NP>(v[j], h[j]);
-        const int off = KC ? r * LDKC + k : k * LDMC + r;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             uint2 w;

@@ -110,6 +110,8 @@ enum { SK_EPI_STORE = 0, SK_EPI_LSTM = 1, SK_EPI_GATE = 2,
        SK_EPI_LSTMB = 3,
        // (fast kernel only) zero-fill job: C[0 .. M*N) = 0, one tile per 4096 floats
        SK_EPI_ZERO = 4,
+       // (fast kernel only) copy job: C[0 .. M*N) = seg[0].A[0 .. M*N), one tile per 4096 floats, 16-byte aligned
+       SK_EPI_COPY = 6,
        // (fast kernel only) temporal attention of one step, TWO workgroups per video (sub_modules.py:678-680):
        //   workgroup (b, part) scores its half of the K frames, e_k = w . tanh(p_b + q_bk), and adds its share of the
        //   UNNORMALISED softmax -- ex_k = exp(e_k - e_0), s = sum ex_k, c = sum ex_k V_bk -- into attn_s[b] / attn_c[b][:]

@@ -526,8 +526,13 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
                                 ((uintptr_t)vproj % 16 == 0) && ((uintptr_t)p.a2w_w % 16 == 0);
         const bool s2_first = s.pre1 != nullptr;          // S2' = h2 W_h2h2 + b rides in launch 1 (teacher forcing) or 2
         SkArgs k1{}, k2{}, k3{};
-        int n1 = 0, n2 = 0;
-        // ---- launch 1 (jobs that gather come first: the index load is one more dependent round trip)
+        int n1 = 0, n2 = 0, n3 = 0;
+        // the state may be updated IN PLACE (xg_step_fwd): cell 1 then runs in launch 2 beside products that still read the
+        // old h1, so its new h1 goes to a scratch row block and rides back into the state with launch 3
+        const bool h1_alias = s.h1o == s.h1;
+        float* h1_new = h1_alias ? w.state_tmp : s.h1o;
+        // ---- launch 1: what the attention and cell 1 wait for (jobs that gather come first: the index load is one more
+        // dependent round trip)
         if (!s.pre1) {  // POS gate: pos' = dropout(relu(W_g xt + b)) * pos + pos                          :682
             SkJob& j = k1.job[n1++];
             j = job_store(B, R, s.gp, R, false);
@@ -535,14 +540,6 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
             j.seg[0] = xt_seg(PK_DGATE, p.dgate_w); j.bias[0] = p.dgate_b;
             j.gate_t = s.pos; j.ldt = R; j.gate_y = s.posg; j.ldy = R;
             j.drop = xg_make_drop(&run, XG_SITE_DGATE, s.t);
-        }
-        if (!s.pre1) {  // S1' = h1 W_h2h + xt W_i2h + both biases (gate-major, cell tiling) -> w.S
-            SkJob& j = k1.job[n1++];
-            j = job_store(B, 4 * R, w.S, 4 * R, false);
-            j.cell_cols = 1; j.R = R;
-            j.nseg = 2;
-            j.seg[0] = seg_nt(w, PK_L1_H2H, s.h1, R, p.l1_h2h_w, R, R); j.bias[0] = p.l1_h2h_b;
-            j.seg[1] = xt_seg(PK_L1_I2H, p.l1_i2h_w); j.bias[1] = p.l1_i2h_b;
         }
         {   // p = h2a([h1 ; h2])                                                                         :677
             SkJob& j = k1.job[n1++];
@@ -558,7 +555,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
             j.nseg = 1;
             j.seg[0] = seg_nt(w, PK_L1_H2H, s.h1, R, p.l1_h2h_w, R, R); j.bias[0] = p.l1_h2h_b;
         }
-        auto s2_job = [&](SkJob& j) {
+        auto s2_job = [&](SkJob& j) {                     // S2' = h2 W_h2h2 + b (gate-major, cell tiling) -> w.S2
             j = job_store(B, 4 * R, w.S2, 4 * R, false);
             j.cell_cols = 1; j.R = R;
             j.nseg = 1;
@@ -572,7 +569,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         }
         k1.njobs = n1;
         XG_TRY(xgk_skinny(st, k1, w.gm));
-        // ---- launch 2: attention || [cell 1] || S2' = h2 W_h2h2 + b
+        // ---- launch 2: attention || rollout: cell 1 = h1 W_h2h + pos' W_a2h + xt W_i2h || S2'
         if (fused_attn) {
             SkJob& j = k2.job[n2++];
             j = SkJob{};
@@ -580,28 +577,38 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
             j.attn_p = s.P; j.attn_q = vproj; j.attn_v = V; j.attn_w = p.a2w_w;
             j.attn_ex = s.alpha; j.attn_s = w.ATS; j.attn_c = w.AFU;
         }
-        if (!s.pre1) {  // cell 1 = pos' W_a2h + b + S1'
+        if (!s.pre1) {
             SkJob& j = k2.job[n2++];
-            a.add = w.S; a.ldadd = 4 * R;
+            a.h_out = h1_new;
             j = job_lstm(a);
-            j.nseg = 1;
-            j.seg[0] = seg_nt(w, PK_L1_A2H, s.posg, R, p.l1_a2h_w, R, R); j.bias[0] = p.l1_a2h_b;
+            j.nseg = 3;
+            j.seg[0] = seg_nt(w, PK_L1_H2H, s.h1, R, p.l1_h2h_w, R, R); j.bias[0] = p.l1_h2h_b;
+            j.seg[1] = seg_nt(w, PK_L1_A2H, s.posg, R, p.l1_a2h_w, R, R); j.bias[1] = p.l1_a2h_b;
+            j.seg[2] = xt_seg(PK_L1_I2H, p.l1_i2h_w); j.bias[2] = p.l1_i2h_b;
         }
         if (!s2_first) s2_job(k2.job[n2++]);
         k2.njobs = n2;
         if (n2 > 0) XG_TRY(xgk_skinny(st, k2, w.gm));
         if (!fused_attn) XG_TRY(xgk_attn_fwd(st, s.P, vproj, V, p.a2w_w, s.alpha, s.af, B, d.K, R, A));
         // ---- launch 3: cell 2 = h1' W_i2h + af W_a2h + S2'                                                :684
-        k3.njobs = 1;
         c.add = w.S2; c.ldadd = 4 * R;
-        k3.job[0] = job_lstm(c);
-        k3.job[0].nseg = 2;
-        k3.job[0].seg[0] = seg_nt(w, PK_L2_I2H, s.h1o, R, p.l2_i2h_w, R, R); k3.job[0].bias[0] = p.l2_i2h_b;
-        k3.job[0].seg[1] = seg_nt(w, PK_L2_A2H, fused_attn ? w.AFU : s.af, R, p.l2_a2h_w, R, R); k3.job[0].bias[1] = p.l2_a2h_b;
-        if (fused_attn) {   // af = c / s while it is staged; the tn == 0 tiles store af and normalise alpha
-            SkSeg& g = k3.job[0].seg[1];
-            g.row_scale = w.ATS; g.scaled_out = s.af; g.ld_out = R; g.ex = s.alpha; g.ex_ld = d.K; g.ex_K = d.K;
+        {
+            SkJob& j = k3.job[n3++];
+            j = job_lstm(c);
+            j.nseg = 2;
+            j.seg[0] = seg_nt(w, PK_L2_I2H, s.pre1 ? s.h1o : h1_new, R, p.l2_i2h_w, R, R); j.bias[0] = p.l2_i2h_b;
+            j.seg[1] = seg_nt(w, PK_L2_A2H, fused_attn ? w.AFU : s.af, R, p.l2_a2h_w, R, R); j.bias[1] = p.l2_a2h_b;
+            if (fused_attn) {   // af = c / s while it is staged; the n-tiles store af and normalise alpha between them
+                SkSeg& g = j.seg[1];
+                g.row_scale = w.ATS; g.scaled_out = s.af; g.ld_out = R; g.ex = s.alpha; g.ex_ld = d.K; g.ex_K = d.K;
+            }
         }
+        if (!s.pre1 && h1_alias) {                           // the new h1 returns to the in-place state
+            SkJob& j = k3.job[n3++];
+            j = SkJob{};
+            j.epi = SK_EPI_COPY; j.M = 1; j.N = B * R; j.C = s.h1o; j.seg[0].A = h1_new;
+        }
+        k3.njobs = n3;
         XG_TRY(xgk_skinny(st, k3, w.gm));
         return XG_OK;
     }

@@ -75,7 +75,10 @@ __device__ __forceinline__ void st_chunk(float* __restrict__ lds, int lane, cons
 #define SK_TRACE_NJOBS 1
 #endif
 __device__ long long sk_trace_buf[4096 * 8];
-#define SK_STAMP(i) do { if (threadIdx.x == 0 && gridDim.y == SK_TRACE_NJOBS) sk_trace_buf[(blockIdx.x + blockIdx.y * gridDim.x) * 8 + (i)] = wall_clock64(); } while (0)
+#ifndef SK_TRACE_GX
+#define SK_TRACE_GX gridDim.x
+#endif
+#define SK_STAMP(i) do { if (threadIdx.x == 0 && gridDim.y == SK_TRACE_NJOBS && gridDim.x == SK_TRACE_GX) sk_trace_buf[(blockIdx.x + blockIdx.y * gridDim.x) * 8 + (i)] = wall_clock64(); } while (0)
 #else
 #define SK_STAMP(i) do {} while (0)
 #endif
@@ -93,9 +96,11 @@ __device__ __forceinline__ unsigned bf16_rne(float x) {
 __device__ __forceinline__ void st_chunk_bf16(unsigned short* __restrict__ lds, int lane, const f32x4 (&v)[4]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
+        typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));      // v_cvt_pk_bf16_f32: RNE, one instruction per pair
+        bf16x2_t lo, hi;
+        lo[0] = (__bf16)v[i][0]; lo[1] = (__bf16)v[i][1]; hi[0] = (__bf16)v[i][2]; hi[1] = (__bf16)v[i][3];
         uint2 pk;
-        pk.x = bf16_rne(v[i][0]) | (bf16_rne(v[i][1]) << 16);
-        pk.y = bf16_rne(v[i][2]) | (bf16_rne(v[i][3]) << 16);
+        pk.x = __builtin_bit_cast(unsigned, lo); pk.y = __builtin_bit_cast(unsigned, hi);
         *reinterpret_cast<uint2*>(lds + (i * 8 + (lane >> 3)) * LDH + ((lane & 7) << 2)) = pk;
     }
 }
@@ -474,6 +479,19 @@ __device__ __forceinline__ void zero_tile(const SkJob& job, int tile) {
     }
 }
 
+// ---- COPY job: one tile = 4096 floats
+template <int NW>
+__device__ __forceinline__ void copy_tile(const SkJob& job, int tile) {
+    const size_t n = (size_t)job.M * job.N;
+    const float* src = job.seg[0].A;
+#pragma unroll
+    for (int u = 0; u < 1024 / (NW * 64); ++u) {
+        const size_t i = ((size_t)tile * 1024 + u * (NW * 64) + threadIdx.x) * 4;
+        if (i + 3 < n) *reinterpret_cast<f32x4*>(job.C + i) = *reinterpret_cast<const f32x4*>(src + i);
+        else for (size_t j = i; j < n; ++j) job.C[j] = src[j];
+    }
+}
+
 // ---- ATTN job (256-thread workgroups): see SK_EPI_ATTN in xg_kernels.h.  Reference: caption_src/sub_modules.py:678-680.
 //   wave w scores rows k0 + w, k0 + w + 4, ... of this half (whole q rows, lane = 16 B); both halves use e_0 as the
 //   softmax shift (the second half scores frame 0 once more: same arithmetic, same bits), so their unnormalised sums simply
@@ -571,6 +589,10 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
     const SkJob& job = args.job[blockIdx.y];
     if (job.epi == SK_EPI_ZERO) {
         if ((size_t)blockIdx.x * 4096 < (size_t)job.M * job.N) zero_tile<NW>(job, blockIdx.x);
+        return;
+    }
+    if (job.epi == SK_EPI_COPY) {
+        if ((size_t)blockIdx.x * 4096 < (size_t)job.M * job.N) copy_tile<NW>(job, blockIdx.x);
         return;
     }
     if (job.epi == SK_EPI_ATTN) {
@@ -746,15 +768,16 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
     int tiles = 0, max_tiles = 0;
     for (int j = 0; j < a.njobs; ++j) {
         SkJob& jb = a.job[j];
-        const bool no_segs = jb.epi == SK_EPI_ZERO || jb.epi == SK_EPI_ATTN;
+        const bool no_segs = jb.epi == SK_EPI_ZERO || jb.epi == SK_EPI_ATTN || jb.epi == SK_EPI_COPY;
         if (jb.M <= 0 || (!no_segs && (jb.N <= 0 || jb.nseg < 1 || jb.nseg > 3))) return XG_EINVAL;
         if (jb.epi == SK_EPI_LSTMB && (jb.N != jb.R || !jb.gates || !jb.c_prev || !jb.c_out || !jb.ds || !jb.dc_prev ||
                                        (jb.accumulate && !jb.C))) return XG_EINVAL;
         jb.tile0 = tiles; a.tile0[j] = tiles;
-        if (jb.epi == SK_EPI_ZERO || jb.epi == SK_EPI_ATTN) {       // fast-kernel-only job types, no matrix segments
+        if (no_segs) {                                              // fast-kernel-only job types, no matrix segments
             int nt;
-            if (jb.epi == SK_EPI_ZERO) {
-                if (!jb.C || ((uintptr_t)jb.C % 16)) return XG_EINVAL;
+            if (jb.epi == SK_EPI_ZERO || jb.epi == SK_EPI_COPY) {
+                if (!jb.C || ((uintptr_t)jb.C % 16) || jb.N <= 0) return XG_EINVAL;
+                if (jb.epi == SK_EPI_COPY && (!jb.seg[0].A || ((uintptr_t)jb.seg[0].A % 16))) return XG_EINVAL;
                 nt = (int)(((size_t)jb.M * jb.N + 4095) / 4096);
             } else {
                 if (!jb.attn_p || !jb.attn_q || !jb.attn_v || !jb.attn_w || !jb.attn_ex || !jb.attn_s || !jb.attn_c) return XG_EINVAL;
@@ -764,7 +787,7 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
                 has_attn = true;
             }
             special = true;
-            tiles += nt;
+            if (jb.epi == SK_EPI_ATTN) tiles += nt;              // (ZERO tiles are over at once: they do not count as occupancy)
             max_tiles = nt > max_tiles ? nt : max_tiles;
             continue;
         }

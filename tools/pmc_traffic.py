@@ -5,8 +5,9 @@ MI355X_MICROARCH.md section HBM); WRITE_SIZE is taken as reported (uncalibrated)
 usage: pmc_traffic.py <fetch_dir> <write_dir> <out.json>"""
 import collections, csv, glob, json, sys
 
-# launches of one xg_step_fwd: state copy + embedding rows, [p || pos' gate], cell 1, attention, cell 2
-STEP = {"step_prep_kernel": 1, "sk_kernel": 3, "attn_fwd_fast": 1}
+# launches of one xg_step_fwd (round 2): three multi-job skinny launches -- [POS gate || p || zero], [attention (two
+# workgroups per video) || cell 1 || S2'], [cell 2 || h1 copy] -- all instances of skf_kernel (4- and 8-wave variants)
+STEP = {"skf_kernel": 3}
 
 
 def per_kernel(d, counter):

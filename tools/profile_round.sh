@@ -1,0 +1,39 @@
+#!/bin/bash
+# One GPU session that regenerates the round's rocprofv3 evidence under gpurun_out/prof_$1 (copy the summaries into
+# profiles/ afterwards).  usage: tools/profile_round.sh r02
+set -u
+R=${1:-rXX}
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$R
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+cd $GRAFT_REPO_ROOT
+# 1. full iteration (configs[1]): kernel trace + stats
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python bench.py --no-cpu-baseline --no-pmc --steps 10 --warmup 3 > $OUT/bench.log 2>&1
+python tools/prof_summary.py $OUT/bench $OUT/${R}_bench_kernel_stats.txt 18 > /dev/null
+python tools/timeline.py $OUT/bench > $OUT/${R}_bench_timeline.txt 2>&1
+# 2. decoder-step launch group: kernel stats, per-launch durations, PMC passes
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step -- python tools/step_group_run.py 200 > $OUT/step.log 2>&1
+python tools/prof_summary.py $OUT/step $OUT/${R}_step_group_kernel_stats.txt 210 > /dev/null
+python tools/step_trace.py $OUT/step >> $OUT/${R}_step_group_kernel_stats.txt
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmcF -- python tools/step_group_run.py 40 > $OUT/pmcF.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmcW -- python tools/step_group_run.py 40 > $OUT/pmcW.log 2>&1
+python tools/pmc_traffic.py $OUT/pmcF $OUT/pmcW $OUT/${R}_step_traffic.json > /dev/null
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY --output-format csv -d $OUT/pmc1 -- python tools/step_group_run.py 40 > $OUT/pmc1.log 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SALU SQ_INSTS_SMEM --output-format csv -d $OUT/pmc2 -- python tools/step_group_run.py 40 > $OUT/pmc2.log 2>&1
+rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc3 -- python tools/step_group_run.py 40 > $OUT/pmc3.log 2>&1
+python tools/pmc_summary.py $OUT/${R}_step_pmc.txt "decoder-step launch group (tools/step_group_run.py, B=128): rocprofv3 --pmc, three passes" $OUT/pmc1 $OUT/pmc2 $OUT/pmc3 > /dev/null
+# 3. SCST iteration (configs[2]) and the bf16 configuration (configs[4] shape)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scst -- python bench.py --no-cpu-baseline --no-pmc --workload scst --steps 10 --warmup 3 > $OUT/scst.log 2>&1
+python tools/prof_summary.py $OUT/scst $OUT/${R}_scst_kernel_stats.txt 18 > /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/xe5 -- python bench.py --no-cpu-baseline --no-pmc --workload xe5 --precision bf16 --steps 8 --warmup 2 > $OUT/xe5.log 2>&1
+python tools/prof_summary.py $OUT/xe5 $OUT/${R}_xe5_bf16_kernel_stats.txt 15 > /dev/null
+# 4. large products
+python tools/ubench/gemm_bench.py > $OUT/${R}_gemm_bench_raw.txt 2>&1
+# 5. the bench lines themselves (un-profiled)
+python bench.py > $OUT/${R}_bench_line.json 2> $OUT/bench_line.err
+python bench.py --no-cpu-baseline --workload scst > $OUT/${R}_bench_line_scst.json 2>/dev/null
+python bench.py --no-cpu-baseline --workload xe5 --precision bf16 > $OUT/${R}_bench_line_xe5_bf16.json 2>/dev/null
+python bench.py --no-cpu-baseline --precision bf16x3 > $OUT/${R}_bench_line_bf16x3.json 2>/dev/null
+# keep the merge small: raw traces stay on the box
+rm -rf $OUT/bench $OUT/step $OUT/scst $OUT/xe5 $OUT/pmcF $OUT/pmcW $OUT/pmc1 $OUT/pmc2 $OUT/pmc3
+ls -la $OUT

@@ -18,13 +18,14 @@ n = 1024 * 8
 buf = (C.c_longlong * n)()
 assert nv.lib().xg_debug_sk_trace(buf, n) == 0
 h = np.array(buf[:], dtype=np.int64).reshape(1024, 8)
+GX = int(os.environ.get("SK_GX", "256"))
 live = h[:, 5] > 0
 t0 = h[live, 0].min()
 us = lambda v: (v - t0) * 0.01
 print("WGs recorded %d ; span %.2f us" % (live.sum(), us(h[live, 5].max())))
 names = ["entry", "prologue", "first chunk", "k loop", "reduce", "epilogue"]
 for y in range(4):
-    rows = h[y * 256:(y + 1) * 256]
+    rows = h[y * GX:(y + 1) * GX]
     rows = rows[rows[:, 5] > 0]
     if not len(rows):
         continue
