@@ -582,8 +582,13 @@ __device__ __forceinline__ void ldA(const float* const (&ap)[4], int c, int klef
 // the launch is resident at once.
 // PREC 1 (XgRun.gemm_mode 1): the packed tiles are bf16 ([i(2)][h(2)][n(32)][8], two 1 KB wave loads), the A chunk is
 // rounded to bf16 on its way into LDS and a 32-deep chunk is two v_mfma_f32_32x32x16_bf16; accumulation / epilogues fp32.
-template <int NW, int PREC>
-__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 4))) skf_kernel(SkArgs args) {
+// SCALE: the launch has a scaled operand (SkSeg.row_scale: cell 2 reading the unnormalised attention context).  Its few
+// extra live values push the kernel over 128 VGPRs into scratch (48 B per lane, ~6 MB written and read back per launch), so
+// only the launches that need it pay for it.
+// (SCALE launches are single 256-tile cell-2 launches, one workgroup per CU: they get the 256-VGPR budget of two waves per
+// SIMD instead of spilling at 128.)
+template <int NW, int PREC, bool SCALE>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SCALE ? 2 : 4, SCALE ? 2 : 4))) skf_kernel(SkArgs args) {
     SK_STAMP(0);
     __shared__ __attribute__((aligned(16))) float smem[NW * 32 * RSF > NW * OPF ? NW * 32 * RSF : NW * OPF];
     const SkJob& job = args.job[blockIdx.y];
@@ -630,8 +635,10 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
     // videos are normalised by ALL its n-tiles, a slice each: loads now, multiply + store at the very end.
     float* rsc_lds = smem + NW * OPF;
     int scaled_seg = -1;
+    if (SCALE) {
 #pragma unroll
-    for (int s = 0; s < 3; ++s) if (s < job.nseg && job.seg[s].row_scale && scaled_seg < 0) scaled_seg = s;
+        for (int s = 0; s < 3; ++s) if (s < job.nseg && job.seg[s].row_scale && scaled_seg < 0) scaled_seg = s;
+    }
     float exv = 0.f, exs = 1.f;
     float* exp_ = nullptr;
     if (scaled_seg >= 0) {
@@ -676,7 +683,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
         const int nfull = sg.K / CK;                 // chunks >= nfull are the (single) k tail: K % 4 == 0 on this path
         // unnormalised attention context as an operand: rows scaled by 1 / s while they are staged; the tn == 0 tiles write
         // the normalised rows back (scaled_out has A's row pitch: checked by the host)
-        const bool wb_seg = sg.row_scale && sg.scaled_out;      // chunk c of the scaled rows is written back by n-tile c % ntn
+        const bool wb_seg = SCALE && sg.row_scale && sg.scaled_out;      // chunk c of the scaled rows is written back by n-tile c % ntn
         const ptrdiff_t wb_delta = wb_seg ? sg.scaled_out - sg.A : 0;
         f32x4 ra[4], rb0[NPB], rb1[NPB];
         if (s == 0) SK_STAMP(1);
@@ -686,7 +693,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4,
         // one chunk: stage A (scaled / written back when it is the attention context), request the NEXT chunk's operands
         // (B into the other register set: no copy), then the 16 MFMAs of this chunk
         auto chunk = [&](int c, const f32x4 (&cur)[NPB], f32x4 (&nxt)[NPB]) {
-            if (sg.row_scale) {
+            if (SCALE && sg.row_scale) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     ra[i] *= rsc_lds[i * 8 + lrow];
@@ -850,13 +857,15 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         static const int force_nw = getenv("XG_SK_NW") ? atoi(getenv("XG_SK_NW")) : 0;      // diagnosis
         const bool nw4 = has_attn || ks > 1 || (force_nw ? force_nw == 4 : tiles > 2 * 256);
         const dim3 grid((max_tiles + 7) & ~7, a.njobs);
-        if (bf16) {
-            if (nw4) hipLaunchKernelGGL((skf_kernel<4, 1>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((skf_kernel<8, 1>), grid, dim3(512), 0, st, a);
-        } else {
-            if (nw4) hipLaunchKernelGGL((skf_kernel<4, 0>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((skf_kernel<8, 0>), grid, dim3(512), 0, st, a);
-        }
+        bool scaled = false;
+        for (int j = 0; j < a.njobs; ++j)
+            for (int q = 0; q < a.job[j].nseg; ++q) scaled = scaled || a.job[j].seg[q].row_scale != nullptr;
+#define XG_SKF(NW_, PREC_) do { \
+            if (scaled) hipLaunchKernelGGL((skf_kernel<NW_, PREC_, true>), grid, dim3(NW_ * 64), 0, st, a); \
+            else hipLaunchKernelGGL((skf_kernel<NW_, PREC_, false>), grid, dim3(NW_ * 64), 0, st, a); } while (0)
+        if (bf16) { if (nw4) XG_SKF(4, 1); else XG_SKF(8, 1); }
+        else      { if (nw4) XG_SKF(4, 0); else XG_SKF(8, 0); }
+#undef XG_SKF
         XG_CHECK_LAUNCH();
         return XG_OK;
     }
