@@ -518,13 +518,16 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
             return g;
         };
         // the attention rides in the second launch as two workgroups per video (SK_EPI_ATTN) when its shapes allow
-        // (rollout form only: there cell 1 and S2' share the launch with it.  Teacher forcing has nothing but S2' to put
-        // beside the attention, and measured better with S2' in launch 1 and the stand-alone attention kernel: 6.85 vs 6.98 ms
-        // per iteration.)
+        // (rollout form only: there cell 1 and S2' share the launch with it.  Under teacher forcing the three candidates --
+        // B: S2' in launch 1 + stand-alone attention, D: cell 2 keeps its h2 segment (K = 3R) + stand-alone attention,
+        // E: the fused attention like the rollout form -- measure 6.77 / 6.73 / 6.74 ms per iteration (the iteration is
+        // throughput-bound across three streams, not bound by this chain); D is the simplest and the default.)
         static const bool no_fused = getenv("XG_NO_FUSED_ATTN") != nullptr;
-        const bool fused_attn = !s.pre1 && !no_fused && A <= 2048 && d.K <= 128 && ((uintptr_t)V % 8 == 0) &&
+        static const char xe_form = getenv("XG_XE_FORM") ? getenv("XG_XE_FORM")[0] : 'D';     // experiment switch (B / D / E)
+        const bool fused_attn = (!s.pre1 || xe_form == 'E') && !no_fused && A <= 2048 && d.K <= 128 && ((uintptr_t)V % 8 == 0) &&
                                 ((uintptr_t)vproj % 16 == 0) && ((uintptr_t)p.a2w_w % 16 == 0);
-        const bool s2_first = s.pre1 != nullptr;          // S2' = h2 W_h2h2 + b rides in launch 1 (teacher forcing) or 2
+        const bool s2_first = s.pre1 != nullptr && xe_form == 'B';          // S2' = h2 W_h2h2 + b rides in launch 1 (teacher forcing) or 2
+        const bool s2_in_cell2 = s.pre1 != nullptr && xe_form == 'D';       // ... or stays a segment of cell 2
         SkArgs k1{}, k2{}, k3{};
         int n1 = 0, n2 = 0, n3 = 0;
         // the state may be updated IN PLACE (xg_step_fwd): cell 1 then runs in launch 2 beside products that still read the
@@ -586,16 +589,17 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
             j.seg[1] = seg_nt(w, PK_L1_A2H, s.posg, R, p.l1_a2h_w, R, R); j.bias[1] = p.l1_a2h_b;
             j.seg[2] = xt_seg(PK_L1_I2H, p.l1_i2h_w); j.bias[2] = p.l1_i2h_b;
         }
-        if (!s2_first) s2_job(k2.job[n2++]);
+        if (!s2_first && !s2_in_cell2) s2_job(k2.job[n2++]);
         k2.njobs = n2;
         if (n2 > 0) XG_TRY(xgk_skinny(st, k2, w.gm));
         if (!fused_attn) XG_TRY(xgk_attn_fwd(st, s.P, vproj, V, p.a2w_w, s.alpha, s.af, B, d.K, R, A));
         // ---- launch 3: cell 2 = h1' W_i2h + af W_a2h + S2'                                                :684
-        c.add = w.S2; c.ldadd = 4 * R;
+        if (!s2_in_cell2) { c.add = w.S2; c.ldadd = 4 * R; }
         {
             SkJob& j = k3.job[n3++];
             j = job_lstm(c);
             j.nseg = 2;
+            if (s2_in_cell2) { j.nseg = 3; j.seg[2] = seg_nt(w, PK_L2_H2H, s.h2, R, p.l2_h2h_w, R, R); j.bias[2] = p.l2_h2h_b; }
             j.seg[0] = seg_nt(w, PK_L2_I2H, s.pre1 ? s.h1o : h1_new, R, p.l2_i2h_w, R, R); j.bias[0] = p.l2_i2h_b;
             j.seg[1] = seg_nt(w, PK_L2_A2H, fused_attn ? w.AFU : s.af, R, p.l2_a2h_w, R, R); j.bias[1] = p.l2_a2h_b;
             if (fused_attn) {   // af = c / s while it is staged; the n-tiles store af and normalise alpha between them

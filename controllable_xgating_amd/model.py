@@ -377,8 +377,8 @@ class SAModel(nn.Module):
     # ------------------------------------------------------------------ reference surface
     def forward(self, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask):
         """SAModel.forward (SAModel.py:67-115): (m,K,F) x2, (m,K), (m,R), (m,T) int64, (m,T) ->
-        log-probs (m,T,V) and category log-probs (m,T,C).  ss_prob must be 0 (scheduled sampling is
-        SURVEY.md 8f-3, not built yet)."""
+        log-probs (m,T,V) and category log-probs (m,T,C).  With self.ss_prob > 0 in train mode the scheduled-sampling
+        path (SAModel.py:89-99, xg_forward_ss) runs instead of the hoisted teacher-forced one."""
         params = self._param_list()
         save = torch.is_grad_enabled() and any(p.requires_grad for p in params)
         if self.training and self.ss_prob > 0.0:                                 # scheduled sampling, SAModel.py:89-99

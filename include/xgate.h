@@ -12,8 +12,11 @@
  *   - extern "C", plain pointers and sizes; no torch / C++ types.
  *   - All tensor pointers are DEVICE pointers (HIP), fp32 unless noted, row-major,
  *     contiguous in the documented shape.  Token / index tensors are int64.
- *   - The caller owns all memory.  The library allocates nothing; scratch and saved
- *     activations live in one caller-provided workspace sized by xg_workspace_bytes().
+ *   - The caller owns all memory; scratch and saved activations live in one caller-provided
+ *     workspace sized by xg_workspace_bytes().  The only thing the library allocates is the
+ *     optional side-stream handle of xg_aux_create (two HIP streams + events, no memory).
+ *   - No library-global mutable state: arithmetic mode, packed weights, side streams and
+ *     data-parallel events all travel in XgRun.
  *     The workspace written by a *_fwd call must be handed unchanged to the matching *_bwd.
  *   - `stream` is a hipStream_t passed as void*.  Every entry point only ENQUEUES work on
  *     that stream and returns; there is no host synchronisation inside the library.
@@ -34,7 +37,7 @@
 extern "C" {
 #endif
 
-#define XG_VERSION 100
+#define XG_VERSION 200   /* 200: XgRun gained packed/aux/event fields, xg_set_grad_event removed, xg_vproj takes XgRun */
 
 enum {
     XG_OK = 0,
