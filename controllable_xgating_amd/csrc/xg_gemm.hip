@@ -269,6 +269,333 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
         }
 }
 
+// ---- persistent form of the 128x128 kernel ("pk") ----------------------------------------------------------------
+// The one-tile-per-workgroup kernel above spends 20-25 % of a tile's lifetime outside its K loop when the reduction is
+// short (logits: K = 512 = 16 slabs): the first slab's load latency, the 64 KB result tile and the dispatch of the next
+// workgroup are paid once per tile by BOTH workgroups of a CU at the same moment (they start in phase and stay in phase),
+// and the last round of tiles is partly empty (3297 tiles on 512 slots = 6.44 rounds, paid as 7).  Here the grid is the
+// 512 resident workgroups (2 per CU, LDS-bound) and each one walks a list of work items (tile, slab range):
+//   * whole tiles first, floor(T / G) per workgroup, in an XCD-contiguous order whose 64 concurrent tiles per XCD form an
+//     8 x 8 block (8 A panels + 8 B panels live in that XCD's L2 instead of 1 + 64);
+//   * then the remaining T mod G tiles as slab units shared evenly by all workgroups (stream-K): a workgroup that owns
+//     only part of a tile's reduction adds its partial tile with fp32 atomics (the launcher zeroes those tiles).
+// The slab pipeline runs ACROSS items: during the last slab of an item the first slab of the next one is already in
+// flight, the result stores (fire-and-forget, no wait) drain under the next item's MFMAs.
+struct PkArgs {
+    const float* A; const float* B; float* C; const float* bias;
+    int M, N, K, lda, ldb, ldc, relu, accumulate;
+    int ntm, ntn, nslab;
+    int rounds;      // whole tiles per workgroup; tiles [0, rounds * G) in swizzled order
+    int tail_wgs;    // workgroup positions [0, tail_wgs) share the slab units of tiles [rounds * G, T)
+};
+
+struct PkItem { int tile, s0, s1; };
+#ifdef PK_TRACE
+__device__ long long pk_trace_buf[512 * 40];
+#define PK_STAMP(i) do { if (threadIdx.x == 0 && (i) < 38) pk_trace_buf[blockIdx.x * 40 + (i)] = wall_clock64(); \
+                         if (threadIdx.x == 0 && (i) == 0) pk_trace_buf[blockIdx.x * 40 + 38] = clock64(); \
+                         if (threadIdx.x == 0 && (i) >= 5) pk_trace_buf[blockIdx.x * 40 + 39] = clock64(); } while (0)
+#else
+#define PK_STAMP(i) do { } while (0)
+#endif
+#ifdef PK_ASM_BARRIER
+// workgroup barrier that orders LDS only: __syncthreads() also waits for every outstanding global store (vmcnt(0)), i.e.
+// for the result tile just written
+#define PK_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#else
+#define PK_BARRIER() __syncthreads()
+#endif
+
+__device__ __forceinline__ void pk_tile_coords(int t, int ntm, int ntn, int& tm, int& tn) {
+    constexpr int GM = 8;                       // tile rows per swizzle group
+    const int per = GM * ntn, grp = t / per, in = t - grp * per;
+    const int first = grp * GM, gsz = min(ntm - first, GM);
+    tn = in / gsz;
+    tm = first + (in - tn * gsz);
+}
+
+// rows x cols sub-matrix (row pitch ld, base 16-byte aligned, ld % 4 == 0) := 0; one workgroup per 1024 columns of a row
+__global__ void __launch_bounds__(256) zero2d_kernel(float* __restrict__ p, int ld, int cols) {
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    float* q = p + (size_t)blockIdx.y * ld + c;
+    if (c + 4 <= cols) *reinterpret_cast<f32x4*>(q) = f32x4{0.f, 0.f, 0.f, 0.f};
+    else for (int j = 0; c + j < cols; ++j) q[j] = 0.f;
+}
+
+template <bool AKC, bool BKC>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm_pk_kernel(PkArgs g) {
+    constexpr int BM = 128, BN = 128, WM = 64, WN = 64, MT = 2, NT = 2;
+    constexpr int A_FL = TileGeom<BM, AKC>::lds_floats, B_FL = TileGeom<BN, BKC>::lds_floats, STAGE = A_FL + B_FL;
+    constexpr int NVA = TileGeom<BM, AKC>::nvec, NVB = TileGeom<BN, BKC>::nvec;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    // position of this workgroup: XCD x owns the contiguous positions [px, px + cnt)
+    const int G = gridDim.x;
+    const int xq = G >> 3, xr = G & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int px = xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq;
+    const int cnt = xcd < xr ? xq + 1 : xq;
+    const int pos = px + idx;
+    const int T = g.ntm * g.ntn, dp_tiles = g.rounds * G;
+    // work list state (wave-uniform)
+    int round = 0;
+    long u = 0, u1 = 0;
+    if (pos < g.tail_wgs) {
+        const long U = (long)(T - dp_tiles) * g.nslab;
+        u = (U * pos) / g.tail_wgs;
+        u1 = (U * (pos + 1)) / g.tail_wgs;
+    }
+    auto next_item = [&](PkItem& it) -> bool {
+        if (round < g.rounds) {
+            it.tile = px * g.rounds + round * cnt + idx;
+            it.s0 = 0; it.s1 = g.nslab;
+            ++round;
+            return true;
+        }
+        if (u < u1) {
+            const int tl = (int)(u / g.nslab);
+            it.tile = dp_tiles + tl;
+            it.s0 = (int)(u - (long)tl * g.nslab);
+            const long left = u1 - u;
+            it.s1 = (int)min((long)g.nslab, (long)it.s0 + left);
+            u += it.s1 - it.s0;
+            return true;
+        }
+        return false;
+    };
+
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int half = lane >> 5, l31 = lane & 31;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    f32x4 ra[NVA], rb[NVB];
+    uint32_t offA[NVA], offB[NVB];
+    const size_t stepA = (AKC ? (size_t)BKS : (size_t)BKS * g.lda) * sizeof(float);
+    const size_t stepB = (BKC ? (size_t)BKS : (size_t)BKS * g.ldb) * sizeof(float);
+    const int nfull = g.K / BKS;
+
+    PkItem cur;
+    if (!next_item(cur)) return;
+    int m0, n0;
+    {
+        int tm, tn;
+        pk_tile_coords(cur.tile, g.ntm, g.ntn, tm, tn);
+        m0 = tm * BM; n0 = tn * BN;
+    }
+    tile_offsets<BM, AKC>(g.lda, m0, g.M, offA);
+    tile_offsets<BN, BKC>(g.ldb, n0, g.N, offB);
+    // bias of the item's columns, fetched when the item starts (the epilogue must not wait on a load)
+    float bv[NT], bvn[NT];
+    auto load_bias = [&](const PkItem& it, int nn0, float (&b)[NT]) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = nn0 + wn * WN + j * 32 + l31;
+            b[j] = (g.bias && it.s0 == 0 && col < g.N) ? g.bias[col] : 0.f;
+        }
+    };
+    load_bias(cur, n0, bv);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) bvn[j] = 0.f;
+    if (cur.s0 < nfull) {
+        load_fast<NVA>(reinterpret_cast<const char*>(g.A) + (size_t)cur.s0 * stepA, offA, ra);
+        load_fast<NVB>(reinterpret_cast<const char*>(g.B) + (size_t)cur.s0 * stepB, offB, rb);
+    } else {
+        load_tile<BM, AKC, true>(g.A, g.lda, m0, cur.s0 * BKS, g.M, g.K, ra);
+        load_tile<BN, BKC, true>(g.B, g.ldb, n0, cur.s0 * BKS, g.N, g.K, rb);
+    }
+    PK_STAMP(0);
+    store_tile<BM, AKC>(smem, ra);
+    store_tile<BN, BKC>(smem + A_FL, rb);
+    __syncthreads();
+    PK_STAMP(1);
+    int item_no = 0;
+
+    auto slab_mfma = [&](int buf) {
+        const float* as = smem + buf * STAGE;
+        const float* bs = as + A_FL;
+#pragma unroll
+        for (int kb = 0; kb < BKS / 8; ++kb) {
+            f32x4 fa[MT], fb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = read_frag<BM, AKC>(as, wm * WM + i * 32 + l31, kb, half);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = read_frag<BN, BKC>(bs, wn * WN + j * 32 + l31, kb, half);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int i = 0; i < MT; ++i)
+#pragma unroll
+                    for (int j = 0; j < NT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+        }
+    };
+
+    int buf = 0;
+    while (true) {                               // one item per trip; the accumulators live in AGPRs across its slab loop
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int j = 0; j < NT; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+        for (int s = cur.s0; s + 1 < cur.s1; ++s) {
+#ifndef GEMM_NO_GLOBAL
+            if (s + 1 < nfull) {
+                load_fast<NVA>(reinterpret_cast<const char*>(g.A) + (size_t)(s + 1) * stepA, offA, ra);
+                load_fast<NVB>(reinterpret_cast<const char*>(g.B) + (size_t)(s + 1) * stepB, offB, rb);
+            } else {
+                load_tile<BM, AKC, true>(g.A, g.lda, m0, (s + 1) * BKS, g.M, g.K, ra);
+                load_tile<BN, BKC, true>(g.B, g.ldb, n0, (s + 1) * BKS, g.N, g.K, rb);
+            }
+#endif
+            slab_mfma(buf);
+#ifdef GEMM_SCHED_BARRIER
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifndef GEMM_NO_LDS_STORE
+            store_tile<BM, AKC>(smem + (buf ^ 1) * STAGE, ra);
+            store_tile<BN, BKC>(smem + (buf ^ 1) * STAGE + A_FL, rb);
+#endif
+#ifndef GEMM_NO_SYNC
+            __syncthreads();
+#endif
+            buf ^= 1;
+        }
+        // last slab of the item: the first slab of the NEXT item is fetched under it
+        PK_STAMP(2 + 4 * item_no);
+        PkItem nx;
+        const bool has = next_item(nx);
+        int nm0 = m0, nn0 = n0;
+        if (has) {
+            int tm, tn;
+            pk_tile_coords(nx.tile, g.ntm, g.ntn, tm, tn);
+            nm0 = tm * BM; nn0 = tn * BN;
+            tile_offsets<BM, AKC>(g.lda, nm0, g.M, offA);
+            tile_offsets<BN, BKC>(g.ldb, nn0, g.N, offB);
+            load_bias(nx, nn0, bvn);
+#ifndef GEMM_NO_GLOBAL
+            if (nx.s0 < nfull) {
+                load_fast<NVA>(reinterpret_cast<const char*>(g.A) + (size_t)nx.s0 * stepA, offA, ra);
+                load_fast<NVB>(reinterpret_cast<const char*>(g.B) + (size_t)nx.s0 * stepB, offB, rb);
+            } else {
+                load_tile<BM, AKC, true>(g.A, g.lda, nm0, nx.s0 * BKS, g.M, g.K, ra);
+                load_tile<BN, BKC, true>(g.B, g.ldb, nn0, nx.s0 * BKS, g.N, g.K, rb);
+            }
+#endif
+        }
+        slab_mfma(buf);
+#ifndef GEMM_NO_LDS_STORE
+        if (has) {
+            store_tile<BM, AKC>(smem + (buf ^ 1) * STAGE, ra);
+            store_tile<BN, BKC>(smem + (buf ^ 1) * STAGE + A_FL, rb);
+        }
+#endif
+        PK_STAMP(3 + 4 * item_no);
+#ifdef GEMM_NO_EPI
+        if (g.M < 0)
+#endif
+        {
+            // result of item `cur`: whole tile -> stores (bias / ReLU; += C via atomics), part of a reduction -> atomics
+            const bool part = cur.s0 != 0 || cur.s1 != g.nslab;
+            const bool atom = part || g.accumulate;
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j) {
+                    const int col = n0 + wn * WN + j * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const float v = acc[i][j][r] + bv[j];
+                        if (row < g.M && col < g.N) {
+                            float* dst = g.C + (size_t)row * g.ldc + col;
+                            if (atom) unsafeAtomicAdd(dst, v);
+                            else *dst = g.relu ? fmaxf(v, 0.f) : v;
+                        }
+                    }
+                }
+        }
+        PK_STAMP(4 + 4 * item_no);
+#ifndef GEMM_NO_SYNC
+        PK_BARRIER();
+#endif
+        PK_STAMP(5 + 4 * item_no);
+        ++item_no;
+        if (!has) break;
+#pragma unroll
+        for (int j = 0; j < NT; ++j) bv[j] = bvn[j];
+        cur = nx; buf ^= 1; m0 = nm0; n0 = nn0;
+    }
+}
+
+// launcher of the persistent kernel; returns XG_OK, or 1 when the shape should take the one-tile-per-workgroup kernels
+template <bool AKC, bool BKC>
+int launch_pk(hipStream_t st, const GemmArgs& a) {
+    static const int disabled = getenv("XG_GEMM_NO_PK") ? 1 : 0;
+    if (disabled || !a.fast || a.M < 128 || a.N < 128) return 1;
+    PkArgs g{a.A, a.B, a.C, a.bias, a.M, a.N, a.K, a.lda, a.ldb, a.ldc, a.relu, a.accumulate, 0, 0, 0, 0, 0};
+    g.ntm = xg_cdiv(a.M, 128); g.ntn = xg_cdiv(a.N, 128); g.nslab = xg_cdiv(a.K, BKS);
+    const long T = (long)g.ntm * g.ntn;
+    const long units = T * g.nslab;
+    // measured (tools/ubench/gemm_bench.py): the persistent form wins 3-6 % when every workgroup has >= ~40 slabs of work
+    // (vocabulary head: logits, dW_logit, dH) and loses 10-15 % to 64x64 tiles + split-K on the mid-size products
+    static const long min_units = getenv("XG_PK_MIN") ? atol(getenv("XG_PK_MIN")) : 40;
+    if (units < 512L * min_units) return 1;
+    static const int env_g = getenv("XG_PK_G") ? atoi(getenv("XG_PK_G")) : 0;
+    static const int env_split = getenv("XG_PK_SPLIT") ? atoi(getenv("XG_PK_SPLIT")) : 1;
+    const int GMAX = env_g > 0 ? env_g : 512;       // 2 workgroups per CU (73.7 KB of LDS each)
+    int G;
+    const bool split = !a.relu && g.nslab >= 2 && env_split;
+    if (!split) {
+        if (T < GMAX) return 1;
+        // whole tiles only (a ReLU epilogue cannot be split): the fewest rounds, evened out over the workgroups; the ragged
+        // last round goes through the tail logic as one whole tile per share
+        G = (int)xg_cdiv64(T, xg_cdiv64(T, GMAX));
+        g.rounds = (int)(T / G);
+        g.tail_wgs = (int)(T - (long)g.rounds * G);
+    } else {
+        G = GMAX;
+        g.rounds = (int)(T / G);
+        const long tail = T - (long)g.rounds * G;
+        const long U = tail * g.nslab;
+        long tw = U / 4;                            // >= 4 slabs per share
+        if (tw > G) tw = G;
+        if (tail > 0 && tw < 1) tw = 1;
+        g.tail_wgs = (int)tw;
+    }
+    // zero the tiles that receive partial sums (non-accumulating products only): every tail tile unless each share is a
+    // whole tile.  The tail is the END of the swizzled order: inside the last group of tile rows it is a set of whole tile
+    // columns plus at most one partial column -- clear the bounding rectangle (whole tiles inside it overwrite the zeros).
+    const long dp = (long)g.rounds * G, tail = T - dp;
+    const bool whole_shares = tail == g.tail_wgs;   // one tile per share (U / tail_wgs == nslab)
+    if (tail > 0 && !whole_shares && !a.accumulate) {
+        if (a.ldc % 4 != 0 || ((uintptr_t)a.C % 16) != 0) return 1;
+        const int per = 8 * g.ntn;
+        const int grp = (int)(dp / per), first = grp * 8, gsz = (g.ntm - first) < 8 ? (g.ntm - first) : 8;
+        const int tn0 = (int)((dp - (long)grp * per) / gsz);
+        const bool one_group = first + gsz >= g.ntm;              // tail confined to the last group
+        const int r0 = first * 128, c0 = one_group ? tn0 * 128 : 0;
+        if (r0 < a.M && c0 < a.N) {      // (hipMemset2DAsync takes 23 us for these 15 MB; this kernel 5)
+            const int rows = a.M - r0, cols = a.N - c0;
+            hipLaunchKernelGGL(zero2d_kernel, dim3(xg_cdiv(cols, 1024), rows), dim3(256), 0, st, a.C + (size_t)r0 * a.ldc + c0, a.ldc, cols);
+            XG_CHECK_LAUNCH();
+        }
+    }
+    const size_t lds = 2 * (TileGeom<128, AKC>::lds_floats + TileGeom<128, BKC>::lds_floats) * sizeof(float);
+    static std::atomic<unsigned> optin{0};
+    XG_TRY(xg_lds_optin(optin, reinterpret_cast<const void*>(&gemm_pk_kernel<AKC, BKC>), (int)lds));
+    hipLaunchKernelGGL((gemm_pk_kernel<AKC, BKC>), dim3(G), dim3(256), lds, st, g);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+
 template <int BM, int BN, bool AKC, bool BKC, bool VEC>
 int launch(hipStream_t st, const GemmArgs& g) {
     const int ntm = xg_cdiv(g.M, BM), ntn = xg_cdiv(g.N, BN);
@@ -316,6 +643,10 @@ int dispatch(hipStream_t st, GemmArgs g, bool vec) {
     if (force) {
         int t = 0, sk = 1;
         if (sscanf(force, "%d,%d", &t, &sk) == 2) { big = t == 128; g.splitk = g.relu ? 1 : (sk < 1 ? 1 : sk); }
+    }
+    if (vec && !force) {
+        const int rc = launch_pk<AKC, BKC>(st, g);
+        if (rc != 1) return rc;
     }
     if (big) return vec ? launch<128, 128, AKC, BKC, true>(st, g) : launch<128, 128, AKC, BKC, false>(st, g);
     return vec ? launch<64, 64, AKC, BKC, true>(st, g) : launch<64, 64, AKC, BKC, false>(st, g);

@@ -49,6 +49,32 @@ def test_gemm_layouts(M, N, K, ta, tb):
         assert float((got - want).abs().max()) <= tol * max(1.0, float(want.abs().max())), (relu, acc)
 
 
+@pytest.mark.parametrize("M,N,K", [(2688, 2000, 516), (1300, 9000, 200), (1408, 512, 20000), (3000, 3000, 256),
+                                   (2688, 20000, 512), (4100, 2052, 96)])
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
+def test_gemm_persistent_kernel_shapes(M, N, K, ta, tb):
+    """Shapes large enough for the persistent 128x128 kernel (whole-tile rounds + stream-K tail with atomics, partial last
+    slab, ragged edges, ReLU without splitting, += C): every element of C against fp64."""
+    from controllable_xgating_amd import _native as nv
+    L = nv.lib()
+    g = torch.Generator(device="cuda").manual_seed(M + 3 * N + 5 * K + ta * 2 + tb)
+    Ad = torch.randn((K, M) if ta else (M, K), generator=g, device="cuda")
+    Bd = torch.randn((N, K) if tb else (K, N), generator=g, device="cuda")
+    bd = torch.randn(N, generator=g, device="cuda")
+    C0 = torch.randn(M, N, generator=g, device="cuda")
+    ref = (Ad.t() if ta else Ad).double() @ (Bd.t() if tb else Bd).double() + bd.double()
+    scale = float(ref.abs().max())
+    for relu, acc in ((0, 0), (1, 0), (0, 1)):
+        Cd = C0.clone()
+        assert L.xg_gemm(None, ta, tb, M, N, K, nv.ptr(Ad), Ad.shape[1], nv.ptr(Bd), Bd.shape[1], nv.ptr(Cd), N, nv.ptr(bd),
+                         relu, acc) == 0
+        want = ref + (C0.double() if acc else 0)
+        if relu:
+            want = want.clamp(min=0)
+        err = float((Cd.double() - want).abs().max()) / scale
+        assert err < 4e-6 * max(1.0, np.sqrt(K / 4096.0)), (relu, acc, err)     # fp32 chain: grows with sqrt(K)
+
+
 def test_gemm_strided_submatrix():
     """W[:, R:2R] column block of h2a.weight as B operand (ldb = 2R) and accumulate, as the step uses it."""
     from controllable_xgating_amd import _native as nv

@@ -17,7 +17,7 @@ int main() {
         const int lda = s.ta ? s.M : s.K, ldb = s.tb ? s.K : s.N;
         for (int it = 0; it < 3; ++it) {
             (void)hipEventRecord(e0);
-            for (int r = 0; r < 10; ++r) xgk_gemm(0, s.ta, s.tb, s.M, s.N, s.K, A, lda, B, ldb, C, s.N, nullptr, false, s.acc);
+            for (int r = 0; r < 10; ++r) xgk_gemm(0, 0, s.ta, s.tb, s.M, s.N, s.K, A, lda, B, ldb, C, s.N, nullptr, false, s.acc);
             (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
             float ms; (void)hipEventElapsedTime(&ms, e0, e1);
             if (it == 2) {
@@ -27,6 +27,15 @@ int main() {
                 printf("   shader clock inside a workgroup: %.2f GHz (%lld clk / %lld ticks of 10 ns)", h[0] / (h[1] * 10.0), h[0], h[1]);
 #endif
                 printf("\n");
+#ifdef PK_TRACE
+                {
+                    static long long h[512 * 40]; (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(pk_trace_buf), sizeof(h));
+                    long long t0 = h[0]; for (int w = 0; w < 512; ++w) if (h[w * 40] && h[w * 40] < t0) t0 = h[w * 40];
+                    { long long mx = 0, mn = 1LL << 62; int wmx = 0; for (int w = 0; w < 512; ++w) { long long last = 0; for (int i = 0; i < 38; ++i) if (h[w * 40 + i] > last) last = h[w * 40 + i]; if (last > mx) { mx = last; wmx = w; } if (last && last < mn) mn = last; }
+                      printf("  first WG end %.1f us, last WG end %.1f us (wg %d)\n", (mn - t0) * 0.01, (mx - t0) * 0.01, wmx); }
+                    for (int w : {0, 1, 8, 100, 255, 256, 511}) { { long long last = 0; for (int i = 0; i < 38; ++i) if (h[w * 40 + i] > last) last = h[w * 40 + i]; printf("  [%.3f GHz]", (h[w * 40 + 39] - h[w * 40 + 38]) / ((last - h[w * 40]) * 10.0)); } printf("  wg %3d:", w); for (int i = 0; i < 30; ++i) printf(" %.1f", (h[w * 40 + i] - t0) * 0.01); printf("\n"); }
+                }
+#endif
             }
         }
         (void)hipFree(A); (void)hipFree(B); (void)hipFree(C);
