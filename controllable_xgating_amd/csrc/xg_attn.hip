@@ -184,6 +184,9 @@ __global__ void __launch_bounds__(FT) attn_fwd_fast(const float* __restrict__ p,
                                                      const float* __restrict__ V, const float* __restrict__ w,
                                                      float* __restrict__ alpha, float* __restrict__ af, int K, int R, int A) {
     extern __shared__ float sm[];                     // e[K] | part[nkp][R]
+#ifdef XG_CHAIN_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     AT_STAMP(0);
     float* se = sm;
     float* part = sm + ((K + 3) & ~3);
@@ -276,6 +279,9 @@ __global__ void __launch_bounds__(FT) attn_bwd_fast(const float* __restrict__ da
                                                      const float* __restrict__ w, const float* __restrict__ alpha,
                                                      float* __restrict__ de, float* __restrict__ dp, int K, int R, int A) {
     extern __shared__ float sm[];                     // dalpha[K]
+#ifdef XG_CHAIN_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     AT_STAMP(0);
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* qb = vproj + (size_t)b * K * A;

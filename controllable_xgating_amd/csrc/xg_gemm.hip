@@ -140,6 +140,7 @@ struct GemmArgs {
     int splitk;   // > 1: the K slabs are divided over `splitk` workgroups per tile; partial tiles are added
                   // into C with hardware fp32 atomics (C pre-zeroed by the launcher unless accumulating)
     int fast;     // vector kernels: offset-based unpredicated loads for the full slabs (all byte offsets < 2^31)
+    int gm;       // tile rows per group of the tile order (xgk_group_rows)
 };
 
 #ifdef GEMM_CLK
@@ -167,7 +168,13 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     }
     const int ks = bid % g.splitk;          // K split index (fastest: the splits of one tile share an XCD)
     bid /= g.splitk;
-    const int tm = bid / ntn, tn = bid % ntn;
+    int tm, tn;
+    {   // grouped order: gm tile rows x ~64/gm tile columns are live together on an XCD (gm + 64/gm operand panels in its L2, not 1 + 64)
+        const int per = g.gm * ntn, grp = bid / per, in = bid - grp * per;
+        const int first = grp * g.gm, gsz = min(ntm - first, g.gm);
+        tn = in / gsz;
+        tm = first + (in - tn * gsz);
+    }
     const int m0 = tm * BM, n0 = tn * BN;
 
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -287,6 +294,7 @@ struct PkArgs {
     int ntm, ntn, nslab;
     int rounds;      // whole tiles per workgroup; tiles [0, rounds * G) in swizzled order
     int tail_wgs;    // workgroup positions [0, tail_wgs) share the slab units of tiles [rounds * G, T)
+    int gm;          // tile rows per group of the swizzled order
 };
 
 struct PkItem { int tile, s0, s1; };
@@ -306,8 +314,7 @@ __device__ long long pk_trace_buf[512 * 40];
 #define PK_BARRIER() __syncthreads()
 #endif
 
-__device__ __forceinline__ void pk_tile_coords(int t, int ntm, int ntn, int& tm, int& tn) {
-    constexpr int GM = 8;                       // tile rows per swizzle group
+__device__ __forceinline__ void pk_tile_coords(int t, int ntm, int ntn, int GM, int& tm, int& tn) {
     const int per = GM * ntn, grp = t / per, in = t - grp * per;
     const int first = grp * GM, gsz = min(ntm - first, GM);
     tn = in / gsz;
@@ -386,7 +393,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     int m0, n0;
     {
         int tm, tn;
-        pk_tile_coords(cur.tile, g.ntm, g.ntn, tm, tn);
+        pk_tile_coords(cur.tile, g.ntm, g.ntn, g.gm, tm, tn);
         m0 = tm * BM; n0 = tn * BN;
     }
     tile_offsets<BM, AKC>(g.lda, m0, g.M, offA);
@@ -475,7 +482,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         int nm0 = m0, nn0 = n0;
         if (has) {
             int tm, tn;
-            pk_tile_coords(nx.tile, g.ntm, g.ntn, tm, tn);
+            pk_tile_coords(nx.tile, g.ntm, g.ntn, g.gm, tm, tn);
             nm0 = tm * BM; nn0 = tn * BN;
             tile_offsets<BM, AKC>(g.lda, nm0, g.M, offA);
             tile_offsets<BN, BKC>(g.ldb, nn0, g.N, offB);
@@ -540,7 +547,7 @@ template <bool AKC, bool BKC>
 int launch_pk(hipStream_t st, const GemmArgs& a) {
     static const int disabled = getenv("XG_GEMM_NO_PK") ? 1 : 0;
     if (disabled || !a.fast || a.M < 128 || a.N < 128) return 1;
-    PkArgs g{a.A, a.B, a.C, a.bias, a.M, a.N, a.K, a.lda, a.ldb, a.ldc, a.relu, a.accumulate, 0, 0, 0, 0, 0};
+    PkArgs g{a.A, a.B, a.C, a.bias, a.M, a.N, a.K, a.lda, a.ldb, a.ldc, a.relu, a.accumulate, 0, 0, 0, 0, 0, a.gm};
     g.ntm = xg_cdiv(a.M, 128); g.ntn = xg_cdiv(a.N, 128); g.nslab = xg_cdiv(a.K, BKS);
     const long T = (long)g.ntm * g.ntn;
     const long units = T * g.nslab;
@@ -577,8 +584,8 @@ int launch_pk(hipStream_t st, const GemmArgs& a) {
     const bool whole_shares = tail == g.tail_wgs;   // one tile per share (U / tail_wgs == nslab)
     if (tail > 0 && !whole_shares && !a.accumulate) {
         if (a.ldc % 4 != 0 || ((uintptr_t)a.C % 16) != 0) return 1;
-        const int per = 8 * g.ntn;
-        const int grp = (int)(dp / per), first = grp * 8, gsz = (g.ntm - first) < 8 ? (g.ntm - first) : 8;
+        const int per = g.gm * g.ntn;
+        const int grp = (int)(dp / per), first = grp * g.gm, gsz = (g.ntm - first) < g.gm ? (g.ntm - first) : g.gm;
         const int tn0 = (int)((dp - (long)grp * per) / gsz);
         const bool one_group = first + gsz >= g.ntm;              // tail confined to the last group
         const int r0 = first * 128, c0 = one_group ? tn0 * 128 : 0;
@@ -644,10 +651,12 @@ int dispatch(hipStream_t st, GemmArgs g, bool vec) {
         int t = 0, sk = 1;
         if (sscanf(force, "%d,%d", &t, &sk) == 2) { big = t == 128; g.splitk = g.relu ? 1 : (sk < 1 ? 1 : sk); }
     }
+    g.gm = xgk_group_rows(g.K);                     // the persistent kernel walks whole reductions
     if (vec && !force) {
         const int rc = launch_pk<AKC, BKC>(st, g);
         if (rc != 1) return rc;
     }
+    g.gm = xgk_group_rows(g.K / g.splitk);
     if (big) return vec ? launch<128, 128, AKC, BKC, true>(st, g) : launch<128, 128, AKC, BKC, false>(st, g);
     return vec ? launch<64, 64, AKC, BKC, true>(st, g) : launch<64, 64, AKC, BKC, false>(st, g);
 }
@@ -661,7 +670,7 @@ int xgk_gemm(hipStream_t st, int mode, bool transA, bool transB, int M, int N, i
     // large products may run on the bf16 matrix cores (split-bf16 or plain bf16); skinny / tiny ones stay fp32
     if ((mode == 1 || mode == 3) && M >= 256 && N >= 64 && K >= 64)
         return xgk_gemm_bf16(st, mode, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate);
-    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1, 0};
+    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1, 0, 1};
     const bool akc = !transA;   // A (M,K) row-major -> k contiguous
     const bool bkc = transB;    // B (N,K) row-major -> k contiguous
     {   // offset-based loads: the largest byte offset inside either operand must fit 31 bits, and the m/n-contiguous

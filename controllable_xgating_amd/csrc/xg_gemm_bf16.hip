@@ -15,6 +15,7 @@
 // Same argument struct, XCD-aware tile order, split-K (fp32 atomics) and epilogue as xg_gemm.hip.
 #include "xg_common.h"
 #include "xg_kernels.h"
+#include <cstdlib>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -29,6 +30,7 @@ constexpr int LDMC = BM + 8;       // m-contiguous image: row stride in bf16
 struct BArgs {
     const float* A; const float* B; float* C; const float* bias;
     int M, N, K, lda, ldb, ldc, relu, accumulate, splitk;
+    int gm;   // tile rows per group of the tile order (xg_kernels.h: xgk_group_rows)
 };
 
 template <bool KC> constexpr int plane_elems() { return KC ? BM * LDKC : BK * LDMC; }
@@ -109,8 +111,11 @@ __device__ __forceinline__ void store_tile(unsigned short* __restrict__ lds, con
             // plain bf16: the hardware's packed round-to-nearest-even convert (v_cvt_pk_bf16_f32), one instruction per pair
             // instead of ~4 integer operations per element (269 -> 294 TF on the vocabulary products).  (A 64-deep,
             // double-buffered variant of this kernel was measured SLOWER, 267 TF: at bf16 rates a slab is 0.2 us of MFMA
-            // against ~1.5 us of load latency, so what is missing is depth of prefetch -- an LDS-DMA ring fed from bf16
-            // operand copies -- not fewer barriers.)
+            // against ~1.5 us of load latency, so what is missing is bytes in flight.  An LDS-DMA variant (fp32 slabs
+            // global_load_lds -> two-stage ring, 2 workgroups per CU, rounding on the LDS -> fragment path) was also
+            // measured: correct, but 64 KB in flight per CU against this kernel's 96 KB of staging registers -- logits
+            // 187 vs 167 us, mid-size 67 vs 46 us, only the weight-gradient layout 5 % ahead; not kept.  What would
+            // help is HALF the bytes: bf16 operand copies in memory.)
             typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
             bf16x2_t lo, hi;
             lo[0] = (__bf16)v[0]; lo[1] = (__bf16)v[1]; hi[0] = (__bf16)v[2]; hi[1] = (__bf16)v[3];
@@ -160,7 +165,13 @@ __global__ void __launch_bounds__(256) gemm_bs_kernel(BArgs g) {
     }
     const int ks = bid % g.splitk;
     bid /= g.splitk;
-    const int tm = bid / ntn, tn = bid % ntn;
+    int tm, tn;
+    {   // grouped order: gm tile rows x ~64/gm tile columns are live together on an XCD (gm + 64/gm operand panels in its L2, not 1 + 64)
+        const int per = g.gm * ntn, grp = bid / per, in = bid - grp * per;
+        const int first = grp * g.gm, gsz = min(ntm - first, g.gm);
+        tn = in / gsz;
+        tm = first + (in - tn * gsz);
+    }
     const int m0 = tm * BM, n0 = tn * BN;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
@@ -267,16 +278,18 @@ int dispatch(hipStream_t st, const BArgs& g, bool akc, bool bkc, bool vec) {
 // planes: 1 = bf16 compute, 3 = split-bf16 (fp32-class accuracy).  Only called for products large enough to tile.
 int xgk_gemm_bf16(hipStream_t st, int planes, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
                   const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate) {
-    BArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1};
+    BArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1, 1};
     const bool akc = !transA, bkc = transB;
     bool vec = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && (lda % 4 == 0) && (ldb % 4 == 0);
     vec = vec && ((akc ? K : M) % 4 == 0) && ((bkc ? K : N) % 4 == 0);
     const long tiles = (long)xg_cdiv(M, BM) * xg_cdiv(N, BN);
     const int nslab = xg_cdiv(K, BK);
-    if (!relu && tiles < 512) {                     // fill the chip (2 workgroups per CU) by splitting deep reductions
+    if (!relu && tiles < 512) {                     // fill the chip by splitting deep reductions (3 workgroups per CU would fit,
+                                                    // but 768 shares were measured slower: dX 52 -> 83 us, more atomics)
         long sk = (512 + tiles - 1) / tiles;
         if (sk > nslab / 8) sk = nslab / 8;
         if (sk >= 2) g.splitk = (int)sk;
     }
+    g.gm = xgk_group_rows(K / g.splitk);
     return planes == 1 ? dispatch<1>(st, g, akc, bkc, vec) : dispatch<3>(st, g, akc, bkc, vec);
 }

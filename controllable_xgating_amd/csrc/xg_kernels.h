@@ -5,6 +5,14 @@
 // ---- xg_gemm.hip
 // `mode` = arithmetic of the product (XgRun.gemm_mode): 0 exact fp32 MFMA, 3 split-bf16, 1 bf16 operands; modes 1 / 3 apply
 // to LARGE products only (M >= 256, N >= 64, K >= 64), everything else is fp32.  An explicit argument: no per-thread state.
+// Tile rows per group of the GEMM kernels' tile order: the ~64 tiles an XCD works on at a time span gm tile rows x 64/gm
+// tile columns, so its 4 MB L2 holds gm + 64/gm operand panels of 128 x k_depth floats instead of 1 + 64 (measured: the
+// bf16 vocabulary product re-read W from HBM at 4.3 TB/s in row-major order).  Deep reductions keep the row-major order:
+// their panels do not fit anyway and consecutive tiles should then share the bigger operand's panel.
+static inline int xgk_group_rows(int k_depth) {
+    const int g = 4096 / (k_depth > 0 ? k_depth : 1);
+    return g < 1 ? 1 : (g > 8 ? 8 : g);
+}
 int xgk_gemm(hipStream_t st, int mode, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
              const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate);
 // xg_gemm_bf16.hip: split-bf16 / bf16 arithmetic for large products (planes = 3 or 1)

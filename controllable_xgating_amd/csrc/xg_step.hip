@@ -589,6 +589,9 @@ __device__ __forceinline__ void ldA(const float* const (&ap)[4], int c, int klef
 // SIMD instead of spilling at 128.)
 template <int NW, int PREC, bool SCALE>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SCALE ? 2 : 4, SCALE ? 2 : 4))) skf_kernel(SkArgs args) {
+#ifdef XG_CHAIN_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
     SK_STAMP(0);
     __shared__ __attribute__((aligned(16))) float smem[NW * 32 * RSF > NW * OPF ? NW * 32 * RSF : NW * OPF];
     const SkJob& job = args.job[blockIdx.y];
