@@ -175,7 +175,7 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode);
 
 // ---- xg_pack.hip : weights re-tiled into MFMA-fragment order (caller-owned shadow, XgRun.packed)
 enum { PK_H2A1 = 0, PK_H2A2, PK_DGATE, PK_L1_I2H, PK_L1_A2H, PK_L1_H2H, PK_L2_I2H, PK_L2_A2H, PK_L2_H2H, PK_ENC_RGB, PK_ENC_OPFL,
-       PKB_L2_A2H, PKB_L2_H2H, PKB_H2A2, PKB_L1_H2H, PKB_ENC_RGB, PKB_ENC_OPFL, PK_COUNT };
+       PKB_L2_A2H, PKB_L2_H2H, PKB_H2A2, PKB_L1_H2H, PKB_ENC_RGB, PKB_ENC_OPFL, PKB_L2_I2H, PKB_H2A1, PK_COUNT };
 struct PackedView { const float* m[PK_COUNT]; int nck[PK_COUNT]; int dtype; };    // dtype 0: fp32 tiles (4 KB), 1: bf16 tiles (2 KB)
 size_t xgk_packed_floats(const XgDims& d);
 bool xgk_packed_view(const XgDims& d, const void* packed, int dtype, PackedView* v);   // false: no / unusable shadow

@@ -23,7 +23,7 @@ namespace {
 // serves one caller stream at a time (two callers on two streams -- the SCST sampled / greedy rollouts -- use two
 // handles).  Everything is joined back onto the caller's stream before an entry point returns, so the stream semantics of
 // the C ABI are unchanged.  XgRun.aux == NULL (or XG_NO_OVERLAP=1): everything runs on the caller's stream.
-constexpr int XG_NEV = 16;
+constexpr int XG_NEV = 64;
 struct XgAux { uint32_t magic; int device; hipStream_t s = nullptr, s2 = nullptr; hipEvent_t ev[XG_NEV]; };
 constexpr uint32_t XG_AUX_MAGIC = 0x58474158u;
 XgAux* aux_of(const XgRun* run) {
@@ -750,12 +750,13 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     (void)TB;
     const size_t BR = (size_t)B * R;
     // The reverse-time recurrence splits into two chains.  Chain 2 (cell 2 + attention: dh2, dc2) never reads anything
-    // chain 1 (cell 1: dh1, dc1) produces, and only chain 2's products (dAF, dE) feed the encoder backward: it runs alone
-    // on the main stream, 4 launches per step.  What it hands to cell 1 -- ds2 W_i2h and dp W_h2a[:, :R] -- is batched over
-    // all steps afterwards (two GEMMs), and chain 1 (2 launches per step) runs on the auxiliary stream under the
-    // encoder backward; its results only feed parameter gradients.
-    // The pointwise LSTM backward of step t-1 runs in the epilogue of the product that completes its dh (the last
-    // launch of step t), so a step of chain 2 is 3 launches and a step of chain 1 is 1.
+    // chain 1 (cell 1: dh1, dc1) produces, and only chain 2's products (dAF, dE) feed the encoder backward: it runs on
+    // the main stream, 3 launches per step.  Chain 1 (1 launch per step) follows ONE STEP BEHIND on the second auxiliary
+    // stream: what cell 1's output at step t-1 receives from chain 2 -- ds2[t-1] W_i2h2 and dp[t] W_h2a[:, :R] -- are two
+    // more segments of the product that carries dh1 back (ds1[t] W_h2h1), so nothing is batched after the loop and the
+    // chain fills the part of chain 2's time in which the vocabulary head's weight gradients are already done.  Its
+    // results only feed parameter gradients.
+    // The pointwise LSTM backward of step t-1 runs in the epilogue of the product that completes its dh.
     const bool fuse = R % 4 == 0;
     int cur = 0;
     for (int j = 0; j < 4; ++j) ZERO(w.dst[0][j], BR);
@@ -773,6 +774,56 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         a.B = B; a.R = R; a.order = XG_ORDER_IFOG; a.mask_mode = XG_MASK_HOLD;
         a.drop = xg_make_drop(&run, XG_SITE_L2, t);
         return a;
+    };
+    hipStream_t s1 = ss.aux2;                 // chain 1 and what depends on it
+    int cur1 = 0;
+    auto cell1_bwd = [&](int t, int c, const float* dh_add) {
+        LstmBwdArgs a{};
+        a.gates = w.G1 + (size_t)t * B * 4 * R; a.ldg = 4 * R;
+        a.c_prev = w.C1 + t * BR; a.ldcp = R; a.c_out = w.C1 + (t + 1) * BR; a.ldco = R;
+        a.mask = mask + (size_t)t * mask_tstride; a.ldm = ldm;
+        a.dh_out = w.dst[c][0]; a.lddh = R; a.dh_add = dh_add; a.lddha = dh_add ? R : 0; a.dc_out = w.dst[c][1]; a.lddc = R;
+        a.ds = w.DS1 + (size_t)t * B * 4 * R; a.ldds = 4 * R;
+        a.dc_prev = w.dst[c ^ 1][1]; a.lddcp = R; a.dh_prev = w.dst[c ^ 1][0]; a.lddhp = R;
+        a.B = B; a.R = R; a.order = XG_ORDER_IFOG; a.mask_mode = XG_MASK_HOLD;
+        a.drop = xg_make_drop(&run, XG_SITE_L1, t);
+        return a;
+    };
+    // what cell 1's output at step t receives from chain 2, as segments:  ds2[t] W_i2h2 (+ dp[t+1] W_h2a[:, :R])
+    auto from_chain2 = [&](SkJob& j, int first, int t) {
+        j.seg[first] = seg_nn(w, PKB_L2_I2H, w.DS2 + (size_t)t * B * 4 * R, 4 * R, p.l2_i2h_w, R, 4 * R);
+        int n = first + 1;
+        if (t + 1 < T) j.seg[n++] = seg_nn(w, PKB_H2A1, w.DP + (size_t)(t + 1) * B * A, A, p.h2a_w, 2 * R, A);
+        j.nseg = n;
+    };
+    // one step of chain 1, enqueued when chain 2 has finished step t (ds2[t-1], dp[t] exist)
+    auto chain1_step = [&](int t) -> int {
+        float* dh1p = w.dst[cur1 ^ 1][0];
+        float* ds1 = w.DS1 + (size_t)t * B * 4 * R;
+        if (!fuse || t == T - 1) {               // stand-alone cell backward: its dh contribution from chain 2 is materialised
+            SkArgs sk{};
+            sk.njobs = 1;
+            sk.job[0] = job_store(B, R, w.DH1X + t * BR, R, false);
+            from_chain2(sk.job[0], 0, t);
+            XG_TRY(xgk_skinny(s1, sk, w.gm));
+            XG_TRY(xgk_lstm_bwd(s1, cell1_bwd(t, cur1, w.DH1X + t * BR)));
+        }
+        SkArgs sk{};
+        sk.njobs = 1;
+        SkJob& j = sk.job[0];
+        if (fuse && t > 0) j = job_lstm_bwd(cell1_bwd(t - 1, cur1 ^ 1, nullptr), dh1p, R);
+        else j = job_store(B, R, dh1p, R, true);
+        j.nseg = 1;
+        j.seg[0] = seg_nn(w, PKB_L1_H2H, ds1, 4 * R, p.l1_h2h_w, R, 4 * R);
+        if (fuse && t > 0) from_chain2(j, 1, t - 1);
+        if (t == 0) {                            // the attention query of step 0 read the INITIAL h1
+            j.seg[1] = seg_nn(w, PKB_H2A1, w.DP, A, p.h2a_w, 2 * R, A);
+            j.nseg = 2;
+        }
+        allow_split(sk, 0, w); j.tickets = w.tickets + 2 * 1024;       // chain 1 runs beside chain 2 / the encoder: own counters
+        XG_TRY(xgk_skinny(s1, sk, w.gm));
+        cur1 ^= 1;
+        return XG_OK;
     };
     for (int t = T - 1; t >= 0; --t) {
         // dH of the early steps comes from the auxiliary stream; fused, step t-1's cell backward runs inside step t
@@ -803,44 +854,12 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
             XG_TRY(xgk_skinny(st, sk, w.gm));
         }
         cur ^= 1;
+        XG_TRY(ss.fork2());                   // chain 2 has finished step t ...
+        XG_TRY(chain1_step(t));               // ... chain 1 may do it
     }
     const int cur2 = cur;
     XG_TRY(ss.fork());                        // chain 2 is complete: DS2, DP, DAF, DE
-    XG_TRY(ss.fork2());
     hipStream_t sx = ss.aux;                  // parameter gradients that only need chain 2
-    hipStream_t s1 = ss.aux2;                 // chain 1 and what depends on it
-    // what cell 1's output receives from chain 2, all steps at once:  DH1X[t] = ds2[t] W_i2h2 + dp[t+1] W_h2a[:, :R]
-    XG_TRY(gemm_nn(s1, w.gm, TB, R, 4 * R, w.DS2, 4 * R, p.l2_i2h_w, R, w.DH1X, R, false));
-    if (T > 1) XG_TRY(gemm_nn(s1, w.gm, (T - 1) * B, R, A, w.DP + (size_t)B * A, A, p.h2a_w, 2 * R, w.DH1X, R, true));
-    int cur1 = 0;
-    auto cell1_bwd = [&](int t, int c) {
-        LstmBwdArgs a{};
-        a.gates = w.G1 + (size_t)t * B * 4 * R; a.ldg = 4 * R;
-        a.c_prev = w.C1 + t * BR; a.ldcp = R; a.c_out = w.C1 + (t + 1) * BR; a.ldco = R;
-        a.mask = mask + (size_t)t * mask_tstride; a.ldm = ldm;
-        a.dh_out = w.dst[c][0]; a.lddh = R; a.dh_add = w.DH1X + t * BR; a.lddha = R; a.dc_out = w.dst[c][1]; a.lddc = R;
-        a.ds = w.DS1 + (size_t)t * B * 4 * R; a.ldds = 4 * R;
-        a.dc_prev = w.dst[c ^ 1][1]; a.lddcp = R; a.dh_prev = w.dst[c ^ 1][0]; a.lddhp = R;
-        a.B = B; a.R = R; a.order = XG_ORDER_IFOG; a.mask_mode = XG_MASK_HOLD;
-        a.drop = xg_make_drop(&run, XG_SITE_L1, t);
-        return a;
-    };
-    for (int t = T - 1; t >= 0; --t) {
-        float* dh1p = w.dst[cur1 ^ 1][0];
-        float* ds1 = w.DS1 + (size_t)t * B * 4 * R;
-        if (!fuse || t == T - 1) XG_TRY(xgk_lstm_bwd(s1, cell1_bwd(t, cur1)));
-        SkArgs sk{};
-        sk.njobs = 1;
-        if (fuse && t > 0) sk.job[0] = job_lstm_bwd(cell1_bwd(t - 1, cur1 ^ 1), dh1p, R);
-        else sk.job[0] = job_store(B, R, dh1p, R, true);
-        sk.job[0].nseg = 1;
-        sk.job[0].seg[0] = seg_nn(w, PKB_L1_H2H, ds1, 4 * R, p.l1_h2h_w, R, 4 * R);
-        allow_split(sk, 0, w); sk.job[0].tickets = w.tickets + 2 * 1024;       // chain 1 runs beside chain 2 / the encoder: own counters
-        XG_TRY(xgk_skinny(s1, sk, w.gm));
-        cur1 ^= 1;
-    }
-    // the attention query of step 0 read the INITIAL h1
-    XG_TRY(gemm_nn(s1, w.gm, B, R, A, w.DP, A, p.h2a_w, 2 * R, w.dst[cur1][0], R, true));
     // ---- after the loop.  Main chain (the encoder backward waits for it): dVproj -> dV.  Everything else is a
     // parameter gradient and goes to the auxiliary stream, under the encoder's recurrent backward.
     XG_TRY(xgk_attn_bwd_post(st, w.P, w.vproj, p.a2w_w, w.DE, w.DVPROJ, g.a2w_w, T, B, K, A));

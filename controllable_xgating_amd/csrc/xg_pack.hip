@@ -17,7 +17,7 @@
 //   NT entries (forward, y = x W^T, W (N,K) row-major):  h2a[:, :R], h2a[:, R:], decoder gate, lstm_1.{i2h,a2h,h2h},
 //       lstm_2.{i2h,a2h,h2h}, encoder W_hh x2.  The 4R-row cell matrices use the cell tiling: tile tn holds hidden units
 //       8 tn .. 8 tn + 7 of all four gates (row r = 8 gate + unit), so one tile carries a unit's whole cell update.
-//   NN entries (backward, dx = dy W, W (Kc,N) row-major): lstm_2.{a2h,h2h}, h2a[:, R:], lstm_1.h2h, encoder W_hh x2.
+//   NN entries (backward, dx = dy W, W (Kc,N) row-major): lstm_2.{a2h,h2h,i2h}, h2a[:, R:], h2a[:, :R], lstm_1.h2h, encoder W_hh x2.
 #include "xg_common.h"
 #include "xg_kernels.h"
 
@@ -45,6 +45,8 @@ void describe(const XgDims& d, const XgParams& p, PackDesc* e) {
     e[PKB_L1_H2H] = {p.l1_h2h_w, R, 4 * R, 1, R, 0};
     e[PKB_ENC_RGB] = {p.lstm_rgb_whh, R, 4 * R, 1, R, 0};
     e[PKB_ENC_OPFL] = {p.lstm_opfl_whh, R, 4 * R, 1, R, 0};
+    e[PKB_L2_I2H] = {p.l2_i2h_w, R, 4 * R, 1, R, 0};
+    e[PKB_H2A1] = {p.h2a_w, R, A, 1, 2 * R, 0};
 }
 
 inline size_t entry_floats(const PackDesc& e) {

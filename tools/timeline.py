@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Text timeline of ONE training iteration from a rocprofv3 --kernel-trace csv: which kernels ran on which HIP
 stream (queue), when, and how much of the iteration each stream / the GPU was busy.  Iterations are delimited by
-clip_adam_kernel.   usage: timeline.py <dir with *_kernel_trace.csv> [iteration index from the end, default 1]"""
+clip_adam_kernel.   usage: timeline.py <dir with *_kernel_trace.csv> [iteration index from the end, default 1] [from_us to_us: list every kernel in the window]"""
 import csv
 import glob
 import sys
@@ -59,6 +59,14 @@ def main():
             else:
                 cur = dict(q=q, s=r["s"], e=r["e"], n=1, names={key: 1}, busy=r["e"] - r["s"])
                 runs.append(cur)
+    if len(sys.argv) > 4:          # detail window [a, b) in us: every kernel
+        a, b = float(sys.argv[3]), float(sys.argv[4])
+        print("\ndetail %g..%g us" % (a, b))
+        for r in it:
+            ts = (r["s"] - t0) / 1e3
+            if a <= ts < b:
+                print("%9.1f %8.1f  q%d  %s" % (ts, (r["e"] - r["s"]) / 1e3, qs.index(r["q"]), r["name"]))
+        return
     for r in sorted(runs, key=lambda r: r["s"]):
         print("%9.1f %9.1f %5d  %-3s %s" % ((r["s"] - t0) / 1e3, (r["e"] - r["s"]) / 1e3, r["n"], qs.index(r["q"]),
                                             ", ".join("%s x%d" % kv for kv in r["names"].items())))
