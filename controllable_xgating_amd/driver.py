@@ -1,6 +1,6 @@
 """Train / eval driver counterpart: the CALL SEQUENCE of the reference's py2-only
 ``caption_src/starttrain.py:84-241`` and ``caption_src/myutils.py:41-85`` restated on top of the HIP model surface.
-Data loading, TensorBoard and the coco-caption metrics are out of scope:
+and ``caption_src/eval_utils.py:18-84`` (eval_split).  Data loading, TensorBoard and the coco-caption metrics are out of scope:
 batches are handed in as dicts of CUDA tensors and the SCST reward scorer is a caller-supplied callable
 (BASELINE.json config 3 stubs CIDEr).
 """
@@ -53,6 +53,61 @@ def get_self_critical_reward(model, feat1, feat2, feat_mask, pos_feat, gen_resul
     m = gen.shape[0]
     diff = scores[:m] - scores[m:]
     return np.repeat(diff[:, np.newaxis], gen.shape[1], 1)
+
+
+def decode_sequence(ix_to_word, seq):
+    """myutils.decode_sequence (myutils.py:88-102): one string per row, the words of the tokens up to (not including) the
+    first token <= 0, joined by single spaces.  ``ix_to_word`` maps int -> str (the reference also accepts str keys from
+    its json vocabulary; both are tried)."""
+    rows = seq.detach().cpu().tolist() if torch.is_tensor(seq) else np.asarray(seq).tolist()
+    out = []
+    for row in rows:
+        words = []
+        for ix in row:
+            if ix <= 0:
+                break
+            words.append(ix_to_word[ix] if ix in ix_to_word else ix_to_word[str(ix)])
+        out.append(" ".join(words))
+    return out
+
+
+def eval_split(model, crit, classify_crit, batches, ix_to_word, eval_kwargs=None, gts_of=None, scorer=None):
+    """eval_utils.eval_split (eval_utils.py:18-84) on the HIP model surface.  ``batches`` yields dicts with the
+    collate fields (data.collate: feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask, cap_classes, class_mask as
+    CUDA tensors, plus ``image_ids``).  Per batch: eval-mode forward -> language + weight_class * category loss
+    (:40-46), then ``model.sample(..., eval_kwargs)`` (greedy, or beam search when eval_kwargs['beam_size'] > 1: :48),
+    decoded with the vocabulary (:55).  Returns (mean loss, predictions, lang_stats) like the reference (:84); the
+    coco-caption metrics are out of scope: ``lang_stats = scorer(captions, references)`` when a scorer and ``gts_of``
+    (image id -> references) are supplied and eval_kwargs['language_eval'] == 1, else None.  The model is put back into
+    train mode at the end, as the reference does (:83)."""
+    kw = dict(eval_kwargs or {})
+    weight_class = kw.get("weight_class", 0.0)
+    model.eval()
+    loss_sum, loss_evals = 0.0, 1e-8                                               # :28-29
+    predictions, gts = [], []
+    with torch.no_grad():
+        for b in batches:
+            out, category = model(b["feats_rgb"], b["feats_opfl"], b["feat_mask"], b["pos_feats"], b["seq"], b["seq_mask"])
+            loss = float(crit(out, b["seq"], b["seq_mask"])) + \
+                weight_class * float(classify_crit(category, b["cap_classes"], b["seq_mask"], b["class_mask"]))
+            loss_sum += loss
+            loss_evals += 1
+            seq, seq_logprobs = model.sample(b["feats_rgb"], b["feats_opfl"], b["feat_mask"], b["pos_feats"], kw)
+            sents = decode_sequence(ix_to_word, seq)
+            lp = seq_logprobs.detach().cpu()
+            for k, sent in enumerate(sents):
+                image_id = b["image_ids"][k] if "image_ids" in b else len(predictions)
+                predictions.append({"image_id": image_id, "caption": sent, "seqLogprob": lp[k].numpy()})
+                if gts_of is not None:
+                    gts.append(gts_of[image_id])
+    if kw.get("verbose", False):
+        for x in predictions[:10]:
+            print("image %s: %s" % (x["image_id"], x["caption"]))
+    lang_stats = None
+    if kw.get("language_eval", 0) == 1 and scorer is not None and gts_of is not None:
+        lang_stats = scorer([x["caption"] for x in predictions], gts)
+    model.train()
+    return loss_sum / loss_evals, predictions, lang_stats
 
 
 def _second_bn_update(bns, r0):

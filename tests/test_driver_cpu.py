@@ -2,7 +2,13 @@
 reference caption_src/starttrain.py:84-107 and caption_src/myopts.py defaults.  CPU only."""
 import argparse
 
-from controllable_xgating_amd.driver import lr_for_epoch, sc_flag_for_epoch, ss_prob_for_epoch
+import json
+import os
+
+import numpy as np
+import torch
+
+from controllable_xgating_amd.driver import decode_sequence, lr_for_epoch, sc_flag_for_epoch, ss_prob_for_epoch
 
 
 def _opt(**kw):
@@ -35,3 +41,13 @@ def test_self_critical_switch():
     o = _opt()
     assert not sc_flag_for_epoch(o, 29) and sc_flag_for_epoch(o, 30)
     assert not sc_flag_for_epoch(_opt(self_critical_after=-1), 1000)
+
+
+def test_decode_sequence_vs_reference_fixture():
+    """myutils.decode_sequence (myutils.py:88-102): fixture recorded from the reference's own function
+    (tools/gen_golden.py:gen_decode): rows cut at the first 0, an empty row, a row without 0, tokens after a 0 ignored."""
+    g = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "decode_seq.json")))
+    vocab_int = {int(k): v for k, v in g["vocab"].items()}
+    seq = np.asarray(g["seq"], dtype=np.int64)
+    assert decode_sequence(vocab_int, torch.from_numpy(seq)) == g["sents"]
+    assert decode_sequence(g["vocab"], seq) == g["sents"]            # json vocabularies have str keys

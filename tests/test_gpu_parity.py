@@ -424,6 +424,51 @@ def test_beam_search_vs_reference_golden(tag):
 
 
 # ---------------------------------------------------------------- driver counterpart
+@pytest.mark.parametrize("beam", [1, 3])
+def test_eval_split_vs_oracle_and_beam_golden(beam):
+    """eval_utils.eval_split (eval_utils.py:18-84): eval-mode loss = language + weight_class * category loss per batch,
+    averaged over batches; captions = decoded greedy tokens (oracle) or beam-search tokens (reference golden); the model
+    is back in train mode afterwards."""
+    from controllable_xgating_amd import ClassiferCriterion, LanguageModelCriterion
+    from controllable_xgating_amd.driver import decode_sequence, eval_split
+    cfg = dict(CFG["tiny"]); cfg["B"] = 3
+    d = pg.make_dims(**cfg)
+    model = make_model(d, train=True)
+    itow = {i: "w%d" % i for i in range(1, d.V)}
+    batches = []
+    for seed in (0, 1):
+        x = to_dev(pg.make_inputs(d, seed=seed, ragged=True))
+        x["image_ids"] = ["vid%d_%d" % (seed, k) for k in range(d.B)]
+        batches.append(x)
+    loss, preds, stats = eval_split(model, LanguageModelCriterion(), ClassiferCriterion(), batches, itow,
+                                    {"beam_size": beam, "weight_class": WEIGHT_CLASS, "language_eval": 1},
+                                    gts_of={i: [i] for b in batches for i in b["image_ids"]},
+                                    scorer=lambda caps, gts: {"n": len(caps), "same": len(caps) == len(gts)})
+    assert model.training and stats == {"n": 2 * d.B, "same": True}
+    assert [p["image_id"] for p in preds] == batches[0]["image_ids"] + batches[1]["image_ids"]
+    P = xo.to_torch_params(pg.make_params(d))
+    want_loss, want_sents = 0.0, []
+    for seed in (0, 1):
+        xi = xo.to_torch_inputs(pg.make_inputs(d, seed=seed, ragged=True))
+        logp, cat, _ = xo.forward_xe(P, xi["feats_rgb"], xi["feats_opfl"], xi["feat_mask"], xi["pos_feats"], xi["seq"], xi["seq_mask"],
+                                     train=False, p=0.0, seed=0, running=xo.new_running(d))
+        want_loss += float(xo.lm_criterion(logp, xi["seq"], xi["seq_mask"])) + \
+            WEIGHT_CLASS * float(xo.cls_criterion(cat, xi["cap_classes"], xi["seq_mask"], xi["class_mask"]))
+        if beam == 1:
+            seq, _ = xo.sample(P, xi["feats_rgb"], xi["feats_opfl"], xi["feat_mask"], xi["pos_feats"], d.L, mode="greedy",
+                               train=False, running=xo.new_running(d))
+            want_sents += decode_sequence(itow, seq)
+    assert abs(loss - want_loss / 2) < 2e-5 * max(1.0, abs(want_loss))
+    if beam == 1:
+        assert [p["caption"] for p in preds] == want_sents
+    else:       # batch 0 is the beam-search golden's input (seed 0, not ragged there: compare only when masks agree)
+        g = load_golden("beam_tiny.npz")
+        x0 = to_dev(pg.make_inputs(d, seed=0))
+        x0["image_ids"] = batches[0]["image_ids"]
+        _, p0, _ = eval_split(model, LanguageModelCriterion(), ClassiferCriterion(), [x0], itow, {"beam_size": int(g["beam_size"])})
+        assert [p["caption"] for p in p0] == decode_sequence(itow, g["seq"])
+
+
 def test_three_iteration_xe_trajectory_vs_oracle_loop():
     """zero_grad -> forward -> criteria -> backward -> clamp +-0.1 -> Adam, three times (starttrain.py:123-137)."""
     import argparse

@@ -356,18 +356,49 @@ def gen_beam(ref, tag, beam_size=3):
     print("wrote", f"beam_{tag}.npz")
 
 
+def gen_decode():
+    """myutils.decode_sequence (caption_src/myutils.py:88-102) is host-only string work in a py2 file that py3 cannot
+    import (print statement at module level): the function's own lines are exec'd from where they lie, on an (N, D)
+    token matrix behind a shim that hands out Python ints like torch 0.3 did.  Fixture: tokens + expected strings."""
+    import json
+    src = open(os.path.join(REF, "myutils.py")).read().splitlines()
+    i0 = next(i for i, l in enumerate(src) if l.startswith("def decode_sequence"))
+    i1 = next(i for i in range(i0 + 1, len(src)) if src[i] and not src[i][0].isspace())
+    ns = {}
+    exec("\n".join(src[i0:i1]), ns)
+
+    class IntMatrix:
+        def __init__(self, a): self.a = a
+        def size(self): return self.a.shape
+        def __getitem__(self, ij): return int(self.a[ij])
+
+    rng = np.random.RandomState(5)
+    seq = rng.randint(1, 40, size=(9, 7)).astype(np.int64)
+    seq[0, 3:] = 0; seq[1, 0] = 0; seq[2, 6] = 0; seq[3, 1] = 0; seq[3, 4] = 7; seq[5, 2:5] = 0; seq[7, :] = 0
+    vocab = {i: "w%d" % i for i in range(1, 40)}
+    vocab[3] = "a"; vocab[7] = "<unk>"; vocab[11] = "it's"
+    want = ns["decode_sequence"](vocab, IntMatrix(seq))
+    with open(os.path.join(GOLD, "decode_seq.json"), "w") as f:
+        json.dump({"seq": seq.tolist(), "vocab": {str(k): v for k, v in vocab.items()}, "sents": want}, f)
+    print("wrote decode_seq.json", want[:4])
+
+
 def main():
     if not os.path.isdir(REF):
         print("reference not present; nothing to do")
         return 0
     os.makedirs(GOLD, exist_ok=True)
     torch.set_num_threads(8)
+    if "--decode-only" in sys.argv:
+        gen_decode()
+        return 0
     round2_only = "--round2-only" in sys.argv          # (import_reference() resets sys.argv for the reference's argparse)
     ref = import_reference()
     if round2_only:          # the fixtures added in round 2 (the older ones regenerate bit-identically)
         gen_greedy_eos(ref)
         gen_traj(ref, "tiny")
         gen_traj(ref, "mid")
+        gen_decode()
         return 0
     gen_xe(ref, "tiny", ragged=False, full=True)
     gen_xe(ref, "tiny", ragged=True, full=True)
@@ -388,6 +419,7 @@ def main():
     gen_greedy_eos(ref)
     gen_traj(ref, "tiny")
     gen_traj(ref, "mid")
+    gen_decode()
     return 0
 
 
