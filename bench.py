@@ -46,12 +46,13 @@ def synth_inputs(B, K, L, V, R, F1, F2, C_, seed, device):
     return {k: v.to(device) for k, v in x.items()}
 
 
-def step_bytes(B, K, R, A, E, save):
-    """ALGORITHMIC bytes of one decoder step: lstmcore weights once + per-video streams."""
+def step_bytes(B, K, R, A, E, save, elem=4):
+    """ALGORITHMIC bytes of one decoder step: lstmcore weights once + per-video streams.  elem = 2 for the
+    bf16 configuration (SURVEY.md 8d prices C5 at 2-byte elements: 84.93 MB per step)."""
     w_core = (2 * R * A + A) + (A + 1) + (E * R + R) + ((E + 2 * R) * 4 * R + 12 * R) + (3 * R * 4 * R + 12 * R)
     per = K * A + K * R + 4 * R + 4 * R + E + R + 1
     s_save = (2 * 4 * R + K + R + R + 2 * R) if save else 0
-    return 4 * (w_core + B * (per + s_save))
+    return elem * (w_core + B * (per + s_save))
 
 
 def step_flops(B, K, R, A, E):
@@ -343,7 +344,9 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * cfg["B"] * T * args.steps / dt * (2 if args.workload == "scst" else 1)
-        bytes_step = step_bytes(cfg["B"], cfg["K"], cfg["R"], cfg["A"], cfg["E"], save=False)
+        bf16 = args.precision == "bf16"
+        bytes_step = step_bytes(cfg["B"], cfg["K"], cfg["R"], cfg["A"], cfg["E"], save=False, elem=2 if bf16 else 4)
+        mfma_peak = 2500.0 if bf16 else 157.3
         achieved = bytes_step / t_step / 1e9
         traffic, traffic_src = (None, None)
         if cfg["B"] == 128 and args.workload == "xe" and args.precision == "fp32":
@@ -372,7 +375,9 @@ def main():
             "config": {"workload": wl,
                        "global_batch": world * cfg["B"], "per_gpu_batch": cfg["B"], "parallelism": "dp%d" % world,
                        "path": args.path, "drop_prob_lm": args.drop, "gemm_precision": args.precision,
-                       "timed_region": "zero_grad + encoder fwd + 21 decoder steps + heads/loss + full backward"
+                       "timed_region": ("zero_grad + sampled + greedy rollouts (31 steps, one 2m-row batch) + reward criterion + backward"
+                                        if args.workload == "scst" else
+                                        "zero_grad + encoder fwd + 21 decoder steps + heads/loss + full backward")
                                        + (" + RCCL grad all-reduce" if world > 1 else "") + " + clip + Adam"},
             "final_loss": round(final_loss, 5),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
@@ -382,8 +387,8 @@ def main():
                          # the same launch group against the OTHER roof (exact-fp32 MFMA, 157.3 TF): at B = 128 the step's
                          # arithmetic intensity (33 FLOP/B) is above the ridge (20), i.e. the MFMA roof is the lower one
                          "mfma_tflops": round(step_flops(cfg["B"], cfg["K"], cfg["R"], cfg["A"], cfg["E"]) / t_step / 1e12, 2),
-                         "mfma_peak_tflops": 157.3,
-                         "mfma_frac": round(step_flops(cfg["B"], cfg["K"], cfg["R"], cfg["A"], cfg["E"]) / t_step / 157.3e12, 4)},
+                         "mfma_peak_tflops": mfma_peak,
+                         "mfma_frac": round(step_flops(cfg["B"], cfg["K"], cfg["R"], cfg["A"], cfg["E"]) / t_step / (mfma_peak * 1e12), 4)},
         }
         parity_fail = None
         if world == 1 and not args.no_cpu_baseline:

@@ -10,8 +10,12 @@
 //              BASELINE.json configs[4] (bf16, tolerance 1e-2).
 // Tile 128x128x32, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles; global -> registers (prefetched
 // one slab ahead) -> split -> LDS planes -> fragments.  LDS images:
-//   k-contiguous operand:  plane[rows][40] bf16 (80-B rows, 5 16-B slots: odd -> conflict-free ds_read_b128 fragments)
-//   m-contiguous operand:  plane[32][rows+8] bf16, fragments gathered with 8 ds_read_u16 (lanes read consecutive rows).
+//   both operand layouts:  plane[rows][40] bf16 (80-B rows, 5 16-B slots: odd -> conflict-free ds_read_b128 fragments).
+//   An m-contiguous operand (weight gradients, data gradients) is TRANSPOSED BY THE THREAD ASSIGNMENT of its global loads:
+//   thread t owns row t & 127 and 16 consecutive k (16 dword loads, each wave-instruction 256 contiguous bytes), so it
+//   writes the same k-contiguous image as the other layout.  (Round 1 kept such an operand as plane[32][rows+8] and gathered
+//   every fragment with 8 ds_read_u16: 128 LDS instructions per wave per slab against 8 MFMAs -- the weight-gradient
+//   products of the hidden-1024 configuration ran at 3 % MFMA utilisation, LDS-issue bound.)
 // Same argument struct, XCD-aware tile order, split-K (fp32 atomics) and epilogue as xg_gemm.hip.
 #include "xg_common.h"
 #include "xg_kernels.h"
@@ -25,7 +29,6 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDKC = BK + 8;       // k-contiguous image: row stride in bf16 (80 B)
-constexpr int LDMC = BM + 8;       // m-contiguous image: row stride in bf16
 
 struct BArgs {
     const float* A; const float* B; float* C; const float* bias;
@@ -33,7 +36,7 @@ struct BArgs {
     int gm;   // tile rows per group of the tile order (xg_kernels.h: xgk_group_rows)
 };
 
-template <bool KC> constexpr int plane_elems() { return KC ? BM * LDKC : BK * LDMC; }
+template <bool KC> constexpr int plane_elems() { return BM * LDKC; }
 
 // ---- fp32 -> bf16 planes
 template <int NP>
@@ -62,26 +65,27 @@ __device__ __forceinline__ void split(float x, unsigned short (&h)[NP]) {
 template <bool KC, bool VEC>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int r0, int k0, int nrows, int K, f32x4 (&regs)[4]) {
     const int t = threadIdx.x;
+    if (!KC) {
+        // element (r, k) at P[k * ld + r]: this thread's row r = t & 127, k = (t >> 7) * 16 + 4 i + j
+        const int cr = min(r0 + (t & 127), nrows - 1), kb = k0 + ((t >> 7) << 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) regs[i][j] = P[(size_t)min(kb + 4 * i + j, K - 1) * ld + cr];
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = t + 256 * i;
-        int r, k;
-        if (KC) { r = f >> 3; k = (f & 7) << 2; }
-        else    { k = f >> 5; r = (f & 31) << 2; }
+        const int r = f >> 3, k = (f & 7) << 2;
         const int gr = r0 + r, gk = k0 + k;
         if (VEC) {
             // the vectorised extent is a multiple of 4, so a float4 is entirely in or entirely out: clamp to the last one
-            const int cr = KC ? min(gr, nrows - 1) : min(gr, nrows - 4);
-            const int ck = KC ? min(gk, K - 4) : min(gk, K - 1);
-            const float* src = KC ? P + (size_t)cr * ld + ck : P + (size_t)ck * ld + cr;
+            const float* src = P + (size_t)min(gr, nrows - 1) * ld + min(gk, K - 4);
             regs[i] = *reinterpret_cast<const f32x4*>(src);
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int cr = KC ? min(gr, nrows - 1) : min(gr + j, nrows - 1);
-                const int ck = KC ? min(gk + j, K - 1) : min(gk, K - 1);
-                regs[i][j] = KC ? P[(size_t)cr * ld + ck] : P[(size_t)ck * ld + cr];
-            }
+            for (int j = 0; j < 4; ++j) regs[i][j] = P[(size_t)min(gr, nrows - 1) * ld + min(gk + j, K - 1)];
         }
     }
 }
@@ -95,18 +99,15 @@ __device__ __forceinline__ void store_tile(unsigned short* __restrict__ lds, con
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = t + 256 * i;
-        int r, k;
+        int r, k;                                  // 4 consecutive k (k .. k + 3) of row r, whichever way they were loaded
         if (KC) { r = f >> 3; k = (f & 7) << 2; }
-        else    { k = f >> 5; r = (f & 31) << 2; }
+        else    { r = t & 127; k = ((t >> 7) << 4) + 4 * i; }
         f32x4 v = regs[i];
         if (edge) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool ok = KC ? (r0 + r < nrows && k0 + k + j < K) : (r0 + r + j < nrows && k0 + k < K);
-                v[j] = ok ? v[j] : 0.f;
-            }
+            for (int j = 0; j < 4; ++j) v[j] = (r0 + r < nrows && k0 + k + j < K) ? v[j] : 0.f;
         }
-        const int off = KC ? r * LDKC + k : k * LDMC + r;
+        const int off = r * LDKC + k;
         if constexpr (NP == 1) {
             // plain bf16: the hardware's packed round-to-nearest-even convert (v_cvt_pk_bf16_f32), one instruction per pair
             // instead of ~4 integer operations per element (269 -> 294 TF on the vocabulary products).  (A 64-deep,
@@ -115,7 +116,11 @@ __device__ __forceinline__ void store_tile(unsigned short* __restrict__ lds, con
             // global_load_lds -> two-stage ring, 2 workgroups per CU, rounding on the LDS -> fragment path) was also
             // measured: correct, but 64 KB in flight per CU against this kernel's 96 KB of staging registers -- logits
             // 187 vs 167 us, mid-size 67 vs 46 us, only the weight-gradient layout 5 % ahead; not kept.  What would
-            // help is HALF the bytes: bf16 operand copies in memory.)
+            // help is HALF the bytes: bf16 operand copies in memory.  Two register sets + two LDS buffers (two slabs of
+            // loads in flight per workgroup, one barrier per slab, 2 workgroups per CU instead of 3) were measured too:
+            // the per-workgroup slab time does not change (1.37 us on the weight-gradient layout either way), so fewer
+            // resident workgroups just lose -- dW_logit 190 -> 281 us.  The kernel moves ~18 TB/s of fp32 operands from L2
+            // to the CUs: it is bound by that fill rate (32 flop per operand byte at 128x128 tiles), not by latency.)
             typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
             bf16x2_t lo, hi;
             lo[0] = (__bf16)v[0]; lo[1] = (__bf16)v[1]; hi[0] = (__bf16)v[2]; hi[1] = (__bf16)v[3];
@@ -140,14 +145,7 @@ __device__ __forceinline__ void store_tile(unsigned short* __restrict__ lds, con
 // ---- LDS -> MFMA fragment: 8 consecutive k (k0..k0+7) of row `row`
 template <bool KC>
 __device__ __forceinline__ bf16x8 read_frag(const unsigned short* __restrict__ plane, int row, int k0) {
-    if (KC) {
-        return *reinterpret_cast<const bf16x8*>(plane + row * LDKC + k0);
-    } else {
-        bf16x8 v;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] = (short)plane[(k0 + j) * LDMC + row];
-        return v;
-    }
+    return *reinterpret_cast<const bf16x8*>(plane + row * LDKC + k0);
 }
 
 template <int NP, bool AKC, bool BKC, bool VEC>
@@ -186,20 +184,8 @@ __global__ void __launch_bounds__(256) gemm_bs_kernel(BArgs g) {
 
     const int nslab_all = (g.K + BK - 1) / BK;
     const int s_begin = (int)(((long)ks * nslab_all) / g.splitk), s_end = (int)(((long)(ks + 1) * nslab_all) / g.splitk);
-    f32x4 ra[4], rb[4];
     const bool edge_a = m0 + BM > g.M, edge_b = n0 + BN > g.N;     // wave-uniform: interior tiles skip the masking
-    load_tile<AKC, VEC>(g.A, g.lda, m0, s_begin * BK, g.M, g.K, ra);
-    load_tile<BKC, VEC>(g.B, g.ldb, n0, s_begin * BK, g.N, g.K, rb);
-    for (int s = s_begin; s < s_end; ++s) {
-        const bool ktail = (s + 1) * BK > g.K;
-        __syncthreads();                                   // everyone is done reading the previous slab
-        store_tile<NP, AKC>(As, ra, m0, s * BK, g.M, g.K, edge_a || ktail);
-        store_tile<NP, BKC>(Bs, rb, n0, s * BK, g.N, g.K, edge_b || ktail);
-        __syncthreads();
-        if (s + 1 < s_end) {                               // next slab's loads fly under this slab's MFMAs
-            load_tile<AKC, VEC>(g.A, g.lda, m0, (s + 1) * BK, g.M, g.K, ra);
-            load_tile<BKC, VEC>(g.B, g.ldb, n0, (s + 1) * BK, g.N, g.K, rb);
-        }
+    auto slab_mfma = [&](const unsigned short* Asb, const unsigned short* Bsb) {
 #pragma unroll
         for (int kk = 0; kk < BK / 16; ++kk) {
             const int k0 = kk * 16 + half * 8;
@@ -207,9 +193,9 @@ __global__ void __launch_bounds__(256) gemm_bs_kernel(BArgs g) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[i][p] = read_frag<AKC>(As + p * plane_elems<AKC>(), wm * 64 + i * 32 + l31, k0);
+                for (int i = 0; i < 2; ++i) fa[i][p] = read_frag<AKC>(Asb + p * plane_elems<AKC>(), wm * 64 + i * 32 + l31, k0);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) fb[j][p] = read_frag<BKC>(Bs + p * plane_elems<BKC>(), wn * 64 + j * 32 + l31, k0);
+                for (int j = 0; j < 2; ++j) fb[j][p] = read_frag<BKC>(Bsb + p * plane_elems<BKC>(), wn * 64 + j * 32 + l31, k0);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -223,6 +209,23 @@ __global__ void __launch_bounds__(256) gemm_bs_kernel(BArgs g) {
                             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][pa], fb[j][sum - pa], acc[i][j], 0, 0, 0);
                 }
         }
+    };
+    {
+    f32x4 ra[4], rb[4];
+    load_tile<AKC, VEC>(g.A, g.lda, m0, s_begin * BK, g.M, g.K, ra);
+    load_tile<BKC, VEC>(g.B, g.ldb, n0, s_begin * BK, g.N, g.K, rb);
+    for (int s = s_begin; s < s_end; ++s) {
+        const bool ktail = (s + 1) * BK > g.K;
+        __syncthreads();                                   // everyone is done reading the previous slab
+        store_tile<NP, AKC>(As, ra, m0, s * BK, g.M, g.K, edge_a || ktail);
+        store_tile<NP, BKC>(Bs, rb, n0, s * BK, g.N, g.K, edge_b || ktail);
+        __syncthreads();
+        if (s + 1 < s_end) {                               // next slab's loads fly under this slab's MFMAs
+            load_tile<AKC, VEC>(g.A, g.lda, m0, (s + 1) * BK, g.M, g.K, ra);
+            load_tile<BKC, VEC>(g.B, g.ldb, n0, (s + 1) * BK, g.N, g.K, rb);
+        }
+        slab_mfma(As, Bs);
+    }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -246,6 +249,157 @@ __global__ void __launch_bounds__(256) gemm_bs_kernel(BArgs g) {
         }
 }
 
+// ---- plain bf16, large tiles ("bx") -------------------------------------------------------------------------------
+// gemm_bs_kernel<1,...> moves ~18 TB/s of fp32 operands from L2 to the CUs -- the chip's operand fill rate -- at
+// 32 flop per operand byte (128 x 128 tiles): that, not the matrix cores, is its bound.  The same staging with TM x TN
+// tiles and WGM x WGN waves (each wave (TM / WGM) x (TN / WGN) as 32 x 32 MFMA tiles) raises the reuse: 256 x 128 tiles,
+// 8 waves, = 43 flop per byte.  Slab s+1's loads fly under slab s's MFMAs.
+template <int ROWS, int THREADS, bool KC>
+__device__ __forceinline__ void bx_load(const float* __restrict__ P, int ld, int r0, int k0, int nrows, int K,
+                                        f32x4 (&regs)[ROWS * 8 / THREADS]) {
+    constexpr int NV = ROWS * 8 / THREADS;                     // float4 per thread per operand per slab
+    const int t = threadIdx.x;
+    if (!KC) {                                                 // transposing assignment: row t % ROWS, NV * 4 consecutive k
+        static_assert(THREADS % ROWS == 0 && (THREADS / ROWS) * NV * 4 == BK, "thread map of the m-contiguous operand");
+        const int cr = min(r0 + (t % ROWS), nrows - 1), kb = k0 + (t / ROWS) * (NV * 4);
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) regs[i][j] = P[(size_t)min(kb + 4 * i + j, K - 1) * ld + cr];
+        return;
+    }
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int f = t + THREADS * i;
+        const int r = f >> 3, k = (f & 7) << 2;
+        regs[i] = *reinterpret_cast<const f32x4*>(P + (size_t)min(r0 + r, nrows - 1) * ld + min(k0 + k, K - 4));
+    }
+}
+template <int ROWS, int THREADS, bool KC>
+__device__ __forceinline__ void bx_store(unsigned short* __restrict__ lds, const f32x4 (&regs)[ROWS * 8 / THREADS], int r0, int k0,
+                                         int nrows, int K, bool edge) {
+    constexpr int NV = ROWS * 8 / THREADS;
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        int r, k;
+        if (KC) { const int f = t + THREADS * i; r = f >> 3; k = (f & 7) << 2; }
+        else    { r = t % ROWS; k = (t / ROWS) * (NV * 4) + 4 * i; }
+        f32x4 v = regs[i];
+        if (edge) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v[j] = (r0 + r < nrows && k0 + k + j < K) ? v[j] : 0.f;
+        }
+        bf16x2_t lo, hi;
+        lo[0] = (__bf16)v[0]; lo[1] = (__bf16)v[1]; hi[0] = (__bf16)v[2]; hi[1] = (__bf16)v[3];
+        uint2 w;
+        w.x = __builtin_bit_cast(unsigned, lo); w.y = __builtin_bit_cast(unsigned, hi);
+        *reinterpret_cast<uint2*>(lds + r * LDKC + k) = w;
+    }
+}
+
+template <int TM, int TN, int WGM, int WGN, bool AKC, bool BKC>
+__global__ void __launch_bounds__(64 * WGM * WGN) gemm_bx_kernel(BArgs g) {
+    constexpr int THREADS = 64 * WGM * WGN, WM = TM / WGM, WN = TN / WGN, MT = WM / 32, NT = WN / 32;
+    constexpr int NVA = TM * 8 / THREADS, NVB = TN * 8 / THREADS;
+    extern __shared__ __attribute__((aligned(16))) unsigned short smem_bx[];
+    unsigned short* As = smem_bx;
+    unsigned short* Bs = smem_bx + TM * LDKC;
+
+    const int ntm = (g.M + TM - 1) / TM, ntn = (g.N + TN - 1) / TN;
+    const int nwg = ntm * ntn * g.splitk;
+    int bid = blockIdx.x;
+    {
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int ks = bid % g.splitk;
+    bid /= g.splitk;
+    int tm, tn;
+    {
+        const int per = g.gm * ntn, grp = bid / per, in = bid - grp * per;
+        const int first = grp * g.gm, gsz = min(ntm - first, g.gm);
+        tn = in / gsz;
+        tm = first + (in - tn * gsz);
+    }
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave / WGN, wn = wave % WGN, half = lane >> 5, l31 = lane & 31;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nslab_all = (g.K + BK - 1) / BK;
+    const int s_begin = (int)(((long)ks * nslab_all) / g.splitk), s_end = (int)(((long)(ks + 1) * nslab_all) / g.splitk);
+    const bool edge_a = m0 + TM > g.M, edge_b = n0 + TN > g.N;
+    f32x4 ra[NVA], rb[NVB];
+    bx_load<TM, THREADS, AKC>(g.A, g.lda, m0, s_begin * BK, g.M, g.K, ra);
+    bx_load<TN, THREADS, BKC>(g.B, g.ldb, n0, s_begin * BK, g.N, g.K, rb);
+    for (int s = s_begin; s < s_end; ++s) {
+        const bool ktail = (s + 1) * BK > g.K;
+        __syncthreads();
+        bx_store<TM, THREADS, AKC>(As, ra, m0, s * BK, g.M, g.K, edge_a || ktail);
+        bx_store<TN, THREADS, BKC>(Bs, rb, n0, s * BK, g.N, g.K, edge_b || ktail);
+        __syncthreads();
+        if (s + 1 < s_end) {
+            bx_load<TM, THREADS, AKC>(g.A, g.lda, m0, (s + 1) * BK, g.M, g.K, ra);
+            bx_load<TN, THREADS, BKC>(g.B, g.ldb, n0, (s + 1) * BK, g.N, g.K, rb);
+        }
+#pragma unroll
+        for (int kk = 0; kk < BK / 16; ++kk) {
+            const int k0 = kk * 16 + half * 8;
+            bf16x8 fa[MT], fb[NT];
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[i] = *reinterpret_cast<const bf16x8*>(As + (wm * WM + i * 32 + l31) * LDKC + k0);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[j] = *reinterpret_cast<const bf16x8*>(Bs + (wn * WN + j * 32 + l31) * LDKC + k0);
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = n0 + wn * WN + j * 32 + l31;
+            if (col >= g.N) continue;
+            const float bv = (g.bias && ks == 0) ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < g.M) {
+                    float* dst = g.C + (size_t)row * g.ldc + col;
+                    float v = acc[i][j][r] + bv;
+                    if (g.splitk > 1) { unsafeAtomicAdd(dst, v); continue; }
+                    if (g.accumulate) v += *dst;
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    *dst = v;
+                }
+            }
+        }
+}
+
+template <int TM, int TN, int WGM, int WGN, bool AKC, bool BKC>
+int launch_bx(hipStream_t st, const BArgs& g) {
+    const int ntm = xg_cdiv(g.M, TM), ntn = xg_cdiv(g.N, TN);
+    if (g.splitk > 1 && !g.accumulate) {
+        if (g.ldc == g.N) { if (hipMemsetAsync(g.C, 0, sizeof(float) * (size_t)g.M * g.N, st) != hipSuccess) return XG_EHIP; }
+        else if (hipMemset2DAsync(g.C, sizeof(float) * g.ldc, 0, sizeof(float) * g.N, g.M, st) != hipSuccess) return XG_EHIP;
+    }
+    constexpr int lds = (TM + TN) * LDKC * (int)sizeof(unsigned short);
+    hipLaunchKernelGGL((gemm_bx_kernel<TM, TN, WGM, WGN, AKC, BKC>), dim3(ntm * ntn * g.splitk), dim3(64 * WGM * WGN), lds, st, g);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
 template <int NP, bool AKC, bool BKC, bool VEC>
 int launch(hipStream_t st, const BArgs& g) {
     const int ntm = xg_cdiv(g.M, BM), ntn = xg_cdiv(g.N, BN);
@@ -289,6 +443,21 @@ int xgk_gemm_bf16(hipStream_t st, int planes, bool transA, bool transB, int M, i
         long sk = (512 + tiles - 1) / tiles;
         if (sk > nslab / 8) sk = nslab / 8;
         if (sk >= 2) g.splitk = (int)sk;
+    }
+    // plain bf16 with a k-contiguous A (forward and data-gradient layouts): 256 x 128 tiles, 43 flop per operand byte instead
+    // of 32 -- logits 170 -> 145 us, PRE 79 -> 59 us; hidden-1024 iteration 9.19 -> 9.02 ms.  Measured and not used: the
+    // weight-gradient layout on these tiles (dW_logit 186 -> 276 us) and 256 x 256 tiles (one workgroup per CU: 10.4 ms).
+    static const bool no_bx = getenv("XG_NO_BX") != nullptr;
+    if (planes == 1 && vec && akc && !no_bx && M >= 256) {
+        const long t2 = (long)xg_cdiv(M, 256) * xg_cdiv(N, 128);
+        g.splitk = 1;
+        if (!relu && t2 < 256) {
+            long sk = (256 + t2 - 1) / t2;
+            if (sk > nslab / 8) sk = nslab / 8;
+            if (sk >= 2) g.splitk = (int)sk;
+        }
+        g.gm = xgk_group_rows(2 * K / g.splitk);
+        return bkc ? launch_bx<256, 128, 4, 2, true, true>(st, g) : launch_bx<256, 128, 4, 2, true, false>(st, g);
     }
     g.gm = xgk_group_rows(K / g.splitk);
     return planes == 1 ? dispatch<1>(st, g, akc, bkc, vec) : dispatch<3>(st, g, akc, bkc, vec);
