@@ -58,6 +58,14 @@ __device__ __forceinline__ void split(float x, unsigned short (&h)[NP]) {
     }
 }
 
+// Buffer descriptor over an operand (base made provably wave-uniform; no bounds: the callers clamp).  The m-contiguous
+// loads use it as `SGPR row offset + per-lane column offset`: the row arithmetic stays on the scalar unit.
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t operand_rsrc(const float* P) {
+    const uint64_t a = reinterpret_cast<uint64_t>(P);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, -1, 0x00020000);
+}
+
 // ---- global -> registers: 4 float4 per thread per operand per slab (same index maps as xg_gemm.hip).
 // Loads are UNCONDITIONAL (out-of-range rows / k are clamped to a valid address) so the compiler keeps all eight in
 // flight under the MFMAs -- a predicated load makes it wait for each one (measured: 8 serialized round trips per
@@ -67,11 +75,17 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
     const int t = threadIdx.x;
     if (!KC) {
         // element (r, k) at P[k * ld + r]: this thread's row r = t & 127, k = (t >> 7) * 16 + 4 i + j
-        const int cr = min(r0 + (t & 127), nrows - 1), kb = k0 + ((t >> 7) << 4);
+        // (the k rows are wave-uniform: saying so keeps their address arithmetic on the scalar unit -- SGPR row base + one
+        // per-lane offset -- instead of 16 64-bit vector multiply-adds per operand per slab)
+        const unsigned cr = (unsigned)min(r0 + (t & 127), nrows - 1);
+        const int kb = k0 + (__builtin_amdgcn_readfirstlane(t >> 7) << 4);
+        const __amdgpu_buffer_rsrc_t rs = operand_rsrc(P);
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) regs[i][j] = P[(size_t)min(kb + 4 * i + j, K - 1) * ld + cr];
+            for (int j = 0; j < 4; ++j)
+                regs[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rs, (int)(cr * 4u), (int)((unsigned)min(kb + 4 * i + j, K - 1) * (unsigned)ld * 4u), 0));
         return;
     }
 #pragma unroll
@@ -261,11 +275,15 @@ __device__ __forceinline__ void bx_load(const float* __restrict__ P, int ld, int
     const int t = threadIdx.x;
     if (!KC) {                                                 // transposing assignment: row t % ROWS, NV * 4 consecutive k
         static_assert(THREADS % ROWS == 0 && (THREADS / ROWS) * NV * 4 == BK, "thread map of the m-contiguous operand");
-        const int cr = min(r0 + (t % ROWS), nrows - 1), kb = k0 + (t / ROWS) * (NV * 4);
+        const unsigned cr = (unsigned)min(r0 + (t % ROWS), nrows - 1);
+        const int kb = k0 + __builtin_amdgcn_readfirstlane(t / ROWS) * (NV * 4);
+        const __amdgpu_buffer_rsrc_t rs = operand_rsrc(P);
 #pragma unroll
         for (int i = 0; i < NV; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) regs[i][j] = P[(size_t)min(kb + 4 * i + j, K - 1) * ld + cr];
+            for (int j = 0; j < 4; ++j)
+                regs[i][j] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                    rs, (int)(cr * 4u), (int)((unsigned)min(kb + 4 * i + j, K - 1) * (unsigned)ld * 4u), 0));
         return;
     }
 #pragma unroll
