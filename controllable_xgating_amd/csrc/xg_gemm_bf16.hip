@@ -10,12 +10,13 @@
 //              BASELINE.json configs[4] (bf16, tolerance 1e-2).
 // Tile 128x128x32, 256 threads = 4 waves (2x2), each wave 64x64 = 2x2 MFMA tiles; global -> registers (prefetched
 // one slab ahead) -> split -> LDS planes -> fragments.  LDS images:
-//   both operand layouts:  plane[rows][40] bf16 (80-B rows, 5 16-B slots: odd -> conflict-free ds_read_b128 fragments).
-//   An m-contiguous operand (weight gradients, data gradients) is TRANSPOSED BY THE THREAD ASSIGNMENT of its global loads:
-//   thread t owns row t & 127 and 16 consecutive k (16 dword loads, each wave-instruction 256 contiguous bytes), so it
-//   writes the same k-contiguous image as the other layout.  (Round 1 kept such an operand as plane[32][rows+8] and gathered
-//   every fragment with 8 ds_read_u16: 128 LDS instructions per wave per slab against 8 MFMAs -- the weight-gradient
-//   products of the hidden-1024 configuration ran at 3 % MFMA utilisation, LDS-issue bound.)
+//   k-contiguous operand:  plane[rows][40] bf16 (80-B rows, 5 16-B slots: odd -> conflict-free ds_read_b128 fragments).
+//   m-contiguous operand (weight / data gradients): 16-byte loads along m, kept in memory order as plane[32 k][rows + 16]
+//   and transposed by the READ: two ds_read_b64_tr_b16 per fragment (tools/ubench/tr16_probe.hip pins what that
+//   instruction returns).  History: round 1 gathered such fragments with 8 ds_read_u16 (LDS-issue bound); transposing by
+//   thread assignment instead (one row, 16 consecutive k per thread) needs 32 dword wave-loads per thread per slab and is
+//   bound by the texture-address unit (16 clk per wave-load whatever its width) -- both 190 us on dW_logit, this form 157.
+//   Operands that are not 16-byte loadable fall back to the thread-assignment form (k-contiguous image).
 // Same argument struct, XCD-aware tile order, split-K (fp32 atomics) and epilogue as xg_gemm.hip.
 #include "xg_common.h"
 #include "xg_kernels.h"
@@ -36,7 +37,13 @@ struct BArgs {
     int gm;   // tile rows per group of the tile order (xg_kernels.h: xgk_group_rows)
 };
 
-template <bool KC> constexpr int plane_elems() { return BM * LDKC; }
+constexpr int LDMC = BM + 16;      // [k][m] image of an m-contiguous operand: row stride in bf16 (288 B: the 4 k rows of a
+                                   // transposing read land 8 banks apart)
+// an m-contiguous operand whose rows are 16-byte loadable keeps its memory order in LDS and is transposed by the READ
+// (ds_read_b64_tr_b16); otherwise it is transposed by the thread assignment of dword loads into the k-contiguous image
+template <bool KC, bool VEC> constexpr bool tr_image() { return !KC && VEC; }
+template <bool KC, bool VEC = false> constexpr int plane_elems() { return tr_image<KC, VEC>() ? BK * LDMC : BM * LDKC; }
+typedef short v4s __attribute__((ext_vector_type(4)));
 
 // ---- fp32 -> bf16 planes
 template <int NP>
@@ -73,6 +80,16 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t operand_rsrc(const float* P) {
 template <bool KC, bool VEC>
 __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, int r0, int k0, int nrows, int K, f32x4 (&regs)[4]) {
     const int t = threadIdx.x;
+    if (tr_image<KC, VEC>()) {
+        // element (r, k) at P[k * ld + r]: 16-byte loads along r (k = f >> 5, r = (f & 31) * 4), kept in that order in LDS
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = t + 256 * i;
+            const int k = f >> 5, r = (f & 31) << 2;
+            regs[i] = *reinterpret_cast<const f32x4*>(P + (size_t)min(k0 + k, K - 1) * ld + min(r0 + r, nrows - 4));
+        }
+        return;
+    }
     if (!KC) {
         // element (r, k) at P[k * ld + r]: this thread's row r = t & 127, k = (t >> 7) * 16 + 4 i + j
         // (the k rows are wave-uniform: saying so keeps their address arithmetic on the scalar unit -- SGPR row base + one
@@ -106,22 +123,24 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
 
 // ---- registers -> (zero the out-of-range lanes) -> split -> LDS planes: 4 consecutive elements of the contiguous
 // dimension = one 8-byte store per plane
-template <int NP, bool KC>
+template <int NP, bool KC, bool VEC>
 __device__ __forceinline__ void store_tile(unsigned short* __restrict__ lds, const f32x4 (&regs)[4], int r0, int k0, int nrows,
                                            int K, bool edge) {
+    constexpr bool TR = tr_image<KC, VEC>();
     const int t = threadIdx.x;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int f = t + 256 * i;
-        int r, k;                                  // 4 consecutive k (k .. k + 3) of row r, whichever way they were loaded
+        int r, k;                                  // 4 consecutive k (k .. k + 3) of row r -- or, TR, 4 consecutive rows at k
         if (KC) { r = f >> 3; k = (f & 7) << 2; }
+        else if (TR) { k = f >> 5; r = (f & 31) << 2; }
         else    { r = t & 127; k = ((t >> 7) << 4) + 4 * i; }
         f32x4 v = regs[i];
         if (edge) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] = (r0 + r < nrows && k0 + k + j < K) ? v[j] : 0.f;
+            for (int j = 0; j < 4; ++j) v[j] = (TR ? (r0 + r + j < nrows && k0 + k < K) : (r0 + r < nrows && k0 + k + j < K)) ? v[j] : 0.f;
         }
-        const int off = r * LDKC + k;
+        const int off = TR ? k * LDMC + r : r * LDKC + k;
         if constexpr (NP == 1) {
             // plain bf16: the hardware's packed round-to-nearest-even convert (v_cvt_pk_bf16_f32), one instruction per pair
             // instead of ~4 integer operations per element (269 -> 294 TF on the vocabulary products).  (A 64-deep,
@@ -151,22 +170,34 @@ __device__ __forceinline__ void store_tile(unsigned short* __restrict__ lds, con
             uint2 w;
             w.x = (unsigned)h[0][p] | ((unsigned)h[1][p] << 16);
             w.y = (unsigned)h[2][p] | ((unsigned)h[3][p] << 16);
-            *reinterpret_cast<uint2*>(lds + p * plane_elems<KC>() + off) = w;
+            *reinterpret_cast<uint2*>(lds + p * plane_elems<KC, VEC>() + off) = w;
         }
     }
 }
 
 // ---- LDS -> MFMA fragment: 8 consecutive k (k0..k0+7) of row `row`
-template <bool KC>
+template <bool KC, bool VEC>
 __device__ __forceinline__ bf16x8 read_frag(const unsigned short* __restrict__ plane, int row, int k0) {
-    return *reinterpret_cast<const bf16x8*>(plane + row * LDKC + k0);
+    if (!tr_image<KC, VEC>()) return *reinterpret_cast<const bf16x8*>(plane + row * LDKC + k0);
+    // [k][m] image: ds_read_b64_tr_b16 hands lane i of a 16-lane group element (i & 3) of the 8 bytes addressed by lanes
+    // (i >> 2) + 4 j, j = 0..3 -- so the lane with in-group index s points at (k = kbase + (s >> 2), m = mbase + 4 (s & 3)) and
+    // receives k = kbase .. kbase + 3 of row mbase + i.  Two reads = the 8 consecutive k of the MFMA fragment.
+    typedef __attribute__((address_space(3))) v4s lds_v4s;
+    const int s = threadIdx.x & 15;
+    const unsigned short* p = plane + (k0 + (s >> 2)) * LDMC + (row & ~15) + ((s & 3) << 2);
+    const v4s lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)p);
+    const v4s hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4s*)(p + 4 * LDMC));
+    bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { v[j] = lo[j]; v[4 + j] = hi[j]; }
+    return v;
 }
 
 template <int NP, bool AKC, bool BKC, bool VEC>
 __global__ void __launch_bounds__(256) gemm_bs_kernel(BArgs g) {
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_bs[];
     unsigned short* As = smem_bs;
-    unsigned short* Bs = smem_bs + NP * plane_elems<AKC>();
+    unsigned short* Bs = smem_bs + NP * plane_elems<AKC, VEC>();
 
     const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN;
     const int nwg = ntm * ntn * g.splitk;
@@ -207,9 +238,9 @@ __global__ void __launch_bounds__(256) gemm_bs_kernel(BArgs g) {
 #pragma unroll
             for (int p = 0; p < NP; ++p) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[i][p] = read_frag<AKC>(Asb + p * plane_elems<AKC>(), wm * 64 + i * 32 + l31, k0);
+                for (int i = 0; i < 2; ++i) fa[i][p] = read_frag<AKC, VEC>(Asb + p * plane_elems<AKC, VEC>(), wm * 64 + i * 32 + l31, k0);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) fb[j][p] = read_frag<BKC>(Bsb + p * plane_elems<BKC>(), wn * 64 + j * 32 + l31, k0);
+                for (int j = 0; j < 2; ++j) fb[j][p] = read_frag<BKC, VEC>(Bsb + p * plane_elems<BKC, VEC>(), wn * 64 + j * 32 + l31, k0);
             }
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -231,8 +262,8 @@ __global__ void __launch_bounds__(256) gemm_bs_kernel(BArgs g) {
     for (int s = s_begin; s < s_end; ++s) {
         const bool ktail = (s + 1) * BK > g.K;
         __syncthreads();                                   // everyone is done reading the previous slab
-        store_tile<NP, AKC>(As, ra, m0, s * BK, g.M, g.K, edge_a || ktail);
-        store_tile<NP, BKC>(Bs, rb, n0, s * BK, g.N, g.K, edge_b || ktail);
+        store_tile<NP, AKC, VEC>(As, ra, m0, s * BK, g.M, g.K, edge_a || ktail);
+        store_tile<NP, BKC, VEC>(Bs, rb, n0, s * BK, g.N, g.K, edge_b || ktail);
         __syncthreads();
         if (s + 1 < s_end) {                               // next slab's loads fly under this slab's MFMAs
             load_tile<AKC, VEC>(g.A, g.lda, m0, (s + 1) * BK, g.M, g.K, ra);
@@ -425,7 +456,7 @@ int launch(hipStream_t st, const BArgs& g) {
         if (g.ldc == g.N) { if (hipMemsetAsync(g.C, 0, sizeof(float) * (size_t)g.M * g.N, st) != hipSuccess) return XG_EHIP; }
         else if (hipMemset2DAsync(g.C, sizeof(float) * g.ldc, 0, sizeof(float) * g.N, g.M, st) != hipSuccess) return XG_EHIP;
     }
-    const size_t lds = (size_t)NP * (plane_elems<AKC>() + plane_elems<BKC>()) * sizeof(unsigned short);
+    const size_t lds = (size_t)NP * (plane_elems<AKC, VEC>() + plane_elems<BKC, VEC>()) * sizeof(unsigned short);
     if (lds > 65536) {
         static std::atomic<unsigned> optin{0};
         XG_TRY(xg_lds_optin(optin, reinterpret_cast<const void*>(&gemm_bs_kernel<NP, AKC, BKC, VEC>), (int)lds));
@@ -457,7 +488,7 @@ int xgk_gemm_bf16(hipStream_t st, int planes, bool transA, bool transB, int M, i
     const long tiles = (long)xg_cdiv(M, BM) * xg_cdiv(N, BN);
     const int nslab = xg_cdiv(K, BK);
     if (!relu && tiles < 512) {                     // fill the chip by splitting deep reductions (3 workgroups per CU would fit,
-                                                    // but 768 shares were measured slower: dX 52 -> 83 us, more atomics)
+                                                    // but 768 shares were measured slower: dX 52 -> 83 us, dW_logit 157 -> 169 us)
         long sk = (512 + tiles - 1) / tiles;
         if (sk > nslab / 8) sk = nslab / 8;
         if (sk >= 2) g.splitk = (int)sk;
