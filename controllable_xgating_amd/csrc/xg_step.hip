@@ -604,7 +604,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
         return;
     }
     if (job.epi == SK_EPI_ATTN) {
-        if (NW == 4 && (int)blockIdx.x < 2 * job.M) {
+        if (NW == 8 && threadIdx.x >= 256) return;      // (written for 4 waves; the upper four leave before its first barrier)
+        if ((int)blockIdx.x < 2 * job.M) {
             if (job.attn_A <= 1536) attn_part<6>(job, blockIdx.x, smem); else attn_part<8>(job, blockIdx.x, smem);
         }
         return;
@@ -858,7 +859,11 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
     }
     if (fast) {
         static const int force_nw = getenv("XG_SK_NW") ? atoi(getenv("XG_SK_NW")) : 0;      // diagnosis
-        const bool nw4 = has_attn || ks > 1 || (force_nw ? force_nw == 4 : tiles > 2 * 256);
+        // A launch that carries the attention: its workgroups are written for 4 waves.  When everything fits the chip in one
+        // round as 8-wave workgroups (<= 512: batches of <= 64 rows) the products keep their 8-way K split and the attention
+        // runs on the first four waves of its workgroups (36.7 vs 38.6 us per step at 64 rows); beyond that 4-wave workgroups
+        // for all, which are all resident (49.4 vs 52.5 us at 128 rows).
+        const bool nw4 = ks > 1 || (force_nw ? force_nw == 4 : (has_attn ? tiles > 2 * 256 : tiles > 2 * 256));
         const dim3 grid((max_tiles + 7) & ~7, a.njobs);
         bool scaled = false;
         for (int j = 0; j < a.njobs; ++j)
