@@ -262,7 +262,8 @@ def main():
     model.train()
     broadcast_parameters(model)
     x = synth_inputs(cfg["B"], cfg["K"], cfg["L"], cfg["V"], cfg["R"], cfg["F1"], cfg["F2"], cfg["C"], seed=rank, device=dev)
-    optim = ClipAdam(model, lr=4e-4, grad_clip=0.1)
+    # clamp + Adam start per parameter group as soon as its gradient is final (XG_NO_UPDATE_OVERLAP=1: after the backward)
+    optim = ClipAdam(model, lr=4e-4, grad_clip=0.1, overlap=os.environ.get("XG_NO_UPDATE_OVERLAP") is None)
     # data parallel: most of the gradient all-reduce runs under the CG encoder's backward (XG_NO_GRAD_OVERLAP=1: one
     # all-reduce after the backward)
     sync = None
@@ -290,6 +291,7 @@ def main():
             loss = rl_crit(slp, gen, reward_b.expand(-1, gen.shape[1]))
         if sync is not None:
             sync.arm()
+        optim.arm()
         loss.backward()
         allreduce_gradients(model)
         optim.step()
@@ -306,6 +308,7 @@ def main():
             loss = crit(logp, x["seq"], x["seq_mask"])
         if sync is not None:
             sync.arm()
+        optim.arm()
         loss.backward()
         allreduce_gradients(model)
         optim.step()

@@ -928,9 +928,14 @@ int heads_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams& g
     // dW_logit / db: parameter gradients, under the loop as well
     XG_TRY(gemm_tn(ss.aux, w.gm, rows, d.V, R, w.LOGITS, d.V, Hout, R, g.logit_w, R));
     XG_TRY(xgk_colsum(ss.aux, w.LOGITS, d.V, rows, d.V, g.logit_b));
-    // data parallel: the vocabulary head's gradients are final here, long before anything else (XgRun.grad_event_head)
-    if (ss.grad_event_head && hipEventRecord(ss.grad_event_head, ss.aux) != hipSuccess) return XG_EHIP;
     XG_TRY(gemm_nn(st, w.gm, rows - r0, R, d.V, w.LOGITS + (size_t)r0 * d.V, d.V, p.logit_w, R, w.DH2OUT + (size_t)r0 * R, R, false));
+    // XgRun.grad_event_head: the vocabulary head's gradients are final, long before anything else, AND logit.* is not read
+    // any more in this backward (the product above was its last reader) -- a caller may all-reduce those gradients and
+    // even update logit.* from here on
+    if (ss.grad_event_head) {
+        XG_TRY(ss.fork());
+        if (hipEventRecord(ss.grad_event_head, ss.aux) != hipSuccess) return XG_EHIP;
+    }
     if (have_cls) {
         XG_TRY(gemm_tn(st, w.gm, rows, d.C, d.H, w.DCL, d.C, w.HC, d.H, g.cls3_w, d.H));
         XG_TRY(xgk_colsum(st, w.DCL, d.C, rows, d.C, g.cls3_b));

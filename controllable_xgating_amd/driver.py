@@ -177,7 +177,8 @@ class Trainer:
         self.model, self.opt, self.scorer = model, opt, reward_scorer
         self.crit, self.classify_crit, self.rl_crit = LanguageModelCriterion(), ClassiferCriterion(), RewardCriterion()
         self.optimizer = ClipAdam(model, lr=opt.learning_rate, weight_decay=getattr(opt, "weight_decay", 0.0),
-                                  grad_clip=getattr(opt, "grad_clip", 0.1))
+                                  grad_clip=getattr(opt, "grad_clip", 0.1),
+                                  overlap=getattr(opt, "overlap_update", True) and next(model.parameters()).is_cuda)
         self.iteration, self.epoch = 1, 0
         self.sc_flag = False
         self.best_val_score = None
@@ -222,6 +223,7 @@ class Trainer:
             info["avg_reward"] = float(np.mean(reward[:, 0])) if reward.size else 0.0
         if self.grad_sync is not None:
             self.grad_sync.arm()
+        self.optimizer.arm()                                                                 # (update overlapped with the backward's tail)
         loss.backward()                                                                      # :134
         allreduce_gradients(model)                                                           # data parallel only
         self.optimizer.step()                                                                # :136-137 (clamp + Adam)

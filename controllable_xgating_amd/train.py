@@ -15,14 +15,31 @@ from .model import _stream
 class ClipAdam:
     """optimizer = optim.Adam(model.parameters(), lr, weight_decay) + clip_gradient(optimizer, clip):
     elementwise clamp of every gradient to +-grad_clip, then Adam with torch defaults
-    (betas 0.9/0.999, eps 1e-8; the reference ignores its --optim_* flags, starttrain.py:76)."""
+    (betas 0.9/0.999, eps 1e-8; the reference ignores its --optim_* flags, starttrain.py:76).
 
-    def __init__(self, model, lr=4e-4, weight_decay=0.0, grad_clip=0.1, betas=(0.9, 0.999), eps=1e-8):
+    ``overlap=True``: the update of a parameter group starts as soon as its gradient is final instead of after the whole
+    backward -- the update is HBM-bound, the backward's tail is matrix-core bound, so they overlap almost for free.  The
+    flat buffers are in xg_param_name order [two_spatial_encoder.* | img_embed / lstmcore / embed | logit.* | classifer.*]
+    and the library records when logit.* is final (XgRun.grad_event_head) and when everything but the encoder is
+    (XgRun.grad_event): ``arm()`` before ``loss.backward()``, then ``step()`` issues three segment updates, two of them on
+    a side stream behind those events.  Same arithmetic, element for element.  In a data-parallel run the segments are
+    updated right behind their all-reduce (train.GradSync.finish)."""
+
+    def __init__(self, model, lr=4e-4, weight_decay=0.0, grad_clip=0.1, betas=(0.9, 0.999), eps=1e-8, overlap=False):
         self.model, self.lr, self.wd, self.clip, self.betas, self.eps = model, lr, weight_decay, grad_clip, betas, eps
         flat = model.flat_parameters()
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
         self.step_count = 0
+        self.overlap = bool(overlap)
+        self._armed = False
+        self._segments_done = False
+        if self.overlap:
+            self._split, self._head = _segment_bounds(model)
+            self._event, self._event_head = torch.cuda.Event(), torch.cuda.Event()
+            self._event.record(); self._event_head.record()      # torch creates the HIP events lazily
+            self._side = torch.cuda.Stream()
+            model._overlap_optimizer = self
 
     def zero_grad(self):
         self.model.flat_grads().zero_()
@@ -30,12 +47,55 @@ class ClipAdam:
     def set_lr(self, lr):                      # myutils.set_lr
         self.lr = lr
 
-    def step(self):
+    def arm(self):
+        """overlap=True: call before loss.backward() (after a GradSync.arm(), if any: the events are shared)."""
+        if not self.overlap:
+            return
+        if getattr(self.model, "_grad_event", None) is None:
+            self.model._grad_event, self.model._grad_event_head = self._event, self._event_head
+            self._own_events = True
+        else:
+            self._own_events = False
+        self._armed = True
+
+    def update_segment(self, a, b):
+        """clamp + Adam of flat[a:b] on the current stream (bias correction of the step in progress)."""
+        if b <= a:
+            return
         flat, g = self.model.flat_parameters(), self.model.flat_grads()
-        self.step_count += 1
-        nv.check(nv.lib().xg_clip_adam(_stream(), flat.numel(), nv.ptr(flat), nv.ptr(g), nv.ptr(self.exp_avg),
-                                       nv.ptr(self.exp_avg_sq), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+        nv.check(nv.lib().xg_clip_adam(_stream(), b - a, nv.ptr(flat[a:b]), nv.ptr(g[a:b]), nv.ptr(self.exp_avg[a:b]),
+                                       nv.ptr(self.exp_avg_sq[a:b]), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                                        self.step_count, self.clip), "xg_clip_adam")
+
+    def begin_step(self):
+        self.step_count += 1
+
+    def step(self):
+        n = self.model.flat_parameters().numel()
+        if self._segments_done:                # a data-parallel GradSync.finish updated every segment behind its all-reduce
+            self._segments_done = False
+        elif self.overlap and self._armed:
+            self.begin_step()
+            ev, ev_head = self.model._grad_event, self.model._grad_event_head
+            main = torch.cuda.current_stream()
+            a0, a1 = self._head
+            self._side.wait_event(ev_head)     # the backward has been enqueued: these are the records it made
+            with torch.cuda.stream(self._side):
+                self.update_segment(a0, a1)
+            self._side.wait_event(ev)
+            with torch.cuda.stream(self._side):
+                self.update_segment(self._split, a0)
+                self.update_segment(a1, n)
+            self.update_segment(0, self._split)          # the encoder's gradients: after the whole backward (stream order)
+            main.wait_stream(self._side)
+        else:
+            self.begin_step()
+            self.update_segment(0, n)
+        if self._armed:
+            if self._own_events:
+                self.model._grad_event = None
+                self.model._grad_event_head = None
+            self._armed = False
         self.model.mark_params_changed()       # the kernel wrote the flat buffer directly: re-pack the recurrent weights
 
     def state_dict(self):
@@ -77,6 +137,17 @@ def allreduce_gradients(model, group=None):
     _reduce(model.flat_grads(), world, group)
 
 
+def _segment_bounds(model):
+    """(first non-encoder element, [logit.weight, end of logit.bias incl. padding)) of the flat buffers."""
+    model._ensure_flat()
+    first_other = next(n for n in nv.PARAM_NAMES if not n.startswith("two_spatial_encoder."))
+    split = model._slices[first_other][0]
+    assert all(n.startswith("two_spatial_encoder.") == (model._slices[n][0] < split) for n in nv.PARAM_NAMES)
+    lw, lb = model._slices["logit.weight"], model._slices["logit.bias"]
+    assert lb[0] > lw[0]
+    return split, (lw[0], lb[0] + (lb[1] + 63) // 64 * 64)
+
+
 class GradSync:
     """Overlaps the gradient all-reduce with the backward pass.  The flat gradient buffer is in xg_param_name order:
     [two_spatial_encoder.* | img_embed / lstmcore / embed | logit.* | classifer.*], and the backward pass finishes it
@@ -91,14 +162,8 @@ class GradSync:
     hidden under ~3 ms / ~1.3 ms of remaining backward; the 26 MB encoder part (~0.15 ms) is what stays exposed."""
 
     def __init__(self, model):
-        model._ensure_flat()
         self.model = model
-        first_other = next(n for n in nv.PARAM_NAMES if not n.startswith("two_spatial_encoder."))
-        self.split = model._slices[first_other][0]
-        assert all(n.startswith("two_spatial_encoder.") == (model._slices[n][0] < self.split) for n in nv.PARAM_NAMES)
-        lw, lb = model._slices["logit.weight"], model._slices["logit.bias"]
-        assert lb[0] > lw[0]
-        self.head = (lw[0], lb[0] + (lb[1] + 63) // 64 * 64)          # [logit.weight, end of logit.bias) incl. padding
+        self.split, self.head = _segment_bounds(model)
         self.event, self.event_head = torch.cuda.Event(), torch.cuda.Event()
         self.event.record(); self.event_head.record()   # torch creates the HIP events lazily: make the handles exist
         self.side = torch.cuda.Stream()
@@ -117,16 +182,28 @@ class GradSync:
         g = self.model.flat_grads()
         main = torch.cuda.current_stream()
         a0, a1 = self.head
+        # an overlapping optimizer (ClipAdam(overlap=True), armed) updates each segment right behind its all-reduce
+        opt = getattr(self.model, "_overlap_optimizer", None)
+        opt = opt if (opt is not None and opt._armed) else None
+        if opt is not None:
+            opt.begin_step()
+        upd = (lambda a, b: opt.update_segment(a, b)) if opt is not None else (lambda a, b: None)
         self.side.wait_event(self.event_head)    # the backward has been enqueued: these are the records it made
         with torch.cuda.stream(self.side):
             _reduce(g[a0:a1], world, group)
+            upd(a0, a1)
         self.side.wait_event(self.event)
         with torch.cuda.stream(self.side):
             _reduce(g[self.split:a0], world, group)
+            upd(self.split, a0)
             if a1 < g.numel():
                 _reduce(g[a1:], world, group)
+                upd(a1, g.numel())
         _reduce(g[:self.split], world, group)    # after the whole backward (main stream order)
+        upd(0, self.split)
         main.wait_stream(self.side)
+        if opt is not None:
+            opt._segments_done = True
         self.model._grad_event = None
         self.model._grad_event_head = None
         self.armed = False

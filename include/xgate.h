@@ -115,7 +115,10 @@ typedef struct XgRun {
                              in xg_param_name order can start the RCCL all-reduce of that suffix under the CG encoder's
                              backward.  NULL = not recorded. */
     void *grad_event_head;/* optional hipEvent_t: recorded earlier still, when logit.weight / logit.bias gradients (a third of
-                             all gradient bytes at V = 20000) are final -- before the reverse-time decoder loop starts. */
+                             all gradient bytes at V = 20000) are final AND logit.* is no longer read by this backward --
+                             before the reverse-time decoder loop starts.  From grad_event on, no parameter outside
+                             two_spatial_encoder.* is read either: a caller may start its optimizer update of those groups
+                             behind the events (train.ClipAdam(overlap=True)). */
 } XgRun;
 
 enum { XG_ROLLOUT_GREEDY = 0, XG_ROLLOUT_SAMPLE = 1, XG_ROLLOUT_REPLAY = 2 };
