@@ -407,6 +407,36 @@ def test_clip_adam_matches_torch_semantics():
     np.testing.assert_allclose(gd.cpu().numpy(), g.clamp(-0.1, 0.1).numpy(), atol=0)
 
 
+def test_overlapped_update_equals_plain_update():
+    """ClipAdam(overlap=True) -- segment updates behind the library's gradient events, two of them on a side stream while
+    the backward is still running -- must leave exactly the parameters / moments / (clamped) gradients of the one fused
+    update after the backward: three XE iterations from the same start, element for element."""
+    from controllable_xgating_amd.train import ClipAdam
+    d = pg.make_dims(**CFG["mid"])
+    x = to_dev(pg.make_inputs(d, seed=0, ragged=True))
+    out = []
+    for overlap in (False, True):
+        model = make_model(d)
+        opt = ClipAdam(model, lr=4e-4, grad_clip=0.1, overlap=overlap)
+        for _ in range(3):
+            opt.zero_grad()
+            loss = model.xe_loss(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+            opt.arm()
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        assert getattr(model, "_grad_event", None) is None
+        out.append(({n: q.detach().clone() for n, q in model.named_parameters()}, float(loss)))
+    (p0, l0), (p1, l1) = out
+    # the weight gradients themselves carry split-K atomics (run-to-run 1e-7 noise), so two runs agree to that level --
+    # except where the TRUE gradient is zero: Adam normalises pure noise there to +-lr per step in any two runs
+    assert abs(l0 - l1) < 1e-5
+    for n in p0:
+        if n in ZERO_GRAD_PARAMS:
+            continue
+        assert float((p0[n] - p1[n]).abs().max()) < 5e-6, n
+
+
 # ---------------------------------------------------------------- beam search (SURVEY.md 8f-2)
 @pytest.mark.parametrize("tag", ["tiny", "c1"])
 def test_beam_search_vs_reference_golden(tag):
