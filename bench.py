@@ -353,19 +353,21 @@ def main():
         achieved = bytes_step / t_step / 1e9
         traffic, traffic_src = (None, None)
         if cfg["B"] == 128 and args.workload == "xe" and args.precision == "fp32":
-            if not args.no_pmc:
+            if not args.no_pmc and world == 1:           # (the two rocprofv3 passes run on rank 0's GPU: single-GPU runs only)
                 traffic, traffic_src = measure_traffic()
+            elif world > 1:
+                traffic_src = "multi-GPU run"
             if traffic is None:                              # fall back to the committed passes, and say so
                 why = traffic_src
                 traffic, traffic_src = load_traffic()
                 if traffic_src:
                     traffic_src += " (committed earlier: live PMC pass unavailable -- %s)" % why
-        wl = {"xe": "configs[1]: 1xMI355X batch %d teacher-forced XE train, 26 frames x (1536+1024), hidden 512, "
-                    "att 1536, emb 468, vocab 20000, seq_len 20 (T=21), fp32" % cfg["B"],
-              "scst": "configs[2]: 1xMI355X SCST iteration (sampled rollout + greedy baseline as one 2m-row batch + RL backward + "
-                      "clip + Adam), batch %d, seq_len 30, 26 frames, hidden 512, vocab 20000, CIDEr reward stubbed" % cfg["B"],
-              "xe5": "configs[4] shape: 1xMI355X batch %d teacher-forced XE train, 40 frames x (1536+1024), hidden 1024, att 1536, "
-                     "vocab 20000, seq_len 20" % cfg["B"]}[args.workload]
+        wl = {"xe": "configs[%s]: %dxMI355X batch %d per GPU teacher-forced XE train, 26 frames x (1536+1024), hidden 512, "
+                    "att 1536, emb 468, vocab 20000, seq_len 20 (T=21), fp32" % ("1" if world == 1 else "3", world, cfg["B"]),
+              "scst": "configs[2]: %dxMI355X SCST iteration (sampled rollout + greedy baseline as one 2m-row batch + RL backward + "
+                      "clip + Adam), batch %d per GPU, seq_len 30, 26 frames, hidden 512, vocab 20000, CIDEr reward stubbed" % (world, cfg["B"]),
+              "xe5": "configs[4] shape: %dxMI355X batch %d per GPU teacher-forced XE train, 40 frames x (1536+1024), hidden 1024, att 1536, "
+                     "vocab 20000, seq_len 20" % (world, cfg["B"])}[args.workload]
         out = {
             "metric": "rollout timesteps/sec, SCST iteration (sample + greedy + RL backward) at batch 64, seq_len 30"
                       if args.workload == "scst" else "decoder timesteps/sec (train fwd+bwd) at batch 128, MSRVTT 26x1536+1024",
