@@ -526,11 +526,12 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         static const char xe_form = getenv("XG_XE_FORM") ? getenv("XG_XE_FORM")[0] : 'D';     // experiment switch (B / D / E)
         const bool fused_attn = (!s.pre1 || xe_form == 'E') && !no_fused && A <= 2048 && d.K <= 128 && ((uintptr_t)V % 8 == 0) &&
                                 ((uintptr_t)vproj % 16 == 0) && ((uintptr_t)p.a2w_w % 16 == 0);
-        const bool s2_first = s.pre1 != nullptr && xe_form == 'B';          // S2' = h2 W_h2h2 + b rides in launch 1 (teacher forcing) or 2
-        // ... or stays a segment of cell 2: teacher forcing (form D), and the rollout form beyond 64 rows, where the second
-        // launch would otherwise be 768 workgroups (1.5 rounds of the chip): 49.4 -> 48.8 us per step at 128 rows, but
-        // 37.1 -> 39.8 us at 64 rows, where everything is resident anyway and the extra K only lengthens cell 2
-        const bool s2_in_cell2 = (s.pre1 != nullptr && xe_form == 'D') || (!s.pre1 && B > 64);
+        // S2' = h2 W_h2h2 + b rides in launch 1 (teacher forcing form B; the rollout form beyond 64 rows, where the three
+        // launches are then 512 / 512 / 256 workgroups, one round each, instead of 256 / 768 / 256: 49.4 -> 46.5 us per step
+        // at 128 rows) or in launch 2 (rollout form up to 64 rows: 37.1 us against 39.2 us in launch 1)
+        const bool s2_first = (s.pre1 != nullptr && xe_form == 'B') || (!s.pre1 && B > 64);
+        const bool s2_in_cell2 = s.pre1 != nullptr && xe_form == 'D';       // ... or stays a segment of cell 2 (measured for the
+                                                                            // rollout form at 128 rows too: 48.3 us)
         SkArgs k1{}, k2{}, k3{};
         int n1 = 0, n2 = 0, n3 = 0;
         // the state may be updated IN PLACE (xg_step_fwd): cell 1 then runs in launch 2 beside products that still read the
