@@ -11,6 +11,7 @@
 // (K,R) tile of V.  HBM/L2-bound: 4*(K*A + K*R + A + R + 2K) bytes per video per step.
 #include "xg_common.h"
 #include "xg_kernels.h"
+#include <cstdlib>
 
 namespace {
 
@@ -355,6 +356,75 @@ __global__ void __launch_bounds__(FT) attn_bwd_fast(const float* __restrict__ da
     AT_STAMP(5);
 }
 
+// The same backward as TWO workgroups per video (512 threads each): every thread's work is dominated by its 2 x K tanh
+// (one 1024-thread workgroup per video keeps 128 CUs busy for ~5 us of VALU each and leaves the other 128 idle), so the
+// attention columns are halved between two CUs; both compute the K dalpha dot products (V is read twice: 53 KB per video)
+// and the softmax backward redundantly, part 0 writes de.  K <= 32, A / 2 even and <= 1024.
+template <int NQ>
+__global__ void __launch_bounds__(512) attn_bwd_split(const float* __restrict__ daf, int lddaf, const float* __restrict__ p,
+                                                      const float* __restrict__ vproj, const float* __restrict__ V,
+                                                      const float* __restrict__ w, const float* __restrict__ alpha,
+                                                      float* __restrict__ de, float* __restrict__ dp, int K, int R, int A) {
+    extern __shared__ float sm[];                     // dalpha[K]
+#ifdef XG_CHAIN_PRIO
+    __builtin_amdgcn_s_setprio(3);
+#endif
+    constexpr int NWV = 8;
+    const int b = blockIdx.x >> 1, part = blockIdx.x & 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* qb = vproj + (size_t)b * K * A;
+    const float* Vb = V + (size_t)b * K * R;
+    const float* dafb = daf + (size_t)b * lddaf;
+    constexpr int DR = 4, DC = 4;                     // rows per wave (K <= 32), float4 chunks per row held in registers
+    float4 dv[DC], vv[DR][DC];
+#pragma unroll
+    for (int c = 0; c < DC; ++c) {
+        const int r = lane * 4 + 256 * c;
+        dv[c] = r < R ? *reinterpret_cast<const float4*>(dafb + r) : make_float4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < DR; ++j) {
+            const int k = wave + j * NWV;
+            vv[j][c] = (r < R && k < K) ? *reinterpret_cast<const float4*>(Vb + (size_t)k * R + r) : make_float4(0, 0, 0, 0);
+        }
+    }
+    const float al_lane = lane < K ? alpha[(size_t)b * K + lane] : 0.f;
+    const int ah = A >> 1;                            // this workgroup's columns: [part * ah, part * ah + ah)
+    const int a0 = part * ah + tid * 2;
+    const bool a_ok = tid * 2 < ah;
+    float2 q[NQ];
+#pragma unroll
+    for (int k = 0; k < NQ; ++k) q[k] = (a_ok && k < K) ? *reinterpret_cast<const float2*>(qb + (size_t)k * A + a0) : make_float2(0, 0);
+    const float2 pa = a_ok ? *reinterpret_cast<const float2*>(p + (size_t)b * A + a0) : make_float2(0, 0);
+    const float2 wa = a_ok ? *reinterpret_cast<const float2*>(w + a0) : make_float2(0, 0);
+#pragma unroll
+    for (int j = 0; j < DR; ++j) {
+        const int k = wave + j * NWV;
+        float acc = 0.f;
+#pragma unroll
+        for (int c = 0; c < DC; ++c)
+            acc += dv[c].x * vv[j][c].x + dv[c].y * vv[j][c].y + dv[c].z * vv[j][c].z + dv[c].w * vv[j][c].w;
+        acc = wave_sum(acc);
+        if (lane == 0 && k < K) sm[k] = acc;
+    }
+    __syncthreads();
+    const float da = lane < K ? sm[lane] : 0.f;
+    const float dot = wave_sum(al_lane * da);
+    const float d_lane = al_lane * (da - dot);
+    if (part == 0 && wave == 0 && lane < K) de[(size_t)b * K + lane] = d_lane;
+    if (a_ok) {
+        float sx = 0.f, sy = 0.f;
+#pragma unroll
+        for (int k = 0; k < NQ; ++k) {
+            if (k < K) {
+                const float dk = xg_readlane(d_lane, k);
+                const float tx = xg_tanh(pa.x + q[k].x), ty = xg_tanh(pa.y + q[k].y);
+                sx += dk * (1.0f - tx * tx);
+                sy += dk * (1.0f - ty * ty);
+            }
+        }
+        *reinterpret_cast<float2*>(dp + (size_t)b * A + a0) = make_float2(sx * wa.x, sy * wa.y);
+    }
+}
+
 }  // namespace
 
 int xgk_attn_fwd(hipStream_t st, const float* p, const float* vproj, const float* V, const float* w, float* alpha,
@@ -391,6 +461,15 @@ int xgk_attn_bwd(hipStream_t st, const float* daf, int lddaf, const float* p, co
     if (K > 8192) return XG_EINVAL;
     const bool al16 = ((uintptr_t)p % 16 == 0) && ((uintptr_t)vproj % 16 == 0) && ((uintptr_t)V % 16 == 0) &&
                       ((uintptr_t)w % 16 == 0) && ((uintptr_t)daf % 16 == 0) && ((uintptr_t)dp % 16 == 0);
+    // two workgroups per video while that still leaves CUs idle (<= 64 videos: SCST iteration 7.88 -> 7.72 ms); at 128 videos
+    // the one-workgroup form already covers half the chip and the iteration is throughput-bound (6.63 vs 6.67 ms split)
+    if (B <= 64 && al16 && A % 4 == 0 && A <= 2048 && R % 4 == 0 && R <= 1024 && lddaf % 4 == 0 && K <= 32) {
+        const size_t lds = (size_t)K * sizeof(float);
+        if (K <= 16) hipLaunchKernelGGL((attn_bwd_split<16>), dim3(2 * B), dim3(512), lds, st, daf, lddaf, p, vproj, V, w, alpha, de, dp, K, R, A);
+        else hipLaunchKernelGGL((attn_bwd_split<32>), dim3(2 * B), dim3(512), lds, st, daf, lddaf, p, vproj, V, w, alpha, de, dp, K, R, A);
+        XG_CHECK_LAUNCH();
+        return XG_OK;
+    }
     if (al16 && A % 4 == 0 && A <= 2 * FT && R % 4 == 0 && R <= 1024 && lddaf % 4 == 0 && K <= 48) {
         const size_t lds = (size_t)K * sizeof(float);
         if (K <= 16) hipLaunchKernelGGL((attn_bwd_fast<16>), dim3(B), dim3(FT), lds, st, daf, lddaf, p, vproj, V, w, alpha, de, dp, K, R, A);
