@@ -350,15 +350,18 @@ __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
         int32_t* maxf = a.maxf + (second ? 1 : 0);
         // pass 1: row max (+ argmax, ties -> lowest index like torch.max) and sum exp for the log-sum-exp
         float best = -INFINITY; int bi = 0x7fffffff;
-        for (int v0 = tid; v0 < a.V; v0 += 8 * RT) {          // 8 loads in flight, then the (branchy) argmax update
-            float f8[8];
+        // every load of the row is issued before any is consumed (24 per thread cover V <= 24576: ONE memory round trip
+        // instead of three), then the (branchy) argmax update
+        constexpr int NLD = 24;
+        for (int v0 = tid; v0 < a.V; v0 += NLD * RT) {
+            float fl[NLD];
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const int v = v0 + j * RT; f8[j] = v < a.V ? x[v] : -INFINITY; }
+            for (int j = 0; j < NLD; ++j) { const int v = v0 + j * RT; fl[j] = v < a.V ? x[v] : -INFINITY; }
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
+            for (int j = 0; j < NLD; ++j) {
                 const int v = v0 + j * RT;
                 if (v < a.V) {
-                    const float f = f8[j];
+                    const float f = fl[j];
                     if (STAGE) xs[v] = f;
                     if (f > best || (f == best && v < bi)) { best = f; bi = v; }
                 }
@@ -381,7 +384,7 @@ __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
         float lse = 0.f;
         if (!lse_from_scan) {
             float se = 0.f;
-            for (int v = tid; v < a.V; v += RT) se += expf(xr[v] - mx);
+            for (int v = tid; v < a.V; v += RT) se += __expf(xr[v] - mx);
             se = block_sum(se, red);
             lse = mx + logf(se);
         }
@@ -397,7 +400,7 @@ __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
             const int v0 = tid * per, v1 = min(a.V, v0 + per);
             const float invt = 1.0f / a.temperature;
             float cs = 0.f;
-            for (int v = v0; v < v1; ++v) cs += expf((xr[v] - mx) * invt);
+            for (int v = v0; v < v1; ++v) cs += __expf((xr[v] - mx) * invt);     // (v_exp_f32; the re-walk below uses the same)
             // block-wide inclusive scan of the RT chunk sums in double (was a 1024-step serial walk by one thread: 50 us)
             double inc = (double)cs;
 #pragma unroll
@@ -422,7 +425,7 @@ __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
                 float run = s_bcast[0]; int pick = min(a.V, v1) - 1;
                 if (pick < v0) pick = a.V - 1;
                 for (int v = v0; v < v1; ++v) {
-                    run += expf((xr[v] - mx) * invt);
+                    run += __expf((xr[v] - mx) * invt);
                     if (run > s_bcast[1]) { pick = v; break; }
                 }
                 s_tok = pick;
