@@ -75,6 +75,52 @@ def test_gemm_persistent_kernel_shapes(M, N, K, ta, tb):
         assert err < 4e-6 * max(1.0, np.sqrt(K / 4096.0)), (relu, acc, err)     # fp32 chain: grows with sqrt(K)
 
 
+_GEMM_FUZZ = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from controllable_xgating_amd import _native as nv
+L = nv.lib()
+rng = np.random.RandomState(11)
+bad = []
+for it in range(36):
+    M = int(rng.choice([130, 257, 384, 511, 777, 1024, 1411, 2688]))
+    N = int(rng.choice([128, 260, 512, 1000, 1536, 2052, 4100]))
+    K = int(rng.choice([32, 96, 132, 468, 512, 1000, 2688]))
+    ta, tb = int(rng.randint(2)), int(rng.randint(2))
+    relu, acc = [(0, 0), (1, 0), (0, 1)][int(rng.randint(3))]
+    mode = int(rng.choice([0, 0, 1, 3]))
+    g = torch.Generator(device="cuda").manual_seed(1000 + it)
+    A = torch.randn((K, M) if ta else (M, K), generator=g, device="cuda")
+    B = torch.randn((N, K) if tb else (K, N), generator=g, device="cuda")
+    b = torch.randn(N, generator=g, device="cuda")
+    C0 = torch.randn(M, N, generator=g, device="cuda")
+    C = C0.clone()
+    assert L.xg_gemm_mode(None, mode, ta, tb, M, N, K, nv.ptr(A), A.shape[1], nv.ptr(B), B.shape[1], nv.ptr(C), N, nv.ptr(b), relu, acc) == 0
+    want = (A.t() if ta else A).double() @ (B.t() if tb else B).double() + b.double() + (C0.double() if acc else 0)
+    if relu:
+        want = want.clamp(min=0)
+    err = float((C.double() - want).abs().max()) / float(want.abs().max())
+    tol = 2e-2 if mode == 1 else 6e-6
+    if not err < tol:
+        bad.append((it, M, N, K, ta, tb, relu, acc, mode, err))
+print("BAD", bad)
+sys.exit(1 if bad else 0)
+"""
+
+
+@pytest.mark.parametrize("pk_min", ["2", "40"])
+def test_gemm_fuzz_all_kernels(pk_min):
+    """36 seeded random products (ragged extents, all four layouts, bias / ReLU / += C, fp32 / bf16 / split-bf16) against fp64,
+    once with the persistent stream-K kernel forced onto every shape that can take it (XG_PK_MIN=2: read at first use, hence
+    the subprocess) and once with the production rule."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, XG_PK_MIN=pk_min)
+    r = subprocess.run([sys.executable, "-c", _GEMM_FUZZ % root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_gemm_strided_submatrix():
     """W[:, R:2R] column block of h2a.weight as B operand (ldb = 2R) and accumulate, as the step uses it."""
     from controllable_xgating_amd import _native as nv
