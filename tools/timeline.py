@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Text timeline of ONE training iteration from a rocprofv3 --kernel-trace csv: which kernels ran on which HIP
 stream (queue), when, and how much of the iteration each stream / the GPU was busy.  Iterations are delimited by
-clip_adam_kernel.   usage: timeline.py <dir with *_kernel_trace.csv> [iteration index from the end, default 1] [from_us to_us: list every kernel in the window]"""
+pack_kernel (the weight re-pack at the head of a forward).   usage: timeline.py <dir with *_kernel_trace.csv> [iteration index from the end, default 1] [from_us to_us: list every kernel in the window]"""
 import csv
 import glob
 import sys
@@ -33,8 +33,14 @@ def main():
     rows = [dict(name=short(r["Kernel_Name"]), q=r.get("Queue_Id", "0"), s=int(r["Start_Timestamp"]), e=int(r["End_Timestamp"]))
             for r in csv.DictReader(open(f))]
     rows.sort(key=lambda r: r["s"])
-    adam = [i for i, r in enumerate(rows) if r["name"].startswith("clip_adam")]
-    lo, hi = adam[-back - 1] + 1, adam[-back] + 1
+    # an iteration starts with the weight re-pack (one pack_kernel per optimizer step, first thing of the next forward); the
+    # update itself is several clip_adam launches on two streams (train.ClipAdam(overlap=True)), so it cannot delimit
+    marks = [i for i, r in enumerate(rows) if r["name"].startswith("pack_kernel")]
+    if len(marks) > back + 1:
+        lo, hi = marks[-back - 1], marks[-back]
+    else:
+        adam = [i for i, r in enumerate(rows) if r["name"].startswith("clip_adam")]
+        lo, hi = adam[-back - 1] + 1, adam[-back] + 1
     it = rows[lo:hi]
     t0, t1 = it[0]["s"], max(r["e"] for r in it)
     qs = sorted({r["q"] for r in it}, key=lambda q: -sum(r["e"] - r["s"] for r in it if r["q"] == q))
