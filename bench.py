@@ -297,9 +297,15 @@ def main():
         optim.step()
         return loss
 
+    sleep_cycles = int(float(os.environ.get("XG_BENCH_SLEEP_MS", "0")) * 2.4e6)           # diagnosis: see below (torch.cuda._sleep counts shader clocks)
+
     def step():
         if args.workload == "scst":
             return step_scst()
+        if sleep_cycles:
+            # diagnosis only: a GPU-side spin at the head of the iteration lets the host run far ahead; if (time - spin) drops
+            # below the normal iteration time, the normal run has host-bound gaps
+            torch.cuda._sleep(sleep_cycles)
         optim.zero_grad()
         if args.path == "fused":
             loss = model.xe_loss(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
