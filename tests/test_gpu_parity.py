@@ -472,7 +472,7 @@ def test_overlapped_update_equals_plain_update():
             opt.step()
         torch.cuda.synchronize()
         assert getattr(model, "_grad_event", None) is None
-        out.append(({n: q.detach().clone() for n, q in model.named_parameters()}, float(loss)))
+        out.append(({n: q.detach().clone() for n, q in model.named_parameters()}, float(loss.detach())))
     (p0, l0), (p1, l1) = out
     # the weight gradients themselves carry split-K atomics (run-to-run 1e-7 noise), so two runs agree to that level --
     # except where the TRUE gradient is zero: Adam normalises pure noise there to +-lr per step in any two runs
