@@ -359,7 +359,7 @@ __global__ void __launch_bounds__(FT) attn_bwd_fast(const float* __restrict__ da
 // The same backward as TWO workgroups per video (512 threads each): every thread's work is dominated by its 2 x K tanh
 // (one 1024-thread workgroup per video keeps 128 CUs busy for ~5 us of VALU each and leaves the other 128 idle), so the
 // attention columns are halved between two CUs; both compute the K dalpha dot products (V is read twice: 53 KB per video)
-// and the softmax backward redundantly, part 0 writes de.  K <= 32, A / 2 even and <= 1024.
+// and the softmax backward redundantly, part 0 writes de.  K <= NQ <= 48, A / 2 even and <= 1024.
 template <int NQ>
 __global__ void __launch_bounds__(512) attn_bwd_split(const float* __restrict__ daf, int lddaf, const float* __restrict__ p,
                                                       const float* __restrict__ vproj, const float* __restrict__ V,
@@ -374,7 +374,7 @@ __global__ void __launch_bounds__(512) attn_bwd_split(const float* __restrict__ 
     const float* qb = vproj + (size_t)b * K * A;
     const float* Vb = V + (size_t)b * K * R;
     const float* dafb = daf + (size_t)b * lddaf;
-    constexpr int DR = 4, DC = 4;                     // rows per wave (K <= 32), float4 chunks per row held in registers
+    constexpr int DR = (NQ + NWV - 1) / NWV, DC = 4;  // rows per wave (K <= NQ), float4 chunks per row held in registers
     float4 dv[DC], vv[DR][DC];
 #pragma unroll
     for (int c = 0; c < DC; ++c) {
@@ -463,10 +463,13 @@ int xgk_attn_bwd(hipStream_t st, const float* daf, int lddaf, const float* p, co
                       ((uintptr_t)w % 16 == 0) && ((uintptr_t)daf % 16 == 0) && ((uintptr_t)dp % 16 == 0);
     // two workgroups per video while that still leaves CUs idle (<= 64 videos: SCST iteration 7.88 -> 7.72 ms); at 128 videos
     // the one-workgroup form already covers half the chip and the iteration is throughput-bound (6.63 vs 6.67 ms split)
-    if (B <= 64 && al16 && A % 4 == 0 && A <= 2048 && R % 4 == 0 && R <= 1024 && lddaf % 4 == 0 && K <= 32) {
+    // ... and for 33-48 frames at any batch: the one-workgroup form holds 48 frames of q per thread under the 128-VGPR cap of a
+    // 1024-thread workgroup and spills (hidden-1024 / 40-frame configuration)
+    if ((B <= 64 || K > 32) && al16 && A % 4 == 0 && A <= 2048 && R % 4 == 0 && R <= 1024 && lddaf % 4 == 0 && K <= 48) {
         const size_t lds = (size_t)K * sizeof(float);
         if (K <= 16) hipLaunchKernelGGL((attn_bwd_split<16>), dim3(2 * B), dim3(512), lds, st, daf, lddaf, p, vproj, V, w, alpha, de, dp, K, R, A);
-        else hipLaunchKernelGGL((attn_bwd_split<32>), dim3(2 * B), dim3(512), lds, st, daf, lddaf, p, vproj, V, w, alpha, de, dp, K, R, A);
+        else if (K <= 32) hipLaunchKernelGGL((attn_bwd_split<32>), dim3(2 * B), dim3(512), lds, st, daf, lddaf, p, vproj, V, w, alpha, de, dp, K, R, A);
+        else hipLaunchKernelGGL((attn_bwd_split<48>), dim3(2 * B), dim3(512), lds, st, daf, lddaf, p, vproj, V, w, alpha, de, dp, K, R, A);
         XG_CHECK_LAUNCH();
         return XG_OK;
     }
