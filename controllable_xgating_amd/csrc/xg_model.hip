@@ -523,7 +523,9 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         // E: the fused attention like the rollout form -- measure 6.77 / 6.73 / 6.74 ms per iteration (the iteration is
         // throughput-bound across three streams, not bound by this chain); D is the simplest and the default.)
         static const bool no_fused = getenv("XG_NO_FUSED_ATTN") != nullptr;
-        static const char xe_form = getenv("XG_XE_FORM") ? getenv("XG_XE_FORM")[0] : 'D';     // experiment switch (B / D / E)
+        // (at hidden 1024 / 40 frames E wins instead: 8.51 vs 8.63 ms -- the stand-alone attention is then 24 us per step)
+        static const char xe_env = getenv("XG_XE_FORM") ? getenv("XG_XE_FORM")[0] : 0;          // experiment switch (B / D / E)
+        const char xe_form = xe_env ? xe_env : (R >= 1024 ? 'E' : 'D');
         const bool fused_attn = (!s.pre1 || xe_form == 'E') && !no_fused && A <= 2048 && d.K <= 128 && ((uintptr_t)V % 8 == 0) &&
                                 ((uintptr_t)vproj % 16 == 0) && ((uintptr_t)p.a2w_w % 16 == 0);
         // S2' = h2 W_h2h2 + b rides in launch 1 (teacher forcing form B; the rollout form beyond 64 rows, where the three
