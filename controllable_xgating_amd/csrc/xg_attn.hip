@@ -185,9 +185,7 @@ __global__ void __launch_bounds__(FT) attn_fwd_fast(const float* __restrict__ p,
                                                      const float* __restrict__ V, const float* __restrict__ w,
                                                      float* __restrict__ alpha, float* __restrict__ af, int K, int R, int A) {
     extern __shared__ float sm[];                     // e[K] | part[nkp][R]
-#ifdef XG_CHAIN_PRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
+    XG_CHAIN_PRIO();
     AT_STAMP(0);
     float* se = sm;
     float* part = sm + ((K + 3) & ~3);
@@ -280,9 +278,7 @@ __global__ void __launch_bounds__(FT) attn_bwd_fast(const float* __restrict__ da
                                                      const float* __restrict__ w, const float* __restrict__ alpha,
                                                      float* __restrict__ de, float* __restrict__ dp, int K, int R, int A) {
     extern __shared__ float sm[];                     // dalpha[K]
-#ifdef XG_CHAIN_PRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
+    XG_CHAIN_PRIO();
     AT_STAMP(0);
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* qb = vproj + (size_t)b * K * A;
@@ -361,14 +357,12 @@ __global__ void __launch_bounds__(FT) attn_bwd_fast(const float* __restrict__ da
 // attention columns are halved between two CUs; both compute the K dalpha dot products (V is read twice: 53 KB per video)
 // and the softmax backward redundantly, part 0 writes de.  K <= NQ <= 48, A / 2 even and <= 1024.
 template <int NQ>
-__global__ void __launch_bounds__(512) attn_bwd_split(const float* __restrict__ daf, int lddaf, const float* __restrict__ p,
+__global__ void __launch_bounds__(512, (NQ <= 32 ? 4 : 2)) attn_bwd_split(const float* __restrict__ daf, int lddaf, const float* __restrict__ p,
                                                       const float* __restrict__ vproj, const float* __restrict__ V,
                                                       const float* __restrict__ w, const float* __restrict__ alpha,
                                                       float* __restrict__ de, float* __restrict__ dp, int K, int R, int A) {
     extern __shared__ float sm[];                     // dalpha[K]
-#ifdef XG_CHAIN_PRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
+    XG_CHAIN_PRIO();
     constexpr int NWV = 8;
     const int b = blockIdx.x >> 1, part = blockIdx.x & 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* qb = vproj + (size_t)b * K * A;
@@ -390,9 +384,13 @@ __global__ void __launch_bounds__(512) attn_bwd_split(const float* __restrict__ 
     const int ah = A >> 1;                            // this workgroup's columns: [part * ah, part * ah + ah)
     const int a0 = part * ah + tid * 2;
     const bool a_ok = tid * 2 < ah;
+    // 4 waves per SIMD (128 VGPRs): an 8-wave workgroup then fits into HALF a CU, beside a background GEMM workgroup
+    // (xg_gemm.hip: XGK_GEMM_BG).  The first half of the q rows is requested up front with the dalpha operands, the second
+    // half when those registers are free again (behind the dot products, its latency under the first half's tanh)
+    constexpr int NQ1 = (NQ + 1) / 2;
     float2 q[NQ];
 #pragma unroll
-    for (int k = 0; k < NQ; ++k) q[k] = (a_ok && k < K) ? *reinterpret_cast<const float2*>(qb + (size_t)k * A + a0) : make_float2(0, 0);
+    for (int k = 0; k < NQ1; ++k) q[k] = (a_ok && k < K) ? *reinterpret_cast<const float2*>(qb + (size_t)k * A + a0) : make_float2(0, 0);
     const float2 pa = a_ok ? *reinterpret_cast<const float2*>(p + (size_t)b * A + a0) : make_float2(0, 0);
     const float2 wa = a_ok ? *reinterpret_cast<const float2*>(w + a0) : make_float2(0, 0);
 #pragma unroll
@@ -405,6 +403,8 @@ __global__ void __launch_bounds__(512) attn_bwd_split(const float* __restrict__ 
         acc = wave_sum(acc);
         if (lane == 0 && k < K) sm[k] = acc;
     }
+#pragma unroll
+    for (int k = NQ1; k < NQ; ++k) q[k] = (a_ok && k < K) ? *reinterpret_cast<const float2*>(qb + (size_t)k * A + a0) : make_float2(0, 0);
     __syncthreads();
     const float da = lane < K ? sm[lane] : 0.f;
     const float dot = wave_sum(al_lane * da);
@@ -465,7 +465,8 @@ int xgk_attn_bwd(hipStream_t st, const float* daf, int lddaf, const float* p, co
     // the one-workgroup form already covers half the chip and the iteration is throughput-bound (6.63 vs 6.67 ms split)
     // ... and for 33-48 frames at any batch: the one-workgroup form holds 48 frames of q per thread under the 128-VGPR cap of a
     // 1024-thread workgroup and spills (hidden-1024 / 40-frame configuration)
-    if ((B <= 64 || K > 32) && al16 && A % 4 == 0 && A <= 2048 && R % 4 == 0 && R <= 1024 && lddaf % 4 == 0 && K <= 48) {
+    static const int one_wg = getenv("XG_ATTN_BWD_ONE") ? 1 : 0;
+    if (!one_wg && al16 && A % 4 == 0 && A <= 2048 && R % 4 == 0 && R <= 1024 && lddaf % 4 == 0 && K <= 48) {
         const size_t lds = (size_t)K * sizeof(float);
         if (K <= 16) hipLaunchKernelGGL((attn_bwd_split<16>), dim3(2 * B), dim3(512), lds, st, daf, lddaf, p, vproj, V, w, alpha, de, dp, K, R, A);
         else if (K <= 32) hipLaunchKernelGGL((attn_bwd_split<32>), dim3(2 * B), dim3(512), lds, st, daf, lddaf, p, vproj, V, w, alpha, de, dp, K, R, A);

@@ -141,6 +141,7 @@ struct GemmArgs {
                   // into C with hardware fp32 atomics (C pre-zeroed by the launcher unless accumulating)
     int fast;     // vector kernels: offset-based unpredicated loads for the full slabs (all byte offsets < 2^31)
     int gm;       // tile rows per group of the tile order (xgk_group_rows)
+    int bg;       // XGK_GEMM_BG: the product runs BESIDE a latency-bound launch chain on another stream (see launch_pk)
 };
 
 #ifdef GEMM_CLK
@@ -557,7 +558,14 @@ int launch_pk(hipStream_t st, const GemmArgs& a) {
     if (units < 512L * min_units) return 1;
     static const int env_g = getenv("XG_PK_G") ? atoi(getenv("XG_PK_G")) : 0;
     static const int env_split = getenv("XG_PK_SPLIT") ? atoi(getenv("XG_PK_SPLIT")) : 1;
-    const int GMAX = env_g > 0 ? env_g : 512;       // 2 workgroups per CU (73.7 KB of LDS each)
+    // 2 workgroups per CU (73.7 KB of LDS each) -- or, for a background product, ONE per CU (LDS padded past half a CU so
+    // that the dispatcher cannot pair them): 512 persistent workgroups own every register file and LDS for the whole
+    // product (0.7 ms for dW_logit), and a recurrent chain on another stream then waits for leftovers -- its step took
+    // 120 us instead of 53 beside dW_logit.  One workgroup per CU leaves 256 VGPRs per SIMD and 78 KB of LDS, exactly one
+    // 8-wave (or two 4-wave) skinny workgroups, and costs the product itself ~10 %.
+    static const int bg_off = getenv("XG_GEMM_NO_BG") ? 1 : 0;
+    const bool bg = a.bg && !bg_off;
+    const int GMAX = env_g > 0 ? env_g : (bg ? 256 : 512);
     int G;
     const bool split = !a.relu && g.nslab >= 2 && env_split;
     if (!split) {
@@ -595,9 +603,10 @@ int launch_pk(hipStream_t st, const GemmArgs& a) {
             XG_CHECK_LAUNCH();
         }
     }
-    const size_t lds = 2 * (TileGeom<128, AKC>::lds_floats + TileGeom<128, BKC>::lds_floats) * sizeof(float);
+    size_t lds = 2 * (TileGeom<128, AKC>::lds_floats + TileGeom<128, BKC>::lds_floats) * sizeof(float);
     static std::atomic<unsigned> optin{0};
-    XG_TRY(xg_lds_optin(optin, reinterpret_cast<const void*>(&gemm_pk_kernel<AKC, BKC>), (int)lds));
+    XG_TRY(xg_lds_optin(optin, reinterpret_cast<const void*>(&gemm_pk_kernel<AKC, BKC>), 84 * 1024));
+    if (bg && lds < 82 * 1024) lds = 82 * 1024;
     hipLaunchKernelGGL((gemm_pk_kernel<AKC, BKC>), dim3(G), dim3(256), lds, st, g);
     XG_CHECK_LAUNCH();
     return XG_OK;
@@ -667,10 +676,12 @@ int xgk_gemm(hipStream_t st, int mode, bool transA, bool transB, int M, int N, i
              const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate) {
     if (M <= 0 || N <= 0) return XG_OK;
     if (K < 0 || !A || !B || !C) return XG_EINVAL;
+    const int bg = (mode & XGK_GEMM_BG) ? 1 : 0;
+    mode &= ~XGK_GEMM_BG;
     // large products may run on the bf16 matrix cores (split-bf16 or plain bf16); skinny / tiny ones stay fp32
     if ((mode == 1 || mode == 3) && M >= 256 && N >= 64 && K >= 64)
         return xgk_gemm_bf16(st, mode, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate);
-    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1, 0, 1};
+    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1, 0, 1, bg};
     const bool akc = !transA;   // A (M,K) row-major -> k contiguous
     const bool bkc = transB;    // B (N,K) row-major -> k contiguous
     {   // offset-based loads: the largest byte offset inside either operand must fit 31 bits, and the m/n-contiguous

@@ -333,6 +333,7 @@ struct RollStepArgs {
 // owner passes read LDS instead of going back to L2 three more times.
 template <bool STAGE>
 __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
+    XG_CHAIN_PRIO();
     extern __shared__ float xs[];
     __shared__ float red[RT / 64];
     __shared__ int redi[RT / 64];

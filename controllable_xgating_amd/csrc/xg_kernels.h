@@ -13,6 +13,9 @@ static inline int xgk_group_rows(int k_depth) {
     const int g = 4096 / (k_depth > 0 ? k_depth : 1);
     return g < 1 ? 1 : (g > 8 ? 8 : g);
 }
+// `mode | XGK_GEMM_BG`: the product is launched on a side stream beside a latency-bound chain of small launches; the
+// persistent kernel then takes half of every CU instead of all of it (xg_gemm.hip: launch_pk)
+enum { XGK_GEMM_BG = 0x100 };
 int xgk_gemm(hipStream_t st, int mode, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
              const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate);
 // xg_gemm_bf16.hip: split-bf16 / bf16 arithmetic for large products (planes = 3 or 1)

@@ -725,7 +725,7 @@ int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatc
         XG_TRY(core_step(st, d, p, run, w, w.Venc, w.vproj, s));
         if (th > 0 && t == th - 1) {
             XG_TRY(ss.fork());
-            XG_TRY(xgk_linear(ss.aux, w.gm, th * B, d.V, R, w.H2 + BR, R, p.logit_w, p.logit_b, w.LOGITS, d.V));
+            XG_TRY(xgk_linear(ss.aux, w.gm | (getenv("XG_FWD_BG") ? XGK_GEMM_BG : 0), th * B, d.V, R, w.H2 + BR, R, p.logit_w, p.logit_b, w.LOGITS, d.V));
             *logit_rows_done = th * B;
         }
     }
@@ -926,15 +926,19 @@ int heads_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams& g
     const int th = (ss.overlap() && !have_cls && rows == TB && d.T >= 4) ? d.T / 2 : 0;
     const int r0 = th * B;
     ss.dh_split_step = th; ss.dh_mark = -1;
+    XG_TRY(gemm_nn(st, w.gm, rows - r0, R, d.V, w.LOGITS + (size_t)r0 * d.V, d.V, p.logit_w, R, w.DH2OUT + (size_t)r0 * R, R, false));
+    // everything below runs BESIDE the reverse-time loop: behind the product above (which the loop waits for and which
+    // therefore gets the whole chip), and as background products (XGK_GEMM_BG: half of every CU stays free for the loop)
+    const int bgm = w.gm | (ss.overlap() && d.K <= 32 ? XGK_GEMM_BG : 0);
     if (th > 0) {
-        XG_TRY(gemm_nn(ss.aux, w.gm, r0, R, d.V, w.LOGITS, d.V, p.logit_w, R, w.DH2OUT, R, false));
+        XG_TRY(ss.fork());
+        XG_TRY(gemm_nn(ss.aux, bgm, r0, R, d.V, w.LOGITS, d.V, p.logit_w, R, w.DH2OUT, R, false));
         ss.dh_mark = ss.mark();
         if (ss.dh_mark == -2) return XG_EHIP;
     }
     // dW_logit / db: parameter gradients, under the loop as well
-    XG_TRY(gemm_tn(ss.aux, w.gm, rows, d.V, R, w.LOGITS, d.V, Hout, R, g.logit_w, R));
+    XG_TRY(gemm_tn(ss.aux, bgm, rows, d.V, R, w.LOGITS, d.V, Hout, R, g.logit_w, R));
     XG_TRY(xgk_colsum(ss.aux, w.LOGITS, d.V, rows, d.V, g.logit_b));
-    XG_TRY(gemm_nn(st, w.gm, rows - r0, R, d.V, w.LOGITS + (size_t)r0 * d.V, d.V, p.logit_w, R, w.DH2OUT + (size_t)r0 * R, R, false));
     // XgRun.grad_event_head: the vocabulary head's gradients are final, long before anything else, AND logit.* is not read
     // any more in this backward (the product above was its last reader) -- a caller may all-reduce those gradients and
     // even update logit.* from here on

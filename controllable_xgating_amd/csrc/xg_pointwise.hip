@@ -88,8 +88,9 @@ __device__ __forceinline__ void lstm_bwd_body(const LstmBwdArgs& a) {
     else                          { ds[2 * R + j] = dsg; ds[3 * R + j] = dso; }
     a.dc_prev[(size_t)b * a.lddcp + j] = dcp;
 }
-__global__ void lstm_bwd_kernel(LstmBwdArgs a) { lstm_bwd_body(a); }
+__global__ void lstm_bwd_kernel(LstmBwdArgs a) { XG_CHAIN_PRIO(); lstm_bwd_body(a); }
 __global__ void lstm_bwd2_kernel(LstmBwdArgs a, LstmBwdArgs b) {
+    XG_CHAIN_PRIO();
     if (blockIdx.y == 0) lstm_bwd_body(a); else lstm_bwd_body(b);
 }
 

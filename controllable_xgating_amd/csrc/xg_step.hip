@@ -325,6 +325,7 @@ __device__ __forceinline__ void sk_epilogue_split(const SkJob& job, float* __res
 // encoder's two cells, [p || cell 1]) then run in one round.  Needs <= 128 VGPRs.
 template <bool VEC, int PREC>     // PREC 0: fp32 MFMA, 1: bf16 MFMA
 __global__ void __launch_bounds__(SKT) __attribute__((amdgpu_waves_per_eu(4, 4))) sk_kernel(SkArgs args) {
+    XG_CHAIN_PRIO();
     SK_STAMP(0);
     // wave-private staging (A chunk + B chunk per wave), re-used as the [SKW][32][32] reduction buffer
     __shared__ __attribute__((aligned(16))) float smem[SKW * 2 * OPF];
@@ -589,9 +590,7 @@ __device__ __forceinline__ void ldA(const float* const (&ap)[4], int c, int klef
 // SIMD instead of spilling at 128.)
 template <int NW, int PREC, bool SCALE>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SCALE ? 2 : 4, SCALE ? 2 : 4))) skf_kernel(SkArgs args) {
-#ifdef XG_CHAIN_PRIO
-    __builtin_amdgcn_s_setprio(3);
-#endif
+    XG_CHAIN_PRIO();
     SK_STAMP(0);
     __shared__ __attribute__((aligned(16))) float smem[NW * 32 * RSF > NW * OPF ? NW * 32 * RSF : NW * OPF];
     const SkJob& job = args.job[blockIdx.y];
