@@ -930,8 +930,8 @@ int heads_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams& g
     // everything below runs BESIDE the reverse-time loop: behind the product above (which the loop waits for and which
     // therefore gets the whole chip), and as background products (XGK_GEMM_BG: half of every CU stays free for the loop)
     const int bgm = w.gm | (ss.overlap() && d.K <= 32 ? XGK_GEMM_BG : 0);
+    XG_TRY(ss.fork());
     if (th > 0) {
-        XG_TRY(ss.fork());
         XG_TRY(gemm_nn(ss.aux, bgm, r0, R, d.V, w.LOGITS, d.V, p.logit_w, R, w.DH2OUT, R, false));
         ss.dh_mark = ss.mark();
         if (ss.dh_mark == -2) return XG_EHIP;
