@@ -23,7 +23,7 @@ namespace {
 // serves one caller stream at a time (two callers on two streams -- the SCST sampled / greedy rollouts -- use two
 // handles).  Everything is joined back onto the caller's stream before an entry point returns, so the stream semantics of
 // the C ABI are unchanged.  XgRun.aux == NULL (or XG_NO_OVERLAP=1): everything runs on the caller's stream.
-constexpr int XG_NEV = 64;
+constexpr int XG_NEV = 64, XG_NRING = 56;     // events: a ring for fork / join pairs + slots for long-lived marks
 struct XgAux { uint32_t magic; int device; hipStream_t s = nullptr, s2 = nullptr; hipEvent_t ev[XG_NEV]; };
 constexpr uint32_t XG_AUX_MAGIC = 0x58474158u;
 XgAux* aux_of(const XgRun* run) {
@@ -38,7 +38,7 @@ XgAux* aux_of(const XgRun* run) {
 struct Streams {
     hipStream_t main, aux, aux2;              // aux2: a second side chain (the decoder backward's cell-1 recurrence)
     XgAux* a;
-    int next = 0;
+    int next = 0, next_mark = 0;
     bool forked = false, forked2 = false;
     int dh_split_step = 0, dh_mark = -1;      // heads_bwd -> decoder_bwd_core hand-off (see heads_bwd)
     hipEvent_t grad_event = nullptr;          // XgRun.grad_event: recorded when every gradient but the encoder's is final
@@ -51,7 +51,7 @@ struct Streams {
     // aux may start work that depends on everything enqueued on main so far
     int fork() {
         if (!a) return XG_OK;
-        hipEvent_t e = a->ev[next++ % XG_NEV];
+        hipEvent_t e = a->ev[next++ % XG_NRING];
         if (hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(aux, e, 0) != hipSuccess) return XG_EHIP;
         forked = true;
         return XG_OK;
@@ -59,7 +59,7 @@ struct Streams {
     // aux2 may start work that depends on everything enqueued on main so far
     int fork2() {
         if (!a) return XG_OK;
-        hipEvent_t e = a->ev[next++ % XG_NEV];
+        hipEvent_t e = a->ev[next++ % XG_NRING];
         if (hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(aux2, e, 0) != hipSuccess) return XG_EHIP;
         forked2 = true;
         return XG_OK;
@@ -67,22 +67,23 @@ struct Streams {
     // main waits for everything enqueued on aux2 so far
     int join2() {
         if (!a || !forked2) return XG_OK;
-        hipEvent_t e = a->ev[next++ % XG_NEV];
+        hipEvent_t e = a->ev[next++ % XG_NRING];
         if (hipEventRecord(e, aux2) != hipSuccess || hipStreamWaitEvent(main, e, 0) != hipSuccess) return XG_EHIP;
         return XG_OK;
     }
     // aux waits for everything enqueued on aux2 so far (then a join() of aux covers both)
     int chain2_into_aux() {
         if (!a || !forked2) return XG_OK;
-        hipEvent_t e = a->ev[next++ % XG_NEV];
+        hipEvent_t e = a->ev[next++ % XG_NRING];
         if (hipEventRecord(e, aux2) != hipSuccess || hipStreamWaitEvent(aux, e, 0) != hipSuccess) return XG_EHIP;
         forked = true;
         return XG_OK;
     }
     // record a point on aux that main can wait for later (returns an event slot, or -1 when not overlapping)
+    // (marks live across many steps of a loop: they come from their own slots, not from the fork / join ring)
     int mark() {
         if (!a) return -1;
-        const int i = next++ % XG_NEV;
+        const int i = XG_NRING + (next_mark++ % (XG_NEV - XG_NRING));
         if (hipEventRecord(a->ev[i], aux) != hipSuccess) return -2;
         return i;
     }
@@ -90,10 +91,14 @@ struct Streams {
         if (!a || i < 0) return XG_OK;
         return hipStreamWaitEvent(main, a->ev[i], 0) == hipSuccess ? XG_OK : XG_EHIP;
     }
+    int wait_mark2(int i) {                   // ... and the second side chain
+        if (!a || i < 0) return XG_OK;
+        return hipStreamWaitEvent(aux2, a->ev[i], 0) == hipSuccess ? XG_OK : XG_EHIP;
+    }
     // main waits for everything enqueued on aux so far
     int join() {
         if (!a || !forked) return XG_OK;
-        hipEvent_t e = a->ev[next++ % XG_NEV];
+        hipEvent_t e = a->ev[next++ % XG_NRING];
         if (hipEventRecord(e, aux) != hipSuccess || hipStreamWaitEvent(main, e, 0) != hipSuccess) return XG_EHIP;
         return XG_OK;
     }
@@ -831,6 +836,40 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         cur1 ^= 1;
         return XG_OK;
     };
+    // Batched weight gradients over a range of steps [t0, t1) (rows t0*B .. t1*B of the stacked per-step buffers; every
+    // product accumulates into the zeroed gradient buffer, so a range split is exact up to summation order).  The steps
+    // the reverse-time loop has already left are done BESIDE the loop on the auxiliary stream, behind the vocabulary
+    // head's products: the loop alone leaves most of the chip idle, and whatever runs under it does not compete with
+    // the encoder's backward afterwards.
+    auto wgrads_chain2 = [&](hipStream_t sq, int t0, int t1) -> int {
+        const int rows = (t1 - t0) * B;
+        if (rows <= 0) return XG_OK;
+        const size_t r0 = (size_t)t0 * B;
+        const float* ds2 = w.DS2 + r0 * 4 * R;
+        const float* dp = w.DP + r0 * A;
+        XG_TRY(gemm_tn(sq, w.gm, rows, 4 * R, R, ds2, 4 * R, w.H1 + BR + r0 * R, R, g.l2_i2h_w, R));
+        XG_TRY(gemm_tn(sq, w.gm, rows, 4 * R, R, ds2, 4 * R, w.AF + r0 * R, R, g.l2_a2h_w, R));
+        XG_TRY(gemm_tn(sq, w.gm, rows, 4 * R, R, ds2, 4 * R, w.H2 + r0 * R, R, g.l2_h2h_w, R));
+        XG_TRY(gemm_tn(sq, w.gm, rows, A, R, dp, A, w.H1 + r0 * R, R, g.h2a_w, 2 * R));
+        XG_TRY(gemm_tn(sq, w.gm, rows, A, R, dp, A, w.H2 + r0 * R, R, g.h2a_w + R, 2 * R));
+        return XG_OK;
+    };
+    auto wgrads_chain1 = [&](hipStream_t sq, int t0, int t1) -> int {
+        const int rows = (t1 - t0) * B;
+        if (rows <= 0) return XG_OK;
+        const size_t r0 = (size_t)t0 * B;
+        const float* ds1 = w.DS1 + r0 * 4 * R;
+        XG_TRY(gemm_tn(sq, w.gm, rows, 4 * R, R, ds1, 4 * R, w.H1 + r0 * R, R, g.l1_h2h_w, R));
+        XG_TRY(gemm_tn(sq, w.gm, rows, 4 * R, E, ds1, 4 * R, w.Xe + r0 * E, E, g.l1_i2h_w, E));
+        XG_TRY(gemm_tn(sq, w.gm, rows, 4 * R, R, ds1, 4 * R, w.POSG + r0 * R, R, g.l1_a2h_w, R));
+        // input side of cell 1: pos' gate, embedding
+        XG_TRY(gemm_nn(sq, w.gm, rows, R, 4 * R, ds1, 4 * R, p.l1_a2h_w, R, w.DPOSG + r0 * R, R, false));
+        XG_TRY(gemm_nn(sq, w.gm, rows, E, 4 * R, ds1, 4 * R, p.l1_i2h_w, E, w.DXe + r0 * E, E, false));
+        return XG_OK;
+    };
+    static const int wg_chunks_env = getenv("XG_WG_CHUNKS") ? atoi(getenv("XG_WG_CHUNKS")) : 2;
+    const int wg_chunks = (ss.overlap() && T >= 8) ? (wg_chunks_env < 1 ? 1 : (wg_chunks_env > 4 ? 4 : wg_chunks_env)) : 1;
+    int wg_hi = T, wg_mark = -1;                 // steps [wg_hi, T) already have their weight gradients enqueued
     for (int t = T - 1; t >= 0; --t) {
         // dH of the early steps comes from the auxiliary stream; fused, step t-1's cell backward runs inside step t
         if (t == ss.dh_split_step - (fuse ? 0 : 1)) XG_TRY(ss.wait_mark(ss.dh_mark));
@@ -862,6 +901,18 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         cur ^= 1;
         XG_TRY(ss.fork2());                   // chain 2 has finished step t ...
         XG_TRY(chain1_step(t));               // ... chain 1 may do it
+        bool boundary = false;                // t == ceil(k T / chunks) for some k in 1 .. chunks - 1
+        for (int k = 1; k < wg_chunks; ++k) boundary = boundary || t == (k * T + wg_chunks - 1) / wg_chunks;
+        if (boundary && t > 0 && t < wg_hi) {
+            // DS2 / DP rows of steps >= t exist on main, DS1 rows of steps >= t on the second side chain
+            XG_TRY(ss.fork());
+            XG_TRY(wgrads_chain2(ss.aux, t, wg_hi));
+            XG_TRY(ss.chain2_into_aux());
+            XG_TRY(wgrads_chain1(ss.aux, t, wg_hi));
+            wg_mark = ss.mark();              // the last one covers the earlier ones (same stream)
+            if (wg_mark == -2) return XG_EHIP;
+            wg_hi = t;
+        }
     }
     const int cur2 = cur;
     XG_TRY(ss.fork());                        // chain 2 is complete: DS2, DP, DAF, DE
@@ -882,21 +933,13 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
             XG_TRY(xgk_colsum(sj, gst[j], R, B, R, gb[j]));
         }
     }
-    // batched weight gradients over all T steps
-    XG_TRY(gemm_tn(sx, w.gm, TB, 4 * R, R, w.DS2, 4 * R, w.H1 + BR, R, g.l2_i2h_w, R));
-    XG_TRY(gemm_tn(sx, w.gm, TB, 4 * R, R, w.DS2, 4 * R, w.AF, R, g.l2_a2h_w, R));
-    XG_TRY(gemm_tn(sx, w.gm, TB, 4 * R, R, w.DS2, 4 * R, w.H2, R, g.l2_h2h_w, R));
+    // batched weight gradients over the steps the loop has not handed out yet
+    XG_TRY(wgrads_chain2(sx, 0, wg_hi));
     XG_TRY(xgk_colsum3(sx, w.DS2, 4 * R, TB, 4 * R, g.l2_i2h_b, g.l2_a2h_b, g.l2_h2h_b));
-    XG_TRY(gemm_tn(s1, w.gm, TB, 4 * R, R, w.DS1, 4 * R, w.H1, R, g.l1_h2h_w, R));
-    XG_TRY(gemm_tn(s1, w.gm, TB, 4 * R, E, w.DS1, 4 * R, w.Xe, E, g.l1_i2h_w, E));
-    XG_TRY(gemm_tn(s1, w.gm, TB, 4 * R, R, w.DS1, 4 * R, w.POSG, R, g.l1_a2h_w, R));
-    XG_TRY(xgk_colsum3(s1, w.DS1, 4 * R, TB, 4 * R, g.l1_i2h_b, g.l1_a2h_b, g.l1_h2h_b));
-    XG_TRY(gemm_tn(sx, w.gm, TB, A, R, w.DP, A, w.H1, R, g.h2a_w, 2 * R));
-    XG_TRY(gemm_tn(sx, w.gm, TB, A, R, w.DP, A, w.H2, R, g.h2a_w + R, 2 * R));
     XG_TRY(xgk_colsum(sx, w.DP, A, TB, A, g.h2a_b));
-    // input side of cell 1: pos' gate, embedding
-    XG_TRY(gemm_nn(s1, w.gm, TB, R, 4 * R, w.DS1, 4 * R, p.l1_a2h_w, R, w.DPOSG, R, false));
-    XG_TRY(gemm_nn(s1, w.gm, TB, E, 4 * R, w.DS1, 4 * R, p.l1_i2h_w, E, w.DXe, E, false));
+    XG_TRY(wgrads_chain1(s1, 0, wg_hi));
+    XG_TRY(xgk_colsum3(s1, w.DS1, 4 * R, TB, 4 * R, g.l1_i2h_b, g.l1_a2h_b, g.l1_h2h_b));
+    XG_TRY(ss.wait_mark2(wg_mark));           // DPOSG / DXe rows of the steps handed out in the loop
     XG_TRY(xgk_gate_bwd(s1, w.DPOSG, R, w.GP, R, x.pos_feats, R, B, w.DGP, R, nullptr, 0, false, TB, R,
                         xg_make_drop(&run, XG_SITE_DGATE, 0)));
     XG_TRY(gemm_tn(s1, w.gm, TB, R, E, w.DGP, R, w.Xe, E, g.dgate_w, E));
