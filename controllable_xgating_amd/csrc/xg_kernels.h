@@ -210,10 +210,11 @@ int xgk_nll_bwd(hipStream_t st, const int64_t* target, const float* mask, const 
                 int roll, const float* sums, float scale, const float* scale_dev, float* dlogp);
 // fused: rows are time-major logits (T*B,V): per-row lse, loss accumulation, and dlogits in place
 int xgk_xent_fwd(hipStream_t st, const float* logits, int ld, const int64_t* seq, const float* mask,
-                 const float* mask2, int B, int T, int V, int roll, float* lse, float* sums2);
+                 const float* mask2, int B, int T, int V, int roll, float* lse, float* sums2, int row0 = 0,
+                 int nrows = -1, bool zero_sums = true);      // rows [row0, row0 + nrows) of the T*B (nrows < 0: to the end)
 int xgk_xent_bwd(hipStream_t st, float* logits_inout, int ld, const int64_t* seq, const float* mask,
                  const float* mask2, int B, int T, int V, int roll, const float* lse, const float* sums2,
-                 const float* scale_dev, float scale);
+                 const float* scale_dev, float scale, int row0 = 0, int nrows = -1);
 // rollout token choice from a (B,V) log-prob matrix
 int xgk_choose(hipStream_t st, const float* logp, int B, int V, int mode, const float* uniforms,
                const int64_t* forced, int64_t forced_stride, float temperature, int64_t* tok, float* tok_logp);

@@ -710,8 +710,10 @@ int decoder_tokens_xe(hipStream_t sx, const XgDims& d, const XgParams& p, const 
 // teacher-forced decoder, states into w.H1/C1/H2/C2 (SAModel.py:85-112).  The vocabulary product of the first half of
 // the steps is issued on the auxiliary stream as soon as those steps are done; *logit_rows_done receives the number of
 // (t,b) rows whose logits are already under way there.
+// early_loss (fused loss path): the cross-entropy rows of those steps follow their logits on the auxiliary stream, under
+// the remaining steps (w.sums must have been zeroed on the main stream before).
 int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatch& x, const XgRun& run, Ws& w,
-                   int* logit_rows_done) {
+                   int* logit_rows_done, bool early_loss = false) {
     hipStream_t st = ss.main;
     const int B = d.B, R = d.R, A = d.A, E = d.E, T = d.T, N = B * d.K;
     const size_t BR = (size_t)B * R;
@@ -732,6 +734,8 @@ int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatc
             XG_TRY(ss.fork());
             XG_TRY(xgk_linear(ss.aux, w.gm | (getenv("XG_FWD_BG") ? XGK_GEMM_BG : 0), th * B, d.V, R, w.H2 + BR, R, p.logit_w, p.logit_b, w.LOGITS, d.V));
             *logit_rows_done = th * B;
+            if (early_loss)
+                XG_TRY(xgk_xent_fwd(ss.aux, w.LOGITS, d.V, x.seq, x.seq_mask, nullptr, B, T, d.V, 1, w.LSE, w.sums, 0, th * B, false));
         }
     }
     return XG_OK;
@@ -957,18 +961,25 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
 }
 
 // heads backward from dlogits (rows,V) in w.LOGITS and dcl (rows,C) in w.DCL -> DH2OUT, head param grads
+// xent (fused loss path): w.LOGITS still holds the LOGITS; dlogits = coef (softmax - onehot) is formed here, in place, the
+// late steps' rows first on the main stream and the early steps' rows on the auxiliary stream beside the first product.
+struct XentBwd { const int64_t* seq; const float* mask; const float* dloss_dev; };
 int heads_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams& g, const XgRun& run, Ws& w, int rows,
-              bool have_cls) {
+              bool have_cls, const XentBwd* xent = nullptr) {
     hipStream_t st = ss.main;
     const int B = d.B, R = d.R, TB = d.T * B;
     const float* Hout = w.H2 + (size_t)B * R;
     if (rows < TB) ZERO(w.DH2OUT + (size_t)rows * R, (size_t)(TB - rows) * R);
-    XG_TRY(ss.fork());                        // dlogits is final
     // dH = dlogits * W: the reverse-time loop starts from the LAST step, so the rows of the late steps go first on the
     // main stream and the early steps' rows are produced on the auxiliary stream while the loop is already running.
     const int th = (ss.overlap() && !have_cls && rows == TB && d.T >= 4) ? d.T / 2 : 0;
     const int r0 = th * B;
     ss.dh_split_step = th; ss.dh_mark = -1;
+    if (xent) XG_TRY(xgk_xent_bwd(st, w.LOGITS, d.V, xent->seq, xent->mask, nullptr, B, d.T, d.V, 1, w.LSE, w.sums,
+                                  xent->dloss_dev, 1.0f, r0, rows - r0));
+    XG_TRY(ss.fork());                        // dlogits of the late rows is final
+    if (xent && r0 > 0) XG_TRY(xgk_xent_bwd(ss.aux, w.LOGITS, d.V, xent->seq, xent->mask, nullptr, B, d.T, d.V, 1, w.LSE,
+                                            w.sums, xent->dloss_dev, 1.0f, 0, r0));
     XG_TRY(gemm_nn(st, w.gm, rows - r0, R, d.V, w.LOGITS + (size_t)r0 * d.V, d.V, p.logit_w, R, w.DH2OUT + (size_t)r0 * R, R, false));
     // everything below runs BESIDE the reverse-time loop: behind the product above (which the loop waits for and which
     // therefore gets the whole chip), and as background products (XGK_GEMM_BG: half of every CU stays free for the loop)
@@ -1383,12 +1394,13 @@ extern "C" int xg_xe_loss_fwd(void* stream, const XgDims* d, const XgParams* p, 
     const int TB = d->T * d->B;
     Streams ss(st, run);
     int rows_done = 0;
+    ZERO(w.sums, 2);                           // both halves of the cross-entropy add into it
     XG_TRY(ss.fork());
     XG_TRY(decoder_tokens_xe(ss.aux, *d, *p, *x, *run, w));
     XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w, &ss));
-    XG_TRY(decoder_fwd_xe(ss, *d, *p, *x, *run, w, &rows_done));
-    XG_TRY(heads_fwd_logits(ss, *d, *p, *run, w, TB, rows_done));
-    XG_TRY(xgk_xent_fwd(st, w.LOGITS, d->V, x->seq, x->seq_mask, nullptr, d->B, d->T, d->V, 1, w.LSE, w.sums));
+    XG_TRY(decoder_fwd_xe(ss, *d, *p, *x, *run, w, &rows_done, true));
+    XG_TRY(heads_fwd_logits(ss, *d, *p, *run, w, TB, rows_done));       // (joins the auxiliary stream)
+    XG_TRY(xgk_xent_fwd(st, w.LOGITS, d->V, x->seq, x->seq_mask, nullptr, d->B, d->T, d->V, 1, w.LSE, w.sums, rows_done, -1, false));
     if (cap_classes) {
         XG_TRY(xgk_xent_fwd(st, w.CL, d->C, cap_classes, x->seq_mask, class_mask, d->B, d->T, d->C, 0, w.LSEC, w.sums + 2));
     } else {
@@ -1407,7 +1419,7 @@ extern "C" int xg_xe_loss_bwd(void* stream, const XgDims* d, const XgParams* p, 
     attach_packed(w, *d, run);
     hipStream_t st = (hipStream_t)stream;
     const int B = d->B, T = d->T, TB = T * B;
-    XG_TRY(xgk_xent_bwd(st, w.LOGITS, d->V, x->seq, x->seq_mask, nullptr, B, T, d->V, 1, w.LSE, w.sums, dloss_dev, 1.0f));
+    const XentBwd xent{x->seq, x->seq_mask, dloss_dev};
     const bool cls = cap_classes != nullptr && weight_class != 0.f;
     if (cls) {
         if (hipMemcpyAsync(w.DCL, w.CL, sizeof(float) * (size_t)TB * d->C, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
@@ -1415,7 +1427,7 @@ extern "C" int xg_xe_loss_bwd(void* stream, const XgDims* d, const XgParams* p, 
                             dloss_dev, weight_class));
     }
     Streams ss(st, run);
-    XG_TRY(heads_bwd(ss, *d, *p, *g, *run, w, TB, cls));
+    XG_TRY(heads_bwd(ss, *d, *p, *g, *run, w, TB, cls, &xent));
     XG_TRY(decoder_bwd_core(ss, *d, *p, *g, *x, *run, w, x->seq_mask, T, 1, x->seq, T, 1));
     XG_TRY(encoder_bwd(ss, *d, *p, *g, *x, *run, w, w.DV));
     return ss.join();
