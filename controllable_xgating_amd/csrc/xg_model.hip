@@ -732,7 +732,9 @@ int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatc
         XG_TRY(core_step(st, d, p, run, w, w.Venc, w.vproj, s));
         if (th > 0 && t == th - 1) {
             XG_TRY(ss.fork());
-            XG_TRY(xgk_linear(ss.aux, w.gm | (getenv("XG_FWD_BG") ? XGK_GEMM_BG : 0), th * B, d.V, R, w.H2 + BR, R, p.logit_w, p.logit_b, w.LOGITS, d.V));
+            // (not a background product: measured with the half-CU attention form beside it, 6.25 vs 6.22 ms -- the forward
+            //  steps are 8-wave launches that fill a CU's register file with or without it)
+            XG_TRY(xgk_linear(ss.aux, w.gm, th * B, d.V, R, w.H2 + BR, R, p.logit_w, p.logit_b, w.LOGITS, d.V));
             *logit_rows_done = th * B;
             if (early_loss)
                 XG_TRY(xgk_xent_fwd(ss.aux, w.LOGITS, d.V, x.seq, x.seq_mask, nullptr, B, T, d.V, 1, w.LSE, w.sums, 0, th * B, false));
