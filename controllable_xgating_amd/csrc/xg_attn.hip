@@ -461,10 +461,11 @@ int xgk_attn_bwd(hipStream_t st, const float* daf, int lddaf, const float* p, co
     if (K > 8192) return XG_EINVAL;
     const bool al16 = ((uintptr_t)p % 16 == 0) && ((uintptr_t)vproj % 16 == 0) && ((uintptr_t)V % 16 == 0) &&
                       ((uintptr_t)w % 16 == 0) && ((uintptr_t)daf % 16 == 0) && ((uintptr_t)dp % 16 == 0);
-    // two workgroups per video while that still leaves CUs idle (<= 64 videos: SCST iteration 7.88 -> 7.72 ms); at 128 videos
-    // the one-workgroup form already covers half the chip and the iteration is throughput-bound (6.63 vs 6.67 ms split)
-    // ... and for 33-48 frames at any batch: the one-workgroup form holds 48 frames of q per thread under the 128-VGPR cap of a
-    // 1024-thread workgroup and spills (hidden-1024 / 40-frame configuration)
+    // two 512-thread workgroups per video whenever the shapes allow: up to 32 frames they hold <= 128 VGPRs, i.e. one of
+    // them fits into the half of a CU a background GEMM workgroup leaves free (xg_gemm.hip: XGK_GEMM_BG) -- the
+    // one-workgroup form (1024 threads x 125 VGPRs) needs an EMPTY CU and waited for one for up to 240 us per step beside
+    // dW_logit.  For 33-48 frames the one-workgroup form would spill (48 frames of q per thread under its 128-VGPR cap).
+    // XG_ATTN_BWD_ONE=1 selects the one-workgroup form for comparison.
     static const int one_wg = getenv("XG_ATTN_BWD_ONE") ? 1 : 0;
     if (!one_wg && al16 && A % 4 == 0 && A <= 2048 && R % 4 == 0 && R <= 1024 && lddaf % 4 == 0 && K <= 48) {
         const size_t lds = (size_t)K * sizeof(float);
