@@ -166,6 +166,31 @@ __global__ void attn_dV_kernel(const float* __restrict__ ALPHA, const float* __r
     dV[idx] = acc ? dV[idx] + s : s;
 }
 
+// The same with the step axis in registers (T <= TMAX): thread = one r of one video, its T values of daf are read ONCE
+// (the kernel above re-reads them for each of the K frames: 143 MB through L2 at config 2, 84 us on the path between the
+// reverse-time loop and the encoder backward); alpha[:, b, :] sits in LDS.  grid (ceil(R / 256), B).
+template <int TMAX>
+__global__ void __launch_bounds__(256) attn_dV_reg_kernel(const float* __restrict__ ALPHA, const float* __restrict__ DAF,
+                                                            int lddaf, int64_t tstride, float* __restrict__ dV, int T, int B,
+                                                            int K, int R, int acc) {
+    extern __shared__ float sal[];          // ALPHA[:, b, :]  (T*K)
+    const int b = blockIdx.y;
+    const int r = blockIdx.x * 256 + threadIdx.x;
+    for (int i = threadIdx.x; i < T * K; i += 256) sal[i] = ALPHA[((size_t)(i / K) * B + b) * K + (i % K)];
+    float d[TMAX];
+#pragma unroll
+    for (int t = 0; t < TMAX; ++t) d[t] = (t < T && r < R) ? DAF[(size_t)t * tstride + (size_t)b * lddaf + r] : 0.f;
+    __syncthreads();
+    if (r >= R) return;
+    for (int k = 0; k < K; ++k) {
+        float s = 0.f;
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) if (t < T) s += sal[t * K + k] * d[t];
+        float* o = dV + ((size_t)b * K + k) * R + r;
+        *o = acc ? *o + s : s;
+    }
+}
+
 
 // ------------------------------------------------------------------------------------------------
 // Fast paths (A % 4 == 0, A <= 2048, R % 4 == 0): one 1024-thread workgroup per video, every global
@@ -493,13 +518,25 @@ int xgk_attn_bwd_post(hipStream_t st, const float* P, const float* vproj, const 
     if ((size_t)T * K * sizeof(float) > 60000) return XG_EINVAL;
     const dim3 grid(xg_cdiv(A, 256), B);
     const size_t lds = (size_t)T * K * sizeof(float);
-    if (T <= 32) hipLaunchKernelGGL((attn_bwd_post_kernel<32>), grid, dim3(256), lds, st, P, vproj, w, DE, dvproj, dw, T, B, K, A);
+    // (the step axis is unrolled to TMAX: 21 steps in a 32-step body wasted a third of the tanh work, 73 us)
+    if (T <= 8) hipLaunchKernelGGL((attn_bwd_post_kernel<8>), grid, dim3(256), lds, st, P, vproj, w, DE, dvproj, dw, T, B, K, A);
+    else if (T <= 24) hipLaunchKernelGGL((attn_bwd_post_kernel<24>), grid, dim3(256), lds, st, P, vproj, w, DE, dvproj, dw, T, B, K, A);
+    else if (T <= 32) hipLaunchKernelGGL((attn_bwd_post_kernel<32>), grid, dim3(256), lds, st, P, vproj, w, DE, dvproj, dw, T, B, K, A);
     else hipLaunchKernelGGL((attn_bwd_post_kernel<0>), grid, dim3(256), lds, st, P, vproj, w, DE, dvproj, dw, T, B, K, A);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
 int xgk_attn_dV(hipStream_t st, const float* ALPHA, const float* DAF, int lddaf, int64_t daf_tstride, float* dV,
                 int T, int B, int K, int R, bool accumulate) {
+    if (T <= 32 && (size_t)T * K * sizeof(float) <= 60000) {
+        const dim3 grid(xg_cdiv(R, 256), B);
+        const size_t lds = (size_t)T * K * sizeof(float);
+        if (T <= 8) hipLaunchKernelGGL((attn_dV_reg_kernel<8>), grid, dim3(256), lds, st, ALPHA, DAF, lddaf, daf_tstride, dV, T, B, K, R, accumulate ? 1 : 0);
+        else if (T <= 24) hipLaunchKernelGGL((attn_dV_reg_kernel<24>), grid, dim3(256), lds, st, ALPHA, DAF, lddaf, daf_tstride, dV, T, B, K, R, accumulate ? 1 : 0);
+        else hipLaunchKernelGGL((attn_dV_reg_kernel<32>), grid, dim3(256), lds, st, ALPHA, DAF, lddaf, daf_tstride, dV, T, B, K, R, accumulate ? 1 : 0);
+        XG_CHECK_LAUNCH();
+        return XG_OK;
+    }
     const int64_t n = (int64_t)B * K * R;
     hipLaunchKernelGGL(attn_dV_kernel, dim3((unsigned)xg_cdiv64(n, 256)), dim3(256), 0, st, ALPHA, DAF, lddaf,
                        daf_tstride, dV, T, B, K, R, accumulate ? 1 : 0);
