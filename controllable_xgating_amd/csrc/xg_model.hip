@@ -119,6 +119,9 @@ struct Ws {
     // ---- rollout
     int64_t* TOK; float *TOKLP, *UNF; int32_t* alive;
     int32_t* tickets;                  // split-K arrival counters (xg_step.hip), SK_MAX_JOBS x 1024, zero between launches
+    // everything a backward pass needs ZERO on entry is one contiguous block (dst[0][*], DAF, the encoder's carried
+    // gradients, the BatchNorm sums, the tickets): one memset on a side stream instead of a dozen on the critical path
+    char* zblock; size_t zbytes; bool zeroed;
     size_t bytes;
     // ---- packed recurrent weights (XgRun.packed; not part of the workspace)
     PackedView pk; bool packed;
@@ -145,10 +148,9 @@ Ws carve(const XgDims& d, void* base) {
         w.Hs[m] = c.take<float>(N * R); w.Cs[m] = c.take<float>(N * R); w.G[m] = c.take<float>(N * 4 * R);
         w.GG[m] = c.take<float>(N * R); w.Hprev[m] = c.take<float>(N * R);
         w.bn_mean[m] = c.take<float>(R); w.bn_var[m] = c.take<float>(R);
-        w.bn_s1[m] = c.take<float>(R); w.bn_s2[m] = c.take<float>(R);
         w.dHs[m] = c.take<float>(N * R); w.dGG[m] = c.take<float>(N * R); w.dS[m] = c.take<float>(N * 4 * R);
-        w.dX[m] = c.take<float>(N * R); w.dHrec[m] = c.take<float>(B * R);
-        w.dCrec[m][0] = c.take<float>(B * R); w.dCrec[m][1] = c.take<float>(B * R);
+        w.dX[m] = c.take<float>(N * R);
+        w.dCrec[m][1] = c.take<float>(B * R);
     }
     w.zeroBR = c.take<float>(B * R); w.S = c.take<float>(B * 4 * R); w.S2 = c.take<float>(B * 4 * R);
     w.Y = c.take<float>(N * 2 * R); w.Venc = c.take<float>(N * R);
@@ -164,15 +166,27 @@ Ws carve(const XgDims& d, void* base) {
     w.LSE = c.take<float>(TB); w.LSEC = c.take<float>(TB); w.sums = c.take<float>(8);
     w.DH2OUT = c.take<float>(TB * R); w.DHC = c.take<float>(TB * H); w.DCL = c.take<float>(TB * C);
     w.DS1 = c.take<float>(TB * 4 * R); w.DS2 = c.take<float>(TB * 4 * R); w.DP = c.take<float>(TB * A);
-    w.DE = c.take<float>(TB * K); w.DAF = c.take<float>(TB * R);
-    for (int i = 0; i < 2; ++i) for (int j = 0; j < 4; ++j) w.dst[i][j] = c.take<float>(B * R);
+    w.DE = c.take<float>(TB * K);
+    for (int j = 0; j < 4; ++j) w.dst[1][j] = c.take<float>(B * R);
     w.DVPROJ = c.take<float>(N * A); w.DV = c.take<float>(N * R); w.DPOSG = c.take<float>(TB * R); w.DH1X = c.take<float>(TB * R);
     w.DGP = c.take<float>(TB * R); w.DXe = c.take<float>(TB * E);
     w.state_tmp = c.take<float>(4 * B * R);
     w.AFU = c.take<float>(B * R + ((B + 3) & ~(size_t)3)); w.ATS = w.AFU + B * R;
     w.TOK = c.take<int64_t>(TB); w.TOKLP = c.take<float>(TB); w.UNF = c.take<float>(TB);
     w.alive = c.take<int32_t>(4);
-    w.tickets = c.take<int32_t>(SK_MAX_JOBS * 1024);
+    {   // the zero block
+        c.off = (c.off + 255) & ~(size_t)255;
+        const size_t z0 = c.off;
+        w.zblock = c.base ? c.base + z0 : nullptr;
+        w.DAF = c.take<float>(TB * R);
+        for (int j = 0; j < 4; ++j) w.dst[0][j] = c.take<float>(B * R);
+        for (int m = 0; m < 2; ++m) {
+            w.dHrec[m] = c.take<float>(B * R); w.dCrec[m][0] = c.take<float>(B * R);
+            w.bn_s1[m] = c.take<float>(R); w.bn_s2[m] = c.take<float>(R);
+        }
+        w.tickets = c.take<int32_t>(SK_MAX_JOBS * 1024);
+        w.zbytes = c.off - z0;
+    }
     w.bytes = (c.off + 255) & ~(size_t)255;
     return w;
 }
@@ -377,8 +391,10 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
     }
     XgRun nodrop = run; nodrop.drop_p = 0.f;
     int curc = 0;
-    for (int m = 0; m < 2; ++m) { ZERO(w.dHrec[m], (size_t)B * R); ZERO(w.dCrec[m][0], (size_t)B * R); }
-    XG_TRY(zero_tickets(st, w, 2));
+    if (!w.zeroed) {
+        for (int m = 0; m < 2; ++m) { ZERO(w.dHrec[m], (size_t)B * R); ZERO(w.dCrec[m][0], (size_t)B * R); }
+        XG_TRY(zero_tickets(st, w, 2));
+    }
     // cell backward of frame i for modality m, reading / writing the carried dc of parity c.  Stand-alone it takes
     // dh = dHs[i] + dHrec; fused into the product dS[i+1] Whh (epilogue) it takes dh = product + dHs[i].
     auto enc_cell_bwd = [&](int m, int i, int c, bool fused) {
@@ -430,7 +446,7 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
         hipStream_t st = (m == 1 && ss.overlap()) ? ss.aux2 : st_outer;
         XG_TRY(gemm_nn(st, w.gm, N, R, 4 * R, w.dS[m], 4 * R, wih[m], R, w.dX[m], R, false));
         // BatchNorm + ReLU + dropout + mask backward (sub_modules.py:121-123)
-        ZERO(w.bn_s1[m], R); ZERO(w.bn_s2[m], R);
+        if (!w.zeroed) { ZERO(w.bn_s1[m], R); ZERO(w.bn_s2[m], R); }
         XG_TRY(xgk_bn_bwd_reduce(st, w.dX[m], w.X[m], w.Z[m], w.bn_mean[m], w.bn_var[m], x.feat_mask, N, R, run.bn_eps,
                                  xg_make_drop(&run, m == 0 ? XG_SITE_EMB_RGB : XG_SITE_EMB_OPFL, 0), w.bn_s1[m], w.bn_s2[m]));
         XG_TRY(xgk_axpy(st, g_bn_b[m], w.bn_s1[m], 1.f, R));
@@ -776,9 +792,13 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     // The pointwise LSTM backward of step t-1 runs in the epilogue of the product that completes its dh.
     const bool fuse = R % 4 == 0;
     int cur = 0;
-    for (int j = 0; j < 4; ++j) ZERO(w.dst[0][j], BR);
-    ZERO(w.DAF, (size_t)T * BR);                 // the dAF products accumulate (split-K across workgroups)
-    XG_TRY(zero_tickets(st, w, SK_MAX_JOBS));
+    if (w.zeroed) {
+        XG_TRY(ss.join2());                      // the zero block (zero_backward_block, second auxiliary stream)
+    } else {
+        for (int j = 0; j < 4; ++j) ZERO(w.dst[0][j], BR);
+        ZERO(w.DAF, (size_t)T * BR);             // the dAF products accumulate (split-K across workgroups)
+        XG_TRY(zero_tickets(st, w, SK_MAX_JOBS));
+    }
     auto cell2_bwd = [&](int t, int c) {          // backward of cell 2 at step t, reading the carried state of parity c
         LstmBwdArgs a{};
         a.gates = w.G2 + (size_t)t * B * 4 * R; a.ldg = 4 * R;
@@ -964,6 +984,17 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
 }
 
 // heads backward from dlogits (rows,V) in w.LOGITS and dcl (rows,C) in w.DCL -> DH2OUT, head param grads
+// Start of a full backward pass: clear the zero block beside whatever the main stream does first (the loss backward and
+// the first data-gradient product); decoder_bwd_core joins it.
+int zero_backward_block(Streams& ss, Ws& w) {
+    w.zeroed = false;
+    if (!ss.overlap()) return XG_OK;
+    XG_TRY(ss.fork2());
+    if (hipMemsetAsync(w.zblock, 0, w.zbytes, ss.aux2) != hipSuccess) return XG_EHIP;
+    w.zeroed = true;
+    return XG_OK;
+}
+
 // xent (fused loss path): w.LOGITS still holds the LOGITS; dlogits = coef (softmax - onehot) is formed here, in place, the
 // late steps' rows first on the main stream and the early steps' rows on the auxiliary stream beside the first product.
 struct XentBwd { const int64_t* seq; const float* mask; const float* dloss_dev; };
@@ -972,6 +1003,7 @@ int heads_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams& g
     hipStream_t st = ss.main;
     const int B = d.B, R = d.R, TB = d.T * B;
     const float* Hout = w.H2 + (size_t)B * R;
+    XG_TRY(zero_backward_block(ss, w));       // (every caller continues with decoder_bwd_core, which joins it)
     if (rows < TB) ZERO(w.DH2OUT + (size_t)rows * R, (size_t)(TB - rows) * R);
     // dH = dlogits * W: the reverse-time loop starts from the LAST step, so the rows of the late steps go first on the
     // main stream and the early steps' rows are produced on the auxiliary stream while the loop is already running.
