@@ -886,6 +886,36 @@ def test_fuzzed_extents_xe_and_greedy_vs_oracle(i):
                 np.testing.assert_allclose(slp_h.cpu().numpy()[b, :n], np.asarray(slp_o)[b, :n], atol=2e-4, err_msg=str(cfg))
 
 
+@pytest.mark.parametrize("cfg", [
+    # vocabulary sizes that select each cross-entropy variant: register-resident rows of 2 / 5 / 8 16-byte pieces per
+    # thread and the streaming kernel beyond 32768 (xg_heads.hip: xgk_xent_fwd), with the early / late row split
+    dict(B=3, K=5, R=16, A=24, E=12, V=8192, C=4, L=5, F1=8, F2=8, H=128),
+    dict(B=3, K=5, R=16, A=24, E=12, V=24004, C=4, L=5, F1=8, F2=8, H=128),
+    dict(B=2, K=4, R=16, A=24, E=12, V=33000, C=4, L=4, F1=8, F2=8, H=128),
+    # more than 32 decoder steps: the attention backward's tail kernels leave their register-resident forms
+    # (xg_attn.hip: attn_bwd_post_kernel<0>, attn_dV_kernel); the weight gradients of the late steps are enqueued under the loop
+    dict(B=4, K=6, R=16, A=24, E=12, V=50, C=4, L=36, F1=8, F2=8, H=128),
+    # 25..32 steps: the 32-step forms
+    dict(B=4, K=6, R=16, A=24, E=12, V=50, C=4, L=27, F1=8, F2=8, H=128),
+], ids=["V8192", "V24004", "V33000", "T37", "T28"])
+def test_kernel_variant_edges_xe_vs_oracle(cfg):
+    d = pg.make_dims(**cfg)
+    P, lo, co, lxe_o, lcls_o, running = run_oracle_xe(d, True, p=0.0, seed=0)
+    model, lh, ch, lxe_h, lcls_h = run_hip_xe(d, True, p=0.0, seed=None)
+    assert abs(lxe_h - lxe_o) < 1e-4, (cfg, lxe_h, lxe_o)
+    np.testing.assert_allclose(lh, lo, atol=3e-4, rtol=0, err_msg=str(cfg))
+    assert_grads_close(model, oracle_grads(P), skip=ZERO_GRAD_PARAMS)
+    # the fused loss path (xg_xe_loss_fwd / _bwd: row-split cross-entropy) against the same oracle gradients
+    x = to_dev(pg.make_inputs(d, seed=0, ragged=True))
+    m2 = make_model(d, train=True)
+    m2.flat_grads().zero_()
+    loss = m2.xe_loss(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"],
+                      x["cap_classes"], x["class_mask"], WEIGHT_CLASS)
+    loss.backward()
+    assert abs(float(loss.detach()) - (lxe_o + WEIGHT_CLASS * lcls_o)) < 1e-4, cfg
+    assert_grads_close(m2, oracle_grads(P), skip=ZERO_GRAD_PARAMS)
+
+
 # ---------------------------------------------------------------- round 2: fixtures that pin what round 1 left unpinned
 def test_greedy_with_natural_eos_token_for_token_vs_reference():
     """greedy_c1_eos.npz: 44 distinct words, rows finish at steps 3..13 (two never do), live top-2 margins >= 2.4e-3 in the
