@@ -244,4 +244,4 @@ int xgk_rollout_dlogits(hipStream_t st, const float* logp, const int64_t* tok, c
 
 // ---- xg_optim.hip
 int xgk_clip_adam(hipStream_t st, int64_t n, float* p, float* g, float* m, float* v, float lr, float b1, float b2,
-                  float eps, float wd, int step, float clip);
+                  float eps, float wd, int step, float clip, bool zero_grad = false);

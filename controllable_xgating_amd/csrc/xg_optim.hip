@@ -5,13 +5,16 @@
 #include "xg_kernels.h"
 
 namespace {
+template <bool ZERO>   // ZERO: the gradient is left at zero instead of clamped (the next iteration's optimizer.zero_grad())
 __global__ void clip_adam_kernel(int64_t n, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                  float* __restrict__ v, float lr, float b1, float b2, float eps, float wd, float bc1,
                                  float sqrt_bc2, float clip) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     float gi = g[i];
-    if (clip > 0.f) { gi = fminf(fmaxf(gi, -clip), clip); g[i] = gi; }   // clamp_ is in place on .grad
+    if (clip > 0.f) gi = fminf(fmaxf(gi, -clip), clip);
+    if (ZERO) g[i] = 0.f;
+    else if (clip > 0.f) g[i] = gi;                                       // clamp_ is in place on .grad
     const float pi = p[i];
     if (wd != 0.f) gi += wd * pi;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
@@ -24,12 +27,14 @@ __global__ void clip_adam_kernel(int64_t n, float* __restrict__ p, float* __rest
 }  // namespace
 
 int xgk_clip_adam(hipStream_t st, int64_t n, float* p, float* g, float* m, float* v, float lr, float b1, float b2,
-                  float eps, float wd, int step, float clip) {
+                  float eps, float wd, int step, float clip, bool zero_grad) {
     if (n <= 0) return XG_OK;
     const double bc1 = 1.0 - pow((double)b1, (double)step);
     const double bc2 = 1.0 - pow((double)b2, (double)step);
-    hipLaunchKernelGGL(clip_adam_kernel, dim3((unsigned)xg_cdiv64(n, 256)), dim3(256), 0, st, n, p, g, m, v, lr, b1, b2,
-                       eps, wd, (float)bc1, (float)sqrt(bc2), clip);
+    if (zero_grad) hipLaunchKernelGGL(clip_adam_kernel<true>, dim3((unsigned)xg_cdiv64(n, 256)), dim3(256), 0, st, n, p, g, m, v,
+                                      lr, b1, b2, eps, wd, (float)bc1, (float)sqrt(bc2), clip);
+    else hipLaunchKernelGGL(clip_adam_kernel<false>, dim3((unsigned)xg_cdiv64(n, 256)), dim3(256), 0, st, n, p, g, m, v, lr, b1,
+                            b2, eps, wd, (float)bc1, (float)sqrt(bc2), clip);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
@@ -38,5 +43,12 @@ extern "C" int xg_clip_adam(void* stream, int64_t n, float* param, float* grad, 
                             float lr, float beta1, float beta2, float eps, float weight_decay, int step, float clip) {
     if (n < 0 || step < 1 || (n > 0 && (!param || !grad || !exp_avg || !exp_avg_sq))) return XG_EINVAL;
     return xgk_clip_adam((hipStream_t)stream, n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay,
-                         step, clip);
+                         step, clip, false);
+}
+
+extern "C" int xg_clip_adam_zero(void* stream, int64_t n, float* param, float* grad, float* exp_avg, float* exp_avg_sq,
+                                 float lr, float beta1, float beta2, float eps, float weight_decay, int step, float clip) {
+    if (n < 0 || step < 1 || (n > 0 && (!param || !grad || !exp_avg || !exp_avg_sq))) return XG_EINVAL;
+    return xgk_clip_adam((hipStream_t)stream, n, param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay,
+                         step, clip, true);
 }

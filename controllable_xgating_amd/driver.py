@@ -178,7 +178,8 @@ class Trainer:
         self.crit, self.classify_crit, self.rl_crit = LanguageModelCriterion(), ClassiferCriterion(), RewardCriterion()
         self.optimizer = ClipAdam(model, lr=opt.learning_rate, weight_decay=getattr(opt, "weight_decay", 0.0),
                                   grad_clip=getattr(opt, "grad_clip", 0.1),
-                                  overlap=getattr(opt, "overlap_update", True) and next(model.parameters()).is_cuda)
+                                  overlap=getattr(opt, "overlap_update", True) and next(model.parameters()).is_cuda,
+                                  fused_zero=getattr(opt, "fused_zero_grad", True))
         self.iteration, self.epoch = 1, 0
         self.sc_flag = False
         self.best_val_score = None

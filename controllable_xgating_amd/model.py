@@ -534,6 +534,7 @@ def _grads_struct(model, device):
     already bound to the model's flat gradient buffer (model.flat_grads()), accumulate there directly
     and hand autograd nothing; otherwise use a fresh zero buffer and return views for autograd."""
     model._ensure_flat()
+    model._grad_writes = getattr(model, "_grad_writes", 0) + 1     # a backward is about to add to the gradient buffer
     if _grads_bound(model):
         if model._gs_cache is None:
             s = nv.XgParams()

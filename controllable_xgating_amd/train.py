@@ -23,15 +23,23 @@ class ClipAdam:
     and the library records when logit.* is final (XgRun.grad_event_head) and when everything but the encoder is
     (XgRun.grad_event): ``arm()`` before ``loss.backward()``, then ``step()`` issues three segment updates, two of them on
     a side stream behind those events.  Same arithmetic, element for element.  In a data-parallel run the segments are
-    updated right behind their all-reduce (train.GradSync.finish)."""
+    updated right behind their all-reduce (train.GradSync.finish).
 
-    def __init__(self, model, lr=4e-4, weight_decay=0.0, grad_clip=0.1, betas=(0.9, 0.999), eps=1e-8, overlap=False):
+    ``fused_zero=True``: the update leaves the gradient buffer at ZERO (xg_clip_adam_zero) instead of clamped, and the
+    ``zero_grad()`` that opens the next iteration (starttrain.py:123) then has nothing to do -- it still clears the buffer
+    if anything wrote to it in between (a backward without a step, an in-place edit of a ``.grad``).  Only the contents of
+    ``.grad`` between ``step()`` and ``zero_grad()`` differ from the reference (clamped values there), which nothing reads."""
+
+    def __init__(self, model, lr=4e-4, weight_decay=0.0, grad_clip=0.1, betas=(0.9, 0.999), eps=1e-8, overlap=False,
+                 fused_zero=False):
         self.model, self.lr, self.wd, self.clip, self.betas, self.eps = model, lr, weight_decay, grad_clip, betas, eps
         flat = model.flat_parameters()
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
         self.step_count = 0
         self.overlap = bool(overlap)
+        self.fused_zero = bool(fused_zero)
+        self._zero_stamp = None                # (model._grad_writes, flat_grads._version) right after a zeroing update
         self._armed = False
         self._segments_done = False
         if self.overlap:
@@ -41,7 +49,12 @@ class ClipAdam:
             self._side = torch.cuda.Stream()
             model._overlap_optimizer = self
 
+    def _grad_stamp(self):
+        return (getattr(self.model, "_grad_writes", 0), self.model.flat_grads()._version)
+
     def zero_grad(self):
+        if self.fused_zero and self._zero_stamp is not None and self._zero_stamp == self._grad_stamp():
+            return                             # the last update left it zero and nothing has written to it since
         self.model.flat_grads().zero_()
 
     def set_lr(self, lr):                      # myutils.set_lr
@@ -63,9 +76,10 @@ class ClipAdam:
         if b <= a:
             return
         flat, g = self.model.flat_parameters(), self.model.flat_grads()
-        nv.check(nv.lib().xg_clip_adam(_stream(), b - a, nv.ptr(flat[a:b]), nv.ptr(g[a:b]), nv.ptr(self.exp_avg[a:b]),
-                                       nv.ptr(self.exp_avg_sq[a:b]), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
-                                       self.step_count, self.clip), "xg_clip_adam")
+        fn = nv.lib().xg_clip_adam_zero if self.fused_zero else nv.lib().xg_clip_adam
+        nv.check(fn(_stream(), b - a, nv.ptr(flat[a:b]), nv.ptr(g[a:b]), nv.ptr(self.exp_avg[a:b]),
+                    nv.ptr(self.exp_avg_sq[a:b]), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                    self.step_count, self.clip), "xg_clip_adam")
 
     def begin_step(self):
         self.step_count += 1
@@ -97,6 +111,7 @@ class ClipAdam:
                 self.model._grad_event_head = None
             self._armed = False
         self.model.mark_params_changed()       # the kernel wrote the flat buffer directly: re-pack the recurrent weights
+        self._zero_stamp = self._grad_stamp() if self.fused_zero else None   # every segment has been updated (and zeroed)
 
     def state_dict(self):
         return dict(exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, step=self.step_count, lr=self.lr)

@@ -292,6 +292,11 @@ int xg_pack_weights(void *stream, const XgDims *d, const XgParams *p, void *pack
 int xg_clip_adam(void *stream, int64_t n, float *param, float *grad, float *exp_avg,
                  float *exp_avg_sq, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int step, float clip);
+/* The same update, but the gradient is left at ZERO instead of clamped: the next iteration's optimizer.zero_grad()
+ * (caption_src/starttrain.py:123) folded into the pass that reads the gradient last -- the clamp already writes it, so
+ * the 144 MB memset at the head of every iteration costs nothing here (train.ClipAdam(fused_zero=True)). */
+int xg_clip_adam_zero(void *stream, int64_t n, float *param, float *grad, float *exp_avg, float *exp_avg_sq, float lr,
+                      float beta1, float beta2, float eps, float weight_decay, int step, float clip);
 
 #ifdef __cplusplus
 }

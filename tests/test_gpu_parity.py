@@ -483,6 +483,49 @@ def test_overlapped_update_equals_plain_update():
         assert float((p0[n] - p1[n]).abs().max()) < 5e-6, n
 
 
+def test_fused_zero_grad_update_equals_plain_update():
+    """ClipAdam(fused_zero=True): the update leaves .grad at zero (xg_clip_adam_zero) and the next zero_grad() is skipped --
+    same parameters as the plain update over three iterations (with and without the overlapped segments); and zero_grad()
+    still clears the buffer when something wrote to it after the update (a backward without a step, an in-place edit)."""
+    from controllable_xgating_amd.train import ClipAdam
+    d = pg.make_dims(**CFG["mid"])
+    x = to_dev(pg.make_inputs(d, seed=0, ragged=True))
+    args = (x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+    out = []
+    for fused, overlap in ((False, False), (True, False), (True, True)):
+        model = make_model(d)
+        opt = ClipAdam(model, lr=4e-4, grad_clip=0.1, overlap=overlap, fused_zero=fused)
+        for _ in range(3):
+            opt.zero_grad()
+            loss = model.xe_loss(*args)
+            opt.arm()
+            loss.backward()
+            opt.step()
+        torch.cuda.synchronize()
+        out.append({n: q.detach().clone() for n, q in model.named_parameters()})
+        g = model.flat_grads()
+        if fused:
+            assert float(g.abs().max()) == 0.0                       # left at zero by the update itself
+            v = g._version
+            opt.zero_grad()
+            assert g._version == v                                     # ... so zero_grad() had nothing to do
+            model.xe_loss(*args).backward()                            # a backward WITHOUT a step
+            assert float(g.abs().max()) > 0.0
+            opt.zero_grad()
+            assert float(g.abs().max()) == 0.0
+            opt.zero_grad(); loss = model.xe_loss(*args); opt.arm(); loss.backward(); opt.step()
+            next(model.parameters()).grad.add_(1.0)                    # an in-place edit of a .grad after the update
+            opt.zero_grad()
+            assert float(g.abs().max()) == 0.0
+        else:
+            assert 0.0 < float(g.abs().max()) <= 0.1 + 1e-7           # the reference leaves the clamped gradient
+    for other in out[1:]:
+        for n in out[0]:
+            if n in ZERO_GRAD_PARAMS:
+                continue
+            assert float((out[0][n] - other[n]).abs().max()) < 5e-6, n
+
+
 # ---------------------------------------------------------------- beam search (SURVEY.md 8f-2)
 @pytest.mark.parametrize("tag", ["tiny", "c1"])
 def test_beam_search_vs_reference_golden(tag):
