@@ -37,7 +37,8 @@
 extern "C" {
 #endif
 
-#define XG_VERSION 200   /* 200: XgRun gained packed/aux/event fields, xg_set_grad_event removed, xg_vproj takes XgRun */
+#define XG_VERSION 201   /* 200: XgRun gained packed/aux/event fields, xg_set_grad_event removed, xg_vproj takes XgRun;
+                            201: + xg_clip_adam_zero */
 
 enum {
     XG_OK = 0,
