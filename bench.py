@@ -27,6 +27,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before the HIP runtime starts (see controllable_xgating_amd/__init__.py)
 import torch  # noqa: E402
 
 
