@@ -391,7 +391,10 @@ def main():
                        "timed_region": ("zero_grad + sampled + greedy rollouts (31 steps, one 2m-row batch) + reward criterion + backward"
                                         if args.workload == "scst" else
                                         "zero_grad + encoder fwd + 21 decoder steps + heads/loss + full backward")
-                                       + (" + RCCL grad all-reduce" if world > 1 else "") + " + clip + Adam"},
+                                       + (" + RCCL grad all-reduce" if world > 1 else "") + " + clip + Adam",
+                       # (zero_grad is fused into the update: train.ClipAdam(fused_zero=True) leaves .grad at zero)
+                       "zero_grad": "fused into the update" if os.environ.get("XG_NO_FUSED_ZERO") is None else "memset",
+                       "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
             "final_loss": round(final_loss, 5),
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                          "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
