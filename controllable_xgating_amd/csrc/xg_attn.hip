@@ -173,21 +173,34 @@ template <int TMAX>
 __global__ void __launch_bounds__(256) attn_dV_reg_kernel(const float* __restrict__ ALPHA, const float* __restrict__ DAF,
                                                             int lddaf, int64_t tstride, float* __restrict__ dV, int T, int B,
                                                             int K, int R, int acc) {
-    extern __shared__ float sal[];          // ALPHA[:, b, :]  (T*K)
     const int b = blockIdx.y;
     const int r = blockIdx.x * 256 + threadIdx.x;
-    for (int i = threadIdx.x; i < T * K; i += 256) sal[i] = ALPHA[((size_t)(i / K) * B + b) * K + (i % K)];
     float d[TMAX];
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) d[t] = (t < T && r < R) ? DAF[(size_t)t * tstride + (size_t)b * lddaf + r] : 0.f;
-    __syncthreads();
     if (r >= R) return;
-    for (int k = 0; k < K; ++k) {
-        float s = 0.f;
+    // alpha[t, b, k] is the same for the whole workgroup: wave-uniform addresses, i.e. scalar loads (eight consecutive frames
+    // per step) and a scalar operand of the fma -- no LDS.  Eight frames at a time; when accumulating, the eight old values
+    // are requested together (a load -> add -> store loop per frame cost a memory round trip each: 87 us for 26 frames)
+    const float* al = ALPHA + (size_t)b * K;
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        float s[8], old[8];
 #pragma unroll
-        for (int t = 0; t < TMAX; ++t) if (t < T) s += sal[t * K + k] * d[t];
-        float* o = dV + ((size_t)b * K + k) * R + r;
-        *o = acc ? *o + s : s;
+        for (int j = 0; j < 8; ++j) {
+            old[j] = acc ? dV[((size_t)b * K + min(k0 + j, K - 1)) * R + r] : 0.f;
+            s[j] = 0.f;
+        }
+#pragma unroll
+        for (int t = 0; t < TMAX; ++t) {
+            if (t < T) {
+                const float* at = al + (size_t)t * B * K;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) s[j] += at[min(k0 + j, K - 1)] * d[t];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+            if (k0 + j < K) dV[((size_t)b * K + k0 + j) * R + r] = old[j] + s[j];
     }
 }
 
@@ -528,9 +541,9 @@ int xgk_attn_bwd_post(hipStream_t st, const float* P, const float* vproj, const 
 }
 int xgk_attn_dV(hipStream_t st, const float* ALPHA, const float* DAF, int lddaf, int64_t daf_tstride, float* dV,
                 int T, int B, int K, int R, bool accumulate) {
-    if (T <= 32 && (size_t)T * K * sizeof(float) <= 60000) {
+    if (T <= 32) {
         const dim3 grid(xg_cdiv(R, 256), B);
-        const size_t lds = (size_t)T * K * sizeof(float);
+        const size_t lds = 0;
         if (T <= 8) hipLaunchKernelGGL((attn_dV_reg_kernel<8>), grid, dim3(256), lds, st, ALPHA, DAF, lddaf, daf_tstride, dV, T, B, K, R, accumulate ? 1 : 0);
         else if (T <= 24) hipLaunchKernelGGL((attn_dV_reg_kernel<24>), grid, dim3(256), lds, st, ALPHA, DAF, lddaf, daf_tstride, dV, T, B, K, R, accumulate ? 1 : 0);
         else hipLaunchKernelGGL((attn_dV_reg_kernel<32>), grid, dim3(256), lds, st, ALPHA, DAF, lddaf, daf_tstride, dV, T, B, K, R, accumulate ? 1 : 0);

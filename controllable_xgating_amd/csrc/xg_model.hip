@@ -946,9 +946,10 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     hipStream_t sx = ss.aux;                  // parameter gradients that only need chain 2
     // ---- after the loop.  Main chain (the encoder backward waits for it): dVproj -> dV.  Everything else is a
     // parameter gradient and goes to the auxiliary stream, under the encoder's recurrent backward.
+    // (dV first, as a plain store: accumulating on top of the product below it would read every element back)
+    XG_TRY(xgk_attn_dV(st, w.ALPHA, w.DAF, R, (int64_t)BR, w.DV, T, B, K, R, false));
     XG_TRY(xgk_attn_bwd_post(st, w.P, w.vproj, p.a2w_w, w.DE, w.DVPROJ, g.a2w_w, T, B, K, A));
-    XG_TRY(gemm_nn(st, w.gm, N, R, A, w.DVPROJ, A, p.v2a_w, R, w.DV, R, false));
-    XG_TRY(xgk_attn_dV(st, w.ALPHA, w.DAF, R, (int64_t)BR, w.DV, T, B, K, R, true));
+    XG_TRY(gemm_nn(st, w.gm, N, R, A, w.DVPROJ, A, p.v2a_w, R, w.DV, R, true));
     // gradients wrt the initial state -> img_embed_* (init_hidden; vbar is detached: SAModel.py:59-62)
     {
         float* gst[4] = {w.dst[cur1][0], w.dst[cur1][1], w.dst[cur2][2], w.dst[cur2][3]};
