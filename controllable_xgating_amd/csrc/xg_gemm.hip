@@ -564,7 +564,8 @@ int launch_pk(hipStream_t st, const GemmArgs& a) {
     // 120 us instead of 53 beside dW_logit.  One workgroup per CU leaves 256 VGPRs per SIMD and 78 KB of LDS, exactly one
     // 8-wave (or two 4-wave) skinny workgroups, and costs the product itself ~10 %.
     static const int bg_off = getenv("XG_GEMM_NO_BG") ? 1 : 0;
-    const bool bg = a.bg && !bg_off;
+    static const int bg_all = getenv("XG_GEMM_FORCE_BG") ? 1 : 0;     // tests: every product takes the background form
+    const bool bg = (a.bg || bg_all) && !bg_off;
     const int GMAX = env_g > 0 ? env_g : (bg ? 256 : 512);
     int G;
     const bool split = !a.relu && g.nslab >= 2 && env_split;

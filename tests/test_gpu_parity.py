@@ -108,15 +108,18 @@ sys.exit(1 if bad else 0)
 """
 
 
-@pytest.mark.parametrize("pk_min", ["2", "40"])
-def test_gemm_fuzz_all_kernels(pk_min):
+@pytest.mark.parametrize("pk_min,bg", [("2", False), ("40", False), ("2", True)])
+def test_gemm_fuzz_all_kernels(pk_min, bg):
     """36 seeded random products (ragged extents, all four layouts, bias / ReLU / += C, fp32 / bf16 / split-bf16) against fp64,
     once with the persistent stream-K kernel forced onto every shape that can take it (XG_PK_MIN=2: read at first use, hence
-    the subprocess) and once with the production rule."""
+    the subprocess), once with the production rule, and once with the persistent kernel in its background form (one
+    workgroup per CU: 256-workgroup grid, padded LDS -- what the side-stream vocabulary products of a training step use)."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, XG_PK_MIN=pk_min)
+    if bg:
+        env["XG_GEMM_FORCE_BG"] = "1"
     r = subprocess.run([sys.executable, "-c", _GEMM_FUZZ % root], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
