@@ -882,6 +882,35 @@ def test_repeated_iterations_are_reproducible_across_streams():
                 assert err <= 1e-5 * np.abs(ref[kind][1]).max() + 1e-8, (kind, rep, float(err))
 
 
+def test_single_stream_path_equals_multi_stream_path():
+    """XgRun.aux = NULL (everything on the caller's stream: no side streams, no background products, no zero block on a side
+    stream) against the default three-stream schedule: same loss, same gradients after an XE backward and after a rollout
+    backward on top of it."""
+    d = pg.make_dims(**CFG["mid"])
+    x = to_dev(pg.make_inputs(d, seed=0, ragged=True))
+    args = (x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+    u = torch.from_numpy(pg.uniform("uni_ss", (d.L + 1, d.B), 5)).cuda()
+    outs = []
+    for single in (False, True):
+        m = make_model(d)
+        if single:
+            m._aux_handle = lambda: None
+        m.flat_grads().zero_()
+        loss = m.xe_loss(*args)
+        loss.backward()
+        torch.cuda.synchronize()
+        g_xe = m.flat_grads().detach().cpu().numpy().copy()
+        gen, slp, greedy, n = m.sample_pair(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"uniforms": u})
+        slp.sum().backward()
+        torch.cuda.synchronize()
+        outs.append((float(loss.detach()), g_xe, m.flat_grads().detach().cpu().numpy().copy(), gen.cpu().numpy()))
+    (l0, a0, b0, s0), (l1, a1, b1, s1) = outs
+    assert abs(l0 - l1) < 5e-6 * max(1.0, abs(l0))
+    assert np.array_equal(s0, s1)
+    assert np.abs(a0 - a1).max() <= 1e-5 * np.abs(a0).max() + 1e-8
+    assert np.abs(b0 - b1).max() <= 1e-5 * np.abs(b0).max() + 1e-8
+
+
 def _fuzz_dims(i):
     """Seeded random extents that hit the kernel-selection edges: R % 8 / % 4 (skinny vs generic cells, fused LSTM
     backward), A % 4 and A > 1024 (attention variants), K > 32 (16 V rows per thread) and K > 64 (serial softmax),
