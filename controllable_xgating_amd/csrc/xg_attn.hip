@@ -218,15 +218,18 @@ __device__ long long attn_trace_buf[1024 * 8];
 #define AT_STAMP(i) do {} while (0)
 #endif
 
-template <int NI, int VMAX>      // NI: 256-column groups of A per lane; VMAX: V rows held per thread (K <= VMAX * nkp)
-__global__ void __launch_bounds__(FT) attn_fwd_fast(const float* __restrict__ p, const float* __restrict__ vproj,
-                                                     const float* __restrict__ V, const float* __restrict__ w,
-                                                     float* __restrict__ alpha, float* __restrict__ af, int K, int R, int A) {
-    extern __shared__ float sm[];                     // e[K] | part[nkp][R]
+// HALF: the same kernel at <= 64 VGPRs (8 waves per SIMD), so that its 16 waves fit into the half of a CU a background GEMM
+// workgroup leaves free (xg_gemm.hip: XGK_GEMM_BG) -- the 128-VGPR form needs an EMPTY CU.  Two waves share a frame, each
+// taking half of the column groups (half the p / w / q registers); their partial scores meet in LDS.
+template <int NI, int VMAX, bool HALF>      // NI: 256-column groups of A per lane; VMAX: V rows held per thread (K <= VMAX * nkp)
+__global__ void __launch_bounds__(FT) __attribute__((amdgpu_waves_per_eu(HALF ? 8 : 4, HALF ? 8 : 4)))
+attn_fwd_fast(const float* __restrict__ p, const float* __restrict__ vproj, const float* __restrict__ V,
+              const float* __restrict__ w, float* __restrict__ alpha, float* __restrict__ af, int K, int R, int A) {
+    extern __shared__ float sm[];                     // e[K] (HALF: two partials) | part[nkp][R]
     XG_CHAIN_PRIO();
     AT_STAMP(0);
     float* se = sm;
-    float* part = sm + ((K + 3) & ~3);
+    float* part = sm + (HALF ? 2 : 1) * ((K + 3) & ~3);
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float* pb = p + (size_t)b * A;
     const float* qb = vproj + (size_t)b * K * A;
@@ -240,30 +243,32 @@ __global__ void __launch_bounds__(FT) attn_fwd_fast(const float* __restrict__ p,
         const int k = mykp + j * nkp;
         vreg[j] = (mykp < nkp && k < K) ? *reinterpret_cast<const float4*>(Vb + (size_t)k * R + myr) : make_float4(0, 0, 0, 0);
     }
-    float4 pr[NI], wr[NI];
+    constexpr int NIW = HALF ? NI / 2 : NI;           // column groups per wave
+    const int g0 = HALF ? (wave & 1) * NIW : 0;       // ... starting at
+    float4 pr[NIW], wr[NIW];
 #pragma unroll
-    for (int i = 0; i < NI; ++i) {
-        const int a = lane * 4 + 256 * i;
+    for (int i = 0; i < NIW; ++i) {
+        const int a = lane * 4 + 256 * (g0 + i);
         const bool ok = a < A;
         pr[i] = ok ? *reinterpret_cast<const float4*>(pb + a) : make_float4(0, 0, 0, 0);
         wr[i] = ok ? *reinterpret_cast<const float4*>(w + a) : make_float4(0, 0, 0, 0);
     }
     AT_STAMP(1);
-    for (int k = wave; k < K; k += FW) {
+    for (int k = HALF ? (wave >> 1) : wave; k < K; k += HALF ? FW / 2 : FW) {
         const float* qk = qb + (size_t)k * A;
-        float4 q[NI];
+        float4 q[NIW];
 #pragma unroll
-        for (int i = 0; i < NI; ++i) {
-            const int a = lane * 4 + 256 * i;
+        for (int i = 0; i < NIW; ++i) {
+            const int a = lane * 4 + 256 * (g0 + i);
             q[i] = a < A ? *reinterpret_cast<const float4*>(qk + a) : make_float4(0, 0, 0, 0);
         }
         float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < NI; ++i)
+        for (int i = 0; i < NIW; ++i)
             acc += wr[i].x * xg_tanh(pr[i].x + q[i].x) + wr[i].y * xg_tanh(pr[i].y + q[i].y) +
                    wr[i].z * xg_tanh(pr[i].z + q[i].z) + wr[i].w * xg_tanh(pr[i].w + q[i].w);
         acc = wave_sum(acc);
-        if (lane == 0) se[k] = acc;
+        if (lane == 0) se[(HALF ? (wave & 1) * ((K + 3) & ~3) : 0) + k] = acc;
     }
     AT_STAMP(2);
     __syncthreads();
@@ -271,7 +276,7 @@ __global__ void __launch_bounds__(FT) attn_fwd_fast(const float* __restrict__ p,
     float4 s4 = make_float4(0, 0, 0, 0);
     if (K <= 64) {
         // softmax over the K scores, once per wave with lane k holding e_k (not K serial expf per thread)
-        const float e = lane < K ? se[lane] : -INFINITY;
+        const float e = lane < K ? (HALF ? se[lane] + se[((K + 3) & ~3) + lane] : se[lane]) : -INFINITY;
         const float mx = wave_max(e);
         const float ex = lane < K ? expf(e - mx) : 0.f;
         const float al_lane = ex * (1.0f / wave_sum(ex));
@@ -466,18 +471,24 @@ __global__ void __launch_bounds__(512, (NQ <= 32 ? 4 : 2)) attn_bwd_split(const 
 }  // namespace
 
 int xgk_attn_fwd(hipStream_t st, const float* p, const float* vproj, const float* V, const float* w, float* alpha,
-                 float* af, int B, int K, int R, int A) {
+                 float* af, int B, int K, int R, int A, bool half_cu) {
     if (K > 8192) return XG_EINVAL;
     const bool al16 = ((uintptr_t)p % 16 == 0) && ((uintptr_t)vproj % 16 == 0) && ((uintptr_t)V % 16 == 0) && ((uintptr_t)w % 16 == 0);
     if (al16 && A % 4 == 0 && A <= 2048 && R % 4 == 0 && R <= 4 * FT && R >= 4) {
         const int r4n = R / 4;
         const int nkp = FT / r4n > 0 ? (FT / r4n < K ? FT / r4n : K) : 1;
         if (K <= 16 * nkp) {
-            const size_t lds = (size_t)(((K + 3) & ~3) + (size_t)nkp * R) * sizeof(float);
+            const int ni = (A + 255) / 256;
+            // the half-CU form: <= 64 frames (one softmax per wave), <= 4 V rows per thread, column groups in pairs
+            const bool half = half_cu && K <= 64 && K <= 4 * nkp;
+            const size_t lds = (size_t)((half ? 2 : 1) * ((K + 3) & ~3) + (size_t)nkp * R) * sizeof(float);
             if (lds <= 60000) {
-                const int ni = (A + 255) / 256;
-#define XG_ATTN_LAUNCH(NI_, VM_) hipLaunchKernelGGL((attn_fwd_fast<NI_, VM_>), dim3(B), dim3(FT), lds, st, p, vproj, V, w, alpha, af, K, R, A)
-                if (K <= 8 * nkp) {
+#define XG_ATTN_LAUNCH(NI_, VM_) hipLaunchKernelGGL((attn_fwd_fast<NI_, VM_, false>), dim3(B), dim3(FT), lds, st, p, vproj, V, w, alpha, af, K, R, A)
+#define XG_ATTN_LAUNCH_H(NI_) hipLaunchKernelGGL((attn_fwd_fast<NI_, 4, true>), dim3(B), dim3(FT), lds, st, p, vproj, V, w, alpha, af, K, R, A)
+                if (half) {
+                    if (ni <= 2) XG_ATTN_LAUNCH_H(2); else if (ni <= 4) XG_ATTN_LAUNCH_H(4);
+                    else if (ni <= 6) XG_ATTN_LAUNCH_H(6); else XG_ATTN_LAUNCH_H(8);
+                } else if (K <= 8 * nkp) {
                     if (ni <= 2) XG_ATTN_LAUNCH(2, 8); else if (ni <= 4) XG_ATTN_LAUNCH(4, 8);
                     else if (ni <= 6) XG_ATTN_LAUNCH(6, 8); else XG_ATTN_LAUNCH(8, 8);
                 } else {                              // e.g. hidden 1024 (4 row parts) x 40 frames
@@ -485,6 +496,7 @@ int xgk_attn_fwd(hipStream_t st, const float* p, const float* vproj, const float
                     else if (ni <= 6) XG_ATTN_LAUNCH(6, 16); else XG_ATTN_LAUNCH(8, 16);
                 }
 #undef XG_ATTN_LAUNCH
+#undef XG_ATTN_LAUNCH_H
                 XG_CHECK_LAUNCH();
                 return XG_OK;
             }

@@ -186,7 +186,7 @@ bool xgk_packed_view(const XgDims& d, const void* packed, int dtype, PackedView*
 // ---- xg_attn.hip
 // per-sample additive attention: e_k = w . tanh(p + q_k), alpha = softmax_k(e), af = sum_k alpha_k V_k
 int xgk_attn_fwd(hipStream_t st, const float* p, const float* vproj, const float* V, const float* w, float* alpha,
-                 float* af, int B, int K, int R, int A);
+                 float* af, int B, int K, int R, int A, bool half_cu = false);   // half_cu: <= 64 VGPRs, fits beside a background GEMM workgroup
 // de[b][k], dp[b][a] from daf[b][r]
 int xgk_attn_bwd(hipStream_t st, const float* daf, int lddaf, const float* p, const float* vproj, const float* V,
                  const float* w, const float* alpha, float* de, float* dp, int B, int K, int R, int A);

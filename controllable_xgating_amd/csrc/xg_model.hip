@@ -501,6 +501,7 @@ struct StepIO {
     float *h1o, *c1o, *h2o, *c2o;     // new state (may alias the previous state on the packed path: see core_step)
     float *P, *alpha, *af, *g1, *g2;  // saved per-step tensors (alpha / gates may be scratch)
     int t;
+    bool half_attn;       // stand-alone attention in its half-CU form (a background product runs beside the steps)
 };
 
 // the packed-weight form of the step needs 16-byte rows everywhere (R % 8 covers R; E and A are checked here)
@@ -619,7 +620,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         if (!s2_first && !s2_in_cell2) s2_job(k2.job[n2++]);
         k2.njobs = n2;
         if (n2 > 0) XG_TRY(xgk_skinny(st, k2, w.gm));
-        if (!fused_attn) XG_TRY(xgk_attn_fwd(st, s.P, vproj, V, p.a2w_w, s.alpha, s.af, B, d.K, R, A));
+        if (!fused_attn) XG_TRY(xgk_attn_fwd(st, s.P, vproj, V, p.a2w_w, s.alpha, s.af, B, d.K, R, A, s.half_attn));
         // ---- launch 3: cell 2 = h1' W_i2h + af W_a2h + S2'                                                :684
         if (!s2_in_cell2) { c.add = w.S2; c.ldadd = 4 * R; }
         {
@@ -736,6 +737,10 @@ int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatc
     XG_TRY(init_and_vproj(ss, d, p, x.feat_mask, w));
     XG_TRY(ss.join());                                                                              // token-side products
     const int th = (ss.overlap() && T >= 4) ? T / 2 : 0;
+    // ... as a background product, with the stand-alone attention in its half-CU form beside it: the 128-VGPR attention
+    // needs an EMPTY CU and waited for the whole persistent product (255 us: the chain simply stopped).  6.16 -> 6.10 ms.
+    static const int fwd_bg_env = getenv("XG_FWD_BG") ? atoi(getenv("XG_FWD_BG")) : 1;
+    const bool fwd_bg = fwd_bg_env && th > 0 && w.gm == 0;
     *logit_rows_done = 0;
     for (int t = 0; t < T; ++t) {
         StepIO s{};
@@ -745,12 +750,11 @@ int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatc
         s.h1o = w.H1 + (t + 1) * BR; s.c1o = w.C1 + (t + 1) * BR; s.h2o = w.H2 + (t + 1) * BR; s.c2o = w.C2 + (t + 1) * BR;
         s.P = w.P + (size_t)t * B * A; s.alpha = w.ALPHA + (size_t)t * B * d.K; s.af = w.AF + t * BR;
         s.g1 = w.G1 + (size_t)t * B * 4 * R; s.g2 = w.G2 + (size_t)t * B * 4 * R; s.t = t;
+        s.half_attn = fwd_bg;
         XG_TRY(core_step(st, d, p, run, w, w.Venc, w.vproj, s));
         if (th > 0 && t == th - 1) {
             XG_TRY(ss.fork());
-            // (not a background product: measured with the half-CU attention form beside it, 6.25 vs 6.22 ms -- the forward
-            //  steps are 8-wave launches that fill a CU's register file with or without it)
-            XG_TRY(xgk_linear(ss.aux, w.gm, th * B, d.V, R, w.H2 + BR, R, p.logit_w, p.logit_b, w.LOGITS, d.V));
+            XG_TRY(xgk_linear(ss.aux, w.gm | (fwd_bg ? XGK_GEMM_BG : 0), th * B, d.V, R, w.H2 + BR, R, p.logit_w, p.logit_b, w.LOGITS, d.V));
             *logit_rows_done = th * B;
             if (early_loss)
                 XG_TRY(xgk_xent_fwd(ss.aux, w.LOGITS, d.V, x.seq, x.seq_mask, nullptr, B, T, d.V, 1, w.LSE, w.sums, 0, th * B, false));
