@@ -400,7 +400,7 @@ __global__ void __launch_bounds__(FT) attn_bwd_fast(const float* __restrict__ da
 // attention columns are halved between two CUs; both compute the K dalpha dot products (V is read twice: 53 KB per video)
 // and the softmax backward redundantly, part 0 writes de.  K <= NQ <= 48, A / 2 even and <= 1024.
 template <int NQ>
-__global__ void __launch_bounds__(512, (NQ <= 32 ? 4 : 2)) attn_bwd_split(const float* __restrict__ daf, int lddaf, const float* __restrict__ p,
+__global__ void __launch_bounds__(512, 4) attn_bwd_split(const float* __restrict__ daf, int lddaf, const float* __restrict__ p,
                                                       const float* __restrict__ vproj, const float* __restrict__ V,
                                                       const float* __restrict__ w, const float* __restrict__ alpha,
                                                       float* __restrict__ de, float* __restrict__ dp, int K, int R, int A) {
@@ -468,6 +468,86 @@ __global__ void __launch_bounds__(512, (NQ <= 32 ? 4 : 2)) attn_bwd_split(const 
     }
 }
 
+// The two-workgroup backward for 33..48 frames at <= 128 VGPRs (the form above needs 221 there: two waves per SIMD, i.e. an
+// all but empty CU, and waited 140 us per step beside the bf16 head products of the hidden-1024 configuration).  Same
+// arithmetic; the operands arrive in stages instead of all up front: the V rows of the dalpha dots three at a time, the q rows
+// in three thirds, each third requested while the previous one is consumed.  Also faster alone (median 21.6 vs 27.2 us per
+// step in situ: four waves per SIMD hide the staged loads); hidden-1024 iteration 8.35 -> 8.20 ms.
+template <int NQ>
+__global__ void __launch_bounds__(512, 4) attn_bwd_split_lr(const float* __restrict__ daf, int lddaf, const float* __restrict__ p,
+                                                            const float* __restrict__ vproj, const float* __restrict__ V,
+                                                            const float* __restrict__ w, const float* __restrict__ alpha,
+                                                            float* __restrict__ de, float* __restrict__ dp, int K, int R, int A) {
+    extern __shared__ float sm[];                     // dalpha[K]
+    XG_CHAIN_PRIO();
+    constexpr int NWV = 8, DC = 4, DR = (NQ + NWV - 1) / NWV, DB = 3, NT = (NQ + 2) / 3;
+    const int b = blockIdx.x >> 1, part = blockIdx.x & 1, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* qb = vproj + (size_t)b * K * A;
+    const float* Vb = V + (size_t)b * K * R;
+    const float* dafb = daf + (size_t)b * lddaf;
+    const int ah = A >> 1;
+    const int a0 = part * ah + tid * 2;
+    const bool a_ok = tid * 2 < ah;
+    float4 dv[DC];
+#pragma unroll
+    for (int c = 0; c < DC; ++c) {
+        const int r = lane * 4 + 256 * c;
+        dv[c] = r < R ? *reinterpret_cast<const float4*>(dafb + r) : make_float4(0, 0, 0, 0);
+    }
+    float2 qa[NT], qc[NT];                            // two thirds in flight at most
+#pragma unroll
+    for (int k = 0; k < NT; ++k) qa[k] = (a_ok && k < K) ? *reinterpret_cast<const float2*>(qb + (size_t)k * A + a0) : make_float2(0, 0);
+    const float al_lane = lane < K ? alpha[(size_t)b * K + lane] : 0.f;
+    const float2 pa = a_ok ? *reinterpret_cast<const float2*>(p + (size_t)b * A + a0) : make_float2(0, 0);
+    const float2 wa = a_ok ? *reinterpret_cast<const float2*>(w + a0) : make_float2(0, 0);
+#pragma unroll
+    for (int j0 = 0; j0 < DR; j0 += DB) {             // dalpha_k = daf . V_k, this wave's rows k = wave + 8 j
+        float4 vv[DB][DC];
+#pragma unroll
+        for (int jj = 0; jj < DB; ++jj)
+#pragma unroll
+            for (int c = 0; c < DC; ++c) {
+                const int r = lane * 4 + 256 * c, k = wave + (j0 + jj) * NWV;
+                vv[jj][c] = (j0 + jj < DR && r < R && k < K) ? *reinterpret_cast<const float4*>(Vb + (size_t)k * R + r) : make_float4(0, 0, 0, 0);
+            }
+#pragma unroll
+        for (int jj = 0; jj < DB; ++jj) {
+            const int k = wave + (j0 + jj) * NWV;
+            float acc = 0.f;
+#pragma unroll
+            for (int c = 0; c < DC; ++c)
+                acc += dv[c].x * vv[jj][c].x + dv[c].y * vv[jj][c].y + dv[c].z * vv[jj][c].z + dv[c].w * vv[jj][c].w;
+            acc = wave_sum(acc);
+            if (lane == 0 && j0 + jj < DR && k < K) sm[k] = acc;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NT; ++k) qc[k] = (a_ok && NT + k < K) ? *reinterpret_cast<const float2*>(qb + (size_t)(NT + k) * A + a0) : make_float2(0, 0);
+    __syncthreads();
+    const float da = lane < K ? sm[lane] : 0.f;
+    const float dot = wave_sum(al_lane * da);
+    const float d_lane = al_lane * (da - dot);
+    if (part == 0 && wave == 0 && lane < K) de[(size_t)b * K + lane] = d_lane;
+    float sx = 0.f, sy = 0.f;
+    auto third = [&](const float2 (&q)[NT], int k0) {
+#pragma unroll
+        for (int k = 0; k < NT; ++k) {
+            if (k0 + k < K) {
+                const float dk = xg_readlane(d_lane, k0 + k);
+                const float tx = xg_tanh(pa.x + q[k].x), ty = xg_tanh(pa.y + q[k].y);
+                sx += dk * (1.0f - tx * tx);
+                sy += dk * (1.0f - ty * ty);
+            }
+        }
+    };
+    third(qa, 0);
+#pragma unroll
+    for (int k = 0; k < NT; ++k) qa[k] = (a_ok && 2 * NT + k < K) ? *reinterpret_cast<const float2*>(qb + (size_t)(2 * NT + k) * A + a0) : make_float2(0, 0);
+    third(qc, NT);
+    third(qa, 2 * NT);
+    if (a_ok) *reinterpret_cast<float2*>(dp + (size_t)b * A + a0) = make_float2(sx * wa.x, sy * wa.y);
+}
+
 }  // namespace
 
 int xgk_attn_fwd(hipStream_t st, const float* p, const float* vproj, const float* V, const float* w, float* alpha,
@@ -514,14 +594,14 @@ int xgk_attn_bwd(hipStream_t st, const float* daf, int lddaf, const float* p, co
     // two 512-thread workgroups per video whenever the shapes allow: up to 32 frames they hold <= 128 VGPRs, i.e. one of
     // them fits into the half of a CU a background GEMM workgroup leaves free (xg_gemm.hip: XGK_GEMM_BG) -- the
     // one-workgroup form (1024 threads x 125 VGPRs) needs an EMPTY CU and waited for one for up to 240 us per step beside
-    // dW_logit.  For 33-48 frames the one-workgroup form would spill (48 frames of q per thread under its 128-VGPR cap).
+    // dW_logit.  For 33-48 frames: the staged form attn_bwd_split_lr (the one-workgroup form would spill there).
     // XG_ATTN_BWD_ONE=1 selects the one-workgroup form for comparison.
     static const int one_wg = getenv("XG_ATTN_BWD_ONE") ? 1 : 0;
     if (!one_wg && al16 && A % 4 == 0 && A <= 2048 && R % 4 == 0 && R <= 1024 && lddaf % 4 == 0 && K <= 48) {
         const size_t lds = (size_t)K * sizeof(float);
         if (K <= 16) hipLaunchKernelGGL((attn_bwd_split<16>), dim3(2 * B), dim3(512), lds, st, daf, lddaf, p, vproj, V, w, alpha, de, dp, K, R, A);
         else if (K <= 32) hipLaunchKernelGGL((attn_bwd_split<32>), dim3(2 * B), dim3(512), lds, st, daf, lddaf, p, vproj, V, w, alpha, de, dp, K, R, A);
-        else hipLaunchKernelGGL((attn_bwd_split<48>), dim3(2 * B), dim3(512), lds, st, daf, lddaf, p, vproj, V, w, alpha, de, dp, K, R, A);
+        else hipLaunchKernelGGL((attn_bwd_split_lr<48>), dim3(2 * B), dim3(512), lds, st, daf, lddaf, p, vproj, V, w, alpha, de, dp, K, R, A);
         XG_CHECK_LAUNCH();
         return XG_OK;
     }

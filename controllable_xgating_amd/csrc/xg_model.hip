@@ -1023,7 +1023,7 @@ int heads_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams& g
     XG_TRY(gemm_nn(st, w.gm, rows - r0, R, d.V, w.LOGITS + (size_t)r0 * d.V, d.V, p.logit_w, R, w.DH2OUT + (size_t)r0 * R, R, false));
     // everything below runs BESIDE the reverse-time loop: behind the product above (which the loop waits for and which
     // therefore gets the whole chip), and as background products (XGK_GEMM_BG: half of every CU stays free for the loop)
-    const int bgm = w.gm | (ss.overlap() && d.K <= 32 ? XGK_GEMM_BG : 0);
+    const int bgm = w.gm | (ss.overlap() && d.K <= 48 ? XGK_GEMM_BG : 0);   // (the attention backward is a half-CU kernel up to 48 frames)
     XG_TRY(ss.fork());
     if (th > 0) {
         XG_TRY(gemm_nn(ss.aux, bgm, r0, R, d.V, w.LOGITS, d.V, p.logit_w, R, w.DH2OUT, R, false));
