@@ -775,7 +775,7 @@ extern "C" int xg_debug_sk_trace(long long* out, int n) {
 int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
     if (a.njobs <= 0 || a.njobs > SK_MAX_JOBS) return XG_EINVAL;
     bool vec = true, generic = false, packed = true, special = false, has_attn = false;
-    int tiles = 0, max_tiles = 0;
+    int tiles = 0, max_tiles = 0, max_k = 0;
     for (int j = 0; j < a.njobs; ++j) {
         SkJob& jb = a.job[j];
         const bool no_segs = jb.epi == SK_EPI_ZERO || jb.epi == SK_EPI_ATTN || jb.epi == SK_EPI_COPY;
@@ -815,6 +815,7 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         for (int s = 0; s < jb.nseg; ++s) {
             SkSeg& sg = jb.seg[s];
             if (!sg.A || !sg.B || sg.K <= 0) return XG_EINVAL;
+            max_k = sg.K > max_k ? sg.K : max_k;
             packed = packed && sg.Bp && sg.nck == xg_cdiv(sg.K, 32);
             if (sg.row_scale && (!sg.Bp || sg.gather || (sg.scaled_out && (sg.ld_out != sg.lda || ((uintptr_t)sg.scaled_out % 16))))) return XG_EINVAL;
             if (sg.gather && !sg.Bp) return XG_EINVAL;        // the row gather exists on the packed path only
@@ -862,7 +863,10 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         // round as 8-wave workgroups (<= 512: batches of <= 64 rows) the products keep their 8-way K split and the attention
         // runs on the first four waves of its workgroups (36.7 vs 38.6 us per step at 64 rows); beyond that 4-wave workgroups
         // for all, which are all resident (49.4 vs 52.5 us at 128 rows).
-        const bool nw4 = ks > 1 || (force_nw ? force_nw == 4 : (has_attn ? tiles > 2 * 256 : tiles > 2 * 256));
+        // (bf16 tiles, hidden 1024: 4-wave workgroups throughout -- half the register footprint per workgroup is easier to place
+        //  beside the bf16 GEMMs of the other streams: 8.20 -> 8.14 ms; at hidden 512 the rule above stands: fp32 6.08 vs 6.09,
+        //  bf16 4.59 vs 4.66 ms)
+        const bool nw4 = ks > 1 || (force_nw ? force_nw == 4 : ((bf16 && max_k >= 1024) || tiles > 2 * 256));
         const dim3 grid((max_tiles + 7) & ~7, a.njobs);
         bool scaled = false;
         for (int j = 0; j < a.njobs; ++j)
