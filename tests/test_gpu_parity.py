@@ -972,7 +972,11 @@ def test_fuzzed_extents_xe_and_greedy_vs_oracle(i):
     dict(B=4, K=6, R=16, A=24, E=12, V=50, C=4, L=36, F1=8, F2=8, H=128),
     # 25..32 steps: the 32-step forms
     dict(B=4, K=6, R=16, A=24, E=12, V=50, C=4, L=27, F1=8, F2=8, H=128),
-], ids=["V8192", "V24004", "V33000", "T37", "T28"])
+    # attention widths that select the 4- and 8-group forms of the half-CU forward attention (xg_attn.hip: attn_fwd_fast<.., HALF>,
+    # used beside the background vocabulary product of the teacher-forced forward) and the matching backward forms
+    dict(B=3, K=9, R=16, A=1024, E=12, V=64, C=4, L=6, F1=8, F2=8, H=128),
+    dict(B=2, K=34, R=16, A=2048, E=12, V=64, C=4, L=6, F1=8, F2=8, H=128),
+], ids=["V8192", "V24004", "V33000", "T37", "T28", "A1024", "A2048K34"])
 def test_kernel_variant_edges_xe_vs_oracle(cfg):
     d = pg.make_dims(**cfg)
     P, lo, co, lxe_o, lcls_o, running = run_oracle_xe(d, True, p=0.0, seed=0)
