@@ -27,7 +27,7 @@ import time
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # before the HIP runtime starts (see controllable_xgating_amd/__init__.py)
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")     # launcher duty, before the HIP runtime starts (see controllable_xgating_amd/__init__.py)
 import torch  # noqa: E402
 
 
@@ -143,14 +143,16 @@ def cpu_baseline(cfg, budget_s=20.0, hip_model=None, hip_x=None):
     """Oracle (port of the reference's CPU path; reference-faithful: v2a(V) recomputed every step).
     Timed at two thread counts (all host cores, and 8 like SURVEY.md's anchors); the faster one is `value`.
     With `hip_model` the leg is also the run's parity check: the HIP model takes the oracle's procedural weights and its
-    XE loss on the very same batch is compared with the oracle's (`parity` in the result)."""
+    XE loss on the very same batch is compared with the oracle's (`parity` in the result).
+    budget_s <= 0 (the secondary lines): ONE forward + backward at 8 threads, no warm-up -- the parity check plus a
+    one-iteration rate."""
     from oracle import paramgen as pg
     d = pg.make_dims(B=cfg["B"], K=cfg["K"], R=cfg["R"], A=cfg["A"], E=cfg["E"], V=cfg["V"], C=cfg["C"], L=cfg["L"],
                      F1=cfg["F1"], F2=cfg["F2"])
     Pn = pg.make_params(d)
     ncores = torch.get_num_threads()
     res = []
-    for nt in sorted({min(8, ncores), ncores}):
+    for nt in (sorted({min(8, ncores), ncores}) if budget_s > 0 else [min(8, ncores)]):
         torch.set_num_threads(nt)
         res.append(_cpu_baseline_once(cfg, d, Pn, budget_s / 2))
     torch.set_num_threads(ncores)
@@ -185,17 +187,310 @@ def _cpu_baseline_once(cfg, d, Pn, budget_s):
         loss.backward()
         return float(loss.item())
     t0 = time.time(); loss0 = it(); warm = time.time() - t0
+    T = cfg["L"] + 1
+    if budget_s <= 0:                            # the one iteration is the sample
+        return dict(value=round(cfg["B"] * T / warm, 1), unit="decoder timesteps/s", cores=torch.get_num_threads(), kind="port",
+                    sample="1 full XE fwd+bwd iteration of the same workload (B=%d, K=%d, R=%d, T=%d, V=%d), no warm-up; oracle with "
+                           "v2a(V) recomputed per step like the reference" % (cfg["B"], cfg["K"], cfg["R"], T, cfg["V"]),
+                    ms_per_step=round(warm * 1e3, 1), loss=loss0)
     n, t0 = 0, time.time()
     while True:
         it(); n += 1
         if time.time() - t0 > budget_s or n >= 4:
             break
     dt = (time.time() - t0) / n
-    T = cfg["L"] + 1
     return dict(value=round(cfg["B"] * T / dt, 1), unit="decoder timesteps/s", cores=torch.get_num_threads(), kind="port",
                 sample="%d full XE fwd+bwd iterations of the same workload (B=%d, T=%d, V=%d) after 1 warm-up (%.1f s); "
                        "oracle with v2a(V) recomputed per step like the reference" % (n, cfg["B"], T, cfg["V"], warm),
                 ms_per_step=round(dt * 1e3, 1), loss=loss0)
+
+
+def rccl_debug_setup(rank):
+    """Ask RCCL for its INIT log in a private file (unless the user already directs NCCL_DEBUG somewhere) so that the channel
+    count of the communicator can be reported with the scaling line."""
+    if "NCCL_DEBUG" in os.environ:
+        return None
+    path = "/tmp/xg_rccl_%d_%d.log" % (os.getpid(), rank)
+    os.environ.update(NCCL_DEBUG="INFO", NCCL_DEBUG_SUBSYS="INIT", NCCL_DEBUG_FILE=path)
+    return path
+
+
+def rccl_channels(path):
+    """{"coll": c, "p2p": p, ...} parsed from RCCL's INIT log ('N coll channels, ... M p2p channels'), or None."""
+    import re
+    try:
+        txt = open(path, errors="replace").read()
+    except Exception:
+        return None
+    m = re.findall(r"(\d+) coll channels, (\d+) collnet channels, (\d+) nvls channels, (\d+) p2p channels", txt)
+    if not m:
+        return None
+    c = m[-1]
+    return {"coll": int(c[0]), "collnet": int(c[1]), "nvls": int(c[2]), "p2p": int(c[3]),
+            "env": {k: os.environ[k] for k in ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "NCCL_NCHANNELS_PER_PEER") if k in os.environ}}
+
+
+def scst_parity(model, cfg, x, reward_b):
+    """SCST leg of the self-check: the HIP model takes the oracle's procedural weights, runs the paired rollout, and the oracle
+    REPLAYS the tokens the HIP sampler drew (oracle/xgate_oracle.py:sample, mode='replay'); the RewardCriterion losses must
+    agree.  (Only the checker runs the oracle; about 5 s of CPU.)"""
+    from oracle import paramgen as pg
+    from oracle import xgate_oracle as xo
+    from controllable_xgating_amd import RewardCriterion
+    from controllable_xgating_amd.driver import scst_rollouts
+    d = pg.make_dims(B=cfg["B"], K=cfg["K"], R=cfg["R"], A=cfg["A"], E=cfg["E"], V=cfg["V"], C=cfg["C"], L=cfg["L"],
+                     F1=cfg["F1"], F2=cfg["F2"])
+    Pn = pg.make_params(d, logit_gain=1.0)
+    Pn["logit.bias"] = Pn["logit.bias"].copy()
+    Pn["logit.bias"][0] += 7.0                              # EOS mass 5-10 % per step: rows finish anywhere in the rollout
+    model.load_state_dict({k: torch.from_numpy(v) for k, v in Pn.items()}, strict=False)
+    model.train()
+    with torch.no_grad():
+        gen, slp, greedy, n = scst_rollouts(model, x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], trim=False)
+        loss_h = float(RewardCriterion()(slp, gen, reward_b, n=n[:1]).item())
+    n_s = int(n[0].item())
+    forced = gen[:, :n_s].cpu()
+    xc = {k: v.cpu() for k, v in x.items()}
+    with torch.no_grad():
+        s_o, lp_o = xo.sample(xo.to_torch_params(Pn), xc["feats_rgb"], xc["feats_opfl"], xc["feat_mask"], xc["pos_feats"], cfg["L"],
+                              mode="replay", forced=forced, train=True, running=xo.new_running(d))
+        loss_o = float(xo.reward_criterion(lp_o, s_o, reward_b.cpu().expand(-1, s_o.shape[1])).item())
+    return {"oracle_loss": loss_o, "hip_loss": loss_h, "delta": abs(loss_h - loss_o), "rollout_width": n_s}
+
+
+def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pmc=True, comm_diag=True):
+    """One timed workload on this rank; returns (json-able dict | None on ranks != 0, parity failure text | None)."""
+    world, rank, dev, use_dist = ctx["world"], ctx["rank"], ctx["dev"], ctx["use_dist"]
+    if use_dist:
+        import torch.distributed as dist
+    from controllable_xgating_amd import LanguageModelCriterion, RewardCriterion, SAModel, make_opt
+    from controllable_xgating_amd import train as tr
+    from controllable_xgating_amd.train import ClipAdam, GradSync, allreduce_gradients, broadcast_parameters
+    from controllable_xgating_amd.driver import scst_rollouts
+
+    cfg = dict(B=args.batch, K=26, R=512, A=1536, E=468, V=20000, C=14, L=20, F1=1536, F2=1024)
+    if workload == "scst":
+        cfg.update(B=64 if args.batch == 128 else args.batch, L=30)
+    if workload == "xe5":          # BASELINE.json configs[4]: hidden 1024, 40 frames, vocab 20k
+        cfg.update(K=40, R=1024)
+    T = cfg["L"] + 1
+    opt = make_opt(None, vocab_size=cfg["V"], seq_length=cfg["L"], drop_prob_lm=args.drop, precision=precision,
+                   rnn_size=cfg["R"], att_size=cfg["A"], input_encoding_size=cfg["E"], feat_size=cfg["F1"], feat_size2=cfg["F2"])
+    model = SAModel(opt).to(dev)
+    model.train()
+    broadcast_parameters(model)
+    x = synth_inputs(cfg["B"], cfg["K"], cfg["L"], cfg["V"], cfg["R"], cfg["F1"], cfg["F2"], cfg["C"], seed=rank, device=dev)
+    # clamp + Adam start per parameter group as soon as its gradient is final (XG_NO_UPDATE_OVERLAP=1: after the backward)
+    optim = ClipAdam(model, lr=4e-4, grad_clip=0.1, overlap=os.environ.get("XG_NO_UPDATE_OVERLAP") is None,
+                     fused_zero=os.environ.get("XG_NO_FUSED_ZERO") is None)
+    # data parallel: most of the gradient all-reduce runs under the CG encoder's backward (XG_NO_GRAD_OVERLAP=1: one
+    # all-reduce after the backward)
+    sync = None
+    if use_dist and os.environ.get("XG_NO_GRAD_OVERLAP") is None:
+        try:
+            sync = GradSync(model)
+        except Exception as e:                   # never lose the run over the overlap: fall back to one all-reduce
+            print("GradSync unavailable (%s): plain all-reduce" % e, file=sys.stderr)
+    crit = LanguageModelCriterion()
+    rl_crit = RewardCriterion()
+    reward_b = torch.randn(cfg["B"], 1, generator=torch.Generator().manual_seed(7)).to(dev)   # CIDEr stubbed (configs[2])
+
+    def step_scst():
+        optim.zero_grad()
+        if os.environ.get("XG_SCST_MODE") in (None, "batched"):      # no host sync anywhere in the iteration
+            gen, slp, greedy, n = scst_rollouts(model, x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], trim=False)
+            loss = rl_crit(slp, gen, reward_b, n=n[:1])
+        else:
+            gen, slp, greedy = scst_rollouts(model, x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"],
+                                             mode=os.environ.get("XG_SCST_MODE"))
+            loss = rl_crit(slp, gen, reward_b.expand(-1, gen.shape[1]))
+        if sync is not None:
+            sync.arm()
+        optim.arm()
+        loss.backward()
+        allreduce_gradients(model)
+        optim.step()
+        return loss
+
+    sleep_cycles = int(float(os.environ.get("XG_BENCH_SLEEP_MS", "0")) * 2.4e6)           # diagnosis: see below (torch.cuda._sleep counts shader clocks)
+
+    def step():
+        if workload == "scst":
+            return step_scst()
+        if sleep_cycles:
+            # diagnosis only: a GPU-side spin at the head of the iteration lets the host run far ahead; if (time - spin) drops
+            # below the normal iteration time, the normal run has host-bound gaps
+            torch.cuda._sleep(sleep_cycles)
+        optim.zero_grad()
+        if args.path == "fused":
+            loss = model.xe_loss(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+        else:
+            logp, _ = model(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+            loss = crit(logp, x["seq"], x["seq_mask"])
+        if sync is not None:
+            sync.arm()
+        optim.arm()
+        loss.backward()
+        allreduce_gradients(model)
+        optim.step()
+        return loss
+
+    def timed(n):
+        """n iterations bracketed by barrier + synchronize on both sides; (this rank's seconds, host enqueue seconds, last loss)"""
+        if use_dist:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss = step()
+        t_enq = time.perf_counter() - t0          # host-side enqueue time (the GPU is still running)
+        torch.cuda.synchronize()
+        t_own = time.perf_counter() - t0
+        if use_dist:
+            dist.barrier()
+        return time.perf_counter() - t0, t_own, t_enq, loss
+
+    for _ in range(warmup):
+        loss = step()
+    dt, dt_own, t_enq, loss = timed(steps)
+    if use_dist:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    final_loss = float(loss.item())
+    # ---- data-parallel diagnosis: the same iterations with the collective switched off (same streams, events and update
+    # segments; only the RCCL kernels are missing) -> what the all-reduce costs each rank, i.e. its EXPOSED part
+    comm = None
+    if use_dist and comm_diag:
+        tr._SKIP_COLLECTIVE = True
+        try:
+            for _ in range(2):
+                step()
+            _, dt_nc, _, _ = timed(steps)
+        finally:
+            tr._SKIP_COLLECTIVE = False
+        broadcast_parameters(model)               # (replicas diverged without the collective: back to rank 0's)
+        mine = {"rank": rank, "ms_per_step": round(dt_own / steps * 1e3, 3), "ms_per_step_no_collective": round(dt_nc / steps * 1e3, 3),
+                "exposed_comm_ms": round((dt_own - dt_nc) / steps * 1e3, 3)}
+        allr = [None] * world
+        dist.all_gather_object(allr, mine)
+        comm = {"per_rank": allr, "gradient_bytes": int(model.flat_grads().numel() * 4),
+                "buckets": "logit | lstmcore+embed+img_embed | classifer | two_spatial_encoder (train.GradSync)" if sync is not None else "one",
+                "rccl_channels": rccl_channels(ctx.get("rccl_log")) if ctx.get("rccl_log") else None,
+                "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())}
+    # host-side enqueue cost of one iteration against an IDLE GPU (the loop above also contains queue back-pressure: the
+    # host runs ahead of the GPU until the launch queue is full), median of 5
+    enq = []
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        step()
+        enq.append(time.perf_counter() - t1)
+    torch.cuda.synchronize()
+    host_enqueue_ms = sorted(enq)[len(enq) // 2] * 1e3
+    # in-situ duration of the T decoder steps inside the timed iteration (XgRun.prof_event0/1: recorded by the library on
+    # the caller's stream around its time loop), median of 5 iterations
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(); e1.record()
+    model._prof_events = (e0, e1)
+    insitu = []
+    for _ in range(5):
+        step()
+        torch.cuda.synchronize()
+        insitu.append(e0.elapsed_time(e1) * 1e3 / T)
+    model._prof_events = None
+    in_situ_us = sorted(insitu)[len(insitu) // 2]
+
+    t_step = measure_step_group(model, x) if rank == 0 else None
+    if rank != 0:
+        return None, None
+    step_rows = 2 * cfg["B"] if workload == "scst" else cfg["B"]      # (the SCST pair is ONE 2m-row batch)
+    if workload == "scst":                       # the stand-alone group at the row count the rollout steps really have
+        x2 = {k: torch.cat([v, v]) for k, v in x.items()}
+        t_step = measure_step_group(model, x2)
+    ms = dt / steps * 1e3
+    value = world * cfg["B"] * T * steps / dt * (2 if workload == "scst" else 1)
+    bf16 = precision == "bf16"
+    bytes_step = step_bytes(step_rows, cfg["K"], cfg["R"], cfg["A"], cfg["E"], save=False, elem=2 if bf16 else 4)
+    bytes_step_saved = step_bytes(step_rows, cfg["K"], cfg["R"], cfg["A"], cfg["E"], save=True, elem=2 if bf16 else 4)
+    mfma_peak = 2500.0 if bf16 else 157.3
+    achieved = bytes_step / t_step / 1e9
+    traffic, traffic_src = (None, None)
+    if cfg["B"] == 128 and workload == "xe" and precision == "fp32":
+        if pmc and not args.no_pmc and world == 1:           # (the two rocprofv3 passes run on rank 0's GPU: single-GPU runs only)
+            traffic, traffic_src = measure_traffic()
+        elif world > 1:
+            traffic_src = "multi-GPU run"
+        if traffic is None:                              # fall back to the committed passes, and say so
+            why = traffic_src
+            traffic, traffic_src = load_traffic()
+            if traffic_src:
+                traffic_src += " (committed earlier: live PMC pass unavailable -- %s)" % why
+    wl = {"xe": "configs[%s]: %dxMI355X batch %d per GPU teacher-forced XE train, 26 frames x (1536+1024), hidden 512, "
+                "att 1536, emb 468, vocab 20000, seq_len 20 (T=21), fp32" % ("1" if world == 1 else "3", world, cfg["B"]),
+          "scst": "configs[2]: %dxMI355X SCST iteration (sampled rollout + greedy baseline as one 2m-row batch + RL backward + "
+                  "clip + Adam), batch %d per GPU, seq_len 30, 26 frames, hidden 512, vocab 20000, CIDEr reward stubbed" % (world, cfg["B"]),
+          "xe5": "configs[4]: %dxMI355X batch %d per GPU teacher-forced XE train, 40 frames x (1536+1024), hidden 1024, att 1536, "
+                 "vocab 20000, seq_len 20, %s" % (world, cfg["B"], precision)}[workload]
+    flops = step_flops(step_rows, cfg["K"], cfg["R"], cfg["A"], cfg["E"])
+    out = {
+        "metric": "rollout timesteps/sec, SCST iteration (sample + greedy + RL backward) at batch 64, seq_len 30"
+                  if workload == "scst" else "decoder timesteps/sec (train fwd+bwd) at batch 128, MSRVTT 26x1536+1024",
+        "value": round(value, 1), "unit": "decoder timesteps/s", "n_gpus": world, "steps": steps,
+        "warmup": warmup, "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
+        "host_loop_ms_per_step": round(t_enq * 1e3 / steps, 3),
+        "higher_is_better": True, "scaling": "weak",
+        "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "f32 via split-bf16 (3 planes, 6 MFMAs)", "bf16": "bf16"}[precision],
+        "data": "synthetic",
+        "config": {"workload": wl,
+                   "global_batch": world * cfg["B"], "per_gpu_batch": cfg["B"], "parallelism": "dp%d" % world,
+                   "path": args.path, "drop_prob_lm": args.drop, "gemm_precision": precision,
+                   "timed_region": ("zero_grad + sampled + greedy rollouts (31 steps, one 2m-row batch) + reward criterion + backward"
+                                    if workload == "scst" else
+                                    "zero_grad + encoder fwd + 21 decoder steps + heads/loss + full backward")
+                                   + (" + RCCL grad all-reduce" if world > 1 else "") + " + clip + Adam",
+                   # (zero_grad is fused into the update: train.ClipAdam(fused_zero=True) leaves .grad at zero)
+                   "zero_grad": "fused into the update" if os.environ.get("XG_NO_FUSED_ZERO") is None else "memset",
+                   "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
+        "final_loss": round(final_loss, 5),
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
+                     "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
+                     "kernel": "decoder step launch group (xg_step_fwd: attention + POS gate + lstm_1 + lstm_2)",
+                     "measured_form": "xg_step_fwd stand-alone, %d rows, inference form (tokens gathered inside the products, state "
+                                      "updated in place, nothing saved), 200 back-to-back calls between two stream events" % step_rows,
+                     "algorithmic_bytes_per_launch": bytes_step, "avg_launch_us": round(t_step * 1e6, 2),
+                     # the same steps where the timed iteration runs them: %s loop of the forward pass (saves on, beside the
+                     # side-stream products), events recorded by the library around its time loop
+                     "in_situ_form": ("rollout loop (token choice + step + vocabulary product per step)" if workload == "scst"
+                                      else "teacher-forced loop (token side hoisted, activations saved)") + ", inside the timed iteration",
+                     "in_situ_us_per_step": round(in_situ_us, 2),
+                     "in_situ_algorithmic_bytes": bytes_step_saved,
+                     "in_situ_frac": None if workload == "scst" else round(bytes_step_saved / (in_situ_us * 1e-6) / 8e12, 4),
+                     # the same launch group against the OTHER roof (exact-fp32 MFMA, 157.3 TF): at B = 128 the step's
+                     # arithmetic intensity (33 FLOP/B) is above the ridge (20), i.e. the MFMA roof is the lower one
+                     "mfma_tflops": round(flops / t_step / 1e12, 2),
+                     "mfma_peak_tflops": mfma_peak,
+                     "mfma_frac": round(flops / t_step / (mfma_peak * 1e12), 4)},
+    }
+    if comm is not None:
+        out["comm"] = comm
+    parity_fail = None
+    if world == 1 and cpu_leg and not args.no_cpu_baseline:
+        tol = 1e-2 if precision == "bf16" else 1e-4        # north_star: 1e-4 on the training loss in fp32, 1e-2 for the bf16 config
+        if workload == "scst":
+            par = scst_parity(model, cfg, x, reward_b)
+            what = "RewardCriterion loss of the HIP paired rollout vs the CPU oracle replaying the tokens it drew (same weights, same batch)"
+        else:
+            cb = cpu_baseline(cfg, args.cpu_budget if workload == "xe" else 0.0, model, x)
+            par = cb.pop("parity", None)
+            out["cpu_baseline"] = cb
+            what = "XE loss of this run's HIP model vs the CPU oracle, same procedural weights, same batch"
+        if par is not None:
+            out["parity_loss_delta"] = round(par["delta"], 7)
+            out["parity"] = {"hip_loss": round(par["hip_loss"], 6), "oracle_loss": round(par["oracle_loss"], 6), "tol": tol, "what": what}
+            if not par["delta"] < tol:
+                parity_fail = "parity (%s %s): |hip - oracle| = %.3g >= %g" % (workload, precision, par["delta"], tol)
+    return out, parity_fail
 
 
 def main():
@@ -214,6 +509,8 @@ def main():
                          "xe5: configs[4] shape (hidden 1024, 40 frames; pair with --precision bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the configs[2] (SCST) and configs[4] (hidden-1024 bf16) lines that the default single-GPU run appends")
     ap.add_argument("--cpu-budget", type=float, default=15.0)
     args = ap.parse_args()
 
@@ -237,10 +534,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("XG_FORCE_DIST") == "1"     # XG_FORCE_DIST: exercise the RCCL path on one GPU
+    ctx = dict(world=world, rank=rank, dev=dev, use_dist=use_dist, rccl_log=None)
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
+        ctx["rccl_log"] = rccl_debug_setup(rank)
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     import __graft_entry__ as ge
@@ -248,181 +547,31 @@ def main():
         ge.build()
     if use_dist:
         dist.barrier()
-    from controllable_xgating_amd import LanguageModelCriterion, SAModel, make_opt
-    from controllable_xgating_amd.train import ClipAdam, GradSync, allreduce_gradients, broadcast_parameters
 
-    cfg = dict(B=args.batch, K=26, R=512, A=1536, E=468, V=20000, C=14, L=20, F1=1536, F2=1024)
-    if args.workload == "scst":
-        cfg.update(B=64 if args.batch == 128 else args.batch, L=30)
-    if args.workload == "xe5":          # BASELINE.json configs[4] shape: hidden 1024, 40 frames (a parity case; measured for DESIGN.md)
-        cfg.update(K=40, R=1024)
-    T = cfg["L"] + 1
-    opt = make_opt(None, vocab_size=cfg["V"], seq_length=cfg["L"], drop_prob_lm=args.drop, precision=args.precision,
-                   rnn_size=cfg["R"], att_size=cfg["A"], input_encoding_size=cfg["E"], feat_size=cfg["F1"], feat_size2=cfg["F2"])
-    model = SAModel(opt).to(dev)
-    model.train()
-    broadcast_parameters(model)
-    x = synth_inputs(cfg["B"], cfg["K"], cfg["L"], cfg["V"], cfg["R"], cfg["F1"], cfg["F2"], cfg["C"], seed=rank, device=dev)
-    # clamp + Adam start per parameter group as soon as its gradient is final (XG_NO_UPDATE_OVERLAP=1: after the backward)
-    optim = ClipAdam(model, lr=4e-4, grad_clip=0.1, overlap=os.environ.get("XG_NO_UPDATE_OVERLAP") is None,
-                     fused_zero=os.environ.get("XG_NO_FUSED_ZERO") is None)
-    # data parallel: most of the gradient all-reduce runs under the CG encoder's backward (XG_NO_GRAD_OVERLAP=1: one
-    # all-reduce after the backward)
-    sync = None
-    if use_dist and os.environ.get("XG_NO_GRAD_OVERLAP") is None:
-        try:
-            sync = GradSync(model)
-        except Exception as e:                   # never lose the run over the overlap: fall back to one all-reduce
-            print("GradSync unavailable (%s): plain all-reduce" % e, file=sys.stderr)
-    crit = LanguageModelCriterion()
-
-    from controllable_xgating_amd import RewardCriterion
-    rl_crit = RewardCriterion()
-    reward_b = torch.randn(cfg["B"], 1, generator=torch.Generator().manual_seed(7)).to(dev)   # CIDEr stubbed (configs[2])
-
-    from controllable_xgating_amd.driver import scst_rollouts
-
-    def step_scst():
-        optim.zero_grad()
-        if os.environ.get("XG_SCST_MODE") in (None, "batched"):      # no host sync anywhere in the iteration
-            gen, slp, greedy, n = scst_rollouts(model, x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], trim=False)
-            loss = rl_crit(slp, gen, reward_b, n=n[:1])
-        else:
-            gen, slp, greedy = scst_rollouts(model, x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"],
-                                             mode=os.environ.get("XG_SCST_MODE"))
-            loss = rl_crit(slp, gen, reward_b.expand(-1, gen.shape[1]))
-        if sync is not None:
-            sync.arm()
-        optim.arm()
-        loss.backward()
-        allreduce_gradients(model)
-        optim.step()
-        return loss
-
-    sleep_cycles = int(float(os.environ.get("XG_BENCH_SLEEP_MS", "0")) * 2.4e6)           # diagnosis: see below (torch.cuda._sleep counts shader clocks)
-
-    def step():
-        if args.workload == "scst":
-            return step_scst()
-        if sleep_cycles:
-            # diagnosis only: a GPU-side spin at the head of the iteration lets the host run far ahead; if (time - spin) drops
-            # below the normal iteration time, the normal run has host-bound gaps
-            torch.cuda._sleep(sleep_cycles)
-        optim.zero_grad()
-        if args.path == "fused":
-            loss = model.xe_loss(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
-        else:
-            logp, _ = model(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
-            loss = crit(logp, x["seq"], x["seq_mask"])
-        if sync is not None:
-            sync.arm()
-        optim.arm()
-        loss.backward()
-        allreduce_gradients(model)
-        optim.step()
-        return loss
-
-    for _ in range(args.warmup):
-        loss = step()
-    if use_dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    t_enq = time.perf_counter() - t0          # host-side enqueue time (the GPU is still running)
-    torch.cuda.synchronize()
-    if use_dist:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    final_loss = float(loss.item())
-    # host-side enqueue cost of one iteration against an IDLE GPU (the loop above also contains queue back-pressure: the
-    # host runs ahead of the GPU until the launch queue is full), median of 5
-    enq = []
-    for _ in range(5):
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        step()
-        enq.append(time.perf_counter() - t1)
-    torch.cuda.synchronize()
-    host_enqueue_ms = sorted(enq)[len(enq) // 2] * 1e3
-
-    t_step = measure_step_group(model, x) if rank == 0 else None
+    out, fail = run_workload(args, args.workload, args.precision, args.steps, args.warmup, ctx)
+    fails = [fail] if fail else []
+    # the default single-GPU run also carries BASELINE.json's other single-GPU configurations (5 warm-up + 10 timed
+    # iterations each, own roofline and parity self-check): configs[2] (SCST) and configs[4] (hidden 1024 / 40 frames, bf16)
+    if (not args.no_secondary and world == 1 and not use_dist and args.workload == "xe" and args.precision == "fp32"
+            and args.batch == 128 and args.path == "fused"):
+        sec = {}
+        for key, (wl_, prec_) in {"scst": ("scst", "fp32"), "xe5_bf16": ("xe5", "bf16")}.items():
+            try:
+                o, f = run_workload(args, wl_, prec_, 10, 5, ctx, pmc=False, comm_diag=False)
+                sec[key] = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "host_enqueue_ms_per_step", "dtype", "config",
+                                              "final_loss", "roofline", "parity_loss_delta", "parity", "steps", "warmup") if k in o}
+                if "cpu_baseline" in o:
+                    sec[key]["cpu_baseline"] = o["cpu_baseline"]
+                if f:
+                    fails.append(f)
+            except Exception as e:                       # never lose the headline over a secondary line
+                sec[key] = {"error": repr(e)}
+                fails.append("secondary %s failed: %r" % (key, e))
+        out["secondary"] = sec
     if rank == 0:
-        ms = dt / args.steps * 1e3
-        value = world * cfg["B"] * T * args.steps / dt * (2 if args.workload == "scst" else 1)
-        bf16 = args.precision == "bf16"
-        bytes_step = step_bytes(cfg["B"], cfg["K"], cfg["R"], cfg["A"], cfg["E"], save=False, elem=2 if bf16 else 4)
-        mfma_peak = 2500.0 if bf16 else 157.3
-        achieved = bytes_step / t_step / 1e9
-        traffic, traffic_src = (None, None)
-        if cfg["B"] == 128 and args.workload == "xe" and args.precision == "fp32":
-            if not args.no_pmc and world == 1:           # (the two rocprofv3 passes run on rank 0's GPU: single-GPU runs only)
-                traffic, traffic_src = measure_traffic()
-            elif world > 1:
-                traffic_src = "multi-GPU run"
-            if traffic is None:                              # fall back to the committed passes, and say so
-                why = traffic_src
-                traffic, traffic_src = load_traffic()
-                if traffic_src:
-                    traffic_src += " (committed earlier: live PMC pass unavailable -- %s)" % why
-        wl = {"xe": "configs[%s]: %dxMI355X batch %d per GPU teacher-forced XE train, 26 frames x (1536+1024), hidden 512, "
-                    "att 1536, emb 468, vocab 20000, seq_len 20 (T=21), fp32" % ("1" if world == 1 else "3", world, cfg["B"]),
-              "scst": "configs[2]: %dxMI355X SCST iteration (sampled rollout + greedy baseline as one 2m-row batch + RL backward + "
-                      "clip + Adam), batch %d per GPU, seq_len 30, 26 frames, hidden 512, vocab 20000, CIDEr reward stubbed" % (world, cfg["B"]),
-              "xe5": "configs[4] shape: %dxMI355X batch %d per GPU teacher-forced XE train, 40 frames x (1536+1024), hidden 1024, att 1536, "
-                     "vocab 20000, seq_len 20" % (world, cfg["B"])}[args.workload]
-        out = {
-            "metric": "rollout timesteps/sec, SCST iteration (sample + greedy + RL backward) at batch 64, seq_len 30"
-                      if args.workload == "scst" else "decoder timesteps/sec (train fwd+bwd) at batch 128, MSRVTT 26x1536+1024",
-            "value": round(value, 1), "unit": "decoder timesteps/s", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
-            "host_loop_ms_per_step": round(t_enq * 1e3 / args.steps, 3),
-            "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "f32 via split-bf16 (3 planes, 6 MFMAs)", "bf16": "bf16"}[args.precision],
-            "data": "synthetic",
-            "config": {"workload": wl,
-                       "global_batch": world * cfg["B"], "per_gpu_batch": cfg["B"], "parallelism": "dp%d" % world,
-                       "path": args.path, "drop_prob_lm": args.drop, "gemm_precision": args.precision,
-                       "timed_region": ("zero_grad + sampled + greedy rollouts (31 steps, one 2m-row batch) + reward criterion + backward"
-                                        if args.workload == "scst" else
-                                        "zero_grad + encoder fwd + 21 decoder steps + heads/loss + full backward")
-                                       + (" + RCCL grad all-reduce" if world > 1 else "") + " + clip + Adam",
-                       # (zero_grad is fused into the update: train.ClipAdam(fused_zero=True) leaves .grad at zero)
-                       "zero_grad": "fused into the update" if os.environ.get("XG_NO_FUSED_ZERO") is None else "memset",
-                       "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
-            "final_loss": round(final_loss, 5),
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
-                         "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
-                         "kernel": "decoder step launch group (xg_step_fwd: attention + POS gate + lstm_1 + lstm_2)",
-                         "algorithmic_bytes_per_launch": bytes_step, "avg_launch_us": round(t_step * 1e6, 2),
-                         # the same launch group against the OTHER roof (exact-fp32 MFMA, 157.3 TF): at B = 128 the step's
-                         # arithmetic intensity (33 FLOP/B) is above the ridge (20), i.e. the MFMA roof is the lower one
-                         "mfma_tflops": round(step_flops(cfg["B"], cfg["K"], cfg["R"], cfg["A"], cfg["E"]) / t_step / 1e12, 2),
-                         "mfma_peak_tflops": mfma_peak,
-                         "mfma_frac": round(step_flops(cfg["B"], cfg["K"], cfg["R"], cfg["A"], cfg["E"]) / t_step / (mfma_peak * 1e12), 4)},
-        }
-        parity_fail = None
-        if world == 1 and not args.no_cpu_baseline:
-            check = args.workload in ("xe", "xe5")          # the oracle leg is the XE iteration of the same shape
-            cb = cpu_baseline(cfg, args.cpu_budget, model if check else None, x)
-            par = cb.pop("parity", None)
-            out["cpu_baseline"] = cb
-            if par is not None:
-                # north_star: training loss within 1e-4 of the reference CPU path in fp32 (1e-2 for the bf16 config)
-                tol = 1e-2 if args.precision == "bf16" else 1e-4
-                out["parity_loss_delta"] = round(par["delta"], 7)
-                out["parity"] = {"hip_loss": round(par["hip_loss"], 6), "oracle_loss": round(par["oracle_loss"], 6), "tol": tol,
-                                 "what": "XE loss of this run's HIP model vs the CPU oracle, same procedural weights, same batch"}
-                if not par["delta"] < tol:
-                    parity_fail = "parity: |hip - oracle| = %.3g >= %g" % (par["delta"], tol)
         print(json.dumps(out))
-        if parity_fail:
-            raise SystemExit(parity_fail)
+        if fails:
+            raise SystemExit("; ".join(fails))
     if use_dist:
         dist.destroy_process_group()
 

@@ -9,7 +9,10 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libxgate_hip.so")
+# XG_LIBRARY: load another build of the same ABI instead (tests / tools: lib/libxgate_hip_diag.so, the -DXG_DIAG build
+# that reads the diagnosis switches of DESIGN.md 6.2 from the environment; the product library reads none)
+LIB_PATH = os.environ.get("XG_LIBRARY") or os.path.join(_HERE, "lib", "libxgate_hip.so")
+LIB_DIAG_PATH = os.path.join(_HERE, "lib", "libxgate_hip_diag.so")
 
 XG_ROLLOUT_GREEDY, XG_ROLLOUT_SAMPLE, XG_ROLLOUT_REPLAY = 0, 1, 2
 
@@ -29,7 +32,8 @@ class XgBatch(C.Structure):
 class XgRun(C.Structure):
     _fields_ = [("train", C.c_int32), ("drop_p", C.c_float), ("seed", C.c_uint32), ("save", C.c_int32),
                 ("bn_momentum", C.c_float), ("bn_eps", C.c_float), ("gemm_mode", C.c_int32), ("packed_dtype", C.c_int32),
-                ("packed", C.c_void_p), ("aux", C.c_void_p), ("grad_event", C.c_void_p), ("grad_event_head", C.c_void_p)]
+                ("packed", C.c_void_p), ("aux", C.c_void_p), ("grad_event", C.c_void_p), ("grad_event_head", C.c_void_p),
+                ("prof_event0", C.c_void_p), ("prof_event1", C.c_void_p)]
 
 
 class XgError(RuntimeError):

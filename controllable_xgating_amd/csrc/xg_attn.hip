@@ -596,7 +596,7 @@ int xgk_attn_bwd(hipStream_t st, const float* daf, int lddaf, const float* p, co
     // one-workgroup form (1024 threads x 125 VGPRs) needs an EMPTY CU and waited for one for up to 240 us per step beside
     // dW_logit.  For 33-48 frames: the staged form attn_bwd_split_lr (the one-workgroup form would spill there).
     // XG_ATTN_BWD_ONE=1 selects the one-workgroup form for comparison.
-    static const int one_wg = getenv("XG_ATTN_BWD_ONE") ? 1 : 0;
+    static const int one_wg = xg_diag_env("XG_ATTN_BWD_ONE") ? 1 : 0;
     if (!one_wg && al16 && A % 4 == 0 && A <= 2048 && R % 4 == 0 && R <= 1024 && lddaf % 4 == 0 && K <= 48) {
         const size_t lds = (size_t)K * sizeof(float);
         if (K <= 16) hipLaunchKernelGGL((attn_bwd_split<16>), dim3(2 * B), dim3(512), lds, st, daf, lddaf, p, vproj, V, w, alpha, de, dp, K, R, A);

@@ -116,5 +116,15 @@ static inline int xg_lds_optin(std::atomic<unsigned>& done, const void* kernel, 
 #define XG_CHAIN_PRIO() __builtin_amdgcn_s_setprio(3)
 #endif
 
+// Diagnosis switches are read from the environment ONLY in a -DXG_DIAG build (lib/libxgate_hip_diag.so, used
+// by tests / tools); the product library has none: xg_diag_env() is a constant there, every `static const ... =
+// xg_diag_env(...)` folds to its default and the library keeps no mutable global state (include/xgate.h).
+#ifdef XG_DIAG
+#include <cstdlib>
+static inline const char* xg_diag_env(const char* name) { return getenv(name); }
+#else
+static inline constexpr const char* xg_diag_env(const char*) { return nullptr; }
+#endif
+
 static inline int xg_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t xg_cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

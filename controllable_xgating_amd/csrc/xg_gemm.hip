@@ -546,7 +546,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 // launcher of the persistent kernel; returns XG_OK, or 1 when the shape should take the one-tile-per-workgroup kernels
 template <bool AKC, bool BKC>
 int launch_pk(hipStream_t st, const GemmArgs& a) {
-    static const int disabled = getenv("XG_GEMM_NO_PK") ? 1 : 0;
+    static const int disabled = xg_diag_env("XG_GEMM_NO_PK") ? 1 : 0;
     if (disabled || !a.fast || a.M < 128 || a.N < 128) return 1;
     PkArgs g{a.A, a.B, a.C, a.bias, a.M, a.N, a.K, a.lda, a.ldb, a.ldc, a.relu, a.accumulate, 0, 0, 0, 0, 0, a.gm};
     g.ntm = xg_cdiv(a.M, 128); g.ntn = xg_cdiv(a.N, 128); g.nslab = xg_cdiv(a.K, BKS);
@@ -554,17 +554,17 @@ int launch_pk(hipStream_t st, const GemmArgs& a) {
     const long units = T * g.nslab;
     // measured (tools/ubench/gemm_bench.py): the persistent form wins 3-6 % when every workgroup has >= ~40 slabs of work
     // (vocabulary head: logits, dW_logit, dH) and loses 10-15 % to 64x64 tiles + split-K on the mid-size products
-    static const long min_units = getenv("XG_PK_MIN") ? atol(getenv("XG_PK_MIN")) : 40;
+    static const long min_units = xg_diag_env("XG_PK_MIN") ? atol(xg_diag_env("XG_PK_MIN")) : 40;
     if (units < 512L * min_units) return 1;
-    static const int env_g = getenv("XG_PK_G") ? atoi(getenv("XG_PK_G")) : 0;
-    static const int env_split = getenv("XG_PK_SPLIT") ? atoi(getenv("XG_PK_SPLIT")) : 1;
+    static const int env_g = xg_diag_env("XG_PK_G") ? atoi(xg_diag_env("XG_PK_G")) : 0;
+    static const int env_split = xg_diag_env("XG_PK_SPLIT") ? atoi(xg_diag_env("XG_PK_SPLIT")) : 1;
     // 2 workgroups per CU (73.7 KB of LDS each) -- or, for a background product, ONE per CU (LDS padded past half a CU so
     // that the dispatcher cannot pair them): 512 persistent workgroups own every register file and LDS for the whole
     // product (0.7 ms for dW_logit), and a recurrent chain on another stream then waits for leftovers -- its step took
     // 120 us instead of 53 beside dW_logit.  One workgroup per CU leaves 256 VGPRs per SIMD and 78 KB of LDS, exactly one
     // 8-wave (or two 4-wave) skinny workgroups, and costs the product itself ~10 %.
-    static const int bg_off = getenv("XG_GEMM_NO_BG") ? 1 : 0;
-    static const int bg_all = getenv("XG_GEMM_FORCE_BG") ? 1 : 0;     // tests: every product takes the background form
+    static const int bg_off = xg_diag_env("XG_GEMM_NO_BG") ? 1 : 0;
+    static const int bg_all = xg_diag_env("XG_GEMM_FORCE_BG") ? 1 : 0;     // tests: every product takes the background form
     const bool bg = (a.bg || bg_all) && !bg_off;
     const int GMAX = env_g > 0 ? env_g : (bg ? 256 : 512);
     int G;
@@ -656,7 +656,7 @@ int dispatch(hipStream_t st, GemmArgs g, bool vec) {
         if (sk >= 2) g.splitk = (int)sk;
     }
     // tuning hook for tools/ubench/gemm_bench.py: XG_GEMM_FORCE="<tile>,<splitk>"
-    static const char* force = getenv("XG_GEMM_FORCE");
+    static const char* force = xg_diag_env("XG_GEMM_FORCE");
     if (force) {
         int t = 0, sk = 1;
         if (sscanf(force, "%d,%d", &t, &sk) == 2) { big = t == 128; g.splitk = g.relu ? 1 : (sk < 1 ? 1 : sk); }

@@ -496,7 +496,7 @@ int xgk_gemm_bf16(hipStream_t st, int planes, bool transA, bool transB, int M, i
     // plain bf16 with a k-contiguous A (forward and data-gradient layouts): 256 x 128 tiles, 43 flop per operand byte instead
     // of 32 -- logits 170 -> 145 us, PRE 79 -> 59 us; hidden-1024 iteration 9.19 -> 9.02 ms.  Measured and not used: the
     // weight-gradient layout on these tiles (dW_logit 186 -> 276 us) and 256 x 256 tiles (one workgroup per CU: 10.4 ms).
-    static const bool no_bx = getenv("XG_NO_BX") != nullptr;
+    static const bool no_bx = xg_diag_env("XG_NO_BX") != nullptr;
     if (planes == 1 && vec && akc && !no_bx && M >= 256) {
         const long t2 = (long)xg_cdiv(M, 256) * xg_cdiv(N, 128);
         g.splitk = 1;

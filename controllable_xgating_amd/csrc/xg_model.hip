@@ -27,7 +27,7 @@ constexpr int XG_NEV = 64, XG_NRING = 56;     // events: a ring for fork / join 
 struct XgAux { uint32_t magic; int device; hipStream_t s = nullptr, s2 = nullptr; hipEvent_t ev[XG_NEV]; };
 constexpr uint32_t XG_AUX_MAGIC = 0x58474158u;
 XgAux* aux_of(const XgRun* run) {
-    static const bool disabled = getenv("XG_NO_OVERLAP") != nullptr;
+    static const bool disabled = xg_diag_env("XG_NO_OVERLAP") != nullptr;
     if (disabled || !run || !run->aux) return nullptr;
     XgAux* a = static_cast<XgAux*>(run->aux);
     int dev = -1;
@@ -238,7 +238,7 @@ inline int zero_tickets(hipStream_t st, const Ws& w, int njobs) {
 }
 // (the tile element type must fit the arithmetic: bf16 tiles for gemm_mode 1, fp32 tiles otherwise)
 inline void attach_packed(Ws& w, const XgDims& d, const XgRun* run) {
-    static const bool disabled = getenv("XG_NO_PACKED") != nullptr;
+    static const bool disabled = xg_diag_env("XG_NO_PACKED") != nullptr;
     w.packed = !disabled && run && run->packed && (run->gemm_mode == 1) == (run->packed_dtype == 1) &&
                xgk_packed_view(d, run->packed, run->packed_dtype, &w.pk);
 }
@@ -544,9 +544,9 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         // B: S2' in launch 1 + stand-alone attention, D: cell 2 keeps its h2 segment (K = 3R) + stand-alone attention,
         // E: the fused attention like the rollout form -- measure 6.77 / 6.73 / 6.74 ms per iteration (the iteration is
         // throughput-bound across three streams, not bound by this chain); D is the simplest and the default.)
-        static const bool no_fused = getenv("XG_NO_FUSED_ATTN") != nullptr;
+        static const bool no_fused = xg_diag_env("XG_NO_FUSED_ATTN") != nullptr;
         // (at hidden 1024 / 40 frames E wins instead: 8.51 vs 8.63 ms -- the stand-alone attention is then 24 us per step)
-        static const char xe_env = getenv("XG_XE_FORM") ? getenv("XG_XE_FORM")[0] : 0;          // experiment switch (B / D / E)
+        static const char xe_env = xg_diag_env("XG_XE_FORM") ? xg_diag_env("XG_XE_FORM")[0] : 0;          // experiment switch (B / D / E)
         const char xe_form = xe_env ? xe_env : (R >= 1024 ? 'E' : 'D');
         const bool fused_attn = (!s.pre1 || xe_form == 'E') && !no_fused && A <= 2048 && d.K <= 128 && ((uintptr_t)V % 8 == 0) &&
                                 ((uintptr_t)vproj % 16 == 0) && ((uintptr_t)p.a2w_w % 16 == 0);
@@ -739,9 +739,10 @@ int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatc
     const int th = (ss.overlap() && T >= 4) ? T / 2 : 0;
     // ... as a background product, with the stand-alone attention in its half-CU form beside it: the 128-VGPR attention
     // needs an EMPTY CU and waited for the whole persistent product (255 us: the chain simply stopped).  6.16 -> 6.10 ms.
-    static const int fwd_bg_env = getenv("XG_FWD_BG") ? atoi(getenv("XG_FWD_BG")) : 1;
+    static const int fwd_bg_env = xg_diag_env("XG_FWD_BG") ? atoi(xg_diag_env("XG_FWD_BG")) : 1;
     const bool fwd_bg = fwd_bg_env && th > 0 && w.gm == 0;
     *logit_rows_done = 0;
+    if (run.prof_event0 && hipEventRecord(static_cast<hipEvent_t>(run.prof_event0), st) != hipSuccess) return XG_EHIP;
     for (int t = 0; t < T; ++t) {
         StepIO s{};
         s.xt = w.Xe + (size_t)t * B * E; s.posg = w.POSG + t * BR; s.pre1 = w.PRE1 + (size_t)t * B * 4 * R;
@@ -760,6 +761,7 @@ int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatc
                 XG_TRY(xgk_xent_fwd(ss.aux, w.LOGITS, d.V, x.seq, x.seq_mask, nullptr, B, T, d.V, 1, w.LSE, w.sums, 0, th * B, false));
         }
     }
+    if (run.prof_event1 && hipEventRecord(static_cast<hipEvent_t>(run.prof_event1), st) != hipSuccess) return XG_EHIP;
     return XG_OK;
 }
 
@@ -897,7 +899,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         XG_TRY(gemm_nn(sq, w.gm, rows, E, 4 * R, ds1, 4 * R, p.l1_i2h_w, E, w.DXe + r0 * E, E, false));
         return XG_OK;
     };
-    static const int wg_chunks_env = getenv("XG_WG_CHUNKS") ? atoi(getenv("XG_WG_CHUNKS")) : 2;
+    static const int wg_chunks_env = xg_diag_env("XG_WG_CHUNKS") ? atoi(xg_diag_env("XG_WG_CHUNKS")) : 2;
     // (fp32 products only: beside the bf16 GEMMs the loop loses more than the products gain, hidden-1024 iteration 8.50 -> 8.72 ms)
     const int wg_chunks = (ss.overlap() && T >= 8 && w.gm == 0) ? (wg_chunks_env < 1 ? 1 : (wg_chunks_env > 4 ? 4 : wg_chunks_env)) : 1;
     int wg_hi = T, wg_mark = -1;                 // steps [wg_hi, T) already have their weight gradients enqueued
@@ -1484,6 +1486,7 @@ static int rollout_impl(hipStream_t st, const XgDims* d, const XgParams* p, cons
     XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w, &es));
     XG_TRY(init_and_vproj(es, *d, *p, x->feat_mask, w));
     if (hipMemsetAsync(w.alive, 0, sizeof(int32_t) * 4, st) != hipSuccess) return XG_EHIP;   // alive[i] = running max finishing step
+    if (run->prof_event0 && hipEventRecord(static_cast<hipEvent_t>(run->prof_event0), st) != hipSuccess) return XG_EHIP;
     for (int t = 0; t < T; ++t) {
         int64_t* tok = w.TOK + (size_t)t * B;
         float* unf = w.UNF + (size_t)t * B;
@@ -1506,6 +1509,7 @@ static int rollout_impl(hipStream_t st, const XgDims* d, const XgParams* p, cons
         if (t + 1 < T)     // the step at t = L is computed and its logits discarded in the reference (:182,:217)
             XG_TRY(xgk_linear(st, w.gm, B, d->V, R, s.h2o, R, p->logit_w, p->logit_b, w.LOGITS + (size_t)t * B * d->V, d->V));
     }
+    if (run->prof_event1 && hipEventRecord(static_cast<hipEvent_t>(run->prof_event1), st) != hipSuccess) return XG_EHIP;
     XG_TRY(xgk_rollout_finalize(st, w.alive, n_steps, T - 1, split < B ? 2 : 1));
     return XG_OK;
 }

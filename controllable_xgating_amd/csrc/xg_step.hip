@@ -829,12 +829,12 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         return XG_OK;
     }
     const bool bf16 = gemm_mode == 1;      // plain-bf16 mode covers the recurrent products too
-    static const bool no_packed = getenv("XG_NO_PACKED") != nullptr;
+    static const bool no_packed = xg_diag_env("XG_NO_PACKED") != nullptr;
     const bool fast = vec && packed && !no_packed;       // (the caller attaches bf16 tiles iff gemm_mode is 1: attach_packed)
     // cross-workgroup split-K for launches that would leave most CUs idle (every job must allow it)
     int ks = 1;
     {
-        static const bool no_split = getenv("XG_NO_SPLITK") != nullptr;
+        static const bool no_split = xg_diag_env("XG_NO_SPLITK") != nullptr;
         bool ok = fast && !special && !no_split;
         int min_chunks = 1 << 30;
         for (int j = 0; j < a.njobs && ok; ++j) {
@@ -848,7 +848,7 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         tiles *= ks; max_tiles *= ks;
     }
     if (special && !fast) return XG_EINVAL;            // ZERO / ATTN jobs and scaled operands exist in the fast kernel only
-    static const bool split_jobs = getenv("XG_SPLIT_JOBS") != nullptr;       // diagnosis: one launch per job
+    static const bool split_jobs = xg_diag_env("XG_SPLIT_JOBS") != nullptr;       // diagnosis: one launch per job
     if (fast && split_jobs && a.njobs > 1 && !special) {
         for (int j = 0; j < a.njobs; ++j) {
             SkArgs one{};
@@ -858,7 +858,7 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         return XG_OK;
     }
     if (fast) {
-        static const int force_nw = getenv("XG_SK_NW") ? atoi(getenv("XG_SK_NW")) : 0;      // diagnosis
+        static const int force_nw = xg_diag_env("XG_SK_NW") ? atoi(xg_diag_env("XG_SK_NW")) : 0;      // diagnosis
         // A launch that carries the attention: its workgroups are written for 4 waves.  When everything fits the chip in one
         // round as 8-wave workgroups (<= 512: batches of <= 64 rows) the products keep their 8-way K split and the attention
         // runs on the first four waves of its workgroups (36.7 vs 38.6 us per step at 64 rows); beyond that 4-wave workgroups

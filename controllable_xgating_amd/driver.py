@@ -79,7 +79,9 @@ def eval_split(model, crit, classify_crit, batches, ix_to_word, eval_kwargs=None
     decoded with the vocabulary (:55).  Returns (mean loss, predictions, lang_stats) like the reference (:84); the
     coco-caption metrics are out of scope: ``lang_stats = scorer(captions, references)`` when a scorer and ``gts_of``
     (image id -> references) are supplied and eval_kwargs['language_eval'] == 1, else None.  The model is put back into
-    train mode at the end, as the reference does (:83)."""
+    train mode at the end, as the reference does (:83).  ``verbose`` defaults to True as in the reference (:18).
+    Note (SAModel.forward): the HIP forward always runs all T = seq.size(1) steps; the reference leaves its loop at the first
+    all-zero token column (SAModel.py:103), which its own collate never produces."""
     kw = dict(eval_kwargs or {})
     weight_class = kw.get("weight_class", 0.0)
     model.eval()
@@ -100,12 +102,16 @@ def eval_split(model, crit, classify_crit, batches, ix_to_word, eval_kwargs=None
                 predictions.append({"image_id": image_id, "caption": sent, "seqLogprob": lp[k].numpy()})
                 if gts_of is not None:
                     gts.append(gts_of[image_id])
-    if kw.get("verbose", False):
+    if kw.get("verbose", True):                                                    # :18 (default True, like the reference)
         for x in predictions[:10]:
             print("image %s: %s" % (x["image_id"], x["caption"]))
     lang_stats = None
     if kw.get("language_eval", 0) == 1 and scorer is not None and gts_of is not None:
-        lang_stats = scorer([x["caption"] for x in predictions], gts)
+        # :66-76: references are the 'tokenized' field of each ground-truth entry; entries without one are dropped
+        # (plain strings are taken as they are: callers that already hold tokenized references)
+        gts_ = [[(i["tokenized"] if isinstance(i, dict) else i) for i in x if not isinstance(i, dict) or "tokenized" in i]
+                for x in gts]
+        lang_stats = scorer([x["caption"] for x in predictions], gts_)
     model.train()
     return loss_sum / loss_evals, predictions, lang_stats
 
@@ -184,7 +190,9 @@ class Trainer:
         self.sc_flag = False
         self.best_val_score = None
         self.patience = 0
-        self.fused = getattr(opt, "fused_xe_loss", False)
+        # the fused loss path (model.xe_loss: no (m,T,V) log-prob tensor, no gradient of it) is the benchmarked one and the
+        # default; opt.fused_xe_loss = False gives the reference's call sequence model() + two criteria, same numbers
+        self.fused = getattr(opt, "fused_xe_loss", True)
         self.grad_sync = None
         if torch.distributed.is_available() and torch.distributed.is_initialized() and \
                 torch.distributed.get_world_size() > 1 and next(model.parameters()).is_cuda:
@@ -215,12 +223,29 @@ class Trainer:
                 loss = loss_language + wc * loss_classify                                    # :129
                 info.update(loss_language=loss_language, loss_classify=loss_classify)
         else:
-            gen_result, sample_logprobs, greedy = scst_rollouts(model, b["feat1"], b["feat2"], b["feat_mask"], b["pos_feat"],
-                                                                mode=getattr(opt, "scst_rollout_mode", None))      # :131 + myutils.py:45
-            reward = get_self_critical_reward(model, b["feat1"], b["feat2"], b["feat_mask"], b["pos_feat"], gen_result,
-                                              self.scorer, greedy_res=greedy)                # :132
-            loss = self.rl_crit(sample_logprobs, gen_result,
-                                torch.from_numpy(reward).float().to(sample_logprobs.device))  # :133
+            mode = getattr(opt, "scst_rollout_mode", None)
+            if mode in (None, "batched") and model.training:
+                # full-width rollout outputs + the device-side early-exit widths: the only host sync of the iteration is the
+                # scorer's own copy of the tokens (the reference syncs every decoder step, SAModel.py:206)
+                gen_f, slp_f, greedy_f, n = scst_rollouts(model, b["feat1"], b["feat2"], b["feat_mask"], b["pos_feat"],
+                                                          mode="batched", trim=False)                      # :131 + myutils.py:45
+                tok = torch.cat([gen_f, greedy_f]).cpu()                                                    # (one copy, one sync)
+                ns = n.cpu()
+                n_s, n_g = int(ns[0]), int(ns[1])
+                m = gen_f.shape[0]
+                gen_result, greedy = tok[:m, :n_s], tok[m:, :n_g]
+                reward = get_self_critical_reward(model, b["feat1"], b["feat2"], b["feat_mask"], b["pos_feat"], gen_result,
+                                                  self.scorer, greedy_res=greedy)            # :132
+                rew = torch.zeros(m, slp_f.shape[1], dtype=torch.float32)
+                rew[:, :n_s] = torch.from_numpy(np.ascontiguousarray(reward)).float()
+                loss = self.rl_crit(slp_f, gen_f, rew.to(slp_f.device), n=n[:1])              # :133
+            else:
+                gen_result, sample_logprobs, greedy = scst_rollouts(model, b["feat1"], b["feat2"], b["feat_mask"], b["pos_feat"],
+                                                                    mode=mode)               # :131 + myutils.py:45
+                reward = get_self_critical_reward(model, b["feat1"], b["feat2"], b["feat_mask"], b["pos_feat"], gen_result,
+                                                  self.scorer, greedy_res=greedy)            # :132
+                loss = self.rl_crit(sample_logprobs, gen_result,
+                                    torch.from_numpy(reward).float().to(sample_logprobs.device))  # :133
             info["avg_reward"] = float(np.mean(reward[:, 0])) if reward.size else 0.0
         if self.grad_sync is not None:
             self.grad_sync.arm()

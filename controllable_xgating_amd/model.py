@@ -177,7 +177,8 @@ class SAModel(nn.Module):
         self._packed_key = None
         self._packed_epoch = 0
         # arithmetic of the large GEMMs: 'fp32' (exact fp32 MFMA), 'bf16x3' (split-bf16, fp32-class accuracy, faster),
-        # 'bf16' (bf16 operands / fp32 accumulate: BASELINE.json configs[4]).  Recurrent steps are always fp32.
+        # 'bf16' (bf16 operands / fp32 accumulate, for the large AND the per-step products: BASELINE.json configs[4]).
+        # The per-step products are exact fp32 in the other two modes.
         self.precision = getattr(opt, "precision", "fp32")
         if self.precision not in ("fp32", "bf16", "bf16x3"):
             raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16'")
@@ -291,7 +292,10 @@ class SAModel(nn.Module):
     def mark_params_changed(self):
         """Tell the model its parameters were rewritten behind torch's back (a HIP kernel on the flat buffer, e.g.
         train.ClipAdam.step): the packed shadow of the recurrent weights is rebuilt before the next call.  Updates made
-        through torch (optimizers, load_state_dict, copy_) are noticed by themselves (tensor version counters)."""
+        through torch on the parameters themselves (optimizers, load_state_dict, ``p.copy_()``, ``p.mul_()`` under
+        no_grad) are noticed by themselves (tensor version counters).  NOT noticed: in-place writes through ``p.data``
+        (``p.data.copy_()``, ``p.data.uniform_()`` -- common in code written against the reference's torch 0.3): ``.data``
+        has its own version counter.  Call this method after such writes."""
         self._packed_epoch += 1
 
     def _aux_handle(self):
@@ -331,9 +335,20 @@ class SAModel(nn.Module):
                 ps = self._params_struct()
                 nv.check(nv.lib().xg_pack_weights(_stream(), C.byref(d), C.byref(ps), C.c_void_p(ptr), C.c_size_t(nbytes), dtype, 1),
                          "xg_pack_weights")
+                # the shadow is (re)written on THIS stream: calls on any other stream must wait for it (a rollout on a side
+                # stream right after an optimizer step, driver.scst_rollouts(mode="streams"))
+                st = torch.cuda.current_stream()
+                ev = torch.cuda.Event()
+                ev.record(st)
+                self._packed_event, self._packed_stream = ev, (st.device.index, st.cuda_stream)
             self._packed_key = key
         if self._packed is None:
             return None
+        ev = getattr(self, "_packed_event", None)
+        if ev is not None:
+            st = torch.cuda.current_stream()
+            if (st.device.index, st.cuda_stream) != self._packed_stream:
+                st.wait_event(ev)
         return (self._packed.data_ptr() + 15) & ~15
 
     def _run(self, save, seed=None):
@@ -350,6 +365,9 @@ class SAModel(nn.Module):
         r.packed = self._packed_ptr()
         r.packed_dtype = 1 if self.precision == "bf16" else 0
         r.aux = self._aux_handle()
+        pe = getattr(self, "_prof_events", None)       # measurement hook (bench.py): a pair of timing events around the T decoder steps
+        if pe is not None:
+            r.prof_event0, r.prof_event1 = pe[0].cuda_event, pe[1].cuda_event
         return r
 
     @staticmethod
@@ -807,15 +825,19 @@ class _RewardFunction(torch.autograd.Function):
         seq = seq.detach()
         seq = seq if (seq.stride(1) == 1 and seq.dtype == torch.int64) else seq.contiguous().long()
         reward = reward.detach()
-        if reward.dim() == 1:
-            reward = reward.unsqueeze(1)
         reward = reward.float() if reward.dtype != torch.float32 else reward
+        if reward.dim() == 0:                  # one scalar for every element (broadcast like the reference's input * reward)
+            reward = reward.reshape(1, 1)
+        if reward.dim() == 1:                  # (m,): one value per video;  (L,) with L != m: one value per position
+            reward = reward.unsqueeze(1) if reward.shape[0] == m or reward.shape[0] == 1 else reward.unsqueeze(0)
+        if reward.shape[0] not in (1, m):
+            raise nv.XgError("reward must broadcast against the (m, L) log-probs")
         if reward.shape[1] == 1:
-            rs_b, rs_t = reward.stride(0), 0
+            rs_b, rs_t = (reward.stride(0) if reward.shape[0] == m else 0), 0
         else:
             if reward.shape[1] < L:
                 raise nv.XgError("reward has fewer columns than the log-probs")
-            rs_b, rs_t = reward.stride(0), reward.stride(1)
+            rs_b, rs_t = (reward.stride(0) if reward.shape[0] == m else 0), reward.stride(1)
         nd = None if n is None else n.detach().reshape(-1)[:1].to(torch.int32)
         sums = torch.empty(2, dtype=torch.float32, device=slp.device)
         nv.check(nv.lib().xg_reward_fwd(_stream(), nv.ptr(slp_c), slp_c.stride(0), nv.ptr(seq), seq.stride(0), nv.ptr(reward),

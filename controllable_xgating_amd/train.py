@@ -71,6 +71,16 @@ class ClipAdam:
             self._own_events = False
         self._armed = True
 
+    def disarm(self):
+        """Back to the single-stream update for THIS iteration: the segment updates of ``step()`` may only run behind the
+        library's grad-ready events when nothing else touches the gradients between the backward and the update.  A plain
+        (un-overlapped) all-reduce does -- it is enqueued after the backward, i.e. after those events -- so
+        ``allreduce_gradients`` calls this and ``step()`` then updates everything in stream order behind the collective."""
+        if self._armed and getattr(self, "_own_events", False):
+            self.model._grad_event = None
+            self.model._grad_event_head = None
+        self._armed = False
+
     def update_segment(self, a, b):
         """clamp + Adam of flat[a:b] on the current stream (bias correction of the step in progress)."""
         if b <= a:
@@ -125,9 +135,14 @@ import os as _os
 _FORCE = _os.environ.get("XG_FORCE_DIST") == "1"      # run the collective even at world size 1 (single-GPU smoke of the path)
 
 
+_SKIP_COLLECTIVE = False    # measurement switch (bench.py: exposed communication = iteration with - without the collective)
+
+
 def _reduce(t, world, group):
     """sum over ranks / world, in place.  RCCL averages inside the collective; gloo (CPU tests) has no AVG."""
     import torch.distributed as dist
+    if _SKIP_COLLECTIVE:
+        return
     if dist.get_backend(group) == "nccl":
         dist.all_reduce(t, op=dist.ReduceOp.AVG, group=group)
     else:
@@ -149,6 +164,12 @@ def allreduce_gradients(model, group=None):
     if sync is not None and sync.armed:
         sync.finish(group)
         return
+    # plain path: ONE collective after the backward.  An armed overlapping optimizer would run its segment updates behind
+    # events recorded DURING the backward, i.e. on un-averaged gradients (and, with fused_zero, leave zeros for this
+    # collective to average): it must take the stream-ordered update instead.
+    opt = getattr(model, "_overlap_optimizer", None)
+    if opt is not None:
+        opt.disarm()
     _reduce(model.flat_grads(), world, group)
 
 

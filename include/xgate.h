@@ -37,8 +37,8 @@
 extern "C" {
 #endif
 
-#define XG_VERSION 201   /* 200: XgRun gained packed/aux/event fields, xg_set_grad_event removed, xg_vproj takes XgRun;
-                            201: + xg_clip_adam_zero */
+#define XG_VERSION 202   /* 200: XgRun gained packed/aux/event fields, xg_set_grad_event removed, xg_vproj takes XgRun;
+                            201: + xg_clip_adam_zero; 202: XgRun.prof_event0/1 */
 
 enum {
     XG_OK = 0,
@@ -120,6 +120,10 @@ typedef struct XgRun {
                              before the reverse-time decoder loop starts.  From grad_event on, no parameter outside
                              two_spatial_encoder.* is read either: a caller may start its optimizer update of those groups
                              behind the events (train.ClipAdam(overlap=True)). */
+    void *prof_event0, *prof_event1; /* optional hipEvent_t pair (created WITH timing): the forward entry points that run the
+                             decoder's time loop (xg_forward_xe, xg_xe_loss_fwd, xg_rollout, xg_rollout_pair) record them on
+                             `stream` right before the first and right after the last decoder step, so a caller can read the
+                             in-situ duration of the T steps (bench.py: roofline.in_situ_us_per_step).  NULL = nothing recorded. */
 } XgRun;
 
 enum { XG_ROLLOUT_GREEDY = 0, XG_ROLLOUT_SAMPLE = 1, XG_ROLLOUT_REPLAY = 2 };

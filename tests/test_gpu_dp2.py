@@ -94,3 +94,63 @@ def test_two_rank_hip_data_parallel_parity(tmp_path):
     s0, s1 = np.load(tmp_path / "s0.npy"), np.load(tmp_path / "s1.npy")
     assert np.array_equal(s0, s1)
     np.testing.assert_allclose(s0, g0, rtol=2e-3, atol=2e-6)
+
+
+def _worker_update(rank, world, port, out_dir):
+    """Three data-parallel training iterations per update path; every path must leave the same parameters / moments on
+    every rank: (a) plain all-reduce + stream-ordered ClipAdam, (b) plain all-reduce + ARMED overlapping ClipAdam(fused_zero)
+    (allreduce_gradients disarms it), (c) GradSync.finish + armed overlapping ClipAdam (segment updates behind each bucket)."""
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    from controllable_xgating_amd import train as tr
+    from oracle import paramgen as pg
+    from oracle import xgate_oracle as xo
+    from tests.util import CFG, make_model
+    d = pg.make_dims(**CFG["mid"])
+    Pn = pg.make_params(d)
+    xs = tr.shard_batch(xo.to_torch_inputs(pg.make_inputs(d, seed=0, ragged=True)), rank, world)
+    xd = {k: v.cuda() for k, v in xs.items()}
+    for mode in ("plain", "plain_overlap", "gradsync_overlap"):
+        model = make_model(d, P=Pn, device="cuda:%d" % rank)
+        tr.broadcast_parameters(model)
+        over = mode != "plain"
+        opt = tr.ClipAdam(model, lr=4e-4, grad_clip=0.1, overlap=over, fused_zero=over)
+        sync = tr.GradSync(model) if mode == "gradsync_overlap" else None
+        for _ in range(3):
+            opt.zero_grad()
+            loss = model.xe_loss(xd["feats_rgb"], xd["feats_opfl"], xd["feat_mask"], xd["pos_feats"], xd["seq"], xd["seq_mask"])
+            if sync is not None:
+                sync.arm()
+            opt.arm()
+            loss.backward()
+            tr.allreduce_gradients(model)
+            opt.step()
+        torch.cuda.synchronize()
+        np.save(os.path.join(out_dir, "%s_p%d.npy" % (mode, rank)), model.flat_parameters().detach().cpu().numpy())
+        np.save(os.path.join(out_dir, "%s_m%d.npy" % (mode, rank)), opt.exp_avg.cpu().numpy())
+        np.save(os.path.join(out_dir, "%s_v%d.npy" % (mode, rank)), opt.exp_avg_sq.cpu().numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_update_paths_agree(tmp_path):
+    if not torch.cuda.is_available() or torch.cuda.device_count() < 2:
+        pytest.skip("needs 2 GPUs (single-rank mechanics: tests/test_gpu_parity.py::test_data_parallel_update_paths_agree_single_rank)")
+    import __graft_entry__ as ge
+    ge.build()
+    import torch.multiprocessing as mp
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    mp.spawn(_worker_update, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    ref = {k: np.load(tmp_path / ("plain_%s0.npy" % k)) for k in "pmv"}
+    for mode in ("plain", "plain_overlap", "gradsync_overlap"):
+        for k in "pmv":
+            a, b = np.load(tmp_path / ("%s_%s0.npy" % (mode, k))), np.load(tmp_path / ("%s_%s1.npy" % (mode, k)))
+            assert np.array_equal(a, b), (mode, k)                 # replicas stay bit-identical
+        np.testing.assert_allclose(np.load(tmp_path / ("%s_m0.npy" % mode)), ref["m"], atol=1e-6 + 2e-3 * np.abs(ref["m"]).max(), err_msg=mode)
+        np.testing.assert_allclose(np.load(tmp_path / ("%s_v0.npy" % mode)), ref["v"], atol=1e-9 + 2e-3 * np.abs(ref["v"]).max(), err_msg=mode)
+        disp = np.abs(np.load(tmp_path / ("%s_p0.npy" % mode)) - ref["p"])
+        assert disp.max() <= 3.1 * 4e-4 and (disp > 4e-5).mean() <= 0.02, (mode, float(disp.max()))

@@ -72,6 +72,46 @@ def test_config2_b128_xe_loss_logprobs_and_every_gradient_vs_oracle(path, ragged
         np.testing.assert_allclose(bn.running_var.cpu().numpy(), running[pre + "running_var"].numpy(), atol=1e-5)
 
 
+# ------------------------------------------------------------------ configs[4]: bf16, hidden 1024, 40 frames, vocab 20k, B = 128
+def test_config5_b128_hidden1024_bf16_and_split_bf16_vs_oracle():
+    """BASELINE.json configs[4] at its FULL size (B = 128, K = 40, R = 1024, V = 20000): the kernel paths only this size
+    takes (4-wave skinny workgroups, the fused-attention step form, the staged 33-48-frame attention backward, 256 x 128 bf16
+    tiles, background products).  precision='bf16': loss within 1e-2 of the fp32 oracle (north_star's tolerance for this
+    config) and every gradient norm within 5 %; precision='bf16x3' (split-bf16, fp32-class): loss within 1e-4."""
+    d = pg.make_dims(**dict(CFG["c5"], B=128, L=20))
+    Pn = pg.make_params(d)
+    xn = pg.make_inputs(d, seed=0, ragged=True)
+    P = xo.to_torch_params(Pn, requires_grad=True)
+    xi = xo.to_torch_inputs(xn)
+    logp_o, _, _ = xo.forward_xe(P, xi["feats_rgb"], xi["feats_opfl"], xi["feat_mask"], xi["pos_feats"], xi["seq"],
+                                 xi["seq_mask"], train=True, running=xo.new_running(d))
+    loss_o = xo.lm_criterion(logp_o, xi["seq"], xi["seq_mask"])
+    loss_o.backward()
+    g_o = oracle_grads(P)
+    del logp_o
+    from controllable_xgating_amd import SAModel, make_opt
+    x = to_dev(xn)
+    for precision, tol in (("bf16", 1e-2), ("bf16x3", 1e-4)):
+        model = SAModel(make_opt(d, precision=precision))
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in Pn.items()}, strict=False)
+        model = model.cuda()
+        model.train()
+        loss = model.xe_loss(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+        loss.backward()
+        torch.cuda.synchronize()
+        assert abs(loss.item() - loss_o.item()) < tol, (precision, loss.item(), loss_o.item())
+        bad = []
+        for name, prm in model.named_parameters():
+            if name in ZERO_GRAD_PARAMS:
+                continue
+            gn, rn = float(prm.grad.double().norm()), float(np.linalg.norm(g_o[name].astype(np.float64)))
+            if not abs(gn - rn) <= (5e-2 if precision == "bf16" else 2e-3) * rn + 1e-6:
+                bad.append((name, gn, rn))
+        assert not bad, (precision, bad)
+        del model
+        torch.cuda.empty_cache()
+
+
 # ------------------------------------------------------------------ configs[2]: SCST, B = 64, seq_len 30
 def _scst_case():
     d = pg.make_dims(**dict(CFG["c1"], B=64, L=30))

@@ -117,7 +117,8 @@ def test_gemm_fuzz_all_kernels(pk_min, bg):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, XG_PK_MIN=pk_min)
+    from controllable_xgating_amd import _native as nv
+    env = dict(os.environ, XG_PK_MIN=pk_min, XG_LIBRARY=nv.LIB_DIAG_PATH)      # the switches exist in the -DXG_DIAG build only
     if bg:
         env["XG_GEMM_FORCE_BG"] = "1"
     r = subprocess.run([sys.executable, "-c", _GEMM_FUZZ % root], env=env, capture_output=True, text=True, timeout=600)
@@ -845,6 +846,125 @@ def test_gradsync_overlapped_allreduce_single_rank():
         tr._FORCE = old_force
         if created:
             dist.destroy_process_group()
+
+
+def test_data_parallel_update_paths_agree_single_rank():
+    """Three training iterations on a one-rank RCCL group (the collective is the identity; streams, events, segment slicing
+    and the optimizer hand-off are what runs): (a) plain all-reduce + stream-ordered ClipAdam, (b) plain all-reduce with an
+    ARMED overlapping ClipAdam(fused_zero) -- allreduce_gradients must disarm it, its segment updates would otherwise run
+    behind events recorded before the collective --, (c) GradSync.finish with the armed overlapping optimizer (the default
+    of driver.Trainer / bench.py: segment updates behind each bucket).  Same parameters and Adam moments after 3 steps."""
+    import torch.distributed as dist
+    from controllable_xgating_amd import train as tr
+    created = False
+    if not dist.is_initialized():
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+        created = True
+    old_force = tr._FORCE
+    tr._FORCE = True
+    try:
+        d = pg.make_dims(**CFG["mid"])
+        Pn = pg.make_params(d)
+        x = to_dev(pg.make_inputs(d, seed=0, ragged=True))
+        outs = {}
+        for mode in ("plain", "plain+overlap", "gradsync+overlap"):
+            model = make_model(d, P=Pn, train=True)
+            over = mode != "plain"
+            opt = tr.ClipAdam(model, lr=4e-4, grad_clip=0.1, overlap=over, fused_zero=over)
+            sync = tr.GradSync(model) if mode.startswith("gradsync") else None
+            for _ in range(3):
+                opt.zero_grad()
+                loss = model.xe_loss(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+                if sync is not None:
+                    sync.arm()
+                opt.arm()
+                loss.backward()
+                tr.allreduce_gradients(model)
+                if mode == "plain+overlap":
+                    assert not opt._armed and model._grad_event is None      # the plain collective disarmed the overlap
+                opt.step()
+            torch.cuda.synchronize()
+            assert opt.step_count == 3
+            if over:                                                        # fused_zero left the gradient buffer at zero
+                assert float(model.flat_grads().abs().max()) == 0.0
+            outs[mode] = (model.flat_parameters().detach().cpu().numpy().copy(), opt.exp_avg.cpu().numpy().copy(),
+                          opt.exp_avg_sq.cpu().numpy().copy(), float(loss.item()))
+        ref = outs["plain"]
+        assert np.abs(ref[1]).max() > 0
+        for mode in ("plain+overlap", "gradsync+overlap"):
+            got = outs[mode]
+            assert abs(got[3] - ref[3]) < 1e-5, (mode, got[3], ref[3])
+            np.testing.assert_allclose(got[1], ref[1], atol=1e-6 + 2e-3 * np.abs(ref[1]).max(), err_msg=mode)
+            np.testing.assert_allclose(got[2], ref[2], atol=1e-9 + 2e-3 * np.abs(ref[2]).max(), err_msg=mode)
+            # Adam normalises: elements with round-off-level gradients may step differently (<= 3 lr after three steps)
+            disp = np.abs(got[0] - ref[0])
+            assert disp.max() <= 3.1 * 4e-4 and (disp > 4e-5).mean() <= 0.02, (mode, float(disp.max()), float((disp > 4e-5).mean()))
+    finally:
+        tr._FORCE = old_force
+        if created:
+            dist.destroy_process_group()
+
+
+def test_packed_weights_are_ordered_across_streams():
+    """The packed shadow of the recurrent weights is rewritten on the stream of the first call after a parameter update; a
+    call on ANOTHER stream right behind it must wait for that pack (model._packed_ptr records an event): a rollout issued on
+    a side stream immediately after an optimizer step gives the same tokens / log-probs as the same rollout on the main stream."""
+    from controllable_xgating_amd import train as tr
+    d = pg.make_dims(**CFG["mid"])
+    Pn = pg.make_params(d, logit_gain=1.0)
+    x = to_dev(pg.make_inputs(d, seed=0))
+    u = torch.from_numpy(pg.uniform("uni_pk", (d.L + 1, d.B), 7)).cuda()
+    outs = []
+    for side_first in (False, True):
+        model = make_model(d, P=Pn, train=True)
+        opt = tr.ClipAdam(model, lr=1e-2, grad_clip=0.1)
+        for it in range(3):
+            opt.zero_grad()
+            loss = model.xe_loss(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+            loss.backward()
+            opt.step()                                           # -> mark_params_changed: the next call re-packs
+            main = torch.cuda.current_stream()
+            side = torch.cuda.Stream()
+            with torch.no_grad():
+                if side_first:                                   # pack happens on `side`; the main-stream call must wait for it
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        model.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"],
+                                     {"sample_max": 1, "async": True, "bn_update": False})
+                seq, slp, n = model.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"],
+                                           {"sample_max": 0, "uniforms": u, "async": True, "bn_update": False})
+                main.wait_stream(side)
+        torch.cuda.synchronize()
+        outs.append((seq.cpu().numpy(), slp.cpu().numpy()))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    np.testing.assert_allclose(outs[0][1], outs[1][1], atol=1e-6)
+
+
+def test_reward_criterion_scalar_and_per_position_rewards():
+    """RewardCriterion broadcasts like the reference's ``input * reward`` (SAModel.py:262): a 0-d scalar, one value per video
+    (m,) / (m, 1), one row (1, L), and the full (m, L) matrix."""
+    from controllable_xgating_amd import RewardCriterion
+    g = torch.Generator().manual_seed(3)
+    m, L = 6, 9
+    slp = (-torch.rand(m, L, generator=g)).cuda().requires_grad_(True)
+    seq = torch.randint(0, 4, (m, L), generator=g).cuda()
+    crit = RewardCriterion()
+
+    def ref(reward):
+        mask = torch.cat([torch.ones(m, 1, device="cuda"), (seq[:, :-1] > 0).float()], 1)
+        return -(slp.detach() * reward * mask).sum() / mask.sum()
+    row = torch.rand(1, L, generator=g).cuda()
+    per_video = torch.rand(m, generator=g).cuda()
+    for reward, full in ((torch.tensor(0.7), torch.full((m, L), 0.7, device="cuda")), (per_video, per_video[:, None].expand(m, L)),
+                         (row, row.expand(m, L)), (0.25, torch.full((m, L), 0.25, device="cuda"))):
+        loss = crit(slp, seq, reward)
+        assert abs(loss.item() - ref(full).item()) < 1e-6
+        loss.backward()
 
 
 def test_repeated_iterations_are_reproducible_across_streams():
