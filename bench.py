@@ -222,12 +222,17 @@ def rccl_channels(path):
         txt = open(path, errors="replace").read()
     except Exception:
         return None
+    env = {k: os.environ[k] for k in ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "NCCL_NCHANNELS_PER_PEER") if k in os.environ}
     m = re.findall(r"(\d+) coll channels, (\d+) collnet channels, (\d+) nvls channels, (\d+) p2p channels", txt)
-    if not m:
-        return None
-    c = m[-1]
-    return {"coll": int(c[0]), "collnet": int(c[1]), "nvls": int(c[2]), "p2p": int(c[3]),
-            "env": {k: os.environ[k] for k in ("NCCL_MIN_NCHANNELS", "NCCL_MAX_NCHANNELS", "NCCL_NCHANNELS_PER_PEER") if k in os.environ}}
+    if m:
+        c = m[-1]
+        return {"coll": int(c[0]), "collnet": int(c[1]), "nvls": int(c[2]), "p2p": int(c[3]), "env": env}
+    m = re.findall(r"Channel (\d+)/(\d+)", txt)          # older log format: one 'Channel ii/nn : ring' line per channel
+    if m:
+        return {"coll": max(int(b) for _, b in m), "env": env}
+    # nothing recognised: hand back the lines that mention channels so the first scaling run can still be read
+    lines = [ln.strip()[-160:] for ln in txt.splitlines() if "hannel" in ln][:6]
+    return {"coll": None, "env": env, "log_lines": lines}
 
 
 def scst_parity(model, cfg, x, reward_b):
@@ -494,6 +499,11 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON: everything else that writes to file descriptor 1 (RCCL prints a version banner
+    # through C stdio when a communicator comes up, rocprofv3 children, ...) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -524,6 +534,7 @@ def main():
         with socket.socket() as sk:
             sk.bind(("127.0.0.1", 0))
             port = sk.getsockname()[1]
+        os.dup2(json_fd, 1)                      # (the launched ranks do their own redirection)
         os.execv(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
                                   "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:])
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -568,12 +579,13 @@ def main():
                 sec[key] = {"error": repr(e)}
                 fails.append("secondary %s failed: %r" % (key, e))
         out["secondary"] = sec
-    if rank == 0:
-        print(json.dumps(out))
-        if fails:
-            raise SystemExit("; ".join(fails))
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
+        if fails:
+            raise SystemExit("; ".join(fails))
 
 
 if __name__ == "__main__":

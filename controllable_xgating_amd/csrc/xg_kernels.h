@@ -129,7 +129,7 @@ enum { SK_EPI_STORE = 0, SK_EPI_LSTM = 1, SK_EPI_GATE = 2,
        //   (zeroed by a ZERO job of the previous launch; two commutative adds per element, so the sum is deterministic).
        //   The cell-2 job of the NEXT launch normalises while it stages af (SkSeg.row_scale) -- no merge launch.
        SK_EPI_ATTN = 5 };
-constexpr int SK_MAX_JOBS = 4;
+constexpr int SK_MAX_JOBS = 5;
 struct SkSeg {
     const float* A; const float* B;   // A (M,K) row-major lda ; B (N,K) row-major ldb, or (K,N) when b_ncontig
     int lda, ldb, K, b_ncontig;
@@ -175,6 +175,29 @@ struct SkJob {
 struct SkArgs { int njobs; int tile0[SK_MAX_JOBS]; SkJob job[SK_MAX_JOBS]; };
 // gemm_mode 1 (plain bf16) rounds the staged chunks to bf16 (LDS-staged kernel); 0 / 3: exact fp32
 int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode);
+
+// ---- xg_dstep.hip : one decoder step (attention + POS gate + the two cells, sub_modules.py:671-687) as ONE dataflow launch
+struct DStepArgs {
+    int B, R, A, E, K, V1;                       // V1 = vocabulary size - 1 (clamp of the token gather)
+    const float *h1, *c1, *h2, *c2;              // state before the step, (B,R) each
+    float *h1o, *c1o, *h2o, *c2o;                // state after the step (may alias the input state: copy_back)
+    float *h1w, *h2w;                            // where the cell epilogues write h1' / h2': h1o / h2o, or scratch rows when in place
+    int copy_back;                               // 1: h1w / h2w are scratch; the last cell-2 tile of each m-tile copies them into h1o / h2o
+    const float* xt; const int64_t* tok; const float* embed;     // xt (B,E) rows, or tokens + embed.weight (gathered inside the products)
+    const float* pos; float* gp; float* posg;    // POS gate: raw feature, saved gate values, gated feature (written unless pre1)
+    const float* pre1;                           // teacher forcing: hoisted token side of cell 1 (B,4R), biases included; else null
+    const float* mask; int ldm;                  // xt_mask: element b at mask[b * ldm]; null = ones
+    float *P, *alpha, *af, *g1, *g2;             // p (B,A), attention weights (B,K) [may be null], context (B,R), gates (B,4R) [may be null]
+    const float *V, *vproj, *a2w;
+    const float *pk_h2a1, *pk_h2a2, *pk_dgate, *pk_l1_i2h, *pk_l1_a2h, *pk_l1_h2h, *pk_l2_i2h, *pk_l2_a2h, *pk_l2_h2h;   // packed tiles
+    const float *h2a_b, *dgate_b, *l1_i2h_b, *l1_a2h_b, *l1_h2h_b, *l2_i2h_b, *l2_a2h_b, *l2_h2h_b;
+    int* ctr;                                    // sync words (xgk_dstep_sync_bytes), zero on entry, left at zero
+    XgDrop drop_gate, drop_l1, drop_l2;
+    int t0_p, t0_att, t0_c1, t0_c2, total;       // first block of each job after the gate tiles (filled in by xgk_dstep)
+};
+size_t xgk_dstep_sync_bytes();
+bool xgk_dstep_ok(const XgDims& d);              // shapes the dataflow kernel takes
+int xgk_dstep(hipStream_t st, DStepArgs& a, int gemm_mode);
 
 // ---- xg_pack.hip : weights re-tiled into MFMA-fragment order (caller-owned shadow, XgRun.packed)
 enum { PK_H2A1 = 0, PK_H2A2, PK_DGATE, PK_L1_I2H, PK_L1_A2H, PK_L1_H2H, PK_L2_I2H, PK_L2_A2H, PK_L2_H2H, PK_ENC_RGB, PK_ENC_OPFL,

@@ -119,6 +119,7 @@ struct Ws {
     // ---- rollout
     int64_t* TOK; float *TOKLP, *UNF; int32_t* alive;
     int32_t* tickets;                  // split-K arrival counters (xg_step.hip), SK_MAX_JOBS x 1024, zero between launches
+    int32_t* dsync;                    // sync words of the dataflow step kernel (xg_dstep.hip): zero between launches
     // everything a backward pass needs ZERO on entry is one contiguous block (dst[0][*], DAF, the encoder's carried
     // gradients, the BatchNorm sums, the tickets): one memset on a side stream instead of a dozen on the critical path
     char* zblock; size_t zbytes; bool zeroed;
@@ -174,6 +175,7 @@ Ws carve(const XgDims& d, void* base) {
     w.AFU = c.take<float>(B * R + ((B + 3) & ~(size_t)3)); w.ATS = w.AFU + B * R;
     w.TOK = c.take<int64_t>(TB); w.TOKLP = c.take<float>(TB); w.UNF = c.take<float>(TB);
     w.alive = c.take<int32_t>(4);
+    w.dsync = c.take<int32_t>(xgk_dstep_sync_bytes() / sizeof(int32_t));
     {   // the zero block
         c.off = (c.off + 255) & ~(size_t)255;
         const size_t z0 = c.off;
@@ -235,6 +237,13 @@ inline void allow_split(SkArgs& sk, int j, const Ws& w) { sk.job[j].ksplit_ok = 
 // backward's cell-1 chain runs on a side stream with block 2 while the encoder backward uses blocks 0-1.)
 inline int zero_tickets(hipStream_t st, const Ws& w, int njobs) {
     return hipMemsetAsync(w.tickets, 0, sizeof(int32_t) * njobs * 1024, st) == hipSuccess ? XG_OK : XG_EHIP;
+}
+// The dataflow step kernel's sync words are zero between launches (its last workgroup leaves them so); whole-sequence entry
+// points clear them once more per sequence, so that a sequence never inherits what an aborted launch left behind.  The
+// single-step entry point (xg_step_fwd) relies on the invariant alone: the workspace contract asks for a zero-filled
+// workspace at first use (include/xgate.h).
+inline int zero_dsync(hipStream_t st, const Ws& w) {
+    return hipMemsetAsync(w.dsync, 0, xgk_dstep_sync_bytes(), st) == hipSuccess ? XG_OK : XG_EHIP;
 }
 // (the tile element type must fit the arithmetic: bf16 tiles for gemm_mode 1, fp32 tiles otherwise)
 inline void attach_packed(Ws& w, const XgDims& d, const XgRun* run) {
@@ -532,6 +541,33 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
     c.gates = s.g2; c.ldg = 4 * R; c.c_out = s.c2o; c.ldco = R; c.h_out = s.h2o; c.ldho = R;
     c.B = B; c.R = R; c.order = XG_ORDER_IFOG; c.mask_mode = XG_MASK_HOLD;
     c.drop = xg_make_drop(&run, XG_SITE_L2, s.t);
+    // The step as ONE dataflow launch (xg_dstep.hip) exists for measurement only (-DXG_DIAG build, XG_DSTEP=1): at 128 rows it
+    // takes 77 us against 46 us for the three launches below (DESIGN.md 4.3 has the in-kernel timeline); it is ahead only
+    // below ~16 rows (30 vs 34 us at 8 rows).
+    static const bool use_dstep = xg_diag_env("XG_DSTEP") != nullptr;
+    if (use_dstep && step_packed(w, d) && xgk_dstep_ok(d) && ((uintptr_t)V % 16 == 0) && ((uintptr_t)vproj % 16 == 0) &&
+        ((uintptr_t)p.a2w_w % 16 == 0)) {
+        DStepArgs a2{};
+        a2.B = B; a2.R = R; a2.A = A; a2.E = E; a2.K = d.K; a2.V1 = d.V - 1;
+        a2.h1 = s.h1; a2.c1 = s.c1; a2.h2 = s.h2; a2.c2 = s.c2;
+        a2.h1o = s.h1o; a2.c1o = s.c1o; a2.h2o = s.h2o; a2.c2o = s.c2o;
+        a2.copy_back = (s.h1o == s.h1 || s.h2o == s.h2) ? 1 : 0;             // in-place state: new h rows via scratch
+        a2.h1w = a2.copy_back ? w.state_tmp : s.h1o;
+        a2.h2w = a2.copy_back ? w.state_tmp + (size_t)B * R : s.h2o;
+        a2.xt = s.xt; a2.tok = s.tok; a2.embed = p.embed_w;
+        a2.pos = s.pos; a2.gp = s.gp; a2.posg = s.posg; a2.pre1 = s.pre1;
+        a2.mask = s.mask; a2.ldm = s.ldm;
+        a2.P = s.P; a2.alpha = s.alpha; a2.af = s.af; a2.g1 = s.g1; a2.g2 = s.g2;
+        a2.V = V; a2.vproj = vproj; a2.a2w = p.a2w_w;
+        a2.pk_h2a1 = w.pk.m[PK_H2A1]; a2.pk_h2a2 = w.pk.m[PK_H2A2]; a2.pk_dgate = w.pk.m[PK_DGATE];
+        a2.pk_l1_i2h = w.pk.m[PK_L1_I2H]; a2.pk_l1_a2h = w.pk.m[PK_L1_A2H]; a2.pk_l1_h2h = w.pk.m[PK_L1_H2H];
+        a2.pk_l2_i2h = w.pk.m[PK_L2_I2H]; a2.pk_l2_a2h = w.pk.m[PK_L2_A2H]; a2.pk_l2_h2h = w.pk.m[PK_L2_H2H];
+        a2.h2a_b = p.h2a_b; a2.dgate_b = p.dgate_b; a2.l1_i2h_b = p.l1_i2h_b; a2.l1_a2h_b = p.l1_a2h_b; a2.l1_h2h_b = p.l1_h2h_b;
+        a2.l2_i2h_b = p.l2_i2h_b; a2.l2_a2h_b = p.l2_a2h_b; a2.l2_h2h_b = p.l2_h2h_b;
+        a2.ctr = w.dsync;
+        a2.drop_gate = xg_make_drop(&run, XG_SITE_DGATE, s.t); a2.drop_l1 = a.drop; a2.drop_l2 = c.drop;
+        return xgk_dstep(st, a2, w.gm);
+    }
     if (step_packed(w, d)) {
         // xt as a matrix operand: the materialised rows, or embed.weight gathered by token
         auto xt_seg = [&](int which, const float* W) {
@@ -554,6 +590,10 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         // launches are then 512 / 512 / 256 workgroups, one round each, instead of 256 / 768 / 256: 49.4 -> 46.5 us per step
         // at 128 rows) or in launch 2 (rollout form up to 64 rows: 37.1 us against 39.2 us in launch 1)
         const bool s2_first = (s.pre1 != nullptr && xe_form == 'B') || (!s.pre1 && B > 64);
+        // rollout form: S1' = h1 W_h2h1 + xt W_i2h1 + b (everything of cell 1 that does not wait for the POS gate) rides in
+        // launch 1 as well, so that launch 2 -- the attention beside cell 1 -- keeps only cell 1's pos' product (K = R)
+        static const int s1_env = xg_diag_env("XG_S1_FIRST") ? atoi(xg_diag_env("XG_S1_FIRST")) : -1;
+        const bool s1_first = !s.pre1 && (s1_env >= 0 ? s1_env != 0 : false);
         const bool s2_in_cell2 = s.pre1 != nullptr && xe_form == 'D';       // ... or stays a segment of cell 2 (measured for the
                                                                             // rollout form at 128 rows too: 48.3 us)
         SkArgs k1{}, k2{}, k3{};
@@ -593,6 +633,14 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
             j.seg[0] = seg_nt(w, PK_L2_H2H, s.h2, R, p.l2_h2h_w, R, R); j.bias[0] = p.l2_h2h_b;
         };
         if (s2_first) s2_job(k1.job[n1++]);
+        if (s1_first) {     // S1' (gate-major, cell tiling) -> w.S
+            SkJob& j = k1.job[n1++];
+            j = job_store(B, 4 * R, w.S, 4 * R, false);
+            j.cell_cols = 1; j.R = R;
+            j.nseg = 2;
+            j.seg[0] = seg_nt(w, PK_L1_H2H, s.h1, R, p.l1_h2h_w, R, R); j.bias[0] = p.l1_h2h_b;
+            j.seg[1] = xt_seg(PK_L1_I2H, p.l1_i2h_w); j.bias[1] = p.l1_i2h_b;
+        }
         if (fused_attn) {   // the attention's accumulators start from zero
             SkJob& j = k1.job[n1++];
             j = SkJob{};
@@ -611,11 +659,17 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         if (!s.pre1) {
             SkJob& j = k2.job[n2++];
             a.h_out = h1_new;
+            if (s1_first) { a.add = w.S; a.ldadd = 4 * R; }
             j = job_lstm(a);
-            j.nseg = 3;
-            j.seg[0] = seg_nt(w, PK_L1_H2H, s.h1, R, p.l1_h2h_w, R, R); j.bias[0] = p.l1_h2h_b;
-            j.seg[1] = seg_nt(w, PK_L1_A2H, s.posg, R, p.l1_a2h_w, R, R); j.bias[1] = p.l1_a2h_b;
-            j.seg[2] = xt_seg(PK_L1_I2H, p.l1_i2h_w); j.bias[2] = p.l1_i2h_b;
+            if (s1_first) {
+                j.nseg = 1;
+                j.seg[0] = seg_nt(w, PK_L1_A2H, s.posg, R, p.l1_a2h_w, R, R); j.bias[0] = p.l1_a2h_b;
+            } else {
+                j.nseg = 3;
+                j.seg[0] = seg_nt(w, PK_L1_H2H, s.h1, R, p.l1_h2h_w, R, R); j.bias[0] = p.l1_h2h_b;
+                j.seg[1] = seg_nt(w, PK_L1_A2H, s.posg, R, p.l1_a2h_w, R, R); j.bias[1] = p.l1_a2h_b;
+                j.seg[2] = xt_seg(PK_L1_I2H, p.l1_i2h_w); j.bias[2] = p.l1_i2h_b;
+            }
         }
         if (!s2_first && !s2_in_cell2) s2_job(k2.job[n2++]);
         k2.njobs = n2;
@@ -735,6 +789,7 @@ int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatc
     const int B = d.B, R = d.R, A = d.A, E = d.E, T = d.T, N = B * d.K;
     const size_t BR = (size_t)B * R;
     XG_TRY(init_and_vproj(ss, d, p, x.feat_mask, w));
+    XG_TRY(zero_dsync(st, w));
     XG_TRY(ss.join());                                                                              // token-side products
     const int th = (ss.overlap() && T >= 4) ? T / 2 : 0;
     // ... as a background product, with the stand-alone attention in its half-CU form beside it: the 128-VGPR attention
@@ -1369,6 +1424,7 @@ extern "C" int xg_forward_ss(void* stream, const XgDims* d, const XgParams* p, c
     Streams es(st, run);
     XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w, &es));
     XG_TRY(init_and_vproj(es, *d, *p, x->feat_mask, w));
+    XG_TRY(zero_dsync(st, w));
     int64_t* sampled = reinterpret_cast<int64_t*>(w.DXe);       // scratch (free until the backward pass)
     for (int t = 0; t < T; ++t) {
         int64_t* tok = w.TOK + (size_t)t * B;
@@ -1485,6 +1541,7 @@ static int rollout_impl(hipStream_t st, const XgDims* d, const XgParams* p, cons
     Streams es(st, run);
     XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w, &es));
     XG_TRY(init_and_vproj(es, *d, *p, x->feat_mask, w));
+    XG_TRY(zero_dsync(st, w));
     if (hipMemsetAsync(w.alive, 0, sizeof(int32_t) * 4, st) != hipSuccess) return XG_EHIP;   // alive[i] = running max finishing step
     if (run->prof_event0 && hipEventRecord(static_cast<hipEvent_t>(run->prof_event0), st) != hipSuccess) return XG_EHIP;
     for (int t = 0; t < T; ++t) {

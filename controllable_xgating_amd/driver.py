@@ -162,7 +162,8 @@ def scst_rollouts(model, feat1, feat2, feat_mask, pos_feat, overlap=True, mode=N
         return gen[:, :n_s], slp[:, :n_s], greedy[:, :n_g]
     r0 = [(m.running_mean.clone(), m.running_var.clone()) for m in bns]
     main = torch.cuda.current_stream()
-    side = torch.cuda.Stream()
+    from .train import shared_stream
+    side = shared_stream("rollout")              # (one side stream per process: see train.shared_stream)
     side.wait_stream(main)
     with torch.cuda.stream(side), torch.no_grad():
         g_seq, _, g_n = model.sample(feat1, feat2, feat_mask, pos_feat, {"sample_max": 1, "async": True, "bn_update": False})

@@ -55,6 +55,13 @@ def _with_grad_event(model, run):
     return r
 
 
+# side-stream handles of the library (xg_aux_create: two HIP streams + events each), ONE per (device, caller stream) for the
+# whole process and never destroyed: every model on that stream shares it.  A handle per model would add two more HIP streams
+# per model, and streams beyond the first handful share the hardware's compute pipes with the earlier ones -- see
+# train.shared_stream for what that costs.
+_AUX_HANDLES = {}
+
+
 class _Holder(nn.Module):
     """Bare container so parameter names nest like the reference's sub-modules."""
 
@@ -75,7 +82,7 @@ class _WorkspacePool:
         n = nv.lib().xg_workspace_bytes(C.byref(dims))
         if n == 0:
             raise nv.XgError("xg_workspace_bytes: invalid dims")
-        return torch.empty(n + 256, dtype=torch.uint8, device=device)
+        return torch.zeros(n + 256, dtype=torch.uint8, device=device)     # zero-filled at first use: include/xgate.h
 
     def take(self, dims, device):
         lst = self.free.setdefault(self._key(dims, device), [])
@@ -172,7 +179,6 @@ class SAModel(nn.Module):
         self._gs_cache = None
         self._offsets = []
         self._call = 0
-        self._aux = {}               # (device, stream) -> xg_aux_create handle (side streams of the entry points)
         self._packed = None          # recurrent weights in MFMA-fragment order (xg_pack_weights), refreshed lazily
         self._packed_key = None
         self._packed_epoch = 0
@@ -302,19 +308,12 @@ class SAModel(nn.Module):
         """Side-stream handle (include/xgate.h: xg_aux_create) for the current device and stream, created on first use."""
         st = torch.cuda.current_stream()
         key = (st.device.index, st.cuda_stream)
-        h = self._aux.get(key)
+        h = _AUX_HANDLES.get(key)
         if h is None:
             out = C.c_void_p()
             nv.check(nv.lib().xg_aux_create(C.byref(out)), "xg_aux_create")
-            h = self._aux[key] = out.value
+            h = _AUX_HANDLES[key] = out.value
         return h
-
-    def __del__(self):
-        try:
-            for h in getattr(self, "_aux", {}).values():
-                nv.lib().xg_aux_destroy(C.c_void_p(h))
-        except Exception:
-            pass
 
     def _packed_ptr(self):
         """Device pointer of the packed recurrent weights (include/xgate.h: xg_pack_weights), valid for the current

@@ -15,6 +15,9 @@
  *   - The caller owns all memory; scratch and saved activations live in one caller-provided
  *     workspace sized by xg_workspace_bytes().  The only thing the library allocates is the
  *     optional side-stream handle of xg_aux_create (two HIP streams + events, no memory).
+ *     A workspace must be ZERO-FILLED once after allocation (hipMemset), before its first use: it
+ *     also holds the inter-workgroup synchronisation words of the step kernels, which every call
+ *     leaves at zero again.
  *   - No library-global mutable state: arithmetic mode, packed weights, side streams and
  *     data-parallel events all travel in XgRun.
  *     The workspace written by a *_fwd call must be handed unchanged to the matching *_bwd.

@@ -125,6 +125,19 @@ def test_gemm_fuzz_all_kernels(pk_min, bg):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+@pytest.mark.parametrize("rows", [40, 128])
+def test_dataflow_step_kernel_equals_three_launch_step(rows):
+    """xg_dstep.hip (the decoder step as ONE dataflow launch: measurement-only, selected with XG_DSTEP=1 in the -DXG_DIAG
+    library) against the product's three-launch step: three chained in-place xg_step_fwd calls on the same inputs, state and
+    attention weights equal to fp32 round-off (tools/dstep_check.py; 40 rows = a ragged second m-tile)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "dstep_check.py")], env=dict(os.environ, DS_B=str(rows)),
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "us per step" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
+
 def test_gemm_strided_submatrix():
     """W[:, R:2R] column block of h2a.weight as B operand (ldb = 2R) and accumulate, as the step uses it."""
     from controllable_xgating_amd import _native as nv
