@@ -286,8 +286,12 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
     broadcast_parameters(model)
     x = synth_inputs(cfg["B"], cfg["K"], cfg["L"], cfg["V"], cfg["R"], cfg["F1"], cfg["F2"], cfg["C"], seed=rank, device=dev)
     # clamp + Adam start per parameter group as soon as its gradient is final (XG_NO_UPDATE_OVERLAP=1: after the backward)
+    # --graph: the fixed-shape XE iteration replayed as ONE HIP graph (train.GraphedXEStep).  Not the default: the capture has to
+    # be single-stream on this ROCm, which costs more GPU time (7.05 vs 6.10 ms) than the 2.4 ms of host work it removes
+    use_graph = (args.graph and not use_dist and workload in ("xe", "xe5") and args.path == "fused" and args.drop == 0.0
+                 and not os.environ.get("XG_BENCH_SLEEP_MS"))
     optim = ClipAdam(model, lr=4e-4, grad_clip=0.1, overlap=os.environ.get("XG_NO_UPDATE_OVERLAP") is None,
-                     fused_zero=os.environ.get("XG_NO_FUSED_ZERO") is None)
+                     fused_zero=os.environ.get("XG_NO_FUSED_ZERO") is None, device_state=use_graph)
     # data parallel: most of the gradient all-reduce runs under the CG encoder's backward (XG_NO_GRAD_OVERLAP=1: one
     # all-reduce after the backward)
     sync = None
@@ -339,6 +343,16 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
         allreduce_gradients(model)
         optim.step()
         return loss
+
+    eager_step = step
+    if use_graph:
+        try:
+            from controllable_xgating_amd.train import GraphedXEStep
+            gstep = GraphedXEStep(model, optim, x)
+            step = lambda: gstep()               # noqa: E731
+        except Exception as e:                   # never lose the run over the capture
+            print("HIP graph capture unavailable (%r): eager launches" % (e,), file=sys.stderr)
+            use_graph = False
 
     def timed(n):
         """n iterations bracketed by barrier + synchronize on both sides; (this rank's seconds, host enqueue seconds, last loss)"""
@@ -393,6 +407,16 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
         enq.append(time.perf_counter() - t1)
     torch.cuda.synchronize()
     host_enqueue_ms = sorted(enq)[len(enq) // 2] * 1e3
+    host_enqueue_eager_ms = None
+    if use_graph:                                # the same iteration as individual launches, for comparison
+        enq = []
+        for _ in range(5):
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            eager_step()
+            enq.append(time.perf_counter() - t1)
+        torch.cuda.synchronize()
+        host_enqueue_eager_ms = sorted(enq)[len(enq) // 2] * 1e3
     # in-situ duration of the T decoder steps inside the timed iteration (XgRun.prof_event0/1: recorded by the library on
     # the caller's stream around its time loop), median of 5 iterations
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -400,7 +424,7 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
     model._prof_events = (e0, e1)
     insitu = []
     for _ in range(5):
-        step()
+        eager_step()                             # (events inside a replayed graph cannot be read: eager launches here)
         torch.cuda.synchronize()
         insitu.append(e0.elapsed_time(e1) * 1e3 / T)
     model._prof_events = None
@@ -444,6 +468,7 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
         "value": round(value, 1), "unit": "decoder timesteps/s", "n_gpus": world, "steps": steps,
         "warmup": warmup, "ms_per_step": round(ms, 3), "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
         "host_loop_ms_per_step": round(t_enq * 1e3 / steps, 3),
+        "host_enqueue_ms_per_step_eager": None if host_enqueue_eager_ms is None else round(host_enqueue_eager_ms, 3),
         "higher_is_better": True, "scaling": "weak",
         "vs_baseline": None, "dtype": {"fp32": "f32", "bf16x3": "f32 via split-bf16 (3 planes, 6 MFMAs)", "bf16": "bf16"}[precision],
         "data": "synthetic",
@@ -456,6 +481,7 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
                                    + (" + RCCL grad all-reduce" if world > 1 else "") + " + clip + Adam",
                    # (zero_grad is fused into the update: train.ClipAdam(fused_zero=True) leaves .grad at zero)
                    "zero_grad": "fused into the update" if os.environ.get("XG_NO_FUSED_ZERO") is None else "memset",
+                   "launch": "one HIP graph replay per iteration (train.GraphedXEStep)" if use_graph else "eager kernel launches",
                    "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
         "final_loss": round(final_loss, 5),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
@@ -519,6 +545,7 @@ def main():
                          "xe5: configs[4] shape (hidden 1024, 40 frames; pair with --precision bf16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the two rocprofv3 --pmc passes that measure roofline.traffic")
+    ap.add_argument("--graph", action="store_true", help="time the HIP-graph replay of the iteration (single-stream capture) instead of eager launches")
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the configs[2] (SCST) and configs[4] (hidden-1024 bf16) lines that the default single-GPU run appends")
     ap.add_argument("--cpu-budget", type=float, default=15.0)

@@ -306,6 +306,8 @@ class SAModel(nn.Module):
 
     def _aux_handle(self):
         """Side-stream handle (include/xgate.h: xg_aux_create) for the current device and stream, created on first use."""
+        if torch.cuda.is_current_stream_capturing():
+            return None      # a HIP graph is being captured: one stream (forked streams crash or replay slowly, train.GraphedXEStep)
         st = torch.cuda.current_stream()
         key = (st.device.index, st.cuda_stream)
         h = _AUX_HANDLES.get(key)
@@ -336,10 +338,13 @@ class SAModel(nn.Module):
                          "xg_pack_weights")
                 # the shadow is (re)written on THIS stream: calls on any other stream must wait for it (a rollout on a side
                 # stream right after an optimizer step, driver.scst_rollouts(mode="streams"))
-                st = torch.cuda.current_stream()
-                ev = torch.cuda.Event()
-                ev.record(st)
-                self._packed_event, self._packed_stream = ev, (st.device.index, st.cuda_stream)
+                if torch.cuda.is_current_stream_capturing():       # (a HIP graph: ordering is the graph's own business)
+                    self._packed_event = None
+                else:
+                    st = torch.cuda.current_stream()
+                    ev = torch.cuda.Event()
+                    ev.record(st)
+                    self._packed_event, self._packed_stream = ev, (st.device.index, st.cuda_stream)
             self._packed_key = key
         if self._packed is None:
             return None

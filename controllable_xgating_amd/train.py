@@ -48,12 +48,20 @@ class ClipAdam:
     ``.grad`` between ``step()`` and ``zero_grad()`` differ from the reference (clamped values there), which nothing reads."""
 
     def __init__(self, model, lr=4e-4, weight_decay=0.0, grad_clip=0.1, betas=(0.9, 0.999), eps=1e-8, overlap=False,
-                 fused_zero=False):
+                 fused_zero=False, device_state=False):
         self.model, self.lr, self.wd, self.clip, self.betas, self.eps = model, lr, weight_decay, grad_clip, betas, eps
         flat = model.flat_parameters()
         self.exp_avg = torch.zeros_like(flat)
         self.exp_avg_sq = torch.zeros_like(flat)
         self.step_count = 0
+        # device_state=True: the step counter, both bias corrections and the learning rate live in device memory
+        # (xg_adam_tick / xg_clip_adam_dev), so that no launch argument changes from step to step: required for
+        # GraphedXEStep (the iteration as a replayed HIP graph), same arithmetic otherwise
+        self.device_state = bool(device_state)
+        self._ticked = False
+        if self.device_state:
+            self._hyper = torch.zeros(4, dtype=torch.float32, device=flat.device)
+            self._hyper[0] = lr
         self.overlap = bool(overlap)
         self.fused_zero = bool(fused_zero)
         self._zero_stamp = None                # (model._grad_writes, flat_grads._version) right after a zeroing update
@@ -75,11 +83,19 @@ class ClipAdam:
         self.model.flat_grads().zero_()
 
     def set_lr(self, lr):                      # myutils.set_lr
+        if self.device_state and lr != self.lr:
+            self._hyper[0] = lr
         self.lr = lr
+
+    def _tick(self):
+        nv.check(nv.lib().xg_adam_tick(_stream(), nv.ptr(self._hyper), self.betas[0], self.betas[1]), "xg_adam_tick")
+        self._ticked = True
 
     def arm(self):
         """overlap=True: call before loss.backward() (after a GradSync.arm(), if any: the events are shared)."""
-        if not self.overlap:
+        if self.device_state and not self._ticked:
+            self._tick()                       # (on the main stream, ahead of the backward: every segment update runs behind it)
+        if not self.overlap or torch.cuda.is_current_stream_capturing():      # (a captured iteration is single-stream)
             return
         if getattr(self.model, "_grad_event", None) is None:
             self.model._grad_event, self.model._grad_event_head = self._event, self._event_head
@@ -103,6 +119,11 @@ class ClipAdam:
         if b <= a:
             return
         flat, g = self.model.flat_parameters(), self.model.flat_grads()
+        if self.device_state:
+            nv.check(nv.lib().xg_clip_adam_dev(_stream(), b - a, nv.ptr(flat[a:b]), nv.ptr(g[a:b]), nv.ptr(self.exp_avg[a:b]),
+                                               nv.ptr(self.exp_avg_sq[a:b]), nv.ptr(self._hyper), self.betas[0], self.betas[1],
+                                               self.eps, self.wd, self.clip, 1 if self.fused_zero else 0), "xg_clip_adam_dev")
+            return
         fn = nv.lib().xg_clip_adam_zero if self.fused_zero else nv.lib().xg_clip_adam
         nv.check(fn(_stream(), b - a, nv.ptr(flat[a:b]), nv.ptr(g[a:b]), nv.ptr(self.exp_avg[a:b]),
                     nv.ptr(self.exp_avg_sq[a:b]), self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
@@ -110,6 +131,10 @@ class ClipAdam:
 
     def begin_step(self):
         self.step_count += 1
+        if self.device_state:
+            if not self._ticked:
+                self._tick()
+            self._ticked = False
 
     def step(self):
         n = self.model.flat_parameters().numel()
@@ -146,6 +171,83 @@ class ClipAdam:
     def load_state_dict(self, sd):
         self.exp_avg.copy_(sd["exp_avg"]); self.exp_avg_sq.copy_(sd["exp_avg_sq"])
         self.step_count, self.lr = sd["step"], sd["lr"]
+        if self.device_state:
+            self._hyper[0] = self.lr
+            self._hyper.view(torch.int32)[3] = int(self.step_count)
+
+
+class GraphedXEStep:
+    """One teacher-forced XE training iteration -- zero_grad, fused forward + loss (SAModel.xe_loss), backward, clamp + Adam
+    and the re-pack of the recurrent weights (starttrain.py:123-137) -- captured ONCE as a HIP graph and replayed: about
+    350 kernel launches become one graph launch (host: 0.09 ms per iteration instead of 2.4 ms).  All shapes are static and
+    nothing in the iteration syncs with the host, which is what makes it capturable; the step-dependent Adam scalars live in
+    device memory (ClipAdam(device_state=True)).
+
+    The captured iteration is SINGLE-STREAM: on ROCm 7.0 a capture that forks onto the library's side streams either crashes
+    in hipStreamEndCapture (backward) or replays node by node (forward: 5.5 ms and 2.7 ms of host time against 2.4 ms eager),
+    so the capture runs with XgRun.aux = NULL and the stream-ordered update.  That gives up the three-stream overlap: 7.05 ms
+    per iteration against 6.10 ms for the eager loop on an idle host (configs[1], tools/graph_probe.py).  Use it when the
+    host cannot keep up with ~350 launches per iteration (many ranks per host, a busy CPU); otherwise the eager loop is
+    faster.  bench.py times the eager loop (--graph selects this one).
+
+    ``batch``: dict of CUDA tensors (feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask [, cap_classes, class_mask]);
+    they are the graph's STATIC inputs: write new data into them with ``copy_`` (``load(batch)``) and call the object.
+    Restrictions: drop_prob_lm == 0 (the dropout seed is a launch argument), ss_prob == 0, single process (the RCCL
+    all-reduce is not captured).  Returns the loss tensor (static: overwritten by each replay)."""
+
+    def __init__(self, model, optimizer, batch, weight_class=0.0, warmup=2):
+        if not optimizer.device_state:
+            raise ValueError("GraphedXEStep needs ClipAdam(device_state=True)")
+        if model.drop_prob_lm > 0 and model.training:
+            raise ValueError("GraphedXEStep: drop_prob_lm must be 0 (the dropout seed is a launch argument)")
+        self.model, self.opt, self.x, self.wc = model, optimizer, dict(batch), float(weight_class)
+        self.graph, self.loss = None, None
+        self._capture(warmup)
+
+    def _iteration(self):
+        m, o, x = self.model, self.opt, self.x
+        o.zero_grad()
+        loss = m.xe_loss(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"],
+                         x.get("cap_classes"), x.get("class_mask"), self.wc)
+        o.arm()
+        loss.backward()
+        o.step()
+        m._packed_ptr()                        # the re-pack belongs to the iteration (it would otherwise open the next one)
+        return loss
+
+    def _capture(self, warmup):
+        m, o = self.model, self.opt
+        # the warm-up iterations (workspaces, side-stream handles, LDS opt-ins must exist before the capture) really train:
+        # snapshot everything they touch and put it back, so that building the graph leaves model and optimizer untouched
+        bufs = [b for b in m.buffers()]
+        snap = [t.clone() for t in (m.flat_parameters(), o.exp_avg, o.exp_avg_sq, o._hyper, m.flat_grads())] + [b.clone() for b in bufs]
+        step0 = o.step_count
+        side = shared_stream("graph")
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):
+                self._iteration()
+            side.synchronize()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph, stream=side):
+                self.loss = self._iteration()      # (recorded, not executed)
+        torch.cuda.current_stream().wait_stream(side)
+        with torch.no_grad():
+            for t, c in zip([m.flat_parameters(), o.exp_avg, o.exp_avg_sq, o._hyper, m.flat_grads()] + bufs, snap):
+                t.copy_(c)
+        o.step_count = step0
+        m.mark_params_changed()
+        m._packed_ptr()                            # the shadow of the restored weights (later re-packs are inside the graph)
+
+    def load(self, batch):
+        for k, v in batch.items():
+            if k in self.x and torch.is_tensor(v):
+                self.x[k].copy_(v)
+
+    def __call__(self):
+        self.graph.replay()
+        self.opt.step_count += 1               # (host mirror of the device-side step counter)
+        return self.loss
 
 
 import os as _os

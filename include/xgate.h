@@ -41,7 +41,7 @@ extern "C" {
 #endif
 
 #define XG_VERSION 202   /* 200: XgRun gained packed/aux/event fields, xg_set_grad_event removed, xg_vproj takes XgRun;
-                            201: + xg_clip_adam_zero; 202: XgRun.prof_event0/1 */
+                            201: + xg_clip_adam_zero; 202: XgRun.prof_event0/1, xg_adam_tick, xg_clip_adam_dev */
 
 enum {
     XG_OK = 0,
@@ -305,6 +305,15 @@ int xg_clip_adam(void *stream, int64_t n, float *param, float *grad, float *exp_
  * the 144 MB memset at the head of every iteration costs nothing here (train.ClipAdam(fused_zero=True)). */
 int xg_clip_adam_zero(void *stream, int64_t n, float *param, float *grad, float *exp_avg, float *exp_avg_sq, float lr,
                       float beta1, float beta2, float eps, float weight_decay, int step, float clip);
+
+/* The same update with its step-dependent scalars in DEVICE memory, so that the launch arguments never change and the whole
+ * training iteration can be captured in a HIP graph and replayed (train.GraphedXEStep): hyper = device float[4] =
+ * {lr, 1 - beta1^t, sqrt(1 - beta2^t), t (int bits)}.  xg_adam_tick advances t by one and refreshes the two corrections (call
+ * it once per optimizer step, before the xg_clip_adam_dev launches of that step); the caller writes lr (and zero-fills the
+ * block once).  zero_grad != 0: the gradient is left at zero (xg_clip_adam_zero). */
+int xg_adam_tick(void *stream, float *hyper, float beta1, float beta2);
+int xg_clip_adam_dev(void *stream, int64_t n, float *param, float *grad, float *exp_avg, float *exp_avg_sq, const float *hyper,
+                     float beta1, float beta2, float eps, float weight_decay, float clip, int zero_grad);
 
 #ifdef __cplusplus
 }

@@ -9,7 +9,7 @@ import numpy as np
 import pytest
 import torch
 
-from controllable_xgating_amd.data import collate, get_sub_frames, make_video_item
+from controllable_xgating_amd.data import CaptionDataset, collate, get_sub_frames, make_video_item, word_categories
 
 REF = "/root/reference/caption_src"
 
@@ -64,3 +64,84 @@ def test_against_reference_helpers():
     mine = collate(items)
     for a, b in zip((out[1], out[2], out[3], out[4], out[5], out[6], out[7], out[8]), mine):
         assert torch.equal(a.float(), b.float())
+
+
+# ------------------------------------------------------------------ on-disk side (data_io.py:51-126, :128-328)
+def _corpus(rng):
+    caps = {"vid1": [dict(caption="A cat runs.", tokenized="a cat runs"), dict(caption="The cat is quickly running away now", tokenized="the cat is quickly running away now"),
+                     dict(caption="", tokenized="")],
+            "vid2": [dict(caption="Two dogs play", tokenized="two dogs play zzz"), dict(caption="dogs", tokenized="dogs")],
+            "vid3": [dict(caption="x", tokenized="and he sings")]}
+    split = ["vid1_0", "vid1_1", "vid1_2", "vid2_0", "vid2_1", "vid3_0"]
+    words = ["a", "cat", "runs", "the", "is", "quickly", "running", "away", "two", "dogs", "play", "and", "he", "sings"]
+    worddict = {wd: i + 2 for i, wd in enumerate(words)}
+    category = {"NN": ["cat"], "NNS": ["dogs"], "VBZ": ["runs", "is", "sings"], "VBG": ["running"], "DT": ["a", "the"], "RB": ["quickly", "away"],
+                "CD": ["two"], "CC": ["and"], "PRP": ["he"], "VBP": ["play"], "XX": ["now"]}
+    f1 = {v: rng.random((n, 6)).astype(np.float32) for v, n in (("vid1", 30), ("vid2", 7), ("vid3", 12))}
+    f2 = {v: rng.random((len(f1[v]), 4)).astype(np.float32) for v in f1}
+    pos = {v: {"states": rng.random((5, 8)).astype(np.float32)} for v in f1}
+    return split, caps, worddict, category, f1, f2, pos
+
+
+def test_word_categories_and_dataset_items():
+    split, caps, worddict, category, f1, f2, pos = _corpus(np.random.default_rng(3))
+    cat = word_categories(category, dict(worddict, **{"<EOS>": 0, "UNK": 1}))
+    assert cat["cat"] == 3 and cat["dogs"] == 3 and cat["runs"] == 2 and cat["quickly"] == 5 and cat["two"] == 11 and cat["he"] == 7
+    assert cat["<EOS>"] == 0 and cat["<UNK>"] == 1 and cat["UNK"] == 1
+    ds = CaptionDataset(split, caps, worddict, category, f1, f2, pos, K=10, seq_length=6)
+    assert ds.ids == ["vid1_0", "vid2_0", "vid2_1", "vid3_0"]                   # empty and 7-token captions dropped (data_io.py:158)
+    it = ds[1]
+    assert it["cap"] == [10, 11, 12, 1] and it["cap_class"] == [11, 3, 2, 1]     # 'zzz' is out of vocabulary -> 1 / category 1
+    assert it["feat1"].shape == (10, 6) and not it["feat1"][7:].any() and it["feat_mask"].tolist() == [[1.0] * 7 + [0.0] * 3]
+    assert torch.equal(it["pos_feat"], torch.from_numpy(pos["vid2"]["states"][-1]))
+    assert it["gts"].tolist() == [[10, 11, 12, 1], [11, 0, 0, 0]]                # the video's references, longest first, zero padded
+    assert CaptionDataset(split, caps, worddict, category, f1, f2, pos, K=10, seq_length=6, test=True).ids == ["vid1_0", "vid2_0", "vid3_0"]
+    batch = collate([ds[i] for i in range(len(ds))])                             # feeds straight into the collate convention
+    assert batch[0].shape == (4, 5) and batch[4].shape == (4, 10, 6)
+
+
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
+def test_dataset_against_reference_classes(tmp_path):
+    import argparse
+    import pickle
+    sys.modules.setdefault("h5py", types.ModuleType("h5py"))
+    sys.path.insert(0, REF)
+    sys.argv = ["x"]
+    import data_io as ref
+    split, caps, worddict, category, f1, f2, pos = _corpus(np.random.default_rng(4))
+    paths = {}
+    for name, obj in (("split", split), ("caps", caps), ("wd", worddict), ("cate", category)):
+        paths[name] = str(tmp_path / (name + ".pkl"))
+        with open(paths[name], "wb") as f:
+            pickle.dump(obj, f)
+    opt = argparse.Namespace(seq_length=6)
+    for test, Ref in ((False, ref.custom_dset_train), (True, ref.custom_dset_test)):
+        r = Ref(paths["split"], paths["caps"], paths["cate"], f1, f2, pos, paths["wd"], K=10, opt=opt)
+        mine = CaptionDataset(split, caps, worddict, category, f1, f2, pos, K=10, seq_length=6, test=test)
+        assert len(r) == len(mine) and r.data_list == mine.ids
+        for i in range(len(mine)):
+            data, cap, cap_class, class_mask, a, b, m, p_, gts = r[i]
+            it = mine[i]
+            assert data == it["id"] and cap == it["cap"] and cap_class == it["cap_class"] and class_mask == it["class_mask"]
+            assert torch.equal(a, it["feat1"]) and torch.equal(b, it["feat2"]) and torch.equal(m, it["feat_mask"]) and torch.equal(p_, it["pos_feat"])
+            assert np.array_equal(gts, it["gts"])
+
+
+def test_hdf5_feature_store_roundtrip(tmp_path):
+    h5py = pytest.importorskip("h5py")
+    if not hasattr(h5py, "File"):                 # (the stand-in module the reference-import tests register, not the real package)
+        pytest.skip("h5py is not installed")
+    split, caps, worddict, category, f1, f2, pos = _corpus(np.random.default_rng(5))
+    for name, store in (("rgb", f1), ("opfl", f2)):
+        with h5py.File(tmp_path / (name + ".hdf5"), "w") as f:
+            for v, arr in store.items():
+                f[v] = arr
+    with h5py.File(tmp_path / "pos.hdf5", "w") as f:
+        for v, g in pos.items():
+            f.create_group(v)["states"] = g["states"]
+    from controllable_xgating_amd.data import open_feature_store
+    ds = CaptionDataset(split, caps, worddict, category, open_feature_store(tmp_path / "rgb.hdf5"), open_feature_store(tmp_path / "opfl.hdf5"),
+                        open_feature_store(tmp_path / "pos.hdf5"), K=10, seq_length=6)
+    ref_ds = CaptionDataset(split, caps, worddict, category, f1, f2, pos, K=10, seq_length=6)
+    for i in range(len(ds)):
+        assert torch.equal(ds[i]["feat1"], ref_ds[i]["feat1"]) and torch.equal(ds[i]["pos_feat"], ref_ds[i]["pos_feat"])

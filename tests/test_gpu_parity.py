@@ -923,6 +923,50 @@ def test_data_parallel_update_paths_agree_single_rank():
             dist.destroy_process_group()
 
 
+def test_graphed_xe_step_equals_the_eager_loop():
+    """train.GraphedXEStep: the whole XE training iteration (zero_grad, fused forward + loss, backward, clamp + Adam with its
+    step-dependent scalars in device memory, weight re-pack) captured once as a HIP graph; four replays give the losses,
+    parameters, Adam moments and BatchNorm statistics of four eager iterations, and building the graph leaves the model
+    untouched.  (The eager loop itself follows the reference trajectory: test_three_iteration_trajectory_vs_reference_adam_golden.)"""
+    from controllable_xgating_amd import train as tr
+    d = pg.make_dims(**CFG["mid"])
+    Pn = pg.make_params(d)
+    x = to_dev(pg.make_inputs(d, seed=0, ragged=True))
+    outs = {}
+    for mode in ("eager", "eager_dev", "graph"):
+        model = make_model(d, P=Pn, train=True)
+        opt = tr.ClipAdam(model, lr=4e-4, grad_clip=0.1, overlap=True, fused_zero=True, device_state=mode != "eager")
+        losses = []
+        if mode == "graph":
+            p0 = model.flat_parameters().clone()
+            step = tr.GraphedXEStep(model, opt, x, weight_class=WEIGHT_CLASS)
+            assert torch.equal(p0, model.flat_parameters()) and opt.step_count == 0      # construction has no side effects
+            for _ in range(4):
+                losses.append(float(step().item()))
+        else:
+            for _ in range(4):
+                opt.zero_grad()
+                loss = model.xe_loss(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"],
+                                     x["cap_classes"], x["class_mask"], WEIGHT_CLASS)
+                opt.arm(); loss.backward(); opt.step()
+                losses.append(float(loss.item()))
+        torch.cuda.synchronize()
+        bn = model.two_spatial_encoder.visual_emb_rgb[1]
+        outs[mode] = (losses, model.flat_parameters().detach().cpu().numpy().copy(), opt.exp_avg.cpu().numpy().copy(),
+                      opt.exp_avg_sq.cpu().numpy().copy(), bn.running_mean.cpu().numpy().copy(), int(bn.num_batches_tracked), opt.step_count)
+    ref = outs["eager"]
+    assert ref[0][3] < ref[0][0]
+    for mode in ("eager_dev", "graph"):
+        got = outs[mode]
+        np.testing.assert_allclose(got[0], ref[0], atol=2e-5, err_msg=mode)
+        np.testing.assert_allclose(got[2], ref[2], atol=1e-6 + 2e-3 * np.abs(ref[2]).max(), err_msg=mode)
+        np.testing.assert_allclose(got[3], ref[3], atol=1e-9 + 2e-3 * np.abs(ref[3]).max(), err_msg=mode)
+        disp = np.abs(got[1] - ref[1])
+        assert disp.max() <= 4.1 * 4e-4 and (disp > 4e-5).mean() <= 0.02, (mode, float(disp.max()), float((disp > 4e-5).mean()))
+        np.testing.assert_allclose(got[4], ref[4], atol=1e-4, err_msg=mode)      # (a function of the updated embedding weights)
+        assert got[5] == ref[5] == 4 and got[6] == 4, (mode, got[5], got[6])
+
+
 def test_packed_weights_are_ordered_across_streams():
     """The packed shadow of the recurrent weights is rewritten on the stream of the first call after a parameter update; a
     call on ANOTHER stream right behind it must wait for that pack (model._packed_ptr records an event): a rollout issued on
