@@ -142,7 +142,31 @@ struct GemmArgs {
     int fast;     // vector kernels: offset-based unpredicated loads for the full slabs (all byte offsets < 2^31)
     int gm;       // tile rows per group of the tile order (xgk_group_rows)
     int bg;       // XGK_GEMM_BG: the product runs BESIDE a latency-bound launch chain on another stream (see launch_pk)
+    // weight-gradient layout only (A m-contiguous = dY^T): csum[q][m] += sum_k A(k, m) for up to three accumulators -- the bias
+    // gradient(s) that belong to the same dY, formed from the A slabs the tn == 0 tiles stream anyway (no second pass over dY)
+    float* csum[3];
 };
+
+// sum of this thread's A-slab registers (m-contiguous operand: 4 consecutive rows m per register, the same 4 for every register
+// of the thread) and, at the end of a reduction range, the workgroup's total per row -> atomics.  `red4` = 256 float4 of LDS.
+template <int BM>
+__device__ __forceinline__ void csum_flush(const f32x4& cs, f32x4* red4, int m0, int M, float* const (&out)[3]) {
+    constexpr int RG = BM / 4;                   // row groups; thread t holds rows 4 (t % RG) .. + 3
+    const int t = threadIdx.x;
+    if (t < RG) {
+        f32x4 v = cs;
+#pragma unroll
+        for (int j = 1; j < 256 / RG; ++j) v += red4[t + j * RG];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = m0 + 4 * t + q;
+            if (row < M) {
+#pragma unroll
+                for (int o = 0; o < 3; ++o) if (out[o]) unsafeAtomicAdd(out[o] + row, v[q]);
+            }
+        }
+    }
+}
 
 #ifdef GEMM_CLK
 __device__ long long gemm_clk_buf[4];
@@ -190,11 +214,11 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    f32x4 ra[TileGeom<BM, AKC>::nvec], rb[TileGeom<BN, BKC>::nvec];
+    constexpr int NVA = TileGeom<BM, AKC>::nvec, NVB = TileGeom<BN, BKC>::nvec;
+    f32x4 ra[NVA], rb[NVB];
     const int nslab_all = (g.K + BKS - 1) / BKS;
     const int s_begin = (int)(((long)ks * nslab_all) / g.splitk), s_end = (int)(((long)(ks + 1) * nslab_all) / g.splitk);
     const int nslab = s_end;
-    constexpr int NVA = TileGeom<BM, AKC>::nvec, NVB = TileGeom<BN, BKC>::nvec;
     uint32_t offA[NVA], offB[NVB];
     const bool fast = VEC && g.fast;
     if (fast) {
@@ -206,6 +230,12 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
     const int nfull = g.K / BKS;                 // slabs below nfull are complete
     load_tile<BM, AKC, VEC>(g.A, g.lda, m0, s_begin * BKS, g.M, g.K, ra);
     load_tile<BN, BKC, VEC>(g.B, g.ldb, n0, s_begin * BKS, g.N, g.K, rb);
+    const bool do_cs = !AKC && VEC && g.csum[0] != nullptr && tn == 0;      // (launcher: csum only with the vector kernels)
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+    if (do_cs) {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) cs += ra[i];
+    }
     store_tile<BM, AKC>(smem, ra);
     store_tile<BN, BKC>(smem + A_FL, rb);
     __syncthreads();
@@ -242,6 +272,10 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
         }
 #ifndef GEMM_NO_LDS_STORE
         if (s + 1 < nslab) {
+            if (do_cs) {
+#pragma unroll
+                for (int i = 0; i < NVA; ++i) cs += ra[i];
+            }
             store_tile<BM, AKC>(smem + (cur ^ 1) * STAGE, ra);
             store_tile<BN, BKC>(smem + (cur ^ 1) * STAGE + A_FL, rb);
         }
@@ -249,6 +283,12 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
 #ifndef GEMM_NO_SYNC
         __syncthreads();
 #endif
+    }
+    if (do_cs) {                                 // (the staging buffers are free: every wave is past its last slab)
+        f32x4* red4 = reinterpret_cast<f32x4*>(smem);
+        red4[threadIdx.x] = cs;
+        __syncthreads();
+        csum_flush<BM>(cs, red4, m0, g.M, g.csum);
     }
 
 #ifdef GEMM_CLK
@@ -296,6 +336,7 @@ struct PkArgs {
     int rounds;      // whole tiles per workgroup; tiles [0, rounds * G) in swizzled order
     int tail_wgs;    // workgroup positions [0, tail_wgs) share the slab units of tiles [rounds * G, T)
     int gm;          // tile rows per group of the swizzled order
+    float* csum[3];  // see GemmArgs::csum
 };
 
 struct PkItem { int tile, s0, s1; };
@@ -392,10 +433,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     PkItem cur;
     if (!next_item(cur)) return;
     int m0, n0;
+    const bool want_cs = !AKC && g.csum[0] != nullptr;
+    bool cs_on, csn_on = false;                  // this item's tile is in tile column 0: it also sums its A slabs per row
+    f32x4 cs = {0.f, 0.f, 0.f, 0.f}, csn = {0.f, 0.f, 0.f, 0.f};
+    f32x4* red4 = reinterpret_cast<f32x4*>(smem + 2 * STAGE);       // 4 KB behind the two stages (launcher adds it)
     {
         int tm, tn;
         pk_tile_coords(cur.tile, g.ntm, g.ntn, g.gm, tm, tn);
         m0 = tm * BM; n0 = tn * BN;
+        cs_on = want_cs && tn == 0;
     }
     tile_offsets<BM, AKC>(g.lda, m0, g.M, offA);
     tile_offsets<BN, BKC>(g.ldb, n0, g.N, offB);
@@ -419,6 +465,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         load_tile<BN, BKC, true>(g.B, g.ldb, n0, cur.s0 * BKS, g.N, g.K, rb);
     }
     PK_STAMP(0);
+    if (cs_on) {
+#pragma unroll
+        for (int i = 0; i < NVA; ++i) cs += ra[i];
+    }
     store_tile<BM, AKC>(smem, ra);
     store_tile<BN, BKC>(smem + A_FL, rb);
     __syncthreads();
@@ -468,6 +518,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             __builtin_amdgcn_sched_barrier(0);
 #endif
 #ifndef GEMM_NO_LDS_STORE
+            if (cs_on) {
+#pragma unroll
+                for (int i = 0; i < NVA; ++i) cs += ra[i];
+            }
             store_tile<BM, AKC>(smem + (buf ^ 1) * STAGE, ra);
             store_tile<BN, BKC>(smem + (buf ^ 1) * STAGE + A_FL, rb);
 #endif
@@ -485,6 +539,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             int tm, tn;
             pk_tile_coords(nx.tile, g.ntm, g.ntn, g.gm, tm, tn);
             nm0 = tm * BM; nn0 = tn * BN;
+            csn_on = want_cs && tn == 0;
             tile_offsets<BM, AKC>(g.lda, nm0, g.M, offA);
             tile_offsets<BN, BKC>(g.ldb, nn0, g.N, offB);
             load_bias(nx, nn0, bvn);
@@ -501,10 +556,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
         slab_mfma(buf);
 #ifndef GEMM_NO_LDS_STORE
         if (has) {
+            csn = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (csn_on) {
+#pragma unroll
+                for (int i = 0; i < NVA; ++i) csn += ra[i];
+            }
             store_tile<BM, AKC>(smem + (buf ^ 1) * STAGE, ra);
             store_tile<BN, BKC>(smem + (buf ^ 1) * STAGE + A_FL, rb);
         }
 #endif
+        if (cs_on) red4[threadIdx.x] = cs;       // (read behind the barrier below)
         PK_STAMP(3 + 4 * item_no);
 #ifdef GEMM_NO_EPI
         if (g.M < 0)
@@ -534,9 +595,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #ifndef GEMM_NO_SYNC
         PK_BARRIER();
 #endif
+        if (cs_on) csum_flush<BM>(cs, red4, m0, g.M, g.csum);
         PK_STAMP(5 + 4 * item_no);
         ++item_no;
         if (!has) break;
+        cs = csn; cs_on = csn_on;
 #pragma unroll
         for (int j = 0; j < NT; ++j) bv[j] = bvn[j];
         cur = nx; buf ^= 1; m0 = nm0; n0 = nn0;
@@ -548,7 +611,8 @@ template <bool AKC, bool BKC>
 int launch_pk(hipStream_t st, const GemmArgs& a) {
     static const int disabled = xg_diag_env("XG_GEMM_NO_PK") ? 1 : 0;
     if (disabled || !a.fast || a.M < 128 || a.N < 128) return 1;
-    PkArgs g{a.A, a.B, a.C, a.bias, a.M, a.N, a.K, a.lda, a.ldb, a.ldc, a.relu, a.accumulate, 0, 0, 0, 0, 0, a.gm};
+    PkArgs g{a.A, a.B, a.C, a.bias, a.M, a.N, a.K, a.lda, a.ldb, a.ldc, a.relu, a.accumulate, 0, 0, 0, 0, 0, a.gm,
+             {a.csum[0], a.csum[1], a.csum[2]}};
     g.ntm = xg_cdiv(a.M, 128); g.ntn = xg_cdiv(a.N, 128); g.nslab = xg_cdiv(a.K, BKS);
     const long T = (long)g.ntm * g.ntn;
     const long units = T * g.nslab;
@@ -604,7 +668,7 @@ int launch_pk(hipStream_t st, const GemmArgs& a) {
             XG_CHECK_LAUNCH();
         }
     }
-    size_t lds = 2 * (TileGeom<128, AKC>::lds_floats + TileGeom<128, BKC>::lds_floats) * sizeof(float);
+    size_t lds = 2 * (TileGeom<128, AKC>::lds_floats + TileGeom<128, BKC>::lds_floats) * sizeof(float) + 4096;   // + csum scratch
     static std::atomic<unsigned> optin{0};
     XG_TRY(xg_lds_optin(optin, reinterpret_cast<const void*>(&gemm_pk_kernel<AKC, BKC>), 84 * 1024));
     if (bg && lds < 82 * 1024) lds = 82 * 1024;
@@ -675,14 +739,27 @@ int dispatch(hipStream_t st, GemmArgs g, bool vec) {
 
 int xgk_gemm(hipStream_t st, int mode, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
              const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate) {
+    return xgk_gemm_cs(st, mode, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, nullptr, nullptr, nullptr);
+}
+
+// the product plus, for the weight-gradient layout (transA: A = dY stored (K rows, M columns)), the column sums of A added into up
+// to three accumulators: cs[m] += sum_k A(k, m) -- the bias gradient(s) of the same dY.  Fused into the fp32 vector kernels (the
+// tiles of tile column 0 sum the A slabs they stream anyway); every other route runs the product and a separate column reduction.
+int xgk_gemm_cs(hipStream_t st, int mode, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
+                const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate, float* cs1, float* cs2,
+                float* cs3) {
     if (M <= 0 || N <= 0) return XG_OK;
     if (K < 0 || !A || !B || !C) return XG_EINVAL;
+    const bool want_cs = cs1 != nullptr;
+    if (want_cs && !transA) return XG_EINVAL;
     const int bg = (mode & XGK_GEMM_BG) ? 1 : 0;
     mode &= ~XGK_GEMM_BG;
     // large products may run on the bf16 matrix cores (split-bf16 or plain bf16); skinny / tiny ones stay fp32
-    if ((mode == 1 || mode == 3) && M >= 256 && N >= 64 && K >= 64)
-        return xgk_gemm_bf16(st, mode, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate);
-    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1, 0, 1, bg};
+    if ((mode == 1 || mode == 3) && M >= 256 && N >= 64 && K >= 64) {
+        XG_TRY(xgk_gemm_bf16(st, mode, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate));
+        return want_cs ? xgk_colsum3(st, A, lda, K, M, cs1, cs2, cs3) : XG_OK;
+    }
+    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1, 0, 1, bg, {nullptr, nullptr, nullptr}};
     const bool akc = !transA;   // A (M,K) row-major -> k contiguous
     const bool bkc = transB;    // B (N,K) row-major -> k contiguous
     {   // offset-based loads: the largest byte offset inside either operand must fit 31 bits, and the m/n-contiguous
@@ -693,6 +770,10 @@ int xgk_gemm(hipStream_t st, int mode, bool transA, bool transB, int M, int N, i
     // 16-byte vector loads need aligned bases, ld % 4 == 0 and the vectorised extent % 4 == 0
     bool vec = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && (lda % 4 == 0) && (ldb % 4 == 0);
     vec = vec && ((akc ? K : M) % 4 == 0) && ((bkc ? K : N) % 4 == 0);
+    if (want_cs) {
+        if (vec) { g.csum[0] = cs1; g.csum[1] = cs2; g.csum[2] = cs3; }
+        else XG_TRY(xgk_colsum3(st, A, lda, K, M, cs1, cs2, cs3));          // (scalar-load kernels: separate pass)
+    }
     if (akc && bkc) return dispatch<true, true>(st, g, vec);
     if (akc && !bkc) return dispatch<true, false>(st, g, vec);
     if (!akc && !bkc) return dispatch<false, false>(st, g, vec);

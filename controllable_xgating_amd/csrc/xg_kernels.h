@@ -18,6 +18,11 @@ static inline int xgk_group_rows(int k_depth) {
 enum { XGK_GEMM_BG = 0x100 };
 int xgk_gemm(hipStream_t st, int mode, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
              const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate);
+// the same product for the weight-gradient layout (transA) with the column sums of A = dY^T as a side output: cs[m] += sum_k A(k, m)
+// for up to three accumulators (cs2 / cs3 may be null) -- the bias gradient(s) of the same dY (xg_gemm.hip)
+int xgk_gemm_cs(hipStream_t st, int mode, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
+                const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate, float* cs1, float* cs2,
+                float* cs3);
 // xg_gemm_bf16.hip: split-bf16 / bf16 arithmetic for large products (planes = 3 or 1)
 int xgk_gemm_bf16(hipStream_t st, int planes, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
                   const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate);

@@ -212,6 +212,12 @@ inline int gemm_tn(hipStream_t st, int mode, int Mrows, int N, int K, const floa
     return xgk_gemm(st, mode, true, false, N, K, Mrows, dY, lddy, X, ldx, dW, lddw, nullptr, false, true);
 }
 
+// ... and the bias gradient(s) of the same dY as a side output of the product: b1[n] (b2, b3) += sum_m dY[m, n]
+inline int gemm_tn_cs(hipStream_t st, int mode, int Mrows, int N, int K, const float* dY, int lddy, const float* X, int ldx,
+                      float* dW, int lddw, float* b1, float* b2 = nullptr, float* b3 = nullptr) {
+    return xgk_gemm_cs(st, mode, true, false, N, K, Mrows, dY, lddy, X, ldx, dW, lddw, nullptr, false, true, b1, b2, b3);
+}
+
 // ---- skinny-job builders
 inline SkSeg seg_nt(const float* A, int lda, const float* W, int ldw, int K) {
     SkSeg s{}; s.A = A; s.B = W; s.lda = lda; s.ldb = ldw; s.K = K; s.b_ncontig = 0; return s;
@@ -383,8 +389,7 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
     if (hipMemcpyAsync(w.dVw, dV_in, sizeof(float) * (size_t)N * R, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
     XG_TRY(xgk_relu_drop_bwd(st, w.dVw, w.Venc, (int64_t)N * R, xg_make_drop(&run, XG_SITE_FUSION, 0)));
     XG_TRY(ss.fork());
-    XG_TRY(gemm_tn(sx, w.gm, N, R, 2 * R, w.dVw, R, w.Y, 2 * R, g.fusion_w, 2 * R));
-    XG_TRY(xgk_colsum(sx, w.dVw, R, N, R, g.fusion_b));
+    XG_TRY(gemm_tn_cs(sx, w.gm, N, R, 2 * R, w.dVw, R, w.Y, 2 * R, g.fusion_w, 2 * R, g.fusion_b));
     XG_TRY(gemm_nn(st, w.gm, N, 2 * R, R, w.dVw, R, p.fusion_w, 2 * R, w.dY, 2 * R, false));
     for (int m = 0; m < 2; ++m) {   // y = g*h + h : dpre -> dGG, dh -> dHs (overwrite)
         XgDrop dr = xg_make_drop(&run, m == 0 ? XG_SITE_GATE_RGB : XG_SITE_GATE_OPFL, 0);
@@ -394,8 +399,7 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
     XG_TRY(ss.fork());
     for (int m = 0; m < 2; ++m) {   // gate m takes source = hidden of the OTHER modality
         const int o = 1 - m;
-        XG_TRY(gemm_tn(sx, w.gm, N, R, R, w.dGG[m], R, w.Hs[o], R, g_gate_w[m], R));
-        XG_TRY(xgk_colsum(sx, w.dGG[m], R, N, R, g_gate_b[m]));
+        XG_TRY(gemm_tn_cs(sx, w.gm, N, R, R, w.dGG[m], R, w.Hs[o], R, g_gate_w[m], R, g_gate_b[m]));
         XG_TRY(gemm_nn(st, w.gm, N, R, R, w.dGG[m], R, gate_w[m], R, w.dHs[o], R, true));
     }
     XgRun nodrop = run; nodrop.drop_p = 0.f;
@@ -447,9 +451,8 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
         if (hipMemsetAsync(w.Hprev[m], 0, sizeof(float) * (size_t)N * R, sx) != hipSuccess) return XG_EHIP;
         if (K > 1)   // one strided 2-D copy covers all videos: rows = B, cols = (K-1)*R
             XG_TRY(xgk_copy2d(sx, w.Hprev[m] + R, K * R, w.Hs[m], K * R, B, (K - 1) * R, false));
-        XG_TRY(gemm_tn(sx, w.gm, N, 4 * R, R, w.dS[m], 4 * R, w.Hprev[m], R, g_whh[m], R));
+        XG_TRY(gemm_tn_cs(sx, w.gm, N, 4 * R, R, w.dS[m], 4 * R, w.Hprev[m], R, g_whh[m], R, g_bih[m], g_bhh[m]));
         XG_TRY(gemm_tn(sx, w.gm, N, 4 * R, R, w.dS[m], 4 * R, w.X[m], R, g_wih[m], R));
-        XG_TRY(xgk_colsum3(sx, w.dS[m], 4 * R, N, 4 * R, g_bih[m], g_bhh[m], nullptr));
         // the optical-flow modality's input-side backward runs beside the rgb one (second auxiliary stream, forked above)
         hipStream_t st_outer = st;
         hipStream_t st = (m == 1 && ss.overlap()) ? ss.aux2 : st_outer;
@@ -462,8 +465,7 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
         XG_TRY(xgk_axpy(st, g_bn_g[m], w.bn_s2[m], 1.f, R));
         XG_TRY(xgk_bn_bwd_apply(st, w.dX[m], w.Z[m], w.bn_mean[m], w.bn_var[m], bn_g[m], w.bn_s1[m], w.bn_s2[m], N, R,
                                 run.bn_eps, run.train != 0));
-        XG_TRY(gemm_tn(st, w.gm, N, R, F[m], w.dX[m], R, feats[m], F[m], g_emb_w[m], F[m]));
-        XG_TRY(xgk_colsum(st, w.dX[m], R, N, R, g_emb_b[m]));
+        XG_TRY(gemm_tn_cs(st, w.gm, N, R, F[m], w.dX[m], R, feats[m], F[m], g_emb_w[m], F[m], g_emb_b[m]));
     }
     return ss.chain2_into_aux();              // the caller's join() of aux then covers the second side chain too
 }
@@ -934,10 +936,10 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         const size_t r0 = (size_t)t0 * B;
         const float* ds2 = w.DS2 + r0 * 4 * R;
         const float* dp = w.DP + r0 * A;
-        XG_TRY(gemm_tn(sq, w.gm, rows, 4 * R, R, ds2, 4 * R, w.H1 + BR + r0 * R, R, g.l2_i2h_w, R));
+        XG_TRY(gemm_tn_cs(sq, w.gm, rows, 4 * R, R, ds2, 4 * R, w.H1 + BR + r0 * R, R, g.l2_i2h_w, R, g.l2_i2h_b, g.l2_a2h_b, g.l2_h2h_b));
         XG_TRY(gemm_tn(sq, w.gm, rows, 4 * R, R, ds2, 4 * R, w.AF + r0 * R, R, g.l2_a2h_w, R));
         XG_TRY(gemm_tn(sq, w.gm, rows, 4 * R, R, ds2, 4 * R, w.H2 + r0 * R, R, g.l2_h2h_w, R));
-        XG_TRY(gemm_tn(sq, w.gm, rows, A, R, dp, A, w.H1 + r0 * R, R, g.h2a_w, 2 * R));
+        XG_TRY(gemm_tn_cs(sq, w.gm, rows, A, R, dp, A, w.H1 + r0 * R, R, g.h2a_w, 2 * R, g.h2a_b));
         XG_TRY(gemm_tn(sq, w.gm, rows, A, R, dp, A, w.H2 + r0 * R, R, g.h2a_w + R, 2 * R));
         return XG_OK;
     };
@@ -946,7 +948,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         if (rows <= 0) return XG_OK;
         const size_t r0 = (size_t)t0 * B;
         const float* ds1 = w.DS1 + r0 * 4 * R;
-        XG_TRY(gemm_tn(sq, w.gm, rows, 4 * R, R, ds1, 4 * R, w.H1 + r0 * R, R, g.l1_h2h_w, R));
+        XG_TRY(gemm_tn_cs(sq, w.gm, rows, 4 * R, R, ds1, 4 * R, w.H1 + r0 * R, R, g.l1_h2h_w, R, g.l1_i2h_b, g.l1_a2h_b, g.l1_h2h_b));
         XG_TRY(gemm_tn(sq, w.gm, rows, 4 * R, E, ds1, 4 * R, w.Xe + r0 * E, E, g.l1_i2h_w, E));
         XG_TRY(gemm_tn(sq, w.gm, rows, 4 * R, R, ds1, 4 * R, w.POSG + r0 * R, R, g.l1_a2h_w, R));
         // input side of cell 1: pos' gate, embedding
@@ -1018,27 +1020,21 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         float* gb[4] = {g.ih1_b, g.ic1_b, g.ih2_b, g.ic2_b};
         for (int j = 0; j < 4; ++j) {
             hipStream_t sj = j < 2 ? s1 : sx;     // h1 / c1 come out of chain 1
-            XG_TRY(gemm_tn(sj, w.gm, B, R, R, gst[j], R, w.vbar, R, gw[j], R));
-            XG_TRY(xgk_colsum(sj, gst[j], R, B, R, gb[j]));
+            XG_TRY(gemm_tn_cs(sj, w.gm, B, R, R, gst[j], R, w.vbar, R, gw[j], R, gb[j]));
         }
     }
     // batched weight gradients over the steps the loop has not handed out yet
-    XG_TRY(wgrads_chain2(sx, 0, wg_hi));
-    XG_TRY(xgk_colsum3(sx, w.DS2, 4 * R, TB, 4 * R, g.l2_i2h_b, g.l2_a2h_b, g.l2_h2h_b));
-    XG_TRY(xgk_colsum(sx, w.DP, A, TB, A, g.h2a_b));
+    XG_TRY(wgrads_chain2(sx, 0, wg_hi));      // (the cells' and h2a's bias gradients ride in these products: gemm_tn_cs)
     XG_TRY(wgrads_chain1(s1, 0, wg_hi));
-    XG_TRY(xgk_colsum3(s1, w.DS1, 4 * R, TB, 4 * R, g.l1_i2h_b, g.l1_a2h_b, g.l1_h2h_b));
     XG_TRY(ss.wait_mark2(wg_mark));           // DPOSG / DXe rows of the steps handed out in the loop
     XG_TRY(xgk_gate_bwd(s1, w.DPOSG, R, w.GP, R, x.pos_feats, R, B, w.DGP, R, nullptr, 0, false, TB, R,
                         xg_make_drop(&run, XG_SITE_DGATE, 0)));
-    XG_TRY(gemm_tn(s1, w.gm, TB, R, E, w.DGP, R, w.Xe, E, g.dgate_w, E));
-    XG_TRY(xgk_colsum(s1, w.DGP, R, TB, R, g.dgate_b));
+    XG_TRY(gemm_tn_cs(s1, w.gm, TB, R, E, w.DGP, R, w.Xe, E, g.dgate_w, E, g.dgate_b));
     XG_TRY(gemm_nn(s1, w.gm, TB, E, R, w.DGP, R, p.dgate_w, E, w.DXe, E, true));
     XG_TRY(xgk_embed_scatter_add(s1, g.embed_w, E, tok, B, tok_bstride, tok_tstride, TB, d.V, w.DXe, E));
     // the hoisted projection's parameter gradients need dVproj (main stream, above)
     XG_TRY(ss.fork());
-    XG_TRY(gemm_tn(sx, w.gm, N, A, R, w.DVPROJ, A, w.Venc, R, g.v2a_w, R));
-    XG_TRY(xgk_colsum(sx, w.DVPROJ, A, N, A, g.v2a_b));
+    XG_TRY(gemm_tn_cs(sx, w.gm, N, A, R, w.DVPROJ, A, w.Venc, R, g.v2a_w, R, g.v2a_b));
     XG_TRY(ss.chain2_into_aux());             // aux now also covers the second side chain
     // everything but two_spatial_encoder.* is final once the auxiliary stream gets here (it has waited for main above)
     if (ss.grad_event && hipEventRecord(ss.grad_event, sx) != hipSuccess) return XG_EHIP;
@@ -1088,8 +1084,7 @@ int heads_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams& g
         if (ss.dh_mark == -2) return XG_EHIP;
     }
     // dW_logit / db: parameter gradients, under the loop as well
-    XG_TRY(gemm_tn(ss.aux, bgm, rows, d.V, R, w.LOGITS, d.V, Hout, R, g.logit_w, R));
-    XG_TRY(xgk_colsum(ss.aux, w.LOGITS, d.V, rows, d.V, g.logit_b));
+    XG_TRY(gemm_tn_cs(ss.aux, bgm, rows, d.V, R, w.LOGITS, d.V, Hout, R, g.logit_w, R, g.logit_b));
     // XgRun.grad_event_head: the vocabulary head's gradients are final, long before anything else, AND logit.* is not read
     // any more in this backward (the product above was its last reader) -- a caller may all-reduce those gradients and
     // even update logit.* from here on
@@ -1098,12 +1093,10 @@ int heads_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams& g
         if (hipEventRecord(ss.grad_event_head, ss.aux) != hipSuccess) return XG_EHIP;
     }
     if (have_cls) {
-        XG_TRY(gemm_tn(st, w.gm, rows, d.C, d.H, w.DCL, d.C, w.HC, d.H, g.cls3_w, d.H));
-        XG_TRY(xgk_colsum(st, w.DCL, d.C, rows, d.C, g.cls3_b));
+        XG_TRY(gemm_tn_cs(st, w.gm, rows, d.C, d.H, w.DCL, d.C, w.HC, d.H, g.cls3_w, d.H, g.cls3_b));
         XG_TRY(gemm_nn(st, w.gm, rows, d.H, d.C, w.DCL, d.C, p.cls3_w, d.H, w.DHC, d.H, false));
         XG_TRY(xgk_relu_drop_bwd(st, w.DHC, w.HC, (int64_t)rows * d.H, xg_make_drop(&run, XG_SITE_CLS, 0)));
-        XG_TRY(gemm_tn(st, w.gm, rows, d.H, R, w.DHC, d.H, Hout, R, g.cls0_w, R));
-        XG_TRY(xgk_colsum(st, w.DHC, d.H, rows, d.H, g.cls0_b));
+        XG_TRY(gemm_tn_cs(st, w.gm, rows, d.H, R, w.DHC, d.H, Hout, R, g.cls0_w, R, g.cls0_b));
         XG_TRY(gemm_nn(st, w.gm, rows, R, d.H, w.DHC, d.H, p.cls0_w, R, w.DH2OUT, R, true));
     }
     return XG_OK;
