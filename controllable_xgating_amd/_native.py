@@ -78,6 +78,8 @@ def lib():
     sigs = {
         "xg_gemm": [vp, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32],
         "xg_gemm_mode": [vp, i32, i32, i32, i32, i32, i32, vp, i32, vp, i32, vp, i32, vp, i32, i32],
+        "xg_gemm_bf16_operands": [vp, i32, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32, vp, i32, vp, i32, i32],
+        "xg_cvt_bf16": [vp, vp, vp, i64],
         "xg_encoder_fwd": [vp, PD, PP, PB, PX, PR, vp, C.c_size_t, vp],
         "xg_encoder_bwd": [vp, PD, PP, PP, PX, PR, vp, C.c_size_t, vp],
         "xg_init_hidden": [vp, PD, PP, vp, vp, vp, C.c_size_t, vp],

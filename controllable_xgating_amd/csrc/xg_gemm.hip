@@ -780,6 +780,17 @@ int xgk_gemm_cs(hipStream_t st, int mode, bool transA, bool transB, int M, int N
     return dispatch<false, true>(st, g, vec);
 }
 
+int xgk_gemm_x(hipStream_t st, int mode, bool transA, bool transB, int M, int N, int K, const float* A, const unsigned short* A16,
+               int lda, const float* B, const unsigned short* B16, int ldb, float* C, int ldc, const float* bias, bool relu,
+               bool accumulate, float* cs1, float* cs2, float* cs3) {
+    if ((mode & ~XGK_GEMM_BG) == 1 && (A16 || B16) && M >= 256 && N >= 64 && K >= 64) {
+        if (cs1 && !transA) return XG_EINVAL;
+        XG_TRY(xgk_gemm_bf16x(st, 1, transA, transB, M, N, K, A, A16, lda, B, B16, ldb, C, ldc, bias, relu, accumulate));
+        return cs1 ? xgk_colsum3(st, A, lda, K, M, cs1, cs2, cs3) : XG_OK;
+    }
+    return xgk_gemm_cs(st, mode, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, cs1, cs2, cs3);
+}
+
 extern "C" int xg_gemm_mode(void* stream, int mode, int transA, int transB, int M, int N, int K, const float* A, int lda,
                             const float* B, int ldb, float* C, int ldc, const float* bias, int relu, int accumulate) {
     if (mode != 0 && mode != 1 && mode != 3) return XG_EINVAL;

@@ -35,6 +35,9 @@ struct BArgs {
     const float* A; const float* B; float* C; const float* bias;
     int M, N, K, lda, ldb, ldc, relu, accumulate, splitk;
     int gm;   // tile rows per group of the tile order (xg_kernels.h: xgk_group_rows)
+    // operands that ALREADY ARE bf16 in memory (same shape / layout, lda / ldb in elements): loaded 16 bytes = 8 elements at a
+    // time and stored into the LDS image as they are -- half the operand bytes from L2, no convert (NP = 1 kernels only)
+    const unsigned short* A16; const unsigned short* B16;
 };
 
 constexpr int LDMC = BM + 16;      // [k][m] image of an m-contiguous operand: row stride in bf16 (288 B: the 4 k rows of a
@@ -121,6 +124,46 @@ __device__ __forceinline__ void load_tile(const float* __restrict__ P, int ld, i
     }
 }
 
+// ---- an operand that is bf16 in memory: 2 x 16-byte loads per thread per slab (8 elements each), straight into the LDS image
+//  KC: thread -> row f >> 2, k = 8 (f & 3);   !KC (m-contiguous, [k][m] image read back transposed): k = f >> 4, 8 rows from 8 (f & 15)
+template <bool KC>
+__device__ __forceinline__ void load_tile16(const unsigned short* __restrict__ P, int ld, int r0, int k0, int nrows, int K, uint4 (&regs)[2]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f = t + 256 * i;
+        if (KC) {
+            const int r = f >> 2, k = (f & 3) << 3;
+            regs[i] = *reinterpret_cast<const uint4*>(P + (size_t)min(r0 + r, nrows - 1) * ld + min(k0 + k, K - 8));
+        } else {
+            const int k = f >> 4, r = (f & 15) << 3;
+            regs[i] = *reinterpret_cast<const uint4*>(P + (size_t)min(k0 + k, K - 1) * ld + min(r0 + r, nrows - 8));
+        }
+    }
+}
+template <bool KC>
+__device__ __forceinline__ void store_tile16(unsigned short* __restrict__ lds, const uint4 (&regs)[2], int r0, int k0, int nrows, int K,
+                                             bool edge) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int f = t + 256 * i;
+        int r, k;
+        if (KC) { r = f >> 2; k = (f & 3) << 3; } else { k = f >> 4; r = (f & 15) << 3; }
+        uint4 v = regs[i];
+        if (edge) {
+            unsigned wds[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool ok = KC ? (r0 + r < nrows && k0 + k + j < K) : (r0 + r + j < nrows && k0 + k < K);
+                if (!ok) wds[j >> 1] &= (j & 1) ? 0x0000FFFFu : 0xFFFF0000u;
+            }
+            v = uint4{wds[0], wds[1], wds[2], wds[3]};
+        }
+        *reinterpret_cast<uint4*>(lds + (KC ? r * LDKC + k : k * LDMC + r)) = v;
+    }
+}
+
 // ---- registers -> (zero the out-of-range lanes) -> split -> LDS planes: 4 consecutive elements of the contiguous
 // dimension = one 8-byte store per plane
 template <int NP, bool KC, bool VEC>
@@ -193,8 +236,9 @@ __device__ __forceinline__ bf16x8 read_frag(const unsigned short* __restrict__ p
     return v;
 }
 
-template <int NP, bool AKC, bool BKC, bool VEC>
+template <int NP, bool AKC, bool BKC, bool VEC, bool A16 = false, bool B16 = false>
 __global__ void __launch_bounds__(256) gemm_bs_kernel(BArgs g) {
+    static_assert(!(A16 || B16) || (NP == 1 && VEC), "bf16 operands: plain-bf16 vector kernels only");
     extern __shared__ __attribute__((aligned(16))) unsigned short smem_bs[];
     unsigned short* As = smem_bs;
     unsigned short* Bs = smem_bs + NP * plane_elems<AKC, VEC>();
@@ -256,19 +300,20 @@ __global__ void __launch_bounds__(256) gemm_bs_kernel(BArgs g) {
         }
     };
     {
-    f32x4 ra[4], rb[4];
-    load_tile<AKC, VEC>(g.A, g.lda, m0, s_begin * BK, g.M, g.K, ra);
-    load_tile<BKC, VEC>(g.B, g.ldb, n0, s_begin * BK, g.N, g.K, rb);
+    f32x4 ra[A16 ? 1 : 4], rb[B16 ? 1 : 4];
+    uint4 ha[2], hb[2];
+    auto loadA = [&](int s) { if constexpr (A16) load_tile16<AKC>(g.A16, g.lda, m0, s * BK, g.M, g.K, ha); else load_tile<AKC, VEC>(g.A, g.lda, m0, s * BK, g.M, g.K, ra); };
+    auto loadB = [&](int s) { if constexpr (B16) load_tile16<BKC>(g.B16, g.ldb, n0, s * BK, g.N, g.K, hb); else load_tile<BKC, VEC>(g.B, g.ldb, n0, s * BK, g.N, g.K, rb); };
+    loadA(s_begin); loadB(s_begin);
     for (int s = s_begin; s < s_end; ++s) {
         const bool ktail = (s + 1) * BK > g.K;
         __syncthreads();                                   // everyone is done reading the previous slab
-        store_tile<NP, AKC, VEC>(As, ra, m0, s * BK, g.M, g.K, edge_a || ktail);
-        store_tile<NP, BKC, VEC>(Bs, rb, n0, s * BK, g.N, g.K, edge_b || ktail);
+        if constexpr (A16) store_tile16<AKC>(As, ha, m0, s * BK, g.M, g.K, edge_a || ktail);
+        else store_tile<NP, AKC, VEC>(As, ra, m0, s * BK, g.M, g.K, edge_a || ktail);
+        if constexpr (B16) store_tile16<BKC>(Bs, hb, n0, s * BK, g.N, g.K, edge_b || ktail);
+        else store_tile<NP, BKC, VEC>(Bs, rb, n0, s * BK, g.N, g.K, edge_b || ktail);
         __syncthreads();
-        if (s + 1 < s_end) {                               // next slab's loads fly under this slab's MFMAs
-            load_tile<AKC, VEC>(g.A, g.lda, m0, (s + 1) * BK, g.M, g.K, ra);
-            load_tile<BKC, VEC>(g.B, g.ldb, n0, (s + 1) * BK, g.N, g.K, rb);
-        }
+        if (s + 1 < s_end) { loadA(s + 1); loadB(s + 1); }   // next slab's loads fly under this slab's MFMAs
         slab_mfma(As, Bs);
     }
     }
@@ -449,7 +494,7 @@ int launch_bx(hipStream_t st, const BArgs& g) {
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
-template <int NP, bool AKC, bool BKC, bool VEC>
+template <int NP, bool AKC, bool BKC, bool VEC, bool A16 = false, bool B16 = false>
 int launch(hipStream_t st, const BArgs& g) {
     const int ntm = xg_cdiv(g.M, BM), ntn = xg_cdiv(g.N, BN);
     if (g.splitk > 1 && !g.accumulate) {
@@ -459,11 +504,19 @@ int launch(hipStream_t st, const BArgs& g) {
     const size_t lds = (size_t)NP * (plane_elems<AKC, VEC>() + plane_elems<BKC, VEC>()) * sizeof(unsigned short);
     if (lds > 65536) {
         static std::atomic<unsigned> optin{0};
-        XG_TRY(xg_lds_optin(optin, reinterpret_cast<const void*>(&gemm_bs_kernel<NP, AKC, BKC, VEC>), (int)lds));
+        XG_TRY(xg_lds_optin(optin, reinterpret_cast<const void*>(&gemm_bs_kernel<NP, AKC, BKC, VEC, A16, B16>), (int)lds));
     }
-    hipLaunchKernelGGL((gemm_bs_kernel<NP, AKC, BKC, VEC>), dim3(ntm * ntn * g.splitk), dim3(256), lds, st, g);
+    hipLaunchKernelGGL((gemm_bs_kernel<NP, AKC, BKC, VEC, A16, B16>), dim3(ntm * ntn * g.splitk), dim3(256), lds, st, g);
     XG_CHECK_LAUNCH();
     return XG_OK;
+}
+
+// plain bf16 with one or both operands already bf16 in memory
+template <bool AKC, bool BKC>
+int dispatch16(hipStream_t st, const BArgs& g) {
+    if (g.A16 && g.B16) return launch<1, AKC, BKC, true, true, true>(st, g);
+    if (g.A16) return launch<1, AKC, BKC, true, true, false>(st, g);
+    return launch<1, AKC, BKC, true, false, true>(st, g);
 }
 
 template <int NP>
@@ -476,15 +529,71 @@ int dispatch(hipStream_t st, const BArgs& g, bool akc, bool bkc, bool vec) {
 #undef XG_BS
 }
 
+// fp32 -> bf16 (round to nearest even, v_cvt_pk_bf16_f32), 8 elements per thread: two 16-byte loads, one 16-byte store
+__global__ void __launch_bounds__(256) cvt_bf16_kernel(const float* __restrict__ src, unsigned short* __restrict__ dst, size_t n8, size_t n) {
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n8) {
+        const f32x4 a = *reinterpret_cast<const f32x4*>(src + i * 8), b = *reinterpret_cast<const f32x4*>(src + i * 8 + 4);
+        bf16x2_t p0, p1, p2, p3;
+        p0[0] = (__bf16)a[0]; p0[1] = (__bf16)a[1]; p1[0] = (__bf16)a[2]; p1[1] = (__bf16)a[3];
+        p2[0] = (__bf16)b[0]; p2[1] = (__bf16)b[1]; p3[0] = (__bf16)b[2]; p3[1] = (__bf16)b[3];
+        *reinterpret_cast<uint4*>(dst + i * 8) = uint4{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1),
+                                                       __builtin_bit_cast(unsigned, p2), __builtin_bit_cast(unsigned, p3)};
+    } else {
+        // tail (and the whole range when it is not 16-byte aligned: n8 = 0): one element per thread of the trailing workgroups
+        const size_t j = n8 * 8 + (i - n8);
+        if (j < n) {
+            unsigned u = __float_as_uint(src[j]);
+            u += 0x7FFFu + ((u >> 16) & 1u);
+            dst[j] = (unsigned short)(u >> 16);
+        }
+    }
+}
+
 }  // namespace
+
+int xgk_cvt_bf16(hipStream_t st, const float* src, unsigned short* dst, size_t n) {
+    if (n == 0) return XG_OK;
+    if (!src || !dst) return XG_EINVAL;
+    const size_t n8 = (((uintptr_t)src % 16) || ((uintptr_t)dst % 16)) ? 0 : n / 8;      // unaligned: everything through the scalar tail
+    hipLaunchKernelGGL(cvt_bf16_kernel, dim3((unsigned)((n8 + (n - n8 * 8) + 255) / 256)), dim3(256), 0, st, src, dst, n8, n);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+
+extern "C" int xg_cvt_bf16(void* stream, const float* src, void* dst, int64_t n) {
+    if (n < 0) return XG_EINVAL;
+    return xgk_cvt_bf16((hipStream_t)stream, src, static_cast<unsigned short*>(dst), (size_t)n);
+}
+extern "C" int xg_gemm_bf16_operands(void* stream, int transA, int transB, int M, int N, int K, const float* A, const void* A16, int lda,
+                                     const float* B, const void* B16, int ldb, float* C, int ldc, const float* bias, int relu,
+                                     int accumulate) {
+    if (M <= 0 || N <= 0) return XG_OK;
+    if (K < 0 || !A || !B || !C) return XG_EINVAL;
+    return xgk_gemm_bf16x((hipStream_t)stream, 1, transA != 0, transB != 0, M, N, K, A, static_cast<const unsigned short*>(A16), lda, B,
+                          static_cast<const unsigned short*>(B16), ldb, C, ldc, bias, relu != 0, accumulate != 0);
+}
 
 // planes: 1 = bf16 compute, 3 = split-bf16 (fp32-class accuracy).  Only called for products large enough to tile.
 int xgk_gemm_bf16(hipStream_t st, int planes, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
                   const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate) {
-    BArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1, 1};
+    return xgk_gemm_bf16x(st, planes, transA, transB, M, N, K, A, nullptr, lda, B, nullptr, ldb, C, ldc, bias, relu, accumulate);
+}
+
+// the same with optional bf16 copies of the operands (A16 / B16: same shape, layout and leading dimension as A / B, or null):
+// where one exists and is 16-byte loadable the kernel reads it instead of converting the fp32 operand on the fly
+int xgk_gemm_bf16x(hipStream_t st, int planes, bool transA, bool transB, int M, int N, int K, const float* A, const unsigned short* A16,
+                   int lda, const float* B, const unsigned short* B16, int ldb, float* C, int ldc, const float* bias, bool relu,
+                   bool accumulate) {
+    BArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1, 1, nullptr, nullptr};
     const bool akc = !transA, bkc = transB;
     bool vec = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && (lda % 4 == 0) && (ldb % 4 == 0);
     vec = vec && ((akc ? K : M) % 4 == 0) && ((bkc ? K : N) % 4 == 0);
+    if (planes == 1 && vec) {      // 16-byte loads of 8 bf16: base, pitch and contiguous extent in multiples of 8 elements
+        if (A16 && (uintptr_t)A16 % 16 == 0 && lda % 8 == 0 && (akc ? K : M) % 8 == 0 && (akc ? K : M) >= 8) g.A16 = A16;
+        if (B16 && (uintptr_t)B16 % 16 == 0 && ldb % 8 == 0 && (bkc ? K : N) % 8 == 0 && (bkc ? K : N) >= 8) g.B16 = B16;
+    }
     const long tiles = (long)xg_cdiv(M, BM) * xg_cdiv(N, BN);
     const int nslab = xg_cdiv(K, BK);
     if (!relu && tiles < 512) {                     // fill the chip by splitting deep reductions (3 workgroups per CU would fit,
@@ -497,7 +606,7 @@ int xgk_gemm_bf16(hipStream_t st, int planes, bool transA, bool transB, int M, i
     // of 32 -- logits 170 -> 145 us, PRE 79 -> 59 us; hidden-1024 iteration 9.19 -> 9.02 ms.  Measured and not used: the
     // weight-gradient layout on these tiles (dW_logit 186 -> 276 us) and 256 x 256 tiles (one workgroup per CU: 10.4 ms).
     static const bool no_bx = xg_diag_env("XG_NO_BX") != nullptr;
-    if (planes == 1 && vec && akc && !no_bx && M >= 256) {
+    if (planes == 1 && vec && akc && !no_bx && M >= 256 && !g.A16 && !g.B16) {
         const long t2 = (long)xg_cdiv(M, 256) * xg_cdiv(N, 128);
         g.splitk = 1;
         if (!relu && t2 < 256) {
@@ -509,5 +618,11 @@ int xgk_gemm_bf16(hipStream_t st, int planes, bool transA, bool transB, int M, i
         return bkc ? launch_bx<256, 128, 4, 2, true, true>(st, g) : launch_bx<256, 128, 4, 2, true, false>(st, g);
     }
     g.gm = xgk_group_rows(K / g.splitk);
+    if (g.A16 || g.B16) {
+        if (akc && bkc) return dispatch16<true, true>(st, g);
+        if (akc && !bkc) return dispatch16<true, false>(st, g);
+        if (!akc && !bkc) return dispatch16<false, false>(st, g);
+        return dispatch16<false, true>(st, g);
+    }
     return planes == 1 ? dispatch<1>(st, g, akc, bkc, vec) : dispatch<3>(st, g, akc, bkc, vec);
 }

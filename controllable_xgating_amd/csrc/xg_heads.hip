@@ -250,7 +250,7 @@ __global__ void __launch_bounds__(RT) xent_fwd_reg_kernel(const float* __restric
 __global__ void __launch_bounds__(RT) xent_bwd_kernel(float* __restrict__ logits, int ld, const int64_t* seq,
                                                         const float* mask, const float* mask2, int B, int T, int V,
                                                         int roll, const float* lse, const float* sums2,
-                                                        const float* scale_dev, float scale, int row0) {
+                                                        const float* scale_dev, float scale, int row0, unsigned short* d16) {
     const int i = row0 + blockIdx.x, t = i / B, b = i % B;
     float* x = logits + (size_t)i * ld;
     const float m = mask[(size_t)b * T + t] * (mask2 ? mask2[(size_t)b * T + t] : 1.f);
@@ -259,7 +259,13 @@ __global__ void __launch_bounds__(RT) xent_bwd_kernel(float* __restrict__ logits
     const float l = lse[i];
     for (int v = threadIdx.x; v < V; v += RT) {
         const float pv = expf(x[v] - l);
-        x[v] = coef * (pv - (v == tg ? 1.f : 0.f));
+        const float gv = coef * (pv - (v == tg ? 1.f : 0.f));
+        x[v] = gv;
+        if (d16) {                               // bf16 copy for the bf16 products that read this gradient (round to nearest even)
+            unsigned u = __float_as_uint(gv);
+            u += 0x7FFFu + ((u >> 16) & 1u);
+            d16[(size_t)i * ld + v] = (unsigned short)(u >> 16);
+        }
     }
 }
 
@@ -623,11 +629,11 @@ int xgk_xent_fwd(hipStream_t st, const float* logits, int ld, const int64_t* seq
 }
 int xgk_xent_bwd(hipStream_t st, float* logits_inout, int ld, const int64_t* seq, const float* mask,
                  const float* mask2, int B, int T, int V, int roll, const float* lse, const float* sums2,
-                 const float* scale_dev, float scale, int row0, int nrows) {
+                 const float* scale_dev, float scale, int row0, int nrows, unsigned short* d16) {
     if (nrows < 0) nrows = B * T - row0;
     if (nrows <= 0) return XG_OK;
     hipLaunchKernelGGL(xent_bwd_kernel, dim3(nrows), dim3(RT), 0, st, logits_inout, ld, seq, mask, mask2, B, T, V, roll,
-                       lse, sums2, scale_dev, scale, row0);
+                       lse, sums2, scale_dev, scale, row0, d16);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }

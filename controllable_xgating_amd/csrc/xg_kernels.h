@@ -23,9 +23,18 @@ int xgk_gemm(hipStream_t st, int mode, bool transA, bool transB, int M, int N, i
 int xgk_gemm_cs(hipStream_t st, int mode, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
                 const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate, float* cs1, float* cs2,
                 float* cs3);
+// ... and with optional bf16 copies of the operands (same shape / layout / leading dimension; null = none): used by the bf16
+// arithmetic (mode 1) of large products, ignored otherwise
+int xgk_gemm_x(hipStream_t st, int mode, bool transA, bool transB, int M, int N, int K, const float* A, const unsigned short* A16,
+               int lda, const float* B, const unsigned short* B16, int ldb, float* C, int ldc, const float* bias, bool relu,
+               bool accumulate, float* cs1 = nullptr, float* cs2 = nullptr, float* cs3 = nullptr);
 // xg_gemm_bf16.hip: split-bf16 / bf16 arithmetic for large products (planes = 3 or 1)
 int xgk_gemm_bf16(hipStream_t st, int planes, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
                   const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate);
+int xgk_gemm_bf16x(hipStream_t st, int planes, bool transA, bool transB, int M, int N, int K, const float* A, const unsigned short* A16,
+                   int lda, const float* B, const unsigned short* B16, int ldb, float* C, int ldc, const float* bias, bool relu,
+                   bool accumulate);
+int xgk_cvt_bf16(hipStream_t st, const float* src, unsigned short* dst, size_t n);      // fp32 -> bf16 (RNE), both 16-byte aligned
 // Y[M,N] (+)= X[M,K] W[N,K]^T + bias   (nn.Linear forward)
 static inline int xgk_linear(hipStream_t st, int mode, int M, int N, int K, const float* X, int ldx, const float* W,
                              const float* bias, float* Y, int ldy, bool relu = false, bool acc = false) {
@@ -207,8 +216,14 @@ int xgk_dstep(hipStream_t st, DStepArgs& a, int gemm_mode);
 // ---- xg_pack.hip : weights re-tiled into MFMA-fragment order (caller-owned shadow, XgRun.packed)
 enum { PK_H2A1 = 0, PK_H2A2, PK_DGATE, PK_L1_I2H, PK_L1_A2H, PK_L1_H2H, PK_L2_I2H, PK_L2_A2H, PK_L2_H2H, PK_ENC_RGB, PK_ENC_OPFL,
        PKB_L2_A2H, PKB_L2_H2H, PKB_H2A2, PKB_L1_H2H, PKB_ENC_RGB, PKB_ENC_OPFL, PKB_L2_I2H, PKB_H2A1, PK_COUNT };
-struct PackedView { const float* m[PK_COUNT]; int nck[PK_COUNT]; int dtype; };    // dtype 0: fp32 tiles (4 KB), 1: bf16 tiles (2 KB)
+// plain bf16 copies (row-major, the parameter's own shape) of the weights of the LARGE products, part of the dtype-1 shadow:
+// the bf16 GEMMs read them instead of converting the fp32 weights on every pass (BASELINE.json configs[4])
+enum { W16_LOGIT = 0, W16_EMB_RGB, W16_EMB_OPFL, W16_WIH_RGB, W16_WIH_OPFL, W16_GATE_RGB, W16_GATE_OPFL, W16_FUSION, W16_V2A,
+       W16_DGATE, W16_L1_I2H, W16_L1_A2H, W16_COUNT };
+struct PackedView { const float* m[PK_COUNT]; int nck[PK_COUNT]; int dtype;       // dtype 0: fp32 tiles (4 KB), 1: bf16 tiles (2 KB)
+                    const unsigned short* w16[W16_COUNT]; };                      // (null for dtype 0)
 size_t xgk_packed_floats(const XgDims& d);
+size_t xgk_packed_total_bytes(const XgDims& d, int dtype);
 bool xgk_packed_view(const XgDims& d, const void* packed, int dtype, PackedView* v);   // false: no / unusable shadow
 
 // ---- xg_attn.hip
@@ -240,9 +255,10 @@ int xgk_nll_bwd(hipStream_t st, const int64_t* target, const float* mask, const 
 int xgk_xent_fwd(hipStream_t st, const float* logits, int ld, const int64_t* seq, const float* mask,
                  const float* mask2, int B, int T, int V, int roll, float* lse, float* sums2, int row0 = 0,
                  int nrows = -1, bool zero_sums = true);      // rows [row0, row0 + nrows) of the T*B (nrows < 0: to the end)
+// d16: optional bf16 copy of the gradient (same pitch in elements), written in the same pass
 int xgk_xent_bwd(hipStream_t st, float* logits_inout, int ld, const int64_t* seq, const float* mask,
                  const float* mask2, int B, int T, int V, int roll, const float* lse, const float* sums2,
-                 const float* scale_dev, float scale, int row0 = 0, int nrows = -1);
+                 const float* scale_dev, float scale, int row0 = 0, int nrows = -1, unsigned short* d16 = nullptr);
 // rollout token choice from a (B,V) log-prob matrix
 int xgk_choose(hipStream_t st, const float* logp, int B, int V, int mode, const float* uniforms,
                const int64_t* forced, int64_t forced_stride, float temperature, int64_t* tok, float* tok_logp);

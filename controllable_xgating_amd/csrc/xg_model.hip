@@ -127,6 +127,10 @@ struct Ws {
     // ---- packed recurrent weights (XgRun.packed; not part of the workspace)
     PackedView pk; bool packed;
     int gm;                            // XgRun.gemm_mode of this call (0 / 1 / 3), handed to every product explicitly
+    // bf16 mirror region (gemm_mode 1): the fp32 element at workspace offset o has its bf16 copy at sh16 + o.  A mirror is valid
+    // only where the code below converted it (cvt16) or a producer wrote it (xent_bwd); the large products of mode 1 read
+    // operands through it where it is valid (m16) -- half the operand bytes from L2, no convert in the GEMM.
+    const float* base_f; const float* end_f; unsigned short* sh16;
 };
 
 struct Carver {
@@ -190,6 +194,10 @@ Ws carve(const XgDims& d, void* base) {
         w.zbytes = c.off - z0;
     }
     w.bytes = (c.off + 255) & ~(size_t)255;
+    w.base_f = reinterpret_cast<const float*>(c.base);
+    w.end_f = c.base ? reinterpret_cast<const float*>(c.base + w.bytes) : nullptr;
+    w.sh16 = c.base ? reinterpret_cast<unsigned short*>(c.base + w.bytes) : nullptr;
+    w.bytes += (w.bytes / 2 + 255) & ~(size_t)255;
     return w;
 }
 
@@ -216,6 +224,33 @@ inline int gemm_tn(hipStream_t st, int mode, int Mrows, int N, int K, const floa
 inline int gemm_tn_cs(hipStream_t st, int mode, int Mrows, int N, int K, const float* dY, int lddy, const float* X, int ldx,
                       float* dW, int lddw, float* b1, float* b2 = nullptr, float* b3 = nullptr) {
     return xgk_gemm_cs(st, mode, true, false, N, K, Mrows, dY, lddy, X, ldx, dW, lddw, nullptr, false, true, b1, b2, b3);
+}
+
+// ---- bf16 operand mirrors / weight copies of the plain-bf16 mode (all null / no-ops in the other modes)
+inline const unsigned short* m16(const Ws& w, const float* p) {
+    return (w.gm == 1 && w.sh16 && p >= w.base_f && p < w.end_f) ? w.sh16 + (p - w.base_f) : nullptr;
+}
+inline int cvt16(hipStream_t st, const Ws& w, const float* p, size_t n) {          // refresh the mirror of p[0 .. n)
+    if (w.gm != 1 || n == 0) return XG_OK;
+    const unsigned short* dst = m16(w, p);
+    if (!dst) return XG_EINVAL;
+    return xgk_cvt_bf16(st, p, const_cast<unsigned short*>(dst), n);
+}
+inline const unsigned short* w16(const Ws& w, int which) {
+    return (w.gm == 1 && w.packed && w.pk.dtype == 1) ? w.pk.w16[which] : nullptr;
+}
+// Y = X W^T + b ; dX = dY W ; dW += dY^T X (+ bias gradients) with optional bf16 copies of the operands
+inline int lin16(hipStream_t st, int mode, int M, int N, int K, const float* X, const unsigned short* X16, int ldx, const float* W,
+                 const unsigned short* W16, const float* bias, float* Y, int ldy, bool relu = false, bool acc = false) {
+    return xgk_gemm_x(st, mode, false, true, M, N, K, X, X16, ldx, W, W16, K, Y, ldy, bias, relu, acc);
+}
+inline int nn16(hipStream_t st, int mode, int M, int N, int Kc, const float* dY, const unsigned short* dY16, int lddy, const float* W,
+                const unsigned short* W16, int ldw, float* dX, int lddx, bool acc) {
+    return xgk_gemm_x(st, mode, false, false, M, N, Kc, dY, dY16, lddy, W, W16, ldw, dX, lddx, nullptr, false, acc);
+}
+inline int tn16(hipStream_t st, int mode, int Mrows, int N, int K, const float* dY, const unsigned short* dY16, int lddy, const float* X,
+                const unsigned short* X16, int ldx, float* dW, int lddw, float* b1 = nullptr, float* b2 = nullptr, float* b3 = nullptr) {
+    return xgk_gemm_x(st, mode, true, false, N, K, Mrows, dY, dY16, lddy, X, X16, ldx, dW, lddw, nullptr, false, true, b1, b2, b3);
 }
 
 // ---- skinny-job builders
@@ -306,7 +341,8 @@ int encoder_fwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgBnSt
     hipStream_t st_main = st;
     for (int m = 0; m < 2; ++m) {
         hipStream_t st = (m == 1 && side) ? ss->aux2 : st_main;
-        XG_TRY(xgk_linear(st, w.gm, N, R, F[m], feats[m], F[m], emb_w[m], emb_b[m], w.Z[m], R));          // sub_modules.py:121,126
+        XG_TRY(lin16(st, w.gm, N, R, F[m], feats[m], nullptr, F[m], emb_w[m], w16(w, m == 0 ? W16_EMB_RGB : W16_EMB_OPFL), emb_b[m],
+                     w.Z[m], R));                                                                           // sub_modules.py:121,126
         if (run.train) {
             XG_TRY(xgk_bn_stats(st, w.Z[m], N, R, w.bn_mean[m], w.bn_var[m], nullptr));
             if (rmean[m] && rvar[m])
@@ -318,7 +354,9 @@ int encoder_fwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgBnSt
         }
         XG_TRY(xgk_bn_apply(st, w.Z[m], w.bn_mean[m], w.bn_var[m], bn_g[m], bn_b[m], x.feat_mask, w.X[m], N, R,
                             run.bn_eps, xg_make_drop(&run, m == 0 ? XG_SITE_EMB_RGB : XG_SITE_EMB_OPFL, 0)));
-        XG_TRY(xgk_linear(st, w.gm, N, 4 * R, R, w.X[m], R, wih[m], bih[m], w.PRE[m], 4 * R));          // hoisted over all K frames
+        XG_TRY(cvt16(st, w, w.X[m], (size_t)N * R));
+        XG_TRY(lin16(st, w.gm, N, 4 * R, R, w.X[m], m16(w, w.X[m]), R, wih[m], w16(w, m == 0 ? W16_WIH_RGB : W16_WIH_OPFL), bih[m],
+                     w.PRE[m], 4 * R));                                                                     // hoisted over all K frames
     }
     if (side) XG_TRY(ss->join2());
     ZERO(w.zeroBR, (size_t)B * R);
@@ -353,15 +391,19 @@ int encoder_fwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgBnSt
         if (R % 8 == 0) XG_TRY(xgk_skinny(st, sk, w.gm));
     }
     // cross gates, all frames at once (gated values are not fed back): sub_modules.py:151-152
-    XG_TRY(xgk_linear(st, w.gm, N, R, R, w.Hs[1], R, p.gate_rgb_w, p.gate_rgb_b, w.GG[0], R, true));
-    XG_TRY(xgk_linear(st, w.gm, N, R, R, w.Hs[0], R, p.gate_opfl_w, p.gate_opfl_b, w.GG[1], R, true));
+    XG_TRY(cvt16(st, w, w.Hs[0], (size_t)N * R));
+    XG_TRY(cvt16(st, w, w.Hs[1], (size_t)N * R));
+    XG_TRY(lin16(st, w.gm, N, R, R, w.Hs[1], m16(w, w.Hs[1]), R, p.gate_rgb_w, w16(w, W16_GATE_RGB), p.gate_rgb_b, w.GG[0], R, true));
+    XG_TRY(lin16(st, w.gm, N, R, R, w.Hs[0], m16(w, w.Hs[0]), R, p.gate_opfl_w, w16(w, W16_GATE_OPFL), p.gate_opfl_b, w.GG[1], R, true));
     for (int m = 0; m < 2; ++m) {
         XgDrop dr = xg_make_drop(&run, m == 0 ? XG_SITE_GATE_RGB : XG_SITE_GATE_OPFL, 0);
         XG_TRY(xgk_gate_fwd(st, w.GG[m], R, w.Hs[m], R, 0, w.Y + (size_t)m * R, 2 * R, N, R, dr, /*step=row%K*/ 1, K,
                             /*b=row/K*/ K, 1 << 30));
     }
-    XG_TRY(xgk_linear(st, w.gm, N, R, 2 * R, w.Y, 2 * R, p.fusion_w, p.fusion_b, w.Venc, R, true));       // :69-70
+    XG_TRY(cvt16(st, w, w.Y, (size_t)N * 2 * R));
+    XG_TRY(lin16(st, w.gm, N, R, 2 * R, w.Y, m16(w, w.Y), 2 * R, p.fusion_w, w16(w, W16_FUSION), p.fusion_b, w.Venc, R, true));   // :69-70
     XG_TRY(xgk_relu_drop_fwd(st, w.Venc, (int64_t)N * R, xg_make_drop(&run, XG_SITE_FUSION, 0)));
+    XG_TRY(cvt16(st, w, w.Venc, (size_t)N * R));
     return XG_OK;
 }
 
@@ -388,19 +430,22 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
 
     if (hipMemcpyAsync(w.dVw, dV_in, sizeof(float) * (size_t)N * R, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
     XG_TRY(xgk_relu_drop_bwd(st, w.dVw, w.Venc, (int64_t)N * R, xg_make_drop(&run, XG_SITE_FUSION, 0)));
+    XG_TRY(cvt16(st, w, w.dVw, (size_t)N * R));
     XG_TRY(ss.fork());
-    XG_TRY(gemm_tn_cs(sx, w.gm, N, R, 2 * R, w.dVw, R, w.Y, 2 * R, g.fusion_w, 2 * R, g.fusion_b));
-    XG_TRY(gemm_nn(st, w.gm, N, 2 * R, R, w.dVw, R, p.fusion_w, 2 * R, w.dY, 2 * R, false));
+    XG_TRY(tn16(sx, w.gm, N, R, 2 * R, w.dVw, m16(w, w.dVw), R, w.Y, m16(w, w.Y), 2 * R, g.fusion_w, 2 * R, g.fusion_b));
+    XG_TRY(nn16(st, w.gm, N, 2 * R, R, w.dVw, m16(w, w.dVw), R, p.fusion_w, w16(w, W16_FUSION), 2 * R, w.dY, 2 * R, false));
     for (int m = 0; m < 2; ++m) {   // y = g*h + h : dpre -> dGG, dh -> dHs (overwrite)
         XgDrop dr = xg_make_drop(&run, m == 0 ? XG_SITE_GATE_RGB : XG_SITE_GATE_OPFL, 0);
         XG_TRY(xgk_gate_bwd(st, w.dY + (size_t)m * R, 2 * R, w.GG[m], R, w.Hs[m], R, 0, w.dGG[m], R, w.dHs[m], R, false,
                             N, R, dr));
     }
+    for (int m = 0; m < 2; ++m) XG_TRY(cvt16(st, w, w.dGG[m], (size_t)N * R));
     XG_TRY(ss.fork());
     for (int m = 0; m < 2; ++m) {   // gate m takes source = hidden of the OTHER modality
         const int o = 1 - m;
-        XG_TRY(gemm_tn_cs(sx, w.gm, N, R, R, w.dGG[m], R, w.Hs[o], R, g_gate_w[m], R, g_gate_b[m]));
-        XG_TRY(gemm_nn(st, w.gm, N, R, R, w.dGG[m], R, gate_w[m], R, w.dHs[o], R, true));
+        XG_TRY(tn16(sx, w.gm, N, R, R, w.dGG[m], m16(w, w.dGG[m]), R, w.Hs[o], m16(w, w.Hs[o]), R, g_gate_w[m], R, g_gate_b[m]));
+        XG_TRY(nn16(st, w.gm, N, R, R, w.dGG[m], m16(w, w.dGG[m]), R, gate_w[m], w16(w, m == 0 ? W16_GATE_RGB : W16_GATE_OPFL), R,
+                    w.dHs[o], R, true));
     }
     XgRun nodrop = run; nodrop.drop_p = 0.f;
     int curc = 0;
@@ -444,6 +489,7 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
             XG_TRY(xgk_skinny(st, sk, w.gm));
         }
     }
+    for (int m = 0; m < 2; ++m) XG_TRY(cvt16(st, w, w.dS[m], (size_t)N * 4 * R));      // read by three products each
     XG_TRY(ss.fork2());                          // before modality 0's work is enqueued on the main stream
     for (int m = 0; m < 2; ++m) {
         // Hprev[b,k] = H[b,k-1], zero at k = 0 : one clean TN GEMM for dW_hh
@@ -451,12 +497,14 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
         if (hipMemsetAsync(w.Hprev[m], 0, sizeof(float) * (size_t)N * R, sx) != hipSuccess) return XG_EHIP;
         if (K > 1)   // one strided 2-D copy covers all videos: rows = B, cols = (K-1)*R
             XG_TRY(xgk_copy2d(sx, w.Hprev[m] + R, K * R, w.Hs[m], K * R, B, (K - 1) * R, false));
-        XG_TRY(gemm_tn_cs(sx, w.gm, N, 4 * R, R, w.dS[m], 4 * R, w.Hprev[m], R, g_whh[m], R, g_bih[m], g_bhh[m]));
-        XG_TRY(gemm_tn(sx, w.gm, N, 4 * R, R, w.dS[m], 4 * R, w.X[m], R, g_wih[m], R));
+        XG_TRY(cvt16(sx, w, w.Hprev[m], (size_t)N * R));
+        XG_TRY(tn16(sx, w.gm, N, 4 * R, R, w.dS[m], m16(w, w.dS[m]), 4 * R, w.Hprev[m], m16(w, w.Hprev[m]), R, g_whh[m], R, g_bih[m], g_bhh[m]));
+        XG_TRY(tn16(sx, w.gm, N, 4 * R, R, w.dS[m], m16(w, w.dS[m]), 4 * R, w.X[m], m16(w, w.X[m]), R, g_wih[m], R));
         // the optical-flow modality's input-side backward runs beside the rgb one (second auxiliary stream, forked above)
         hipStream_t st_outer = st;
         hipStream_t st = (m == 1 && ss.overlap()) ? ss.aux2 : st_outer;
-        XG_TRY(gemm_nn(st, w.gm, N, R, 4 * R, w.dS[m], 4 * R, wih[m], R, w.dX[m], R, false));
+        XG_TRY(nn16(st, w.gm, N, R, 4 * R, w.dS[m], m16(w, w.dS[m]), 4 * R, wih[m], w16(w, m == 0 ? W16_WIH_RGB : W16_WIH_OPFL), R,
+                    w.dX[m], R, false));
         // BatchNorm + ReLU + dropout + mask backward (sub_modules.py:121-123)
         if (!w.zeroed) { ZERO(w.bn_s1[m], R); ZERO(w.bn_s2[m], R); }
         XG_TRY(xgk_bn_bwd_reduce(st, w.dX[m], w.X[m], w.Z[m], w.bn_mean[m], w.bn_var[m], x.feat_mask, N, R, run.bn_eps,
@@ -495,7 +543,7 @@ int init_hidden(hipStream_t st, const XgDims& d, const XgParams& p, const float*
 int init_and_vproj(Streams& ss, const XgDims& d, const XgParams& p, const float* feat_mask, Ws& w) {
     const int N = d.B * d.K;
     XG_TRY(ss.fork2());
-    XG_TRY(xgk_linear(ss.aux2, w.gm, N, d.A, d.R, w.Venc, d.R, p.v2a_w, p.v2a_b, w.vproj, d.A));
+    XG_TRY(lin16(ss.aux2, w.gm, N, d.A, d.R, w.Venc, m16(w, w.Venc), d.R, p.v2a_w, w16(w, W16_V2A), p.v2a_b, w.vproj, d.A));
     XG_TRY(init_hidden(ss.main, d, p, w.Venc, feat_mask, w, w.H1, w.C1, w.H2, w.C2));
     return ss.join2();
 }
@@ -776,7 +824,8 @@ int decoder_tokens_xe(hipStream_t sx, const XgDims& d, const XgParams& p, const 
     XG_TRY(xgk_gate_fwd(sx, w.GP, R, x.pos_feats, R, B, w.POSG, R, TB, R, xg_make_drop(&run, XG_SITE_DGATE, 0),
                         /*step=row/B*/ B, 1 << 30, /*b=row%B*/ 1, B));
     XG_TRY(xgk_linear(sx, w.gm, TB, 4 * R, E, w.Xe, E, p.l1_i2h_w, p.l1_i2h_b, w.PRE1, 4 * R));
-    XG_TRY(xgk_linear(sx, w.gm, TB, 4 * R, R, w.POSG, R, p.l1_a2h_w, p.l1_a2h_b, w.PRE1, 4 * R, false, true));
+    XG_TRY(cvt16(sx, w, w.POSG, (size_t)TB * R));
+    XG_TRY(lin16(sx, w.gm, TB, 4 * R, R, w.POSG, m16(w, w.POSG), R, p.l1_a2h_w, w16(w, W16_L1_A2H), p.l1_a2h_b, w.PRE1, 4 * R, false, true));
     return XG_OK;
 }
 
@@ -812,7 +861,9 @@ int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatc
         XG_TRY(core_step(st, d, p, run, w, w.Venc, w.vproj, s));
         if (th > 0 && t == th - 1) {
             XG_TRY(ss.fork());
-            XG_TRY(xgk_linear(ss.aux, w.gm | (fwd_bg ? XGK_GEMM_BG : 0), th * B, d.V, R, w.H2 + BR, R, p.logit_w, p.logit_b, w.LOGITS, d.V));
+            XG_TRY(cvt16(ss.aux, w, w.H2 + BR, (size_t)th * B * R));
+            XG_TRY(lin16(ss.aux, w.gm | (fwd_bg ? XGK_GEMM_BG : 0), th * B, d.V, R, w.H2 + BR, m16(w, w.H2 + BR), R, p.logit_w,
+                         w16(w, W16_LOGIT), p.logit_b, w.LOGITS, d.V));
             *logit_rows_done = th * B;
             if (early_loss)
                 XG_TRY(xgk_xent_fwd(ss.aux, w.LOGITS, d.V, x.seq, x.seq_mask, nullptr, B, T, d.V, 1, w.LSE, w.sums, 0, th * B, false));
@@ -827,8 +878,9 @@ int heads_fwd_logits(Streams& ss, const XgDims& d, const XgParams& p, const XgRu
     hipStream_t st = ss.main;
     const int B = d.B, R = d.R;
     const float* Hout = w.H2 + (size_t)B * R;
-    XG_TRY(xgk_linear(st, w.gm, rows - rows_done, d.V, R, Hout + (size_t)rows_done * R, R, p.logit_w, p.logit_b,
-                      w.LOGITS + (size_t)rows_done * d.V, d.V));
+    XG_TRY(cvt16(st, w, Hout + (size_t)rows_done * R, (size_t)(rows - rows_done) * R));
+    XG_TRY(lin16(st, w.gm, rows - rows_done, d.V, R, Hout + (size_t)rows_done * R, m16(w, Hout + (size_t)rows_done * R), R, p.logit_w,
+                 w16(w, W16_LOGIT), p.logit_b, w.LOGITS + (size_t)rows_done * d.V, d.V));
     XG_TRY(xgk_linear(st, w.gm, rows, d.H, R, Hout, R, p.cls0_w, p.cls0_b, w.HC, d.H, true));
     XG_TRY(xgk_gate_fwd(st, w.HC, d.H, nullptr, 0, 0, nullptr, 0, rows, d.H, xg_make_drop(&run, XG_SITE_CLS, 0), B, 1 << 30,
                         1, B));
@@ -936,11 +988,15 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         const size_t r0 = (size_t)t0 * B;
         const float* ds2 = w.DS2 + r0 * 4 * R;
         const float* dp = w.DP + r0 * A;
-        XG_TRY(gemm_tn_cs(sq, w.gm, rows, 4 * R, R, ds2, 4 * R, w.H1 + BR + r0 * R, R, g.l2_i2h_w, R, g.l2_i2h_b, g.l2_a2h_b, g.l2_h2h_b));
-        XG_TRY(gemm_tn(sq, w.gm, rows, 4 * R, R, ds2, 4 * R, w.AF + r0 * R, R, g.l2_a2h_w, R));
-        XG_TRY(gemm_tn(sq, w.gm, rows, 4 * R, R, ds2, 4 * R, w.H2 + r0 * R, R, g.l2_h2h_w, R));
-        XG_TRY(gemm_tn_cs(sq, w.gm, rows, A, R, dp, A, w.H1 + r0 * R, R, g.h2a_w, 2 * R, g.h2a_b));
-        XG_TRY(gemm_tn(sq, w.gm, rows, A, R, dp, A, w.H2 + r0 * R, R, g.h2a_w + R, 2 * R));
+        const float *h1n = w.H1 + BR + r0 * R, *h1 = w.H1 + r0 * R, *h2 = w.H2 + r0 * R, *af = w.AF + r0 * R;
+        // (bf16 mode: mirrors of this range's operands -- each is read by two or three of the products below)
+        XG_TRY(cvt16(sq, w, ds2, (size_t)rows * 4 * R)); XG_TRY(cvt16(sq, w, dp, (size_t)rows * A));
+        XG_TRY(cvt16(sq, w, h1, (size_t)(rows + B) * R)); XG_TRY(cvt16(sq, w, h2, (size_t)rows * R)); XG_TRY(cvt16(sq, w, af, (size_t)rows * R));
+        XG_TRY(tn16(sq, w.gm, rows, 4 * R, R, ds2, m16(w, ds2), 4 * R, h1n, m16(w, h1n), R, g.l2_i2h_w, R, g.l2_i2h_b, g.l2_a2h_b, g.l2_h2h_b));
+        XG_TRY(tn16(sq, w.gm, rows, 4 * R, R, ds2, m16(w, ds2), 4 * R, af, m16(w, af), R, g.l2_a2h_w, R));
+        XG_TRY(tn16(sq, w.gm, rows, 4 * R, R, ds2, m16(w, ds2), 4 * R, h2, m16(w, h2), R, g.l2_h2h_w, R));
+        XG_TRY(tn16(sq, w.gm, rows, A, R, dp, m16(w, dp), A, h1, m16(w, h1), R, g.h2a_w, 2 * R, g.h2a_b));
+        XG_TRY(tn16(sq, w.gm, rows, A, R, dp, m16(w, dp), A, h2, m16(w, h2), R, g.h2a_w + R, 2 * R));
         return XG_OK;
     };
     auto wgrads_chain1 = [&](hipStream_t sq, int t0, int t1) -> int {
@@ -948,12 +1004,14 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         if (rows <= 0) return XG_OK;
         const size_t r0 = (size_t)t0 * B;
         const float* ds1 = w.DS1 + r0 * 4 * R;
-        XG_TRY(gemm_tn_cs(sq, w.gm, rows, 4 * R, R, ds1, 4 * R, w.H1 + r0 * R, R, g.l1_h2h_w, R, g.l1_i2h_b, g.l1_a2h_b, g.l1_h2h_b));
-        XG_TRY(gemm_tn(sq, w.gm, rows, 4 * R, E, ds1, 4 * R, w.Xe + r0 * E, E, g.l1_i2h_w, E));
-        XG_TRY(gemm_tn(sq, w.gm, rows, 4 * R, R, ds1, 4 * R, w.POSG + r0 * R, R, g.l1_a2h_w, R));
+        const float *h1 = w.H1 + r0 * R, *posg = w.POSG + r0 * R;
+        XG_TRY(cvt16(sq, w, ds1, (size_t)rows * 4 * R)); XG_TRY(cvt16(sq, w, h1, (size_t)rows * R)); XG_TRY(cvt16(sq, w, posg, (size_t)rows * R));
+        XG_TRY(tn16(sq, w.gm, rows, 4 * R, R, ds1, m16(w, ds1), 4 * R, h1, m16(w, h1), R, g.l1_h2h_w, R, g.l1_i2h_b, g.l1_a2h_b, g.l1_h2h_b));
+        XG_TRY(tn16(sq, w.gm, rows, 4 * R, E, ds1, m16(w, ds1), 4 * R, w.Xe + r0 * E, nullptr, E, g.l1_i2h_w, E));
+        XG_TRY(tn16(sq, w.gm, rows, 4 * R, R, ds1, m16(w, ds1), 4 * R, posg, m16(w, posg), R, g.l1_a2h_w, R));
         // input side of cell 1: pos' gate, embedding
-        XG_TRY(gemm_nn(sq, w.gm, rows, R, 4 * R, ds1, 4 * R, p.l1_a2h_w, R, w.DPOSG + r0 * R, R, false));
-        XG_TRY(gemm_nn(sq, w.gm, rows, E, 4 * R, ds1, 4 * R, p.l1_i2h_w, E, w.DXe + r0 * E, E, false));
+        XG_TRY(nn16(sq, w.gm, rows, R, 4 * R, ds1, m16(w, ds1), 4 * R, p.l1_a2h_w, w16(w, W16_L1_A2H), R, w.DPOSG + r0 * R, R, false));
+        XG_TRY(nn16(sq, w.gm, rows, E, 4 * R, ds1, m16(w, ds1), 4 * R, p.l1_i2h_w, w16(w, W16_L1_I2H), E, w.DXe + r0 * E, E, false));
         return XG_OK;
     };
     static const int wg_chunks_env = xg_diag_env("XG_WG_CHUNKS") ? atoi(xg_diag_env("XG_WG_CHUNKS")) : 2;
@@ -1012,7 +1070,8 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     // (dV first, as a plain store: accumulating on top of the product below it would read every element back)
     XG_TRY(xgk_attn_dV(st, w.ALPHA, w.DAF, R, (int64_t)BR, w.DV, T, B, K, R, false));
     XG_TRY(xgk_attn_bwd_post(st, w.P, w.vproj, p.a2w_w, w.DE, w.DVPROJ, g.a2w_w, T, B, K, A));
-    XG_TRY(gemm_nn(st, w.gm, N, R, A, w.DVPROJ, A, p.v2a_w, R, w.DV, R, true));
+    XG_TRY(cvt16(st, w, w.DVPROJ, (size_t)N * A));
+    XG_TRY(nn16(st, w.gm, N, R, A, w.DVPROJ, m16(w, w.DVPROJ), A, p.v2a_w, w16(w, W16_V2A), R, w.DV, R, true));
     // gradients wrt the initial state -> img_embed_* (init_hidden; vbar is detached: SAModel.py:59-62)
     {
         float* gst[4] = {w.dst[cur1][0], w.dst[cur1][1], w.dst[cur2][2], w.dst[cur2][3]};
@@ -1034,7 +1093,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     XG_TRY(xgk_embed_scatter_add(s1, g.embed_w, E, tok, B, tok_bstride, tok_tstride, TB, d.V, w.DXe, E));
     // the hoisted projection's parameter gradients need dVproj (main stream, above)
     XG_TRY(ss.fork());
-    XG_TRY(gemm_tn_cs(sx, w.gm, N, A, R, w.DVPROJ, A, w.Venc, R, g.v2a_w, R, g.v2a_b));
+    XG_TRY(tn16(sx, w.gm, N, A, R, w.DVPROJ, m16(w, w.DVPROJ), A, w.Venc, m16(w, w.Venc), R, g.v2a_w, R, g.v2a_b));
     XG_TRY(ss.chain2_into_aux());             // aux now also covers the second side chain
     // everything but two_spatial_encoder.* is final once the auxiliary stream gets here (it has waited for main above)
     if (ss.grad_event && hipEventRecord(ss.grad_event, sx) != hipSuccess) return XG_EHIP;
@@ -1058,6 +1117,8 @@ int zero_backward_block(Streams& ss, Ws& w) {
 struct XentBwd { const int64_t* seq; const float* mask; const float* dloss_dev; };
 int heads_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams& g, const XgRun& run, Ws& w, int rows,
               bool have_cls, const XentBwd* xent = nullptr) {
+    // bf16 mode: the vocabulary products read a bf16 copy of dlogits (215 MB in fp32): the fused loss path's xent kernel writes
+    // it in the same pass; every other producer of dlogits is followed by one conversion pass here
     hipStream_t st = ss.main;
     const int B = d.B, R = d.R, TB = d.T * B;
     const float* Hout = w.H2 + (size_t)B * R;
@@ -1068,23 +1129,28 @@ int heads_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams& g
     const int th = (ss.overlap() && !have_cls && rows == TB && d.T >= 4) ? d.T / 2 : 0;
     const int r0 = th * B;
     ss.dh_split_step = th; ss.dh_mark = -1;
+    unsigned short* dl16 = const_cast<unsigned short*>(m16(w, w.LOGITS));
     if (xent) XG_TRY(xgk_xent_bwd(st, w.LOGITS, d.V, xent->seq, xent->mask, nullptr, B, d.T, d.V, 1, w.LSE, w.sums,
-                                  xent->dloss_dev, 1.0f, r0, rows - r0));
+                                  xent->dloss_dev, 1.0f, r0, rows - r0, dl16));
+    else XG_TRY(cvt16(st, w, w.LOGITS, (size_t)rows * d.V));
     XG_TRY(ss.fork());                        // dlogits of the late rows is final
     if (xent && r0 > 0) XG_TRY(xgk_xent_bwd(ss.aux, w.LOGITS, d.V, xent->seq, xent->mask, nullptr, B, d.T, d.V, 1, w.LSE,
-                                            w.sums, xent->dloss_dev, 1.0f, 0, r0));
-    XG_TRY(gemm_nn(st, w.gm, rows - r0, R, d.V, w.LOGITS + (size_t)r0 * d.V, d.V, p.logit_w, R, w.DH2OUT + (size_t)r0 * R, R, false));
+                                            w.sums, xent->dloss_dev, 1.0f, 0, r0, dl16));
+    XG_TRY(cvt16(st, w, Hout, (size_t)rows * R));         // (the rollouts' forward does not mirror H2; 11 MB)
+    const unsigned short* hout16 = m16(w, Hout);
+    XG_TRY(nn16(st, w.gm, rows - r0, R, d.V, w.LOGITS + (size_t)r0 * d.V, m16(w, w.LOGITS + (size_t)r0 * d.V), d.V, p.logit_w,
+                w16(w, W16_LOGIT), R, w.DH2OUT + (size_t)r0 * R, R, false));
     // everything below runs BESIDE the reverse-time loop: behind the product above (which the loop waits for and which
     // therefore gets the whole chip), and as background products (XGK_GEMM_BG: half of every CU stays free for the loop)
     const int bgm = w.gm | (ss.overlap() && d.K <= 48 ? XGK_GEMM_BG : 0);   // (the attention backward is a half-CU kernel up to 48 frames)
     XG_TRY(ss.fork());
     if (th > 0) {
-        XG_TRY(gemm_nn(ss.aux, bgm, r0, R, d.V, w.LOGITS, d.V, p.logit_w, R, w.DH2OUT, R, false));
+        XG_TRY(nn16(ss.aux, bgm, r0, R, d.V, w.LOGITS, m16(w, w.LOGITS), d.V, p.logit_w, w16(w, W16_LOGIT), R, w.DH2OUT, R, false));
         ss.dh_mark = ss.mark();
         if (ss.dh_mark == -2) return XG_EHIP;
     }
     // dW_logit / db: parameter gradients, under the loop as well
-    XG_TRY(gemm_tn_cs(ss.aux, bgm, rows, d.V, R, w.LOGITS, d.V, Hout, R, g.logit_w, R, g.logit_b));
+    XG_TRY(tn16(ss.aux, bgm, rows, d.V, R, w.LOGITS, m16(w, w.LOGITS), d.V, Hout, hout16, R, g.logit_w, R, g.logit_b));
     // XgRun.grad_event_head: the vocabulary head's gradients are final, long before anything else, AND logit.* is not read
     // any more in this backward (the product above was its last reader) -- a caller may all-reduce those gradients and
     // even update logit.* from here on
@@ -1643,6 +1709,12 @@ extern "C" int xg_rollout_bwd(void* stream, const XgDims* d, const XgParams* p, 
     // dlogits of step t-1's output from the token drawn at step t (SAModel.py:195)
     // LOGITS holds raw logits, LSE their log-sum-exp; every step in one launch
     XG_TRY(xgk_rollout_dlogits_lse(st, w.LOGITS, w.LSE, w.TOK + B, dseq_logp, T - 1, B, d->V, T - 1));
+    {   // bf16 mode: this workspace may be the compacted half of a paired rollout (xg_rollout_compact copies no mirrors): the
+        // encoder-side operands the backward reads through their bf16 mirrors are converted again
+        const size_t NR = (size_t)B * d->K * d->R;
+        for (int m = 0; m < 2; ++m) { XG_TRY(cvt16(st, w, w.X[m], NR)); XG_TRY(cvt16(st, w, w.Hs[m], NR)); }
+        XG_TRY(cvt16(st, w, w.Y, 2 * NR)); XG_TRY(cvt16(st, w, w.Venc, NR));
+    }
     Streams ss(st, run);
     XG_TRY(heads_bwd(ss, *d, *p, *g, *run, w, (T - 1) * B, false));
     XG_TRY(decoder_bwd_core(ss, *d, *p, *g, *x, *run, w, w.UNF, 1, B, w.TOK, 1, B));

@@ -103,7 +103,46 @@ __global__ void __launch_bounds__(256) pack_kernel(PackArgs a) {
     }
 }
 
+// ---- plain bf16 copies of the large products' weights (W16_*), one launch: segment table, 8 elements per thread
+struct W16Desc { const float* src; size_t n; };
+void describe_w16(const XgDims& d, const XgParams& p, W16Desc* e) {
+    const size_t R = d.R, A = d.A, E = d.E, V = d.V;
+    e[W16_LOGIT] = {p.logit_w, V * R};
+    e[W16_EMB_RGB] = {p.emb_rgb_w, R * d.F1}; e[W16_EMB_OPFL] = {p.emb_opfl_w, R * d.F2};
+    e[W16_WIH_RGB] = {p.lstm_rgb_wih, 4 * R * R}; e[W16_WIH_OPFL] = {p.lstm_opfl_wih, 4 * R * R};
+    e[W16_GATE_RGB] = {p.gate_rgb_w, R * R}; e[W16_GATE_OPFL] = {p.gate_opfl_w, R * R};
+    e[W16_FUSION] = {p.fusion_w, R * 2 * R}; e[W16_V2A] = {p.v2a_w, A * R};
+    e[W16_DGATE] = {p.dgate_w, R * E}; e[W16_L1_I2H] = {p.l1_i2h_w, 4 * R * E}; e[W16_L1_A2H] = {p.l1_a2h_w, 4 * R * R};
+}
+inline size_t w16_bytes(size_t n) { return (n * 2 + 255) & ~(size_t)255; }
+struct CvtArgs { const float* src[W16_COUNT]; unsigned short* dst[W16_COUNT]; unsigned n8[W16_COUNT]; unsigned wg0[W16_COUNT + 1]; };
+__global__ void __launch_bounds__(256) cvt_multi_kernel(CvtArgs a) {
+    int e = 0;
+    for (int i = 1; i < W16_COUNT; ++i) if (blockIdx.x >= a.wg0[i]) e = i;
+    const unsigned i8 = (blockIdx.x - a.wg0[e]) * 256u + threadIdx.x;
+    if (i8 >= a.n8[e]) return;
+    typedef float f32x4_t __attribute__((ext_vector_type(4)));
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    const f32x4_t x = *reinterpret_cast<const f32x4_t*>(a.src[e] + (size_t)i8 * 8), y = *reinterpret_cast<const f32x4_t*>(a.src[e] + (size_t)i8 * 8 + 4);
+    bf16x2_t p0, p1, p2, p3;
+    p0[0] = (__bf16)x[0]; p0[1] = (__bf16)x[1]; p1[0] = (__bf16)x[2]; p1[1] = (__bf16)x[3];
+    p2[0] = (__bf16)y[0]; p2[1] = (__bf16)y[1]; p3[0] = (__bf16)y[2]; p3[1] = (__bf16)y[3];
+    *reinterpret_cast<uint4*>(a.dst[e] + (size_t)i8 * 8) = uint4{__builtin_bit_cast(unsigned, p0), __builtin_bit_cast(unsigned, p1),
+                                                                 __builtin_bit_cast(unsigned, p2), __builtin_bit_cast(unsigned, p3)};
+}
+
 }  // namespace
+
+size_t xgk_packed_total_bytes(const XgDims& d, int dtype) {
+    size_t n = ((xgk_packed_floats(d) * (dtype == 1 ? 2 : 4)) + 255) & ~(size_t)255;
+    if (dtype == 1) {
+        XgParams p{};
+        W16Desc e[W16_COUNT];
+        describe_w16(d, p, e);
+        for (int i = 0; i < W16_COUNT; ++i) n += w16_bytes(e[i].n);
+    }
+    return n;
+}
 
 size_t xgk_packed_floats(const XgDims& d) {
     XgParams p{};
@@ -128,19 +167,32 @@ bool xgk_packed_view(const XgDims& d, const void* packed, int dtype, PackedView*
         off += entry_floats(e[i]) * esz;
     }
     v->dtype = dtype;
+    for (int i = 0; i < W16_COUNT; ++i) v->w16[i] = nullptr;
+    if (dtype == 1 && d.V > 1 && d.F1 > 0 && d.F2 > 0) {       // (the element counts of the weight copies need the full dims)
+        W16Desc we[W16_COUNT];
+        describe_w16(d, p, we);
+        off = (off + 255) & ~(size_t)255;
+        for (int i = 0; i < W16_COUNT; ++i) {
+            // 16-byte loadable rows only (the GEMM falls back to the fp32 weight otherwise: xgk_gemm_bf16x checks pitch % 8)
+            v->w16[i] = reinterpret_cast<const unsigned short*>(base + off);
+            off += w16_bytes(we[i].n);
+        }
+    }
     return true;
 }
 
 extern "C" size_t xg_packed_bytes(const XgDims* d, int dtype) {
     if (!d || d->R <= 0 || d->A <= 0 || d->E <= 0 || d->R % 8 != 0 || (dtype != 0 && dtype != 1)) return 0;
-    return xgk_packed_floats(*d) * (dtype == 1 ? 2 : 4);
+    if (dtype == 1 && (d->V <= 1 || d->F1 <= 0 || d->F2 <= 0)) return 0;
+    return xgk_packed_total_bytes(*d, dtype);
 }
 
 extern "C" int xg_pack_weights(void* stream, const XgDims* d, const XgParams* p, void* packed, size_t packed_bytes,
                                int dtype, int with_backward) {
     if (!d || !p || !packed || d->R <= 0 || d->A <= 0 || d->E <= 0) return XG_EINVAL;
     if (d->R % 8 != 0 || ((uintptr_t)packed % 16) != 0 || (dtype != 0 && dtype != 1)) return XG_EINVAL;
-    if (packed_bytes < xgk_packed_floats(*d) * (dtype == 1 ? 2 : 4)) return XG_EWORKSPACE;
+    if (dtype == 1 && (d->V <= 1 || d->F1 <= 0 || d->F2 <= 0)) return XG_EINVAL;
+    if (packed_bytes < xgk_packed_total_bytes(*d, dtype)) return XG_EWORKSPACE;
     PackArgs a{};
     describe(*d, *p, a.e);
     PackedView v;
@@ -158,5 +210,20 @@ extern "C" int xg_pack_weights(void* stream, const XgDims* d, const XgParams* p,
     a.tile0[a.last] = tiles;
     hipLaunchKernelGGL(pack_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
     XG_CHECK_LAUNCH();
+    if (dtype == 1) {                            // the plain bf16 copies of the large products' weights
+        W16Desc we[W16_COUNT];
+        describe_w16(*d, *p, we);
+        CvtArgs c{};
+        unsigned wgs = 0;
+        for (int i = 0; i < W16_COUNT; ++i) {
+            if (!we[i].src || ((uintptr_t)we[i].src % 16) || we[i].n % 8) return XG_EINVAL;
+            c.src[i] = we[i].src; c.dst[i] = const_cast<unsigned short*>(v.w16[i]); c.n8[i] = (unsigned)(we[i].n / 8);
+            c.wg0[i] = wgs;
+            wgs += (c.n8[i] + 255) / 256;
+        }
+        c.wg0[W16_COUNT] = wgs;
+        hipLaunchKernelGGL(cvt_multi_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, c);
+        XG_CHECK_LAUNCH();
+    }
     return XG_OK;
 }

@@ -152,6 +152,13 @@ int xg_gemm_mode(void *stream, int mode, int transA, int transB, int M, int N, i
                  const float *A, int lda, const float *B, int ldb, float *C, int ldc,
                  const float *bias, int relu, int accumulate);
 
+/* bf16 arithmetic (gemm_mode 1) with operands that ALREADY ARE bf16 in memory: A16 / B16 are optional bf16 copies of A / B (same
+ * shape, layout and leading dimension; 16-byte aligned; NULL = convert the fp32 operand on the fly).  Where a copy exists the
+ * kernel moves half the operand bytes.  xg_cvt_bf16 makes such a copy (round to nearest even).  BASELINE.json configs[4]. */
+int xg_gemm_bf16_operands(void *stream, int transA, int transB, int M, int N, int K, const float *A, const void *A16, int lda,
+                          const float *B, const void *B16, int ldb, float *C, int ldc, const float *bias, int relu, int accumulate);
+int xg_cvt_bf16(void *stream, const float *src, void *dst /* bf16 */, int64_t n);
+
 /* ---- CG encoder: EncoderLstm_two_fc.forward (caption_src/sub_modules.py:118-159) ---- */
 int xg_encoder_fwd(void *stream, const XgDims *d, const XgParams *p, const XgBnState *bn,
                    const XgBatch *x, const XgRun *run, void *ws, size_t ws_bytes,
