@@ -247,6 +247,7 @@ __global__ void __launch_bounds__(RT) xent_fwd_reg_kernel(const float* __restric
     xent_row_finish(mx, s, red, x, i, b, t, T, seq, mask, mask2, roll, lse_out, sums2);
 }
 // dlogits = coef * (softmax - onehot), coef = scale * mask / sum(mask), in place
+template <bool BF>     // BF: also write a bf16 copy of the gradient (the bf16 products read it: gemm_mode 1)
 __global__ void __launch_bounds__(RT) xent_bwd_kernel(float* __restrict__ logits, int ld, const int64_t* seq,
                                                         const float* mask, const float* mask2, int B, int T, int V,
                                                         int roll, const float* lse, const float* sums2,
@@ -261,7 +262,7 @@ __global__ void __launch_bounds__(RT) xent_bwd_kernel(float* __restrict__ logits
         const float pv = expf(x[v] - l);
         const float gv = coef * (pv - (v == tg ? 1.f : 0.f));
         x[v] = gv;
-        if (d16) {                               // bf16 copy for the bf16 products that read this gradient (round to nearest even)
+        if (BF) {                                // (round to nearest even)
             unsigned u = __float_as_uint(gv);
             u += 0x7FFFu + ((u >> 16) & 1u);
             d16[(size_t)i * ld + v] = (unsigned short)(u >> 16);
@@ -632,8 +633,10 @@ int xgk_xent_bwd(hipStream_t st, float* logits_inout, int ld, const int64_t* seq
                  const float* scale_dev, float scale, int row0, int nrows, unsigned short* d16) {
     if (nrows < 0) nrows = B * T - row0;
     if (nrows <= 0) return XG_OK;
-    hipLaunchKernelGGL(xent_bwd_kernel, dim3(nrows), dim3(RT), 0, st, logits_inout, ld, seq, mask, mask2, B, T, V, roll,
-                       lse, sums2, scale_dev, scale, row0, d16);
+    if (d16) hipLaunchKernelGGL(xent_bwd_kernel<true>, dim3(nrows), dim3(RT), 0, st, logits_inout, ld, seq, mask, mask2, B, T, V, roll,
+                                lse, sums2, scale_dev, scale, row0, d16);
+    else hipLaunchKernelGGL(xent_bwd_kernel<false>, dim3(nrows), dim3(RT), 0, st, logits_inout, ld, seq, mask, mask2, B, T, V, roll,
+                            lse, sums2, scale_dev, scale, row0, d16);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }

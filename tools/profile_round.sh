@@ -8,8 +8,8 @@ mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 # 1. full iteration (configs[1]): kernel trace + stats
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python bench.py --no-cpu-baseline --no-pmc --steps 10 --warmup 3 > $OUT/bench.log 2>&1
-python tools/prof_summary.py $OUT/bench $OUT/${R}_bench_kernel_stats.txt 18 > /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python bench.py --no-cpu-baseline --no-pmc --no-secondary --steps 10 --warmup 3 > $OUT/bench.log 2>&1
+python tools/prof_summary.py $OUT/bench $OUT/${R}_bench_kernel_stats.txt 23 > /dev/null
 python tools/timeline.py $OUT/bench > $OUT/${R}_bench_timeline.txt 2>&1
 # 2. decoder-step launch group: kernel stats, per-launch durations, PMC passes
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step -- python tools/step_group_run.py 200 > $OUT/step.log 2>&1
@@ -27,13 +27,21 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/scst -- python benc
 python tools/prof_summary.py $OUT/scst $OUT/${R}_scst_kernel_stats.txt 18 > /dev/null
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/xe5 -- python bench.py --no-cpu-baseline --no-pmc --workload xe5 --precision bf16 --steps 8 --warmup 2 > $OUT/xe5.log 2>&1
 python tools/prof_summary.py $OUT/xe5 $OUT/${R}_xe5_bf16_kernel_stats.txt 15 > /dev/null
-# 4. large products
+# 4. large products; bf16 operands in memory vs converted on the fly; L2 / fabric fill rates
 python tools/ubench/gemm_bench.py > $OUT/${R}_gemm_bench_raw.txt 2>&1
+python tools/ubench/gemm16_bench.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Libr\|amdgpu.ids" > $OUT/${R}_gemm_bf16_operands.txt
+(cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/fill_bench fill_bench.hip 2>/dev/null; timeout 200 /tmp/fill_bench) > $OUT/${R}_fill_bench.txt 2>&1
+# 4b. the round's experiments: the step as one dataflow launch (in-kernel timeline), HIP-graph capture variants
+python tools/dstep_trace.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Libr\|amdgpu.ids" > $OUT/${R}_dstep_timeline.txt
+for b in 8 32 64 128 256; do echo "rows $b: $(DS_B=$b timeout 300 python tools/dstep_check.py 2>&1 | grep 'us per step')"; done > $OUT/${R}_dstep_vs_three_launches.txt
+python tools/graph_probe.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Libr\|amdgpu.ids" > $OUT/${R}_graph_probe.txt
 # 5. the bench lines themselves (un-profiled)
 python bench.py > $OUT/${R}_bench_line.json 2> $OUT/bench_line.err
 python bench.py --no-cpu-baseline --workload scst > $OUT/${R}_bench_line_scst.json 2>/dev/null
 python bench.py --no-cpu-baseline --workload xe5 --precision bf16 > $OUT/${R}_bench_line_xe5_bf16.json 2>/dev/null
 python bench.py --no-cpu-baseline --precision bf16x3 > $OUT/${R}_bench_line_bf16x3.json 2>/dev/null
+python bench.py --no-cpu-baseline --no-pmc --no-secondary --graph > $OUT/${R}_bench_line_graph.json 2>/dev/null
+XG_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-pmc > $OUT/${R}_bench_line_one_rank_rccl.json 2>/dev/null
 # keep the merge small: raw traces stay on the box
 rm -rf $OUT/bench $OUT/step $OUT/scst $OUT/xe5 $OUT/pmcF $OUT/pmcW $OUT/pmc1 $OUT/pmc2 $OUT/pmc3
 ls -la $OUT
