@@ -381,22 +381,25 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
     # segments; only the RCCL kernels are missing) -> what the all-reduce costs each rank, i.e. its EXPOSED part
     comm = None
     if use_dist and comm_diag:
-        tr._SKIP_COLLECTIVE = True
         try:
-            for _ in range(2):
-                step()
-            _, dt_nc, _, _ = timed(steps)
-        finally:
-            tr._SKIP_COLLECTIVE = False
-        broadcast_parameters(model)               # (replicas diverged without the collective: back to rank 0's)
-        mine = {"rank": rank, "ms_per_step": round(dt_own / steps * 1e3, 3), "ms_per_step_no_collective": round(dt_nc / steps * 1e3, 3),
-                "exposed_comm_ms": round((dt_own - dt_nc) / steps * 1e3, 3)}
-        allr = [None] * world
-        dist.all_gather_object(allr, mine)
-        comm = {"per_rank": allr, "gradient_bytes": int(model.flat_grads().numel() * 4),
-                "buckets": "logit | lstmcore+embed+img_embed | classifer | two_spatial_encoder (train.GradSync)" if sync is not None else "one",
-                "rccl_channels": rccl_channels(ctx.get("rccl_log")) if ctx.get("rccl_log") else None,
-                "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())}
+            tr._SKIP_COLLECTIVE = True
+            try:
+                for _ in range(2):
+                    step()
+                _, dt_nc, _, _ = timed(steps)
+            finally:
+                tr._SKIP_COLLECTIVE = False
+            broadcast_parameters(model)           # (replicas diverged without the collective: back to rank 0's)
+            mine = {"rank": rank, "ms_per_step": round(dt_own / steps * 1e3, 3), "ms_per_step_no_collective": round(dt_nc / steps * 1e3, 3),
+                    "exposed_comm_ms": round((dt_own - dt_nc) / steps * 1e3, 3)}
+            allr = [None] * world
+            dist.all_gather_object(allr, mine)
+            comm = {"per_rank": allr, "gradient_bytes": int(model.flat_grads().numel() * 4),
+                    "buckets": "logit | lstmcore+embed+img_embed | classifer | two_spatial_encoder (train.GradSync)" if sync is not None else "one",
+                    "rccl_channels": rccl_channels(ctx.get("rccl_log")) if ctx.get("rccl_log") else None,
+                    "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())}
+        except Exception as e:                    # never lose the scaling line over the diagnosis
+            comm = {"error": repr(e)}
     # host-side enqueue cost of one iteration against an IDLE GPU (the loop above also contains queue back-pressure: the
     # host runs ahead of the GPU until the launch queue is full), median of 5
     enq = []
