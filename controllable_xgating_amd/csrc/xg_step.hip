@@ -568,6 +568,12 @@ __device__ __forceinline__ void attn_part(const SkJob& job, int tile, float* sme
 //   * the job is blockIdx.y: everything the prologue needs comes from ONE round of scalar loads.
 //   * reduction buffer rows are 40 floats apart: conflict-free for the column-wise reads of the cell epilogue.
 constexpr int RSF = 40;
+#ifndef SKF_DEPTH_A
+#define SKF_DEPTH_A(PREC, SCALE) 1
+#endif
+#ifndef SKF_DEPTH_B
+#define SKF_DEPTH_B(PREC, SCALE) 1
+#endif
 template <bool HAS_TAIL>
 __device__ __forceinline__ void ldA(const float* const (&ap)[4], int c, int kleft /* K - c*32 - lcol */, f32x4 (&v)[4]) {
 #pragma unroll
@@ -688,14 +694,28 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
         // the normalised rows back (scaled_out has A's row pitch: checked by the host)
         const bool wb_seg = SCALE && sg.row_scale && sg.scaled_out;      // chunk c of the scaled rows is written back by n-tile c % ntn
         const ptrdiff_t wb_delta = wb_seg ? sg.scaled_out - sg.A : 0;
-        f32x4 ra[4], rb0[NPB], rb1[NPB];
+        // Operands are requested DA / DB chunks ahead of their MFMAs: 1 = ping-pong B sets, one A set (reloaded right behind its
+        // LDS store); 2 = three B sets / two A sets (-DSKF_DEPTH_A / -DSKF_DEPTH_B).  Depth 2 was measured and is NOT the default:
+        // it needs 10-12 registers beyond the 128 of four waves per SIMD (the cell epilogue's prefetched operands then live in
+        // scratch across the K loop) and the step got slower, 49.0 vs 46.2 us fp32, 8.49 vs 8.17 ms per hidden-1024 bf16 iteration.
+        constexpr int DA = SKF_DEPTH_A(PREC, SCALE), DB = SKF_DEPTH_B(PREC, SCALE);     // chunks ahead: activations / weights
+        f32x4 ra0[4], ra1[DA == 2 ? 4 : 1], rb0[NPB], rb1[NPB], rb2[DB == 2 ? NPB : 1];
         if (s == 0) SK_STAMP(1);
+        auto ldB = [&](int c, f32x4 (&b)[NPB]) {
 #pragma unroll
-        for (int i = 0; i < NPB; ++i) rb0[i] = *reinterpret_cast<const f32x4*>(bp + (size_t)c0 * TILE + i * 256);
-        if (c0 < nfull) ldA<false>(ap, c0, 0, ra); else ldA<true>(ap, c0, sg.K - c0 * CK - lcol, ra);
-        // one chunk: stage A (scaled / written back when it is the attention context), request the NEXT chunk's operands
-        // (B into the other register set: no copy), then the 16 MFMAs of this chunk
-        auto chunk = [&](int c, const f32x4 (&cur)[NPB], f32x4 (&nxt)[NPB]) {
+            for (int i = 0; i < NPB; ++i) b[i] = *reinterpret_cast<const f32x4*>(bp + (size_t)c * TILE + i * 256);
+        };
+        auto ldAc = [&](int c, f32x4 (&a)[4]) {
+            if (c < nfull) ldA<false>(ap, c, 0, a); else ldA<true>(ap, c, sg.K - c * CK - lcol, a);
+        };
+        ldB(c0, rb0); ldAc(c0, ra0);
+        if (c0 + 1 < c1) {
+            if constexpr (DB == 2) ldB(c0 + 1, rb1);
+            if constexpr (DA == 2) ldAc(c0 + 1, ra1);
+        }
+        // one chunk: stage A (scaled / written back when it is the attention context), request chunk `cn`'s operands (A into the
+        // registers just stored, B into a free set: no copies), then the 16 MFMAs of this chunk
+        auto chunk = [&](int c, f32x4 (&ra)[4], const f32x4 (&cur)[NPB], f32x4 (&nxt)[NPB]) {
             if (SCALE && sg.row_scale) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -707,11 +727,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
             if (PREC == 1) st_chunk_bf16(reinterpret_cast<unsigned short*>(As), lane, ra);
             else st_chunk(As, lane, ra);
             if (s == 0 && c == c0) SK_STAMP(2);
-            if (c + 1 < c1) {
-#pragma unroll
-                for (int i = 0; i < NPB; ++i) nxt[i] = *reinterpret_cast<const f32x4*>(bp + (size_t)(c + 1) * TILE + i * 256);
-                if (c + 1 < nfull) ldA<false>(ap, c + 1, 0, ra); else ldA<true>(ap, c + 1, sg.K - (c + 1) * CK - lcol, ra);
-            }
+            if (c + DB < c1) ldB(c + DB, nxt);
+            if (c + DA < c1) ldAc(c + DA, ra);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (PREC == 1) {
@@ -732,9 +749,22 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         };
-        for (int c = c0; c < c1; c += 2) {
-            chunk(c, rb0, rb1);
-            if (c + 1 < c1) chunk(c + 1, rb1, rb0);
+        // register sets: A alternates (period 2) when DA == 2; B rotates over three sets (period 3) when DB == 2, ping-pongs otherwise
+        auto& A1 = *reinterpret_cast<f32x4 (*)[4]>(DA == 2 ? ra1 : ra0);
+        if constexpr (DB == 2) {
+            for (int c = c0; c < c1; c += 6) {
+                chunk(c, ra0, rb0, rb2);
+                if (c + 1 < c1) chunk(c + 1, A1, rb1, rb0);
+                if (c + 2 < c1) chunk(c + 2, ra0, rb2, rb1);
+                if (c + 3 < c1) chunk(c + 3, A1, rb0, rb2);
+                if (c + 4 < c1) chunk(c + 4, ra0, rb1, rb0);
+                if (c + 5 < c1) chunk(c + 5, A1, rb2, rb1);
+            }
+        } else {
+            for (int c = c0; c < c1; c += 2) {
+                chunk(c, ra0, rb0, rb1);
+                if (c + 1 < c1) chunk(c + 1, A1, rb1, rb0);
+            }
         }
     }
     SK_STAMP(3);

@@ -57,10 +57,12 @@ if __name__ == "__main__":
         from controllable_xgating_amd import _native as nv
         res = {}
         variants = [("dstep", {"XG_LIBRARY": nv.LIB_DIAG_PATH, "XG_DSTEP": "1"}), ("three_launch", {})]
-        for v in os.environ.get("DS_VARIANTS", "").split(";"):       # e.g. DS_VARIANTS="s1first:XG_S1_FIRST=1"
+        for v in os.environ.get("DS_VARIANTS", "").split(";"):       # e.g. DS_VARIANTS="s1first:XG_S1_FIRST=1;v2:XG_LIBRARY=/path/lib.so"
             if v:
-                nm, kv = v.split(":")
-                variants.append((nm, dict([kv.split("=")], XG_LIBRARY=nv.LIB_DIAG_PATH)))
+                nm, kvs = v.split(":", 1)                              # name:KEY=VAL[,KEY=VAL...]; XG_LIBRARY may be given
+                env = dict(XG_LIBRARY=nv.LIB_DIAG_PATH)
+                env.update(kv.split("=", 1) for kv in kvs.split(","))
+                variants.append((nm, env))
         for name, env in variants:
             f = "/tmp/dstep_%s.pt" % name
             r = subprocess.run(["timeout", "120", sys.executable, os.path.abspath(__file__), "child", f], env=dict(os.environ, **env),
