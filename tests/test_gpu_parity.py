@@ -808,6 +808,40 @@ def test_scst_rollout_modes_equal_the_sequential_reference_order():
             assert err <= 2e-6 + 2e-3 * scale, (n, err, scale)
 
 
+def test_scst_paired_rollout_bf16_mirrors_survive_the_compaction():
+    """precision='bf16' (gemm_mode 1): the large products read bf16 mirrors of their operands in the workspace.  The paired
+    SCST rollout runs in a 2m-row workspace and its sampled half is COMPACTED into an m-row workspace for the backward
+    (xg_rollout_compact copies no mirrors: xg_rollout_bwd converts the encoder-side operands again).  Gradients of the paired
+    path == gradients of the plain m-row rollout with the same draws, at sizes where every product takes the bf16 kernels
+    (B K >= 256, T B >= 256, all pitches multiples of 8)."""
+    from controllable_xgating_amd import RewardCriterion, SAModel, make_opt
+    from controllable_xgating_amd.driver import scst_rollouts
+    d = pg.make_dims(B=16, K=20, R=256, A=384, E=64, V=2000, C=14, L=20, F1=96, F2=64)
+    Pn = pg.make_params(d, logit_gain=1.0)
+    x = to_dev(pg.make_inputs(d, seed=0))
+    u = torch.from_numpy(pg.uniform("uni_bf", (d.L + 1, d.B), 13)).cuda()
+    reward = torch.from_numpy(pg.uniform("rew_bf", (d.B, 1), 5)).cuda() - 0.5
+    outs = []
+    for mode in ("sequential", "batched"):
+        model = SAModel(make_opt(d, precision="bf16"))
+        model.load_state_dict({k: torch.from_numpy(v) for k, v in Pn.items()}, strict=False)
+        model = model.cuda(); model.train()
+        gen, slp, greedy = scst_rollouts(model, x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], mode=mode, uniforms=u)
+        loss = RewardCriterion()(slp, gen, reward.expand(-1, gen.shape[1]))
+        loss.backward()
+        torch.cuda.synchronize()
+        outs.append((gen.cpu().numpy(), float(loss.item()), {n: q.grad.detach().cpu().numpy().copy() for n, q in model.named_parameters()}))
+    a, b = outs
+    assert a[0].shape == b[0].shape and (a[0] != b[0]).mean() < 0.02          # (bf16 logits: a rare near-tie may flip a draw)
+    if np.array_equal(a[0], b[0]):
+        assert abs(a[1] - b[1]) < 2e-3 * max(1.0, abs(a[1]))
+        for n in a[2]:
+            if n in ZERO_GRAD_PARAMS:
+                continue
+            err, scale = float(np.abs(a[2][n] - b[2][n]).max()), float(np.abs(a[2][n]).max())
+            assert err <= 1e-6 + 3e-2 * scale, (n, err, scale)
+
+
 def test_gradsync_overlapped_allreduce_single_rank():
     """train.GradSync: the two-part all-reduce started from the library's grad-ready event (XgRun.grad_event) leaves
     the same gradients as the plain path (single-rank RCCL group: the collective is the identity, the event / stream /
