@@ -102,6 +102,7 @@ def lib():
         "xg_nll_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp, f32, vp, vp],
         "xg_clip_adam": [vp, i64, vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, f32],
         "xg_clip_adam_zero": [vp, i64, vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, f32],
+        "xg_workspace_init": [vp, vp, C.c_size_t],
         "xg_adam_tick": [vp, vp, f32, f32],
         "xg_clip_adam_dev": [vp, i64, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, i32],
         "xg_pack_weights": [vp, PD, PP, vp, C.c_size_t, i32, i32],

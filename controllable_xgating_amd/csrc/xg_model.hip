@@ -842,7 +842,8 @@ int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatc
     XG_TRY(init_and_vproj(ss, d, p, x.feat_mask, w));
     XG_TRY(zero_dsync(st, w));
     XG_TRY(ss.join());                                                                              // token-side products
-    const int th = (ss.overlap() && T >= 4) ? T / 2 : 0;
+    static const int th_env = xg_diag_env("XG_FWD_TH") ? atoi(xg_diag_env("XG_FWD_TH")) : -1;      // diagnosis: where the early product starts
+    const int th = (ss.overlap() && T >= 4) ? (th_env > 0 && th_env < T ? th_env : T / 2) : 0;
     // ... as a background product, with the stand-alone attention in its half-CU form beside it: the 128-VGPR attention
     // needs an EMPTY CU and waited for the whole persistent product (255 us: the chain simply stopped).  6.16 -> 6.10 ms.
     static const int fwd_bg_env = xg_diag_env("XG_FWD_BG") ? atoi(xg_diag_env("XG_FWD_BG")) : 1;
@@ -1126,7 +1127,8 @@ int heads_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams& g
     if (rows < TB) ZERO(w.DH2OUT + (size_t)rows * R, (size_t)(TB - rows) * R);
     // dH = dlogits * W: the reverse-time loop starts from the LAST step, so the rows of the late steps go first on the
     // main stream and the early steps' rows are produced on the auxiliary stream while the loop is already running.
-    const int th = (ss.overlap() && !have_cls && rows == TB && d.T >= 4) ? d.T / 2 : 0;
+    static const int bth_env = xg_diag_env("XG_BWD_TH") ? atoi(xg_diag_env("XG_BWD_TH")) : -1;
+    const int th = (ss.overlap() && !have_cls && rows == TB && d.T >= 4) ? (bth_env > 0 && bth_env < d.T ? bth_env : d.T / 2) : 0;
     const int r0 = th * B;
     ss.dh_split_step = th; ss.dh_mark = -1;
     unsigned short* dl16 = const_cast<unsigned short*>(m16(w, w.LOGITS));
@@ -1244,6 +1246,11 @@ extern "C" int xg_param_numel(const XgDims* d, int i, int64_t* numel) {
 extern "C" size_t xg_workspace_bytes(const XgDims* d) {
     if (!dims_ok(d)) return 0;
     return carve(*d, nullptr).bytes;
+}
+
+extern "C" int xg_workspace_init(void* stream, void* ws, size_t ws_bytes) {
+    if (!ws || (uintptr_t)ws % 256 != 0) return XG_EINVAL;
+    return hipMemsetAsync(ws, 0, ws_bytes, (hipStream_t)stream) == hipSuccess ? XG_OK : XG_EHIP;
 }
 
 extern "C" int xg_encoder_fwd(void* stream, const XgDims* d, const XgParams* p, const XgBnState* bn, const XgBatch* x,

@@ -138,6 +138,8 @@ int xg_param_count(void);
 const char *xg_param_name(int index);                 /* state_dict key of XgParams field `index` */
 int xg_param_numel(const XgDims *d, int index, int64_t *numel);
 size_t xg_workspace_bytes(const XgDims *d);           /* covers every entry point below for dims d */
+/* zero-fills a freshly allocated workspace (the one-time initialisation the conventions above ask for; a hipMemsetAsync) */
+int xg_workspace_init(void *stream, void *ws, size_t ws_bytes);
 
 /* ---- building block: fp32 GEMM on MFMA -------------------------------------------
  * C[M,N] = op(A) * op(B) (+ bias[n]) (+ C if accumulate), optional ReLU.
