@@ -300,6 +300,7 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
             sync = GradSync(model)
         except Exception as e:                   # never lose the run over the overlap: fall back to one all-reduce
             print("GradSync unavailable (%s): plain all-reduce" % e, file=sys.stderr)
+    state = {"overlap_comm": True}              # data parallel: bucketed all-reduce under the backward (GradSync) vs one collective after it
     crit = LanguageModelCriterion()
     rl_crit = RewardCriterion()
     reward_b = torch.randn(cfg["B"], 1, generator=torch.Generator().manual_seed(7)).to(dev)   # CIDEr stubbed (configs[2])
@@ -313,7 +314,7 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
             gen, slp, greedy = scst_rollouts(model, x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"],
                                              mode=os.environ.get("XG_SCST_MODE"))
             loss = rl_crit(slp, gen, reward_b.expand(-1, gen.shape[1]))
-        if sync is not None:
+        if sync is not None and state["overlap_comm"]:
             sync.arm()
         optim.arm()
         loss.backward()
@@ -336,7 +337,7 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
         else:
             logp, _ = model(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
             loss = crit(logp, x["seq"], x["seq_mask"])
-        if sync is not None:
+        if sync is not None and state["overlap_comm"]:
             sync.arm()
         optim.arm()
         loss.backward()
@@ -371,6 +372,21 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
 
     for _ in range(warmup):
         loss = step()
+    comm_choice = None
+    if use_dist and sync is not None and (world > 1 or os.environ.get("XG_FORCE_DIST") == "2"):
+        # Which all-reduce schedule is faster HERE is decided by measurement, not by expectation: the overlapped buckets share the
+        # CUs with the backward's chains and background products, and RCCL's kernels have never run beside them on more than one
+        # rank on the build pool.  Three iterations each way (max over ranks), the faster one is timed; both are reported.
+        tried = {}
+        for name, ov in (("overlapped_buckets", True), ("one_collective_after_backward", False)):
+            state["overlap_comm"] = ov
+            step()
+            t3, _, _, _ = timed(3)
+            tt = torch.tensor([t3], device=dev, dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            tried[name] = round(float(tt.item()) / 3 * 1e3, 3)
+        state["overlap_comm"] = tried["overlapped_buckets"] <= tried["one_collective_after_backward"]
+        comm_choice = {"ms_per_step_tried": tried, "timed": "overlapped_buckets" if state["overlap_comm"] else "one_collective_after_backward"}
     dt, dt_own, t_enq, loss = timed(steps)
     if use_dist:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
@@ -394,8 +410,9 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
                     "exposed_comm_ms": round((dt_own - dt_nc) / steps * 1e3, 3)}
             allr = [None] * world
             dist.all_gather_object(allr, mine)
-            comm = {"per_rank": allr, "gradient_bytes": int(model.flat_grads().numel() * 4),
-                    "buckets": "logit | lstmcore+embed+img_embed | classifer | two_spatial_encoder (train.GradSync)" if sync is not None else "one",
+            comm = {"per_rank": allr, "gradient_bytes": int(model.flat_grads().numel() * 4), "schedule": comm_choice,
+                    "buckets": "logit | lstmcore+embed+img_embed | classifer | two_spatial_encoder (train.GradSync)"
+                               if (sync is not None and state["overlap_comm"]) else "one",
                     "rccl_channels": rccl_channels(ctx.get("rccl_log")) if ctx.get("rccl_log") else None,
                     "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())}
         except Exception as e:                    # never lose the scaling line over the diagnosis
@@ -574,7 +591,7 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    use_dist = world > 1 or os.environ.get("XG_FORCE_DIST") == "1"     # XG_FORCE_DIST: exercise the RCCL path on one GPU
+    use_dist = world > 1 or os.environ.get("XG_FORCE_DIST") in ("1", "2")    # XG_FORCE_DIST: exercise the RCCL path on one GPU
     ctx = dict(world=world, rank=rank, dev=dev, use_dist=use_dist, rccl_log=None)
     if use_dist:
         import torch.distributed as dist
