@@ -20,6 +20,7 @@
 #include "xg_kernels.h"
 #include <cstdio>
 #include <cstdlib>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -132,6 +133,83 @@ __device__ __forceinline__ f32x4 read_frag(const float* __restrict__ lds, int ro
         v[3] = p[3 * (ROWS + 4)];
         return v;
     }
+}
+
+// sched_group_barrier pipeline of one block: M MFMAs with D LDS instructions and V global loads spread evenly between them
+// (the block's first MFMAs depend on nothing issued in the block, so an MFMA group always comes first)
+template <int M, int D, int V>
+__device__ __forceinline__ void w1_interleave() {
+    constexpr int MEM = D + V;
+    if constexpr (M == 0) {
+        if constexpr (V > 0) __builtin_amdgcn_sched_group_barrier(0x020, V, 0);
+        if constexpr (D > 0) __builtin_amdgcn_sched_group_barrier(0x080, D, 0);
+    } else if constexpr (MEM == 0) {
+        __builtin_amdgcn_sched_group_barrier(0x008, M, 0);
+    } else if constexpr (MEM >= M) {
+        constexpr int K = (MEM + M - 1) / M, v = V < K ? V : K, d = K - v;
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (v > 0) __builtin_amdgcn_sched_group_barrier(0x020, v, 0);
+        if constexpr (d > 0) __builtin_amdgcn_sched_group_barrier(0x080, d, 0);
+        w1_interleave<M - 1, D - d, V - v>();
+    } else {
+        constexpr int mm = M / MEM;
+        __builtin_amdgcn_sched_group_barrier(0x008, mm, 0);
+        if constexpr (V > 0) { __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); w1_interleave<M - mm, D, V - 1>(); }
+        else { __builtin_amdgcn_sched_group_barrier(0x080, 1, 0); w1_interleave<M - mm, D - 1, V>(); }
+    }
+}
+
+// One 32-deep slab of MFMAs out of the LDS images.  Default: per 8-deep block [fragment reads][4 MT NT MFMAs], scheduled by the
+// compiler ([reads][s_waitcnt][MFMAs]: a wave's matrix pipe idles for one LDS round trip per block, which the other waves of the
+// SIMD cover).  -DGEMM_FRAG_PIPE: the fragments of block kb + 1 are requested BEFORE the MFMAs of block kb (two fragment sets,
+// order pinned with sched_barrier) -- measured (tools/ubench/gemm_ablate.py, round 3): no gain on k-contiguous operands
+// (enc embed 55.8 -> 54.8 us with everything but LDS reads + MFMAs compiled out) and a loss on m-contiguous ones (wgrad TN
+// 58.8 -> 69.2 us): with two or more waves per SIMD the round trip was already hidden, and the pinned order costs more than it hides.
+template <int BM, int BN, bool AKC, bool BKC, int MT, int NT>
+__device__ __forceinline__ void slab_mfma_pipelined(const float* __restrict__ as, const float* __restrict__ bs, int arow, int brow,
+                                                    int half, f32x16 (&acc)[MT][NT]) {
+#ifndef GEMM_FRAG_PIPE
+#pragma unroll
+    for (int kb = 0; kb < BKS / 8; ++kb) {
+        f32x4 fa[MT], fb[NT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) fa[i] = read_frag<BM, AKC>(as, arow + i * 32, kb, half);
+#pragma unroll
+        for (int j = 0; j < NT; ++j) fb[j] = read_frag<BN, BKC>(bs, brow + j * 32, kb, half);
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
+    }
+#else
+    f32x4 fa[2][MT], fb[2][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) fa[0][i] = read_frag<BM, AKC>(as, arow + i * 32, 0, half);
+#pragma unroll
+    for (int j = 0; j < NT; ++j) fb[0][j] = read_frag<BN, BKC>(bs, brow + j * 32, 0, half);
+#pragma unroll
+    for (int kb = 0; kb < BKS / 8; ++kb) {
+        const int c = kb & 1, n = c ^ 1;
+        if (kb + 1 < BKS / 8) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[n][i] = read_frag<BM, AKC>(as, arow + i * 32, kb + 1, half);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[n][j] = read_frag<BN, BKC>(bs, brow + j * 32, kb + 1, half);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int i = 0; i < MT; ++i)
+#pragma unroll
+                for (int j = 0; j < NT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][kk], fb[c][j][kk], acc[i][j], 0, 0, 0);
+        if (kb + 1 < BKS / 8) w1_interleave<4 * MT * NT, MT * (AKC ? 1 : 2) + NT * (BKC ? 1 : 2), 0>();
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#endif
 }
 
 struct GemmArgs {
@@ -255,21 +333,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
 #endif
         const float* as = smem + cur * STAGE;
         const float* bs = as + A_FL;
-#pragma unroll
-        for (int kb = 0; kb < BKS / 8; ++kb) {
-            f32x4 fa[MT], fb[NT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) fa[i] = read_frag<BM, AKC>(as, wm * WM + i * 32 + l31, kb, half);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = read_frag<BN, BKC>(bs, wn * WN + j * 32 + l31, kb, half);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
-        }
+        slab_mfma_pipelined<BM, BN, AKC, BKC, MT, NT>(as, bs, wm * WM + l31, wn * WN + l31, half, acc);
 #ifndef GEMM_NO_LDS_STORE
         if (s + 1 < nslab) {
             if (do_cs) {
@@ -315,6 +379,265 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
                 }
             }
         }
+}
+
+// ---- one workgroup per CU, deep slabs ("w1") -----------------------------------------------------------------------
+// For products whose output divides into roughly ONE round of tiles for the 256 CUs (the mid-size shapes: 3328 x 512, 2048 x 512,
+// 3328 x 1536 ...).  The kernels above need two or more workgroups per CU to cover each other's stalls -- per slab a wave waits
+// for its global loads (issued one 32-deep slab = 0.5-2 us earlier), stores, meets the barrier and waits for the first
+// fragments -- and with one wave per SIMD they run at 55-65 % of the matrix rate (wgrad TN 2048 x 512 x 2688 as 256 tiles of 64 x 64:
+// 83.6 us, the vendor library's 256-tile kernel: 52.6).  Here ONE wave per SIMD has to keep its matrix pipe busy by itself:
+//   * slabs are BK = 128 / 64 / 32 deep by tile area, 4096-8192 MFMA cycles each: the next slab's global loads (issued at the top
+//     of the slab, one register set) have a whole slab to land, and there is one barrier per slab instead of four;
+//   * inside a slab the operand fragments of 8-deep block kb + 1 are requested before the MFMAs of block kb (two fragment sets,
+//     order pinned), and the LDS stores of the next slab are spread over the last quarter of the blocks (its stage is idle);
+//   * what is left exposed per slab is the barrier and the first fragment round trip.
+// k-contiguous images have a row stride of BK + 4 floats (an odd number of 16-byte slots: ds_read_b128 fragments are conflict-free).
+template <int ROWS, int BK, bool KC>
+struct TileW {
+    static constexpr int ld = KC ? BK + 4 : ROWS + 4;
+    static constexpr int lds_floats = KC ? ROWS * (BK + 4) : BK * (ROWS + 4);
+    static constexpr int nvec = ROWS * BK / 4 / 256;        // float4 per thread per slab
+    static_assert(ROWS * BK % 1024 == 0, "tile must divide over 256 threads");
+};
+template <int ROWS, int BK, bool KC>
+__device__ __forceinline__ void w1_offsets(int ld, int r0, int nrows, uint32_t (&off)[TileW<ROWS, BK, KC>::nvec]) {
+    const int t = threadIdx.x;
+#pragma unroll
+    for (int i = 0; i < TileW<ROWS, BK, KC>::nvec; ++i) {
+        const int f = t + 256 * i;
+        if (KC) {
+            const int r = f / (BK / 4), k = (f % (BK / 4)) << 2;
+            off[i] = (uint32_t)(((size_t)min(r0 + r, nrows - 1) * ld + k) * sizeof(float));
+        } else {
+            const int k = f / (ROWS / 4), r = (f % (ROWS / 4)) << 2;
+            off[i] = (uint32_t)(((size_t)k * ld + min(r0 + r, nrows - 4)) * sizeof(float));
+        }
+    }
+}
+template <int ROWS, int BK, bool KC>
+__device__ __forceinline__ void w1_store_one(float* __restrict__ lds, int i, const f32x4& v) {
+    const int f = threadIdx.x + 256 * i;
+    if (KC) {
+        const int r = f / (BK / 4), k = (f % (BK / 4)) << 2;
+        *reinterpret_cast<f32x4*>(lds + r * (BK + 4) + k) = v;
+    } else {
+        const int k = f / (ROWS / 4), r = (f % (ROWS / 4)) << 2;
+        *reinterpret_cast<f32x4*>(lds + k * (ROWS + 4) + r) = v;
+    }
+}
+template <int ROWS, int BK, bool KC>
+__device__ __forceinline__ f32x4 w1_frag(const float* __restrict__ lds, int row, int kb, int half) {
+    if (KC) return *reinterpret_cast<const f32x4*>(lds + row * (BK + 4) + kb * 8 + half * 4);
+    const float* p = lds + (kb * 8 + half * 4) * (ROWS + 4) + row;
+    f32x4 v;
+    v[0] = p[0]; v[1] = p[ROWS + 4]; v[2] = p[2 * (ROWS + 4)]; v[3] = p[3 * (ROWS + 4)];
+    return v;
+}
+
+#ifdef W1_TRACE
+__device__ long long w1_trace_buf[256 * 8];
+#define W1_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 256) { w1_trace_buf[blockIdx.x * 8 + (i)] = wall_clock64(); \
+                                                                       if ((i) == 1) w1_trace_buf[blockIdx.x * 8 + 4] = clock64(); \
+                                                                       if ((i) == 2) w1_trace_buf[blockIdx.x * 8 + 5] = clock64(); } } while (0)
+#else
+#define W1_STAMP(i) do { } while (0)
+#endif
+template <int BM, int BN, int BK, bool AKC, bool BKC>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) gemm_w1_kernel(GemmArgs g) {
+    W1_STAMP(0);
+    constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32, NB = BK / 8;
+    constexpr int A_FL = TileW<BM, BK, AKC>::lds_floats, B_FL = TileW<BN, BK, BKC>::lds_floats, STAGE = A_FL + B_FL;
+    constexpr int NVA = TileW<BM, BK, AKC>::nvec, NVB = TileW<BN, BK, BKC>::nvec, NV = NVA + NVB;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int ntm = (g.M + BM - 1) / BM, ntn = (g.N + BN - 1) / BN, nwg = ntm * ntn;
+    int bid = blockIdx.x;
+    {   // XCD-aware grouped tile order (as gemm_kernel)
+        const int q = nwg / 8, r = nwg % 8, xcd = bid % 8, idx = bid / 8;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int tm, tn;
+    {
+        const int per = g.gm * ntn, grp = bid / per, in = bid - grp * per;
+        const int first = grp * g.gm, gsz = min(ntm - first, g.gm);
+        tn = in / gsz;
+        tm = first + (in - tn * gsz);
+    }
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    const int arow = wm * WM + l31, brow = wn * WN + l31;
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    uint32_t offA[NVA], offB[NVB];
+    w1_offsets<BM, BK, AKC>(g.lda, m0, g.M, offA);
+    w1_offsets<BN, BK, BKC>(g.ldb, n0, g.N, offB);
+    const size_t stepA = (AKC ? (size_t)BK : (size_t)BK * g.lda) * sizeof(float);
+    const size_t stepB = (BKC ? (size_t)BK : (size_t)BK * g.ldb) * sizeof(float);
+    const char* pa = reinterpret_cast<const char*>(g.A);
+    const char* pb = reinterpret_cast<const char*>(g.B);
+    const int ns = g.K / BK;                     // (launcher: K % BK == 0)
+    // TWO register sets of global loads: slab x travels in set x & 1, requested at the top of slab x - 2 and stored into LDS at
+    // the end of slab x - 1 -- 1.75 slabs for the loads to land (measured: 1.3-2.6 us under load, i.e. more than one slab)
+    f32x4 ra[2][NVA], rb[2][NVB];
+    float bv[NT];                                // bias of this lane's columns: requested now, used in the epilogue
+#pragma unroll
+    for (int j = 0; j < NT; ++j) {
+        const int col = n0 + wn * WN + j * 32 + l31;
+        bv[j] = (g.bias && col < g.N) ? g.bias[col] : 0.f;
+    }
+    load_fast<NVA>(pa, offA, ra[0]);
+    load_fast<NVB>(pb, offB, rb[0]);
+    if (ns > 1) {
+        load_fast<NVA>(pa + stepA, offA, ra[1]);
+        load_fast<NVB>(pb + stepB, offB, rb[1]);
+    }
+#pragma unroll
+    for (int i = 0; i < NVA; ++i) w1_store_one<BM, BK, AKC>(smem, i, ra[0][i]);
+#pragma unroll
+    for (int i = 0; i < NVB; ++i) w1_store_one<BN, BK, BKC>(smem + A_FL, i, rb[0][i]);
+    __syncthreads();
+    W1_STAMP(1);
+
+    // One slab as straight-line code (SET = s & 1; LOAD: slab s + 2 exists and is requested here; STORE: slab s + 1 exists and goes
+    // to LDS here).  Per 8-deep block the memory instructions -- this block's share of the global loads (first blocks), the
+    // fragment reads of block kb + 1, this block's share of the LDS stores (last blocks) -- are INTERLEAVED with the block's MFMAs
+    // (sched_group_barrier pipeline): a wave issues in order, and a cluster of 12-20 LDS / VMEM instructions between two MFMA
+    // groups keeps the matrix pipe waiting while the four waves' requests queue up at the CU's one LDS pipe and one texture
+    // addresser (measured: 300-370 cycles per block, 76-105 cycles per MFMA instead of 64, whatever else the schedule did).
+    // A pipeline STAGE is BD 8-deep blocks (16 MFMAs or more: the fragments a stage needs are requested one stage ahead, and an LDS
+    // round trip is 130-250 cycles -- with 4-MFMA stages the MFMAs caught up with their own operands at every block)
+    constexpr int BD = MT * NT <= 2 ? (MT * NT == 1 ? 4 : 2) : 1;
+    constexpr int NS = NB / BD;                               // stages per slab
+    static_assert(NB % BD == 0 && NS >= 2, "");
+    constexpr int WS = NS >= 8 ? NS / 4 : (NS >= 4 ? 2 : 1);  // stages over which a slab's LDS stores are spread (the last ones)
+    constexpr int NLS = NS - WS;                              // stages that carry global loads (the first ones)
+    constexpr int PERW = (NV + WS - 1) / WS, PERL = (NV + NLS - 1) / NLS;
+    constexpr int FRA = AKC ? 1 : 2, FRB = BKC ? 1 : 2;       // LDS instructions per fragment (b128, or two ds_read2_b32)
+    auto slab = [&](int s, auto set_tag, auto load_tag, auto store_tag) {
+        constexpr int SET = decltype(set_tag)::value;          // == s & 1
+        constexpr bool LOAD = decltype(load_tag)::value, STORE = decltype(store_tag)::value;
+        const float* as = smem + SET * STAGE;
+        const float* bs = as + A_FL;
+        float* was = smem + (SET ^ 1) * STAGE;
+        float* wbs = was + A_FL;
+        const char* la = pa + (size_t)(s + 2) * stepA;
+        const char* lb = pb + (size_t)(s + 2) * stepB;
+        f32x4 fa[2][BD][MT], fb[2][BD][NT];
+#pragma unroll
+        for (int d = 0; d < BD; ++d) {
+#pragma unroll
+            for (int i = 0; i < MT; ++i) fa[0][d][i] = w1_frag<BM, BK, AKC>(as, arow + i * 32, d, half);
+#pragma unroll
+            for (int j = 0; j < NT; ++j) fb[0][d][j] = w1_frag<BN, BK, BKC>(bs, brow + j * 32, d, half);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int st = 0; st < NS; ++st) {
+            const int c = st & 1, n = c ^ 1;
+            if (LOAD && st < NLS) {               // this set's slab is in LDS: reuse the registers for slab s + 2
+#pragma unroll
+                for (int q = 0; q < PERL; ++q) {
+                    const int i = st * PERL + q;
+                    if (i < NVA) ra[SET][i] = *reinterpret_cast<const f32x4*>(la + offA[i]);
+                    else if (i < NV) rb[SET][i - NVA] = *reinterpret_cast<const f32x4*>(lb + offB[i - NVA]);
+                }
+            }
+            if (st + 1 < NS) {
+#pragma unroll
+                for (int d = 0; d < BD; ++d) {
+#pragma unroll
+                    for (int i = 0; i < MT; ++i) fa[n][d][i] = w1_frag<BM, BK, AKC>(as, arow + i * 32, (st + 1) * BD + d, half);
+#pragma unroll
+                    for (int j = 0; j < NT; ++j) fb[n][d][j] = w1_frag<BN, BK, BKC>(bs, brow + j * 32, (st + 1) * BD + d, half);
+                }
+            }
+            if (STORE && st >= NLS) {             // the other set (slab s + 1, requested 1.75 slabs ago) goes to LDS
+                const int w = st - NLS;
+#pragma unroll
+                for (int q = 0; q < PERW; ++q) {
+                    const int i = w * PERW + q;
+                    if (i < NVA) w1_store_one<BM, BK, AKC>(was, i, ra[SET ^ 1][i]);
+                    else if (i < NV) w1_store_one<BN, BK, BKC>(wbs, i - NVA, rb[SET ^ 1][i - NVA]);
+                }
+            }
+#pragma unroll
+            for (int d = 0; d < BD; ++d)
+#pragma unroll
+                for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                    for (int i = 0; i < MT; ++i)
+#pragma unroll
+                        for (int j = 0; j < NT; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][d][i][kk], fb[c][d][j][kk], acc[i][j], 0, 0, 0);
+            // the pipeline of this stage (counts are upper bounds: a group that finds fewer instructions is simply shorter)
+            constexpr int NM = 4 * BD * MT * NT, NFR = BD * (MT * FRA + NT * FRB);
+            if (st < NLS) {
+                if (st + 1 < NS) w1_interleave<NM, NFR, LOAD ? PERL : 0>();
+                else w1_interleave<NM, 0, LOAD ? PERL : 0>();
+            } else {
+                if (st + 1 < NS) w1_interleave<NM, NFR + (STORE ? PERW : 0), 0>();
+                else w1_interleave<NM, STORE ? PERW : 0, 0>();
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    };
+    {
+        using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>;
+        using Y = std::true_type; using N = std::false_type;
+        int s = 0;
+        for (; s + 3 < ns; s += 2) {             // both slabs of the pair have a slab two ahead
+            slab(s, T0{}, Y{}, Y{});
+            slab(s + 1, T1{}, Y{}, Y{});
+        }
+        // the last two or three slabs (s is even here)
+        if (s + 2 < ns) {                        // three left: s (loads s + 2), s + 1, s + 2
+            slab(s, T0{}, Y{}, Y{});
+            slab(s + 1, T1{}, N{}, Y{});
+            slab(s + 2, T0{}, N{}, N{});
+        } else if (s + 1 < ns) {                 // two left
+            slab(s, T0{}, N{}, Y{});
+            slab(s + 1, T1{}, N{}, N{});
+        } else if (s < ns) {
+            slab(s, T0{}, N{}, N{});
+        }
+    }
+    W1_STAMP(2);
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = n0 + wn * WN + j * 32 + l31;
+            if (col >= g.N) continue;
+            float old[16];
+            if (g.accumulate) {                  // all 16 reads in flight before the first add
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    old[r] = row < g.M ? g.C[(size_t)row * g.ldc + col] : 0.f;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                if (row < g.M) {
+                    float v = acc[i][j][r] + bv[j];
+                    if (g.accumulate) v += old[r];
+                    if (g.relu) v = fmaxf(v, 0.f);
+                    g.C[(size_t)row * g.ldc + col] = v;
+                }
+            }
+        }
+    W1_STAMP(3);
 }
 
 // ---- persistent form of the 128x128 kernel ("pk") ----------------------------------------------------------------
@@ -371,9 +694,9 @@ __global__ void __launch_bounds__(256) zero2d_kernel(float* __restrict__ p, int 
     else for (int j = 0; c + j < cols; ++j) q[j] = 0.f;
 }
 
-template <bool AKC, bool BKC>
+template <int BM, int BN, bool AKC, bool BKC>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) gemm_pk_kernel(PkArgs g) {
-    constexpr int BM = 128, BN = 128, WM = 64, WN = 64, MT = 2, NT = 2;
+    constexpr int WM = BM / 2, WN = BN / 2, MT = WM / 32, NT = WN / 32;
     constexpr int A_FL = TileGeom<BM, AKC>::lds_floats, B_FL = TileGeom<BN, BKC>::lds_floats, STAGE = A_FL + B_FL;
     constexpr int NVA = TileGeom<BM, AKC>::nvec, NVB = TileGeom<BN, BKC>::nvec;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -478,21 +801,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     auto slab_mfma = [&](int buf) {
         const float* as = smem + buf * STAGE;
         const float* bs = as + A_FL;
-#pragma unroll
-        for (int kb = 0; kb < BKS / 8; ++kb) {
-            f32x4 fa[MT], fb[NT];
-#pragma unroll
-            for (int i = 0; i < MT; ++i) fa[i] = read_frag<BM, AKC>(as, wm * WM + i * 32 + l31, kb, half);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) fb[j] = read_frag<BN, BKC>(bs, wn * WN + j * 32 + l31, kb, half);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int i = 0; i < MT; ++i)
-#pragma unroll
-                    for (int j = 0; j < NT; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
-        }
+        slab_mfma_pipelined<BM, BN, AKC, BKC, MT, NT>(as, bs, wm * WM + l31, wn * WN + l31, half, acc);
     };
 
     int buf = 0;
@@ -607,18 +916,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 }
 
 // launcher of the persistent kernel; returns XG_OK, or 1 when the shape should take the one-tile-per-workgroup kernels
-template <bool AKC, bool BKC>
-int launch_pk(hipStream_t st, const GemmArgs& a) {
+template <int BM, int BN, bool AKC, bool BKC>
+int launch_pk(hipStream_t st, const GemmArgs& a, long min_units_default) {
     static const int disabled = xg_diag_env("XG_GEMM_NO_PK") ? 1 : 0;
-    if (disabled || !a.fast || a.M < 128 || a.N < 128) return 1;
+    if (disabled || !a.fast || a.M < BM || a.N < BN) return 1;
     PkArgs g{a.A, a.B, a.C, a.bias, a.M, a.N, a.K, a.lda, a.ldb, a.ldc, a.relu, a.accumulate, 0, 0, 0, 0, 0, a.gm,
              {a.csum[0], a.csum[1], a.csum[2]}};
-    g.ntm = xg_cdiv(a.M, 128); g.ntn = xg_cdiv(a.N, 128); g.nslab = xg_cdiv(a.K, BKS);
+    g.ntm = xg_cdiv(a.M, BM); g.ntn = xg_cdiv(a.N, BN); g.nslab = xg_cdiv(a.K, BKS);
     const long T = (long)g.ntm * g.ntn;
     const long units = T * g.nslab;
     // measured (tools/ubench/gemm_bench.py): the persistent form wins 3-6 % when every workgroup has >= ~40 slabs of work
     // (vocabulary head: logits, dW_logit, dH) and loses 10-15 % to 64x64 tiles + split-K on the mid-size products
-    static const long min_units = xg_diag_env("XG_PK_MIN") ? atol(xg_diag_env("XG_PK_MIN")) : 40;
+    static const long min_units_env = xg_diag_env("XG_PK_MIN") ? atol(xg_diag_env("XG_PK_MIN")) : -1;
+    const long min_units = min_units_env >= 0 ? min_units_env : min_units_default;
     if (units < 512L * min_units) return 1;
     static const int env_g = xg_diag_env("XG_PK_G") ? atoi(xg_diag_env("XG_PK_G")) : 0;
     static const int env_split = xg_diag_env("XG_PK_SPLIT") ? atoi(xg_diag_env("XG_PK_SPLIT")) : 1;
@@ -661,18 +971,18 @@ int launch_pk(hipStream_t st, const GemmArgs& a) {
         const int grp = (int)(dp / per), first = grp * g.gm, gsz = (g.ntm - first) < g.gm ? (g.ntm - first) : g.gm;
         const int tn0 = (int)((dp - (long)grp * per) / gsz);
         const bool one_group = first + gsz >= g.ntm;              // tail confined to the last group
-        const int r0 = first * 128, c0 = one_group ? tn0 * 128 : 0;
+        const int r0 = first * BM, c0 = one_group ? tn0 * BN : 0;
         if (r0 < a.M && c0 < a.N) {      // (hipMemset2DAsync takes 23 us for these 15 MB; this kernel 5)
             const int rows = a.M - r0, cols = a.N - c0;
             hipLaunchKernelGGL(zero2d_kernel, dim3(xg_cdiv(cols, 1024), rows), dim3(256), 0, st, a.C + (size_t)r0 * a.ldc + c0, a.ldc, cols);
             XG_CHECK_LAUNCH();
         }
     }
-    size_t lds = 2 * (TileGeom<128, AKC>::lds_floats + TileGeom<128, BKC>::lds_floats) * sizeof(float) + 4096;   // + csum scratch
+    size_t lds = 2 * (TileGeom<BM, AKC>::lds_floats + TileGeom<BN, BKC>::lds_floats) * sizeof(float) + 4096;   // + csum scratch
     static std::atomic<unsigned> optin{0};
-    XG_TRY(xg_lds_optin(optin, reinterpret_cast<const void*>(&gemm_pk_kernel<AKC, BKC>), 84 * 1024));
+    XG_TRY(xg_lds_optin(optin, reinterpret_cast<const void*>(&gemm_pk_kernel<BM, BN, AKC, BKC>), 84 * 1024));
     if (bg && lds < 82 * 1024) lds = 82 * 1024;
-    hipLaunchKernelGGL((gemm_pk_kernel<AKC, BKC>), dim3(G), dim3(256), lds, st, g);
+    hipLaunchKernelGGL((gemm_pk_kernel<BM, BN, AKC, BKC>), dim3(G), dim3(256), lds, st, g);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
@@ -692,6 +1002,58 @@ int launch(hipStream_t st, const GemmArgs& g) {
     hipLaunchKernelGGL((gemm_kernel<BM, BN, AKC, BKC, VEC>), dim3(ntm * ntn * g.splitk), dim3(256), lds, st, g);
     XG_CHECK_LAUNCH();
     return XG_OK;
+}
+
+// launcher of the one-workgroup-per-CU kernel: picks the tile (wave grid 2 x 2 of 32 x 32 MFMA tiles) whose ONE round over the 256 CUs
+// wastes the least, returns 1 when no candidate covers the chip well enough (or the shape is not its kind)
+template <int BM, int BN, int BK, bool AKC, bool BKC>
+int launch_w1(hipStream_t st, const GemmArgs& g) {
+    const int ntm = xg_cdiv(g.M, BM), ntn = xg_cdiv(g.N, BN);
+    constexpr size_t lds = 2 * (TileW<BM, BK, AKC>::lds_floats + TileW<BN, BK, BKC>::lds_floats) * sizeof(float);
+    static_assert(lds <= 160 * 1024, "LDS stages do not fit a CU");
+    static std::atomic<unsigned> optin{0};
+    XG_TRY(xg_lds_optin(optin, reinterpret_cast<const void*>(&gemm_w1_kernel<BM, BN, BK, AKC, BKC>), (int)lds));
+    hipLaunchKernelGGL((gemm_w1_kernel<BM, BN, BK, AKC, BKC>), dim3(ntm * ntn), dim3(256), lds, st, g);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+struct W1Tile { int bm, bn, bk; };
+constexpr W1Tile W1_TILES[] = {{64, 64, 128}, {64, 128, 64}, {128, 64, 64}, {128, 128, 64}, {128, 192, 32}, {192, 128, 32},
+                               {128, 256, 32}, {256, 128, 32}};     // (with the slab depth: 4096-8192 MFMA cycles per slab)
+template <bool AKC, bool BKC>
+int dispatch_w1(hipStream_t st, const GemmArgs& g) {
+    static const int off = xg_diag_env("XG_GEMM_NO_W1") ? 1 : 0;
+    if (off || !g.fast || g.csum[0] || g.bg || g.K < 256) return 1;
+    static const char* force = xg_diag_env("XG_W1_TILE");           // diagnosis: "bm,bn"
+    int fbm = 0, fbn = 0;
+    if (force) sscanf(force, "%d,%d", &fbm, &fbn);
+    int best = -1;
+    double best_eff = 0.0;
+    for (int c = 0; c < (int)(sizeof(W1_TILES) / sizeof(W1_TILES[0])); ++c) {
+        const W1Tile& t = W1_TILES[c];
+        if (g.K % t.bk || g.M < t.bm / 2 || g.N < t.bn / 2) continue;
+        const long tiles = (long)xg_cdiv(g.M, t.bm) * xg_cdiv(g.N, t.bn);
+        if (force) { if (t.bm == fbm && t.bn == fbn) { best = c; best_eff = 1.0; } continue; }
+        if (tiles > 256) continue;
+        // useful fraction of the chip's matrix time in that one round; larger tiles stream fewer operand bytes per flop
+        const double eff = (double)g.M * g.N / (256.0 * t.bm * t.bn);
+        const double score = eff * (t.bm * t.bn >= 128 * 128 ? 1.03 : (t.bm * t.bn >= 64 * 128 ? 1.0 : 0.97));
+        if (score > best_eff) { best_eff = score; best = c; }
+    }
+    if (best < 0 || best_eff < 0.70) return 1;
+    GemmArgs a = g;
+    a.splitk = 1;
+    a.gm = xgk_group_rows(g.K);
+    switch (best) {
+        case 0: return launch_w1<64, 64, 128, AKC, BKC>(st, a);
+        case 1: return launch_w1<64, 128, 64, AKC, BKC>(st, a);
+        case 2: return launch_w1<128, 64, 64, AKC, BKC>(st, a);
+        case 3: return launch_w1<128, 128, 64, AKC, BKC>(st, a);
+        case 4: return launch_w1<128, 192, 32, AKC, BKC>(st, a);
+        case 5: return launch_w1<192, 128, 32, AKC, BKC>(st, a);
+        case 6: return launch_w1<128, 256, 32, AKC, BKC>(st, a);
+        default: return launch_w1<256, 128, 32, AKC, BKC>(st, a);
+    }
 }
 
 template <bool AKC, bool BKC>
@@ -727,7 +1089,16 @@ int dispatch(hipStream_t st, GemmArgs g, bool vec) {
     }
     g.gm = xgk_group_rows(g.K);                     // the persistent kernel walks whole reductions
     if (vec && !force) {
-        const int rc = launch_pk<AKC, BKC>(st, g);
+        const int rc1 = dispatch_w1<AKC, BKC>(st, g);
+        if (rc1 != 1) return rc1;
+    }
+    if (vec && !force) {
+        // diagnosis: XG_PK_TILE = 1 (128 x 64 tiles) / 2 (64 x 64) sends the product to the persistent stream-K kernel over smaller tiles
+        static const int pk_tile = xg_diag_env("XG_PK_TILE") ? atoi(xg_diag_env("XG_PK_TILE")) : 0;
+        int rc = 1;
+        if (pk_tile == 1) rc = launch_pk<128, 64, AKC, BKC>(st, g, 8);
+        else if (pk_tile == 2) rc = launch_pk<64, 64, AKC, BKC>(st, g, 8);
+        if (rc == 1) rc = launch_pk<128, 128, AKC, BKC>(st, g, 40);
         if (rc != 1) return rc;
     }
     g.gm = xgk_group_rows(g.K / g.splitk);

@@ -125,6 +125,50 @@ def test_gemm_fuzz_all_kernels(pk_min, bg):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+_GEMM_W1 = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from controllable_xgating_amd import _native as nv
+L = nv.lib()
+bad = []
+for (M, N, K) in ((1000, 516, 512), (3328, 512, 1536), (260, 2052, 256)):
+    for ta, tb in ((0, 1), (0, 0), (1, 0), (1, 1)):
+        g = torch.Generator(device="cuda").manual_seed(M + 3 * N + 5 * K + ta * 2 + tb)
+        A = torch.randn((K, M) if ta else (M, K), generator=g, device="cuda")
+        B = torch.randn((N, K) if tb else (K, N), generator=g, device="cuda")
+        b = torch.randn(N, generator=g, device="cuda")
+        C0 = torch.randn(M, N, generator=g, device="cuda")
+        ref = (A.t() if ta else A).double() @ (B.t() if tb else B).double() + b.double()
+        scale = float(ref.abs().max())
+        for relu, acc in ((0, 0), (1, 0), (0, 1)):
+            Cd = C0.clone()
+            rc = L.xg_gemm(None, ta, tb, M, N, K, nv.ptr(A), A.shape[1], nv.ptr(B), B.shape[1], nv.ptr(Cd), N, nv.ptr(b), relu, acc)
+            want = ref + (C0.double() if acc else 0)
+            if relu: want = want.clamp(min=0)
+            err = float((Cd.double() - want).abs().max()) / scale
+            if rc != 0 or not err < 4e-6: bad.append((M, N, K, ta, tb, relu, acc, rc, err))
+print("bad", bad)
+sys.exit(1 if bad else 0)
+"""
+
+
+@pytest.mark.parametrize("tile", ["auto", "64,64", "64,128", "128,64", "128,128", "128,192", "192,128", "128,256", "256,128"])
+def test_gemm_one_workgroup_per_cu_kernel(tile):
+    """xg_gemm.hip's deep-slab kernel for products of about one round of tiles (gemm_w1_kernel: two register sets of global
+    loads, MFMAs interleaved with the LDS / global instructions): every tile shape forced onto ragged products (XG_W1_TILE of the
+    -DXG_DIAG library; rows / columns past the edge, one and several rounds of workgroups, 2-12 slabs), all four layouts,
+    bias / ReLU / += C, every element against fp64; "auto" = the production rule on the same shapes."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from controllable_xgating_amd import _native as nv
+    env = dict(os.environ, XG_LIBRARY=nv.LIB_DIAG_PATH)
+    if tile != "auto":
+        env["XG_W1_TILE"] = tile
+    r = subprocess.run([sys.executable, "-c", _GEMM_W1 % root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 @pytest.mark.parametrize("rows", [40, 128])
 def test_dataflow_step_kernel_equals_three_launch_step(rows):
     """xg_dstep.hip (the decoder step as ONE dataflow launch: measurement-only, selected with XG_DSTEP=1 in the -DXG_DIAG
