@@ -679,6 +679,79 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
         // tile is 512 float-sized words: 2 pieces of 256, an fp32 tile 1024: 4 pieces)
         constexpr int TILE = PREC == 1 ? 512 : 1024, NPB = PREC == 1 ? 2 : 4;
         const float* bp = sg.Bp + ((size_t)tn * nc) * TILE + (size_t)(half * 32 + l31) * 4;
+#ifdef SKF_DIRECT_A
+        // ---- A straight from global memory in MFMA-fragment order (no LDS image, no wave barriers): lane (row l31, half h) owns
+        // k in [16 h, 16 h + 16) of a 32-deep chunk = 64 contiguous bytes of its row (bf16: two runs of 8 k = 32 bytes each).
+        // Costs coalescing (every load instruction touches 32 rows) -- measured against the staged form, see DESIGN 4.3.
+        {
+            int row = min(m0 + l31, job.M - 1);
+            if (sg.gather) {
+                const int64_t t = sg.gather[(size_t)row * sg.gstride];
+                row = (int)(t < 0 ? 0 : (t > sg.gather_max ? sg.gather_max : t));
+            }
+            const float* adp = sg.A + (size_t)row * sg.lda;
+            const int nfull = sg.K / CK;
+            const bool wb_seg = SCALE && sg.row_scale && sg.scaled_out;
+            const ptrdiff_t wb_delta = wb_seg ? sg.scaled_out - sg.A : 0;
+            const float rs = (SCALE && sg.row_scale) ? rsc_lds[l31] : 1.0f;
+            auto koff = [&](int i) { return PREC == 1 ? (i >> 1) * 16 + half * 8 + (i & 1) * 4 : half * 16 + i * 4; };
+            f32x4 da0[4], da1[4], rb0[NPB], rb1[NPB];
+            auto ldB = [&](int c, f32x4 (&b)[NPB]) {
+#pragma unroll
+                for (int i = 0; i < NPB; ++i) b[i] = *reinterpret_cast<const f32x4*>(bp + (size_t)c * TILE + i * 256);
+            };
+            auto ldD = [&](int c, f32x4 (&a)[4]) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int k = c * CK + koff(i);
+                    const f32x4 t = *reinterpret_cast<const f32x4*>(adp + (c < nfull ? k : min(k, sg.K - 4)));
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    a[i] = (c < nfull || k < sg.K) ? t : z;
+                }
+            };
+            if (s == 0) SK_STAMP(1);
+            ldB(c0, rb0); ldD(c0, da0);
+            auto chunk = [&](int c, f32x4 (&a)[4], f32x4 (&an)[4], const f32x4 (&cur)[NPB], f32x4 (&nxt)[NPB]) {
+                if (c + 1 < c1) { ldB(c + 1, nxt); ldD(c + 1, an); }
+                if (SCALE && sg.row_scale) {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        a[i] *= rs;
+                        const int k = c * CK + koff(i);
+                        if (wb_seg && c % ntn == tn && m0 + l31 < job.M && k < sg.K)
+                            *reinterpret_cast<f32x4*>(const_cast<float*>(adp) + wb_delta + k) = a[i];
+                    }
+                }
+                if (s == 0 && c == c0) SK_STAMP(2);
+                if (PREC == 1) {
+                    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        unsigned w[4];
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) {
+                            bf16x2_t lo, hi;
+                            lo[0] = (__bf16)a[2 * i + q][0]; lo[1] = (__bf16)a[2 * i + q][1];
+                            hi[0] = (__bf16)a[2 * i + q][2]; hi[1] = (__bf16)a[2 * i + q][3];
+                            w[2 * q] = __builtin_bit_cast(unsigned, lo); w[2 * q + 1] = __builtin_bit_cast(unsigned, hi);
+                        }
+                        const uint4 pk = {w[0], w[1], w[2], w[3]};
+                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pk), __builtin_bit_cast(bf16x8, cur[i]), acc, 0, 0, 0);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], cur[i][kk], acc, 0, 0, 0);
+                }
+            };
+            for (int c = c0; c < c1; c += 2) {
+                chunk(c, da0, da1, rb0, rb1);
+                if (c + 1 < c1) chunk(c + 1, da1, da0, rb1, rb0);
+            }
+        }
+    }
+#else
         const float* ap[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
@@ -767,6 +840,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
             }
         }
     }
+#endif
     SK_STAMP(3);
     __syncthreads();
     float (*red)[32][RSF] = reinterpret_cast<float (*)[32][RSF]>(smem);
