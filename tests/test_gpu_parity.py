@@ -217,7 +217,7 @@ def run_hip_xe(d, ragged, p=0.0, seed=None, weight_class=WEIGHT_CLASS):
     if seed is not None:
         model._run_seed_override = seed
         orig = model._run
-        model._run = lambda save, s=None: orig(save, seed)
+        model._run = lambda save, s=None, **kw: orig(save, seed, **kw)
     logp, cat = model(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
     l_xe = LanguageModelCriterion()(logp, x["seq"], x["seq_mask"])
     l_cls = ClassiferCriterion()(cat, x["cap_classes"], x["seq_mask"], x["class_mask"])
