@@ -370,6 +370,25 @@ struct RollStepArgs {
     int split;                // rows >= split of a SAMPLE rollout decode greedily and report into maxf[1] (paired SCST rollout)
 };
 
+// the per-row bookkeeping of a rollout step once its token is chosen (one thread): unfinished &= it > 0 ; it *= unfinished ;
+// append (SAModel.py:200-210), the running "first step at which every row is finished" (:211-215)
+__device__ __forceinline__ void roll_bookkeep(const RollStepArgs& a, int b, int mode, int64_t tk, float lp, float lse, int32_t* maxf) {
+    const float u = (a.t == 1 ? 1.0f : a.unf_prev[b]) * (tk > 0 ? 1.0f : 0.0f);
+    if (mode != XG_ROLLOUT_REPLAY) {
+        const bool was = a.t == 1 ? true : a.unf_prev[b] > 0.f;
+        if (was && u == 0.f) atomicMax(maxf, a.t);                 // this row finishes at step t
+        else if (u > 0.f && a.t == a.T - 1) atomicMax(maxf, a.T);  // never finished
+    } else if (a.t == a.T - 1) {
+        atomicMax(maxf, a.T);
+    }
+    a.unf[b] = u;
+    a.lse[b] = lse;
+    a.tok[b] = tk;                                                   // xt = embed(it) uses the raw draw (:198)
+    a.tok_logp[b] = lp;
+    a.seq[(size_t)b * (a.T - 1) + (a.t - 1)] = mode == XG_ROLLOUT_REPLAY ? tk : (u > 0.f ? tk : 0);
+    a.seq_logp[(size_t)b * (a.T - 1) + (a.t - 1)] = lp;
+}
+
 // STAGE: the row's V logits are parked in LDS by the first pass (V * 4 bytes <= 150 KB), so the log-sum-exp / chunk-sum /
 // owner passes read LDS instead of going back to L2 three more times.
 template <bool STAGE>
@@ -476,22 +495,7 @@ __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
             tk = s_tok;
         }
         if (tid == 0) {
-            const float lp = xr[tk] - lse;
-            // unfinished &= it > 0 ; it *= unfinished ; append (:200-210)
-            const float u = (a.t == 1 ? 1.0f : a.unf_prev[b]) * (tk > 0 ? 1.0f : 0.0f);
-            if (mode != XG_ROLLOUT_REPLAY) {
-                const bool was = a.t == 1 ? true : a.unf_prev[b] > 0.f;
-                if (was && u == 0.f) atomicMax(maxf, a.t);                 // this row finishes at step t
-                else if (u > 0.f && a.t == a.T - 1) atomicMax(maxf, a.T);  // never finished
-            } else if (a.t == a.T - 1) {
-                atomicMax(maxf, a.T);
-            }
-            a.unf[b] = u;
-            a.lse[b] = lse;
-            a.tok[b] = tk;                                                   // xt = embed(it) uses the raw draw (:198)
-            a.tok_logp[b] = lp;
-            a.seq[(size_t)b * (a.T - 1) + (a.t - 1)] = mode == XG_ROLLOUT_REPLAY ? tk : (u > 0.f ? tk : 0);
-            a.seq_logp[(size_t)b * (a.T - 1) + (a.t - 1)] = lp;
+            roll_bookkeep(a, b, mode, tk, xr[tk] - lse, lse, maxf);
             s_tok = tk;
         }
     }
@@ -499,6 +503,264 @@ __global__ void __launch_bounds__(RT) rollout_step_kernel(RollStepArgs a) {
     const int64_t tk = s_tok;
     for (int e = tid; e < a.E; e += RT) a.xt[(size_t)b * a.E + e] = a.table[(size_t)tk * a.E + e];
 }
+// ------------------------------------------------------------------------------------------------
+// Rollout steps of at most 128 rows (round 3): the vocabulary product and the token choice as TWO light launches instead of a
+// (B, V) product that writes 10 MB of logits and a one-workgroup-per-row pass that reads them back three times.
+//   vocab_part_kernel   logits tile = h2' W_logit^T + b for ALL rows x 32 vocabulary columns per workgroup (4 waves, one 32 x 32
+//                       MFMA tile each, the W slab shared), and in its epilogue the tile's per-row statistics: max, argmax (lowest
+//                       column on ties), sum exp(x - max), sum exp((x - max) / temperature).  The logits themselves are stored only
+//                       for rows that need them later (sampled rows: the draw re-reads ONE tile of its row, the SCST backward
+//                       all of it; greedy rows of a paired rollout: never).
+//   roll_select_kernel  one workgroup per row over the V / 32 tile statistics (10 KB instead of 80 KB): log-sum-exp, greedy
+//                       argmax, inverse-CDF draw (block scan over the tile sums in double, then a walk through the one tile that
+//                       holds the target), the bookkeeping and the embedding gather of rollout_step_kernel.
+// Same arithmetic as rollout_step_kernel up to the grouping of the sums (by tile instead of by thread chunk).
+typedef float v_f32x16 __attribute__((ext_vector_type(16)));
+typedef float v_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int VT_LD = 36;                 // LDS row stride of a 32-deep slab (floats): conflict-free b128 fragment reads
+struct VocabPartArgs {
+    const float* H; int ldh;              // (B, R) rows
+    const float* W; const float* bias;    // (V, R) row-major, (V)
+    int B, R, V;
+    float* logits; int wr_rows;           // rows [0, wr_rows) of the (B, V) logits are stored
+    float* part;                          // (B, ntiles, 4): max, sum exp(x - max), sum exp((x - max) / T), argmax column (int bits)
+    float inv_t;
+};
+__global__ void __launch_bounds__(256) vocab_part_kernel(VocabPartArgs a) {
+    XG_CHAIN_PRIO();
+    __shared__ __attribute__((aligned(16))) float smem[2 * (128 + 32) * VT_LD];
+    constexpr int STAGE = (128 + 32) * VT_LD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+    const int n0 = blockIdx.x * 32, ntiles = gridDim.x;
+    // per-thread load pieces of a slab: A 128 x 32 -> 4 float4 (row f >> 3, k (f & 7) * 4), W 32 x 32 -> 1 float4
+    const float* ap[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i;
+        ap[i] = a.H + (size_t)min(f >> 3, a.B - 1) * a.ldh + ((f & 7) << 2);
+    }
+    const float* wp = a.W + (size_t)min(n0 + (tid >> 3), a.V - 1) * a.R + ((tid & 7) << 2);
+    // global loads run TWO slabs ahead of their MFMAs (two register sets): a slab is only 16 MFMAs per wave, a third of a load's
+    // round trip even with three workgroups per CU
+    v_f32x4 ra[2][4], rw[2];
+    auto ld = [&](int s, v_f32x4 (&xa)[4], v_f32x4& xw) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xa[i] = *reinterpret_cast<const v_f32x4*>(ap[i] + s * 32);
+        xw = *reinterpret_cast<const v_f32x4*>(wp + s * 32);
+    };
+    auto st = [&](int buf, const v_f32x4 (&xa)[4], const v_f32x4& xw) {
+        float* As = smem + buf * STAGE;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i;
+            *reinterpret_cast<v_f32x4*>(As + (f >> 3) * VT_LD + ((f & 7) << 2)) = xa[i];
+        }
+        *reinterpret_cast<v_f32x4*>(As + 128 * VT_LD + (tid >> 3) * VT_LD + ((tid & 7) << 2)) = xw;
+    };
+    v_f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    const int ns = a.R / 32;
+    ld(0, ra[0], rw[0]);
+    if (ns > 1) ld(1, ra[1], rw[1]);
+    st(0, ra[0], rw[0]);
+    __syncthreads();
+    auto slab = [&](int s, v_f32x4 (&mine)[4], v_f32x4& minew, const v_f32x4 (&other)[4], const v_f32x4& otherw) {
+        if (s + 2 < ns) ld(s + 2, mine, minew);          // (this set's slab s is in LDS)
+        const float* As = smem + (s & 1) * STAGE;
+        const float* Bs = As + 128 * VT_LD;
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const v_f32x4 fa = *reinterpret_cast<const v_f32x4*>(As + (wave * 32 + l31) * VT_LD + kb * 8 + half * 4);
+            const v_f32x4 fb = *reinterpret_cast<const v_f32x4*>(Bs + l31 * VT_LD + kb * 8 + half * 4);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk], fb[kk], acc, 0, 0, 0);
+        }
+        if (s + 1 < ns) st((s + 1) & 1, other, otherw);   // slab s + 1: requested two slabs ago
+        __syncthreads();
+    };
+    for (int s = 0; s < ns; s += 2) {
+        slab(s, ra[0], rw[0], ra[1], rw[1]);
+        if (s + 1 < ns) slab(s + 1, ra[1], rw[1], ra[0], rw[0]);
+    }
+    // epilogue through LDS (the staging buffers are free: every wave is past the loop's last barrier): the tile as [128][33],
+    // then thread (row, half-row) walks 16 columns -- a dozen LDS reads and two exchanges with its neighbour instead of 16 five-step
+    // shuffle reductions per wave, and the stored rows leave as 16-byte pieces
+    constexpr int TL = 33;
+    float* tl = smem;
+    {
+        const int col = n0 + l31;
+        const float bv = col < a.V ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) tl[(wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * TL + l31] = acc[r] + bv;
+    }
+    __syncthreads();
+    const int row = tid >> 1, h = tid & 1, c0 = n0 + h * 16;
+    float x[16];
+    float m = -INFINITY; int mc = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        x[j] = c0 + j < a.V ? tl[row * TL + h * 16 + j] : -INFINITY;
+        if (x[j] > m) { m = x[j]; mc = c0 + j; }          // (ascending columns: the first maximum stays)
+    }
+    {
+        const float om = __shfl_xor(m, 1, 64); const int oc = __shfl_xor(mc, 1, 64);
+        if (om > m || (om == m && oc < mc)) { m = om; mc = oc; }
+    }
+    float e1 = 0.f, et = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const float d = x[j] - m;                         // (-inf for columns past V: exp -> 0)
+        const float e = __expf(d);
+        e1 += e;
+        et += a.inv_t == 1.0f ? e : __expf(d * a.inv_t);
+    }
+    e1 += __shfl_xor(e1, 1, 64); et += __shfl_xor(et, 1, 64);
+    if (row < a.B) {
+        if (h == 0) {
+            v_f32x4 pv = {m, e1, et, __int_as_float(mc)};
+            *reinterpret_cast<v_f32x4*>(a.part + ((size_t)row * ntiles + blockIdx.x) * 4) = pv;
+        }
+        if (row < a.wr_rows) {
+            float* dst = a.logits + (size_t)row * a.V + c0;
+            if ((a.V & 3) == 0 && c0 + 16 <= a.V) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    v_f32x4 v = {x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]};
+                    *reinterpret_cast<v_f32x4*>(dst + 4 * j) = v;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < 16; ++j) if (c0 + j < a.V) dst[j] = x[j];
+            }
+        }
+    }
+}
+
+constexpr int ST = 256;                   // threads of a selection workgroup
+struct RollSelectArgs {
+    RollStepArgs r;                       // (r.logits = the rows stored by vocab_part_kernel; r.t >= 1)
+    const float* part; int ntiles;
+};
+__global__ void __launch_bounds__(ST) roll_select_kernel(RollSelectArgs q) {
+    XG_CHAIN_PRIO();
+    const RollStepArgs& a = q.r;
+    __shared__ float redf[ST / 64]; __shared__ int redi[ST / 64]; __shared__ double wave_tot[ST / 64];
+    __shared__ double s_d[2]; __shared__ float s_f[2];
+    __shared__ int s_owner; __shared__ int64_t s_tok;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool second = b >= a.split;
+    const int mode = (second && a.mode == XG_ROLLOUT_SAMPLE) ? XG_ROLLOUT_GREEDY : a.mode;
+    int32_t* maxf = a.maxf + (second ? 1 : 0);
+    const int nt = q.ntiles, per = (nt + ST - 1) / ST;           // tiles per thread, contiguous: thread tid owns [tid per, ..)
+    const v_f32x4* pr = reinterpret_cast<const v_f32x4*>(q.part) + (size_t)b * nt;
+    constexpr int PMAX = 4;                                     // V <= 32 * 4 * 256 (launcher)
+    v_f32x4 pv[PMAX];
+    float best = -INFINITY; int bi = 0x7fffffff;
+#pragma unroll
+    for (int i = 0; i < PMAX; ++i) {
+        const int j = tid * per + i;
+        const v_f32x4 z = {-INFINITY, 0.f, 0.f, 0.f};
+        pv[i] = (i < per && j < nt) ? pr[j] : z;
+        const int c = __float_as_int(pv[i][3]);
+        if (i < per && j < nt && (pv[i][0] > best || (pv[i][0] == best && c < bi))) { best = pv[i][0]; bi = c; }
+    }
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+    }
+    if (lane == 0) { redf[wave] = best; redi[wave] = bi; }
+    __syncthreads();
+    best = redf[0]; bi = redi[0];
+    for (int i = 1; i < ST / 64; ++i)
+        if (redf[i] > best || (redf[i] == best && redi[i] < bi)) { best = redf[i]; bi = redi[i]; }
+    const float mx = best;
+    // this thread's share of sum exp(x - mx) and of the temperature-scaled weights, tile by tile
+    const float invt = 1.0f / a.temperature;
+    float w1[PMAX], wt[PMAX];
+    double c1 = 0.0, ct = 0.0;
+#pragma unroll
+    for (int i = 0; i < PMAX; ++i) {
+        const bool on = i < per && tid * per + i < nt;
+        w1[i] = on ? pv[i][1] * __expf(pv[i][0] - mx) : 0.f;
+        wt[i] = on ? pv[i][2] * __expf((pv[i][0] - mx) * invt) : 0.f;
+        c1 += (double)w1[i]; ct += (double)wt[i];
+    }
+    // block-wide inclusive scan of the temperature-scaled chunk sums (tile order = column order) + block sum of the plain ones
+    double inc = ct, tot1 = c1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot1 += __shfl_xor(tot1, o, 64);
+    __syncthreads();
+    if (lane == 63) wave_tot[wave] = inc;
+    if (lane == 0) redf[wave] = (float)tot1;
+    if (tid == 0) s_owner = ST - 1;
+    __syncthreads();
+    double off = 0.0, tot = 0.0; float se = 0.f;
+#pragma unroll
+    for (int i = 0; i < ST / 64; ++i) { const double wtot = wave_tot[i]; if (i < wave) off += wtot; tot += wtot; se += redf[i]; }
+    inc += off;
+    const float lse = mx + logf(se);
+    int64_t tk; float xtk = mx;
+    if (mode == XG_ROLLOUT_GREEDY) {
+        tk = bi;
+    } else if (mode == XG_ROLLOUT_REPLAY) {
+        tk = a.forced[(size_t)b * a.fstride];
+        tk = tk < 0 ? 0 : (tk >= a.V ? a.V - 1 : tk);
+        xtk = a.logits[(size_t)b * a.V + tk];
+    } else {
+        // inverse CDF over w_v = exp((logit_v - max) / temperature) (:190-194): the first thread whose running sum passes the
+        // target owns the draw, walks its tiles' sums to the tile that holds it, then that tile's 32 logits
+        const double target = (double)a.uniforms[b] * tot;
+        if (inc > target) atomicMin(&s_owner, tid);
+        __syncthreads();
+        if (tid == s_owner) {
+            double run = inc - ct;
+            int jt = min(nt, tid * per + per) - 1;               // (rounding: the last tile of the share if nothing passes)
+            if (jt < tid * per) jt = nt - 1;
+#pragma unroll
+            for (int i = 0; i < PMAX; ++i) {
+                if (i < per && tid * per + i < nt) {
+                    if (run + (double)wt[i] > target) { jt = tid * per + i; break; }
+                    run += (double)wt[i];
+                }
+            }
+            s_d[0] = run; s_d[1] = target; s_owner = jt;
+        }
+        __syncthreads();
+        if (wave == 0) {     // the 32 logits of that tile: one load each, a shuffle scan, the first lane whose running sum passes
+            const int jt = s_owner, v = jt * 32 + (lane & 31);
+            const bool on = lane < 32 && v < a.V;
+            const float xv = on ? a.logits[(size_t)b * a.V + v] : 0.f;
+            float e = on ? __expf((xv - mx) * invt) : 0.f;
+#pragma unroll
+            for (int o = 1; o < 32; o <<= 1) {
+                const float up = __shfl_up(e, o, 64);
+                if ((lane & 31) >= o) e += up;
+            }
+            const bool pass = on && (float)s_d[0] + e > (float)s_d[1];
+            const unsigned long long m = __ballot(pass);
+            const int nvalid = min(32, a.V - jt * 32);
+            const int pl = m ? __ffsll((long long)m) - 1 : nvalid - 1;
+            const float xp = __shfl(xv, pl, 64);
+            if (lane == 0) { s_tok = jt * 32 + pl; s_f[0] = xp; }
+        }
+        __syncthreads();
+        tk = s_tok; xtk = s_f[0];
+    }
+    if (tid == 0) {
+        roll_bookkeep(a, b, mode, tk, xtk - lse, lse, maxf);
+        s_tok = tk;
+    }
+    __syncthreads();
+    const int64_t t2 = s_tok;
+    for (int e = tid; e < a.E; e += ST) a.xt[(size_t)b * a.E + e] = a.table[(size_t)t2 * a.E + e];
+}
+
 __global__ void rollout_finalize_kernel(const int32_t* maxf, int32_t* n_steps, int Tm1, int nparts) {
     for (int i = 0; i < nparts; ++i) {
         const int m = maxf[i];                    // = max over the part's rows of their finishing step, or T
@@ -661,6 +923,30 @@ int xgk_rollout_step(hipStream_t st, int B, const float* logits, const float* un
     } else {
         hipLaunchKernelGGL((rollout_step_kernel<false>), dim3(B), dim3(RT), 0, st, a);
     }
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+// the vocabulary product of a rollout step with per-tile row statistics, then the token choice over them (see vocab_part_kernel).
+// `part` = (B, ceil(V / 32), 4) floats of scratch.  Returns 1 when the shape is not this path's (caller takes the two old launches).
+bool xgk_vocab_select_ok(int B, int R, int V, const float* H, int ldh, const float* W) {
+    return B >= 1 && B <= 128 && R % 32 == 0 && R >= 32 && V >= 32 && V <= 32 * 4 * ST && ldh % 4 == 0 &&
+           ((uintptr_t)H % 16) == 0 && ((uintptr_t)W % 16) == 0;
+}
+int xgk_vocab_part(hipStream_t st, int B, int R, int V, const float* H, int ldh, const float* W, const float* bias, float* logits,
+                   int wr_rows, float* part, float temperature) {
+    VocabPartArgs a{H, ldh, W, bias, B, R, V, logits, wr_rows, part, 1.0f / temperature};
+    hipLaunchKernelGGL(vocab_part_kernel, dim3(xg_cdiv(V, 32)), dim3(256), 0, st, a);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_roll_select(hipStream_t st, int B, const float* logits, const float* part, const float* uniforms, const int64_t* forced,
+                    int64_t fstride, const float* unf_prev, const float* table, int64_t* tok, float* tok_logp, float* unf,
+                    float* lse, int64_t* seq, float* seq_logp, int32_t* maxf, float* xt, float temperature, int V, int E,
+                    int t, int T, int mode, int split) {
+    if (t < 1) return XG_EINVAL;
+    RollSelectArgs q{{logits, uniforms, forced, fstride, unf_prev, table, tok, tok_logp, unf, lse, seq, seq_logp, maxf, xt,
+                      temperature, V, E, t, T, mode, split}, part, xg_cdiv(V, 32)};
+    hipLaunchKernelGGL(roll_select_kernel, dim3(B), dim3(ST), 0, st, q);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }

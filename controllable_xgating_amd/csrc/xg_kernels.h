@@ -268,6 +268,14 @@ int xgk_rollout_step(hipStream_t st, int B, const float* logits, const float* un
                      float* lse, int64_t* seq, float* seq_logp, int32_t* maxf, float* xt, float temperature, int V, int E,
                      int t, int T, int mode, int split);
 int xgk_rollout_finalize(hipStream_t st, const int32_t* maxf, int32_t* n_steps, int Tm1, int nparts);
+// rollout steps of <= 128 rows: vocabulary product with per-tile row statistics + token choice over them (xg_heads.hip)
+bool xgk_vocab_select_ok(int B, int R, int V, const float* H, int ldh, const float* W);
+int xgk_vocab_part(hipStream_t st, int B, int R, int V, const float* H, int ldh, const float* W, const float* bias, float* logits,
+                   int wr_rows, float* part, float temperature);
+int xgk_roll_select(hipStream_t st, int B, const float* logits, const float* part, const float* uniforms, const int64_t* forced,
+                    int64_t fstride, const float* unf_prev, const float* table, int64_t* tok, float* tok_logp, float* unf,
+                    float* lse, int64_t* seq, float* seq_logp, int32_t* maxf, float* xt, float temperature, int V, int E,
+                    int t, int T, int mode, int split);
 // all steps in one launch: rows (steps, B) of logits / lse / tok, dslp (B, dstride)
 int xgk_rollout_dlogits_lse(hipStream_t st, float* logits, const float* lse, const int64_t* tok, const float* dslp,
                             int64_t dstride, int B, int V, int steps);

@@ -117,7 +117,7 @@ struct Ws {
     float *state_tmp;
     float *AFU, *ATS;                  // unnormalised attention context (B,R) and softmax denominators (B), contiguous
     // ---- rollout
-    int64_t* TOK; float *TOKLP, *UNF; int32_t* alive;
+    int64_t* TOK; float *TOKLP, *UNF; int32_t* alive; float* VPART;
     int32_t* tickets;                  // split-K arrival counters (xg_step.hip), SK_MAX_JOBS x 1024, zero between launches
     int32_t* dsync;                    // sync words of the dataflow step kernel (xg_dstep.hip): zero between launches
     // everything a backward pass needs ZERO on entry is one contiguous block (dst[0][*], DAF, the encoder's carried
@@ -179,6 +179,8 @@ Ws carve(const XgDims& d, void* base) {
     w.AFU = c.take<float>(B * R + ((B + 3) & ~(size_t)3)); w.ATS = w.AFU + B * R;
     w.TOK = c.take<int64_t>(TB); w.TOKLP = c.take<float>(TB); w.UNF = c.take<float>(TB);
     w.alive = c.take<int32_t>(4);
+    c.off = (c.off + 15) & ~(size_t)15;
+    w.VPART = c.take<float>(B * ((V + 31) / 32) * 4);         // per-tile row statistics of a rollout step's vocabulary product
     w.dsync = c.take<int32_t>(xgk_dstep_sync_bytes() / sizeof(int32_t));
     {   // the zero block
         c.off = (c.off + 255) & ~(size_t)255;
@@ -1610,16 +1612,30 @@ static int rollout_impl(hipStream_t st, const XgDims* d, const XgParams* p, cons
     XG_TRY(zero_dsync(st, w));
     if (hipMemsetAsync(w.alive, 0, sizeof(int32_t) * 4, st) != hipSuccess) return XG_EHIP;   // alive[i] = running max finishing step
     if (run->prof_event0 && hipEventRecord(static_cast<hipEvent_t>(run->prof_event0), st) != hipSuccess) return XG_EHIP;
+    // Rollout steps of <= 128 rows, fp32: the vocabulary product leaves per-tile row statistics and the token choice reads those
+    // (xg_heads.hip: vocab_part_kernel / roll_select_kernel) -- 10 MB of logits per step are neither written (greedy rows) nor read
+    // back three times.  Rows whose logits are needed afterwards are still stored: sampled rows (the draw re-reads one tile; the
+    // SCST backward the whole row), replayed rows, every row of a rollout that keeps its activations.
+    static const bool no_fused_select = xg_diag_env("XG_NO_FUSED_SELECT") != nullptr;
+    const bool fused_select = !no_fused_select && w.gm == 0 && xgk_vocab_select_ok(B, R, d->V, w.H2, R, p->logit_w);
+    const int wr_rows = mode == XG_ROLLOUT_SAMPLE ? split : ((mode == XG_ROLLOUT_REPLAY || run->save) ? B : 0);
     for (int t = 0; t < T; ++t) {
         int64_t* tok = w.TOK + (size_t)t * B;
         float* unf = w.UNF + (size_t)t * B;
         float* xt = w.Xe + (size_t)t * B * E;
+        const float* prev_logits = t >= 1 ? w.LOGITS + (size_t)(t - 1) * B * d->V : nullptr;
         // token choice from the previous step's raw logits + bookkeeping + embedding gather: one launch (:183-215)
-        XG_TRY(xgk_rollout_step(st, B, t >= 1 ? w.LOGITS + (size_t)(t - 1) * B * d->V : nullptr,
-                                uniforms ? uniforms + (size_t)t * split : nullptr, (forced && t >= 1) ? forced + (t - 1) : nullptr,
-                                T - 1, t >= 2 ? unf - B : nullptr, p->embed_w, tok, w.TOKLP + (size_t)t * B, unf,
-                                t >= 1 ? w.LSE + (size_t)(t - 1) * B : nullptr, seq, seq_logp, w.alive, xt, temperature, d->V, E,
-                                t, T, mode, split));
+        if (t >= 1 && fused_select)
+            XG_TRY(xgk_roll_select(st, B, prev_logits, w.VPART, uniforms ? uniforms + (size_t)t * split : nullptr,
+                                   forced ? forced + (t - 1) : nullptr, T - 1, t >= 2 ? unf - B : nullptr, p->embed_w, tok,
+                                   w.TOKLP + (size_t)t * B, unf, w.LSE + (size_t)(t - 1) * B, seq, seq_logp, w.alive, xt, temperature,
+                                   d->V, E, t, T, mode, split));
+        else
+            XG_TRY(xgk_rollout_step(st, B, prev_logits,
+                                    uniforms ? uniforms + (size_t)t * split : nullptr, (forced && t >= 1) ? forced + (t - 1) : nullptr,
+                                    T - 1, t >= 2 ? unf - B : nullptr, p->embed_w, tok, w.TOKLP + (size_t)t * B, unf,
+                                    t >= 1 ? w.LSE + (size_t)(t - 1) * B : nullptr, seq, seq_logp, w.alive, xt, temperature, d->V, E,
+                                    t, T, mode, split));
         float* gp = w.GP + t * BR;
         float* posg = w.POSG + t * BR;
         StepIO s{};
@@ -1629,8 +1645,13 @@ static int rollout_impl(hipStream_t st, const XgDims* d, const XgParams* p, cons
         s.P = w.P + (size_t)t * B * A; s.alpha = w.ALPHA + (size_t)t * B * d->K; s.af = w.AF + t * BR;
         s.g1 = w.G1 + (size_t)t * B * 4 * R; s.g2 = w.G2 + (size_t)t * B * 4 * R; s.t = t;
         XG_TRY(core_step(st, *d, *p, *run, w, w.Venc, w.vproj, s));
-        if (t + 1 < T)     // the step at t = L is computed and its logits discarded in the reference (:182,:217)
-            XG_TRY(xgk_linear(st, w.gm, B, d->V, R, s.h2o, R, p->logit_w, p->logit_b, w.LOGITS + (size_t)t * B * d->V, d->V));
+        if (t + 1 < T) {   // the step at t = L is computed and its logits discarded in the reference (:182,:217)
+            if (fused_select)
+                XG_TRY(xgk_vocab_part(st, B, R, d->V, s.h2o, R, p->logit_w, p->logit_b, w.LOGITS + (size_t)t * B * d->V, wr_rows,
+                                      w.VPART, temperature > 0.f ? temperature : 1.0f));
+            else
+                XG_TRY(xgk_linear(st, w.gm, B, d->V, R, s.h2o, R, p->logit_w, p->logit_b, w.LOGITS + (size_t)t * B * d->V, d->V));
+        }
     }
     if (run->prof_event1 && hipEventRecord(static_cast<hipEvent_t>(run->prof_event1), st) != hipSuccess) return XG_EHIP;
     XG_TRY(xgk_rollout_finalize(st, w.alive, n_steps, T - 1, split < B ? 2 : 1));

@@ -169,6 +169,19 @@ def test_gemm_one_workgroup_per_cu_kernel(tile):
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
 
+def test_rollout_token_choice_over_tile_statistics_equals_the_row_pass():
+    """Rollout steps of <= 128 rows take xg_heads.hip's vocab_part_kernel (vocabulary product + per-tile row statistics, logits
+    stored for the sampled / replayed rows only) and roll_select_kernel (token choice over the statistics); the older (B, V)
+    product + one-workgroup-per-row pass stays for every other shape.  Same paired SCST rollout (sampled half with temperatures
+    0.7 / 1 / 1.3, greedy half), a replay of its tokens and the SCST backward through both: tokens identical, log-probs and
+    gradient norms to fp32 round-off, on vocabularies that are / are not multiples of the 32-column tile (tools/select_check.py)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "select_check.py")], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "bad []" in r.stdout, r.stdout[-2500:] + r.stderr[-2500:]
+
+
 @pytest.mark.parametrize("rows", [40, 128])
 def test_dataflow_step_kernel_equals_three_launch_step(rows):
     """xg_dstep.hip (the decoder step as ONE dataflow launch: measurement-only, selected with XG_DSTEP=1 in the -DXG_DIAG
@@ -1077,7 +1090,8 @@ def test_packed_weights_are_ordered_across_streams():
         torch.cuda.synchronize()
         outs.append((seq.cpu().numpy(), slp.cpu().numpy()))
     assert np.array_equal(outs[0][0], outs[1][0])
-    np.testing.assert_allclose(outs[0][1], outs[1][1], atol=1e-6)
+    # (a few ulp: the two halves of a video's attention context meet in fp32 atomics, whose order follows the scheduling)
+    np.testing.assert_allclose(outs[0][1], outs[1][1], atol=5e-6)
 
 
 def test_reward_criterion_scalar_and_per_position_rewards():
