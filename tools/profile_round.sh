@@ -31,6 +31,11 @@ python tools/prof_summary.py $OUT/xe5 $OUT/${R}_xe5_bf16_kernel_stats.txt 15 > /
 python tools/ubench/gemm_bench.py > $OUT/${R}_gemm_bench_raw.txt 2>&1
 python tools/ubench/gemm16_bench.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Libr\|amdgpu.ids" > $OUT/${R}_gemm_bf16_operands.txt
 (cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/fill_bench fill_bench.hip 2>/dev/null; timeout 200 /tmp/fill_bench) > $OUT/${R}_fill_bench.txt 2>&1
+# 4a. fp32 GEMM yardsticks: vendor library on the same shapes, MFMA issue rate, in-kernel stamps of the one-workgroup-per-CU kernel
+{ echo "# tools/ubench/lib_gemm_bench.py: the vendor fp32 GEMM (torch.mm -> hipBLASLt / Tensile) on the same shapes, as a yardstick (not used by the product)."; python tools/ubench/lib_gemm_bench.py 2>&1 | grep -v "amdgpu.ids"; } > $OUT/${R}_vendor_gemm_yardstick.txt
+(cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/mfma_rate mfma_rate.hip 2>/dev/null; { echo "# tools/ubench/mfma_rate.hip: issue rate of the fp32 MFMAs with nothing else in the loop (256 workgroups)."; timeout 100 /tmp/mfma_rate; }) > $OUT/${R}_mfma_rate.txt 2>&1
+(/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -munsafe-fp-atomics -DXG_DIAG -DW1_TRACE -Iinclude tools/ubench/w1_ubench.hip -o /tmp/w1_ubench 2>/dev/null; { echo "# tools/ubench/w1_ubench.hip (-DW1_TRACE): in-kernel stamps of gemm_w1_kernel -- prologue, slab loop (shader clocks), epilogue -- per workgroup"; timeout 100 /tmp/w1_ubench; }) > $OUT/${R}_gemm_w1_trace.txt 2>&1
+python tools/select_check.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Libr\|amdgpu.ids" > $OUT/${R}_rollout_select_check.txt
 # 4b. the round's experiments: the step as one dataflow launch (in-kernel timeline), HIP-graph capture variants
 python tools/dstep_trace.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Libr\|amdgpu.ids" > $OUT/${R}_dstep_timeline.txt
 for b in 8 32 64 128 256; do echo "rows $b: $(DS_B=$b timeout 300 python tools/dstep_check.py 2>&1 | grep 'us per step')"; done > $OUT/${R}_dstep_vs_three_launches.txt
