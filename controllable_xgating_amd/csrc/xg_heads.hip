@@ -5,6 +5,8 @@
 // coalesced loads, max / sum-exp are reduced with wave64 shuffles + LDS across the 16 waves.
 #include "xg_common.h"
 #include "xg_kernels.h"
+#include <type_traits>
+#include <cstdlib>
 
 namespace {
 
@@ -637,10 +639,190 @@ __global__ void __launch_bounds__(256) vocab_part_kernel(VocabPartArgs a) {
     }
 }
 
+// sched_group_barrier pipeline of one block: M MFMAs with D LDS instructions and V global loads spread evenly between them
+// (as xg_gemm.hip's w1_interleave: a lone wave per SIMD must not issue its memory instructions in a cluster)
+template <int M, int D, int V>
+__device__ __forceinline__ void vt_interleave() {
+    constexpr int MEM = D + V;
+    if constexpr (M == 0) {
+        if constexpr (V > 0) __builtin_amdgcn_sched_group_barrier(0x020, V, 0);
+        if constexpr (D > 0) __builtin_amdgcn_sched_group_barrier(0x080, D, 0);
+    } else if constexpr (MEM == 0) {
+        __builtin_amdgcn_sched_group_barrier(0x008, M, 0);
+    } else if constexpr (MEM >= M) {
+        constexpr int K = (MEM + M - 1) / M, v = V < K ? V : K, d = K - v;
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        if constexpr (v > 0) __builtin_amdgcn_sched_group_barrier(0x020, v, 0);
+        if constexpr (d > 0) __builtin_amdgcn_sched_group_barrier(0x080, d, 0);
+        vt_interleave<M - 1, D - d, V - v>();
+    } else {
+        constexpr int mm = M / MEM;
+        __builtin_amdgcn_sched_group_barrier(0x008, mm, 0);
+        if constexpr (V > 0) { __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); vt_interleave<M - mm, D, V - 1>(); }
+        else { __builtin_amdgcn_sched_group_barrier(0x080, 1, 0); vt_interleave<M - mm, D - 1, V>(); }
+    }
+}
+
+// The same product over 80-column tiles: V = 20000 is 250 tiles -- ONE per CU, where the 32-column tiles are 625 on 256 CUs (three
+// on some, two on others: 81 % of the matrix time of the busiest CU is useful).  16 x 16 x 4 MFMAs (a tile is 2 x 5 of them per wave:
+// rows 32 w + 16 rb .., columns 16 g ..), one workgroup per CU = one wave per SIMD, so every LDS / global instruction sits between
+// MFMAs (vt_interleave).  k order inside a 16-deep block: lane group g = lane / 16 owns k = 4 g .. 4 g + 3 (one ds_read_b128 per
+// fragment, the same permutation for both operands).
+constexpr int V16_TW = 80, V16_NG = 5;
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) vocab_part16_kernel(VocabPartArgs a) {
+    XG_CHAIN_PRIO();
+    constexpr int STAGE = (128 + V16_TW) * VT_LD;                   // floats per LDS stage
+    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = (lane >> 4) << 2;
+    const int n0 = blockIdx.x * V16_TW, ntiles = gridDim.x;
+    const float* ap[4]; const float* wp[3];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int f = tid + 256 * i;
+        ap[i] = a.H + (size_t)min(f >> 3, a.B - 1) * a.ldh + ((f & 7) << 2);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int f = min(tid + 256 * i, V16_TW * 8 - 1);            // (pieces past the 80 x 32 slab repeat its last one: never stored)
+        wp[i] = a.W + (size_t)min(n0 + (f >> 3), a.V - 1) * a.R + ((f & 7) << 2);
+    }
+    const bool w2_on = tid + 512 < V16_TW * 8;
+    // two register sets of global loads (as gemm_w1_kernel): slab x travels in set x & 1, requested at the top of slab x - 2 and
+    // stored into LDS during the second block of slab x - 1 -- a slab is 2560 MFMA cycles, a loaded round trip is longer
+    v_f32x4 ra[2][4], rw[2][3];
+    v_f32x4 acc[2][V16_NG];
+#pragma unroll
+    for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+        for (int gi = 0; gi < V16_NG; ++gi) acc[rb][gi] = v_f32x4{0.f, 0.f, 0.f, 0.f};
+    const int ns = a.R / 32;
+    auto load_slab = [&](int s, v_f32x4 (&xa)[4], v_f32x4 (&xw)[3]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) xa[i] = *reinterpret_cast<const v_f32x4*>(ap[i] + s * 32);
+#pragma unroll
+        for (int i = 0; i < 3; ++i) xw[i] = *reinterpret_cast<const v_f32x4*>(wp[i] + s * 32);
+    };
+    auto store_slab = [&](float* As, const v_f32x4 (&xa)[4], const v_f32x4 (&xw)[3]) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int f = tid + 256 * i;
+            *reinterpret_cast<v_f32x4*>(As + (f >> 3) * VT_LD + ((f & 7) << 2)) = xa[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int f = tid + 256 * i;
+            if (i < 2 || w2_on) *reinterpret_cast<v_f32x4*>(As + (128 + (f >> 3)) * VT_LD + ((f & 7) << 2)) = xw[i];
+        }
+    };
+    load_slab(0, ra[0], rw[0]);
+    if (ns > 1) load_slab(1, ra[1], rw[1]);
+    store_slab(smem, ra[0], rw[0]);
+    __syncthreads();
+    auto slab = [&](int s, auto set_tag, auto load_tag, auto store_tag) {
+        constexpr int SET = decltype(set_tag)::value;                // == s & 1
+        constexpr bool LOAD = decltype(load_tag)::value, STORE = decltype(store_tag)::value;      // slab s + 2 / s + 1 exist
+        const float* As = smem + SET * STAGE;
+        const float* Bs = As + 128 * VT_LD;
+        float* Ns = smem + (SET ^ 1) * STAGE;
+        v_f32x4 fa[2][2], fb[2][V16_NG];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) fa[0][rb] = *reinterpret_cast<const v_f32x4*>(As + (wave * 32 + rb * 16 + l15) * VT_LD + g4);
+#pragma unroll
+        for (int gi = 0; gi < V16_NG; ++gi) fb[0][gi] = *reinterpret_cast<const v_f32x4*>(Bs + (gi * 16 + l15) * VT_LD + g4);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb) {                            // two 16-deep blocks per slab: 40 MFMAs each
+            if (LOAD && kb == 0) load_slab(s + 2, ra[SET], rw[SET]);
+            if (kb == 0) {
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb) fa[1][rb] = *reinterpret_cast<const v_f32x4*>(As + (wave * 32 + rb * 16 + l15) * VT_LD + 16 + g4);
+#pragma unroll
+                for (int gi = 0; gi < V16_NG; ++gi) fb[1][gi] = *reinterpret_cast<const v_f32x4*>(Bs + (gi * 16 + l15) * VT_LD + 16 + g4);
+            }
+            if (STORE && kb == 1) store_slab(Ns, ra[SET ^ 1], rw[SET ^ 1]);
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+                    for (int gi = 0; gi < V16_NG; ++gi)
+                        acc[rb][gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[kb][rb][kk], fb[kb][gi][kk], acc[rb][gi], 0, 0, 0);
+            if (kb == 0) vt_interleave<40, 2 + V16_NG, LOAD ? 7 : 0>();
+            else vt_interleave<40, STORE ? 7 : 0, 0>();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    };
+    {
+        using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>;
+        using Y = std::true_type; using N = std::false_type;
+        int s = 0;
+        for (; s + 3 < ns; s += 2) { slab(s, T0{}, Y{}, Y{}); slab(s + 1, T1{}, Y{}, Y{}); }
+        if (s + 2 < ns) { slab(s, T0{}, Y{}, Y{}); slab(s + 1, T1{}, N{}, Y{}); slab(s + 2, T0{}, N{}, N{}); }
+        else if (s + 1 < ns) { slab(s, T0{}, N{}, Y{}); slab(s + 1, T1{}, N{}, N{}); }
+        else if (s < ns) slab(s, T0{}, N{}, N{});
+    }
+    // epilogue through LDS as vocab_part_kernel: the tile as [128][81]; MFMA result layout: column 16 gi + l15, rows 4 (lane / 16) + r
+    constexpr int TL = V16_TW + 1;
+    float* tl = smem;
+#pragma unroll
+    for (int gi = 0; gi < V16_NG; ++gi) {
+        const int col = n0 + gi * 16 + l15;
+        const float bv = col < a.V ? a.bias[col] : 0.f;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) tl[(wave * 32 + rb * 16 + g4 + r) * TL + gi * 16 + l15] = acc[rb][gi][r] + bv;
+    }
+    __syncthreads();
+    constexpr int HW = V16_TW / 2;                                  // columns per (row, half-row) thread
+    const int row = tid >> 1, h = tid & 1, c0 = n0 + h * HW;
+    float x[HW];
+    float m = -INFINITY; int mc = 0x7fffffff;
+#pragma unroll
+    for (int j = 0; j < HW; ++j) {
+        x[j] = c0 + j < a.V ? tl[row * TL + h * HW + j] : -INFINITY;
+        if (x[j] > m) { m = x[j]; mc = c0 + j; }
+    }
+    {
+        const float om = __shfl_xor(m, 1, 64); const int oc = __shfl_xor(mc, 1, 64);
+        if (om > m || (om == m && oc < mc)) { m = om; mc = oc; }
+    }
+    float e1 = 0.f, et = 0.f;
+#pragma unroll
+    for (int j = 0; j < HW; ++j) {
+        const float d = x[j] - m;
+        const float e = __expf(d);
+        e1 += e;
+        et += a.inv_t == 1.0f ? e : __expf(d * a.inv_t);
+    }
+    e1 += __shfl_xor(e1, 1, 64); et += __shfl_xor(et, 1, 64);
+    if (row < a.B) {
+        if (h == 0) {
+            v_f32x4 pv = {m, e1, et, __int_as_float(mc)};
+            *reinterpret_cast<v_f32x4*>(a.part + ((size_t)row * ntiles + blockIdx.x) * 4) = pv;
+        }
+        if (row < a.wr_rows) {
+            float* dst = a.logits + (size_t)row * a.V + c0;
+            if ((a.V & 3) == 0 && c0 + HW <= a.V) {
+#pragma unroll
+                for (int j = 0; j < HW / 4; ++j) {
+                    v_f32x4 v = {x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]};
+                    *reinterpret_cast<v_f32x4*>(dst + 4 * j) = v;
+                }
+            } else {
+#pragma unroll
+                for (int j = 0; j < HW; ++j) if (c0 + j < a.V) dst[j] = x[j];
+            }
+        }
+    }
+}
+
 constexpr int ST = 256;                   // threads of a selection workgroup
 struct RollSelectArgs {
     RollStepArgs r;                       // (r.logits = the rows stored by vocab_part_kernel; r.t >= 1)
     const float* part; int ntiles;
+    int tw;                               // columns per tile statistic (32: vocab_part_kernel, 80: vocab_part16_kernel)
 };
 __global__ void __launch_bounds__(ST) roll_select_kernel(RollSelectArgs q) {
     XG_CHAIN_PRIO();
@@ -732,22 +914,27 @@ __global__ void __launch_bounds__(ST) roll_select_kernel(RollSelectArgs q) {
             s_d[0] = run; s_d[1] = target; s_owner = jt;
         }
         __syncthreads();
-        if (wave == 0) {     // the 32 logits of that tile: one load each, a shuffle scan, the first lane whose running sum passes
-            const int jt = s_owner, v = jt * 32 + (lane & 31);
-            const bool on = lane < 32 && v < a.V;
-            const float xv = on ? a.logits[(size_t)b * a.V + v] : 0.f;
-            float e = on ? __expf((xv - mx) * invt) : 0.f;
+        if (wave == 0) {     // the logits of that tile (<= 128: two per lane), a shuffle scan, the first column whose running sum passes
+            const int jt = s_owner, v0 = jt * q.tw, nvalid = min(q.tw, a.V - v0);
+            const float* xrow = a.logits + (size_t)b * a.V + v0;
+            const bool on0 = lane < nvalid, on1 = lane + 64 < nvalid;
+            const float x0 = on0 ? xrow[lane] : 0.f, x1 = on1 ? xrow[lane + 64] : 0.f;
+            float e0 = on0 ? __expf((x0 - mx) * invt) : 0.f, e1s = on1 ? __expf((x1 - mx) * invt) : 0.f;
 #pragma unroll
-            for (int o = 1; o < 32; o <<= 1) {
-                const float up = __shfl_up(e, o, 64);
-                if ((lane & 31) >= o) e += up;
+            for (int o = 1; o < 64; o <<= 1) {
+                const float u0 = __shfl_up(e0, o, 64), u1 = __shfl_up(e1s, o, 64);
+                if (lane >= o) { e0 += u0; e1s += u1; }
             }
-            const bool pass = on && (float)s_d[0] + e > (float)s_d[1];
-            const unsigned long long m = __ballot(pass);
-            const int nvalid = min(32, a.V - jt * 32);
-            const int pl = m ? __ffsll((long long)m) - 1 : nvalid - 1;
-            const float xp = __shfl(xv, pl, 64);
-            if (lane == 0) { s_tok = jt * 32 + pl; s_f[0] = xp; }
+            const float base = (float)s_d[0], tf = (float)s_d[1];
+            const float tot0 = __shfl(e0, 63, 64);
+            const unsigned long long m0 = __ballot(on0 && base + e0 > tf);
+            const unsigned long long m1 = __ballot(on1 && base + tot0 + e1s > tf);
+            int pl;
+            if (m0) pl = __ffsll((long long)m0) - 1;
+            else if (m1) pl = 64 + __ffsll((long long)m1) - 1;
+            else pl = nvalid - 1;
+            const float xp = pl < 64 ? __shfl(x0, pl, 64) : __shfl(x1, pl - 64, 64);
+            if (lane == 0) { s_tok = v0 + pl; s_f[0] = xp; }
         }
         __syncthreads();
         tk = s_tok; xtk = s_f[0];
@@ -932,10 +1119,18 @@ bool xgk_vocab_select_ok(int B, int R, int V, const float* H, int ldh, const flo
     return B >= 1 && B <= 128 && R % 32 == 0 && R >= 32 && V >= 32 && V <= 32 * 4 * ST && ldh % 4 == 0 &&
            ((uintptr_t)H % 16) == 0 && ((uintptr_t)W % 16) == 0;
 }
+// tile width of the statistics: 80 columns (one 16 x 16 x 4 tile set per CU-sized workgroup) from a vocabulary of 4096 on, where the
+// balance over the 256 CUs is what matters; 32 columns below (XG_VOCAB_TW=32 / 80 of the -DXG_DIAG build forces either)
+int xgk_vocab_tile_width(int V) {
+    static const int forced = xg_diag_env("XG_VOCAB_TW") ? atoi(xg_diag_env("XG_VOCAB_TW")) : 0;
+    if (forced == 32 || forced == V16_TW) return forced;
+    return V >= 4096 ? V16_TW : 32;
+}
 int xgk_vocab_part(hipStream_t st, int B, int R, int V, const float* H, int ldh, const float* W, const float* bias, float* logits,
                    int wr_rows, float* part, float temperature) {
     VocabPartArgs a{H, ldh, W, bias, B, R, V, logits, wr_rows, part, 1.0f / temperature};
-    hipLaunchKernelGGL(vocab_part_kernel, dim3(xg_cdiv(V, 32)), dim3(256), 0, st, a);
+    if (xgk_vocab_tile_width(V) == V16_TW) hipLaunchKernelGGL(vocab_part16_kernel, dim3(xg_cdiv(V, V16_TW)), dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(vocab_part_kernel, dim3(xg_cdiv(V, 32)), dim3(256), 0, st, a);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
@@ -944,8 +1139,9 @@ int xgk_roll_select(hipStream_t st, int B, const float* logits, const float* par
                     float* lse, int64_t* seq, float* seq_logp, int32_t* maxf, float* xt, float temperature, int V, int E,
                     int t, int T, int mode, int split) {
     if (t < 1) return XG_EINVAL;
+    const int tw = xgk_vocab_tile_width(V);
     RollSelectArgs q{{logits, uniforms, forced, fstride, unf_prev, table, tok, tok_logp, unf, lse, seq, seq_logp, maxf, xt,
-                      temperature, V, E, t, T, mode, split}, part, xg_cdiv(V, 32)};
+                      temperature, V, E, t, T, mode, split}, part, xg_cdiv(V, tw), tw};
     hipLaunchKernelGGL(roll_select_kernel, dim3(B), dim3(ST), 0, st, q);
     XG_CHECK_LAUNCH();
     return XG_OK;
