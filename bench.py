@@ -61,6 +61,20 @@ def step_flops(B, K, R, A, E):
     return 2.0 * B * (2 * R * A + E * R + (E + 2 * R) * 4 * R + 3 * R * 4 * R + K * A + K * R)
 
 
+def iteration_flops(cfg):
+    """Multiply-adds x 2 of ONE teacher-forced training iteration (forward; the backward is counted as twice that: a data-gradient
+    and a weight-gradient product for every forward product): encoder input side and recurrence, cross gates + fusion, v2a(V), the
+    token side, T decoder steps, vocabulary and category heads.  Elementwise work, attention tanh / softmax and the update are not
+    counted -- this prices the iteration against the matrix roof only."""
+    B, K, R, A, E, V, C, T = (cfg[k] for k in ("B", "K", "R", "A", "E", "V", "C", "L"))
+    T = T + 1
+    F1, F2, N = cfg["F1"], cfg["F2"], cfg["B"] * cfg["K"]
+    enc = 2.0 * N * R * (F1 + F2) + 2 * 2.0 * N * 4 * R * R + K * 2 * 2.0 * B * 4 * R * R + 2 * 2.0 * N * R * R + 2.0 * N * R * 2 * R
+    dec = 2.0 * N * A * R + T * step_flops(B, K, R, A, E)
+    heads = 2.0 * T * B * R * V + 2.0 * T * B * R * C
+    return 3.0 * (enc + dec + heads)
+
+
 def measure_step_group(model, x, reps=200):
     """Average duration of ONE decoder-step launch group (xg_step_fwd) with events on the library's stream."""
     from controllable_xgating_amd import _native as nv
@@ -523,6 +537,13 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
                      "mfma_peak_tflops": mfma_peak,
                      "mfma_frac": round(flops / t_step / (mfma_peak * 1e12), 4)},
     }
+    if workload != "scst":
+        # the WHOLE iteration against the matrix roof: chains, products and the update share the chip for dt / steps seconds
+        it_flop = iteration_flops(cfg)
+        out["roofline"]["iteration"] = {"bound": "mfma", "flop": it_flop, "achieved": round(it_flop / (dt / steps) / 1e12, 1),
+                                        "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(it_flop / (dt / steps) / (mfma_peak * 1e12), 4),
+                                        "what": "2 x multiply-adds of one training iteration (forward + twice that for the backward) over "
+                                                "ms_per_step, against the dense MFMA peak of the products' arithmetic"}
     if comm is not None:
         out["comm"] = comm
     parity_fail = None
