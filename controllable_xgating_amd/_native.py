@@ -98,6 +98,7 @@ def lib():
         "xg_aux_destroy": [vp],
         "xg_rollout_pair": [vp, PD, PP, PB, PX, PR, i32, vp, f32, vp, C.c_size_t, vp, vp, vp],
         "xg_rollout_compact": [vp, PD, vp, C.c_size_t, PD, vp, C.c_size_t],
+        "xg_rollout_pair_compact": [vp, PD, PP, PB, PX, PR, i32, vp, f32, vp, C.c_size_t, PD, vp, C.c_size_t, vp, vp, vp],
         "xg_nll_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
         "xg_nll_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp, f32, vp, vp],
         "xg_clip_adam": [vp, i64, vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, f32],

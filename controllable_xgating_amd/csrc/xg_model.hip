@@ -1601,9 +1601,13 @@ extern "C" int xg_xe_loss_bwd(void* stream, const XgDims* d, const XgParams* p, 
 
 // One rollout over d.B rows.  split < d.B (SAMPLE mode only): rows [0, split) sample with uniforms (T, split), rows
 // [split, B) decode greedily -- the SCST pair (starttrain.py:131 + myutils.py:45) as ONE batch; n_steps then has two entries.
+// logits_alt (paired rollout whose sampled half will be compacted for the backward): the raw logits of rows [0, split) go there,
+// (T - 1) blocks of `split` rows, instead of into this workspace -- they are two thirds of what a compaction would copy.  Only the
+// tile-statistics path writes row subsets: *used_alt tells the caller whether it happened.
 static int rollout_impl(hipStream_t st, const XgDims* d, const XgParams* p, const XgBnState* bn, const XgBatch* x,
                         const XgRun* run, int mode, const float* uniforms, const int64_t* forced, float temperature, Ws& w,
-                        int64_t* seq, float* seq_logp, int32_t* n_steps, int split) {
+                        int64_t* seq, float* seq_logp, int32_t* n_steps, int split, float* logits_alt = nullptr,
+                        bool* used_alt = nullptr) {
     const int B = d->B, R = d->R, E = d->E, A = d->A, T = d->T, N = B * d->K;
     const size_t BR = (size_t)B * R;
     Streams es(st, run);
@@ -1619,11 +1623,14 @@ static int rollout_impl(hipStream_t st, const XgDims* d, const XgParams* p, cons
     static const bool no_fused_select = xg_diag_env("XG_NO_FUSED_SELECT") != nullptr;
     const bool fused_select = !no_fused_select && w.gm == 0 && xgk_vocab_select_ok(B, R, d->V, w.H2, R, p->logit_w);
     const int wr_rows = mode == XG_ROLLOUT_SAMPLE ? split : ((mode == XG_ROLLOUT_REPLAY || run->save) ? B : 0);
+    const bool alt = logits_alt != nullptr && fused_select && mode == XG_ROLLOUT_SAMPLE && split < B;
+    if (used_alt) *used_alt = alt;
+    auto logits_of = [&](int t) { return alt ? logits_alt + (size_t)t * split * d->V : w.LOGITS + (size_t)t * B * d->V; };
     for (int t = 0; t < T; ++t) {
         int64_t* tok = w.TOK + (size_t)t * B;
         float* unf = w.UNF + (size_t)t * B;
         float* xt = w.Xe + (size_t)t * B * E;
-        const float* prev_logits = t >= 1 ? w.LOGITS + (size_t)(t - 1) * B * d->V : nullptr;
+        const float* prev_logits = t >= 1 ? logits_of(t - 1) : nullptr;
         // token choice from the previous step's raw logits + bookkeeping + embedding gather: one launch (:183-215)
         if (t >= 1 && fused_select)
             XG_TRY(xgk_roll_select(st, B, prev_logits, w.VPART, uniforms ? uniforms + (size_t)t * split : nullptr,
@@ -1647,7 +1654,7 @@ static int rollout_impl(hipStream_t st, const XgDims* d, const XgParams* p, cons
         XG_TRY(core_step(st, *d, *p, *run, w, w.Venc, w.vproj, s));
         if (t + 1 < T) {   // the step at t = L is computed and its logits discarded in the reference (:182,:217)
             if (fused_select)
-                XG_TRY(xgk_vocab_part(st, B, R, d->V, s.h2o, R, p->logit_w, p->logit_b, w.LOGITS + (size_t)t * B * d->V, wr_rows,
+                XG_TRY(xgk_vocab_part(st, B, R, d->V, s.h2o, R, p->logit_w, p->logit_b, logits_of(t), wr_rows,
                                       w.VPART, temperature > 0.f ? temperature : 1.0f));
             else
                 XG_TRY(xgk_linear(st, w.gm, B, d->V, R, s.h2o, R, p->logit_w, p->logit_b, w.LOGITS + (size_t)t * B * d->V, d->V));
@@ -1684,14 +1691,9 @@ extern "C" int xg_rollout_pair(void* stream, const XgDims* d2, const XgParams* p
 
 // Everything xg_rollout_bwd reads, for the FIRST d1->B rows of a rollout that ran over d2->B >= d1->B rows: encoder-side
 // tensors are row prefixes, decoder-side tensors are per-step blocks (pitch B2 -> B1).
-extern "C" int xg_rollout_compact(void* stream, const XgDims* d2, const void* ws2, size_t ws2_bytes, const XgDims* d1,
-                                  void* ws1, size_t ws1_bytes) {
-    Ws a, b;
-    XG_TRY(check(d2, const_cast<void*>(ws2), ws2_bytes, &a));
-    XG_TRY(check(d1, ws1, ws1_bytes, &b));
+static int compact_impl(hipStream_t st, const XgDims* d2, const Ws& a, const XgDims* d1, Ws& b, bool skip_logits) {
     if (d1->B > d2->B || d1->K != d2->K || d1->R != d2->R || d1->A != d2->A || d1->E != d2->E || d1->V != d2->V ||
         d1->T != d2->T || d1->F1 != d2->F1 || d1->F2 != d2->F2 || d1->C != d2->C || d1->H != d2->H) return XG_EINVAL;
-    hipStream_t st = (hipStream_t)stream;
     const size_t B1 = d1->B, B2 = d2->B, K = d1->K, R = d1->R, A = d1->A, E = d1->E, V = d1->V, T = d1->T, N1 = B1 * K;
     CompactArgs ca{};
     auto prefix = [&](void* dst, const void* src, size_t nfloats) -> int {
@@ -1718,12 +1720,41 @@ extern "C" int xg_rollout_compact(void* stream, const XgDims* d2, const void* ws
     XG_TRY(blocks(b.H2, a.H2, R, T + 1)); XG_TRY(blocks(b.C2, a.C2, R, T + 1));
     XG_TRY(blocks(b.G1, a.G1, 4 * R, T)); XG_TRY(blocks(b.G2, a.G2, 4 * R, T));
     XG_TRY(blocks(b.P, a.P, A, T)); XG_TRY(blocks(b.ALPHA, a.ALPHA, K, T)); XG_TRY(blocks(b.AF, a.AF, R, T));
-    XG_TRY(blocks(b.LOGITS, a.LOGITS, V, T - 1)); XG_TRY(blocks(b.LSE, a.LSE, 1, T));
+    if (!skip_logits) XG_TRY(blocks(b.LOGITS, a.LOGITS, V, T - 1));     // (skipped: the rollout wrote them into `b` itself)
+    XG_TRY(blocks(b.LSE, a.LSE, 1, T));
     XG_TRY(blocks(b.TOK, a.TOK, 2, T));                       // int64 = 2 floats wide
     XG_TRY(blocks(b.TOKLP, a.TOKLP, 1, T)); XG_TRY(blocks(b.UNF, a.UNF, 1, T));
     XG_TRY(xgk_compact(st, ca));
     ZERO(b.zeroBR, B1 * R);                                   // the encoder's initial state (read by its backward)
     return XG_OK;
+}
+
+extern "C" int xg_rollout_compact(void* stream, const XgDims* d2, const void* ws2, size_t ws2_bytes, const XgDims* d1,
+                                  void* ws1, size_t ws1_bytes) {
+    Ws a, b;
+    XG_TRY(check(d2, const_cast<void*>(ws2), ws2_bytes, &a));
+    XG_TRY(check(d1, ws1, ws1_bytes, &b));
+    return compact_impl((hipStream_t)stream, d2, a, d1, b, false);
+}
+
+// xg_rollout_pair + xg_rollout_compact in one call: the sampled rows' logits -- 154 MB of the 230 MB a compaction copies at
+// B = 64, L = 30, V = 20000 -- are written into the compacted workspace by the rollout itself (when its token choice runs over
+// tile statistics: <= 128 rows, fp32; otherwise the two steps run as they are).
+extern "C" int xg_rollout_pair_compact(void* stream, const XgDims* d2, const XgParams* p, const XgBnState* bn, const XgBatch* x2,
+                                       const XgRun* run, int n_sample, const float* uniforms, float temperature, void* ws2,
+                                       size_t ws2_bytes, const XgDims* d1, void* ws1, size_t ws1_bytes, int64_t* seq,
+                                       float* seq_logp, int32_t* n_steps) {
+    Ws w, b;
+    XG_TRY(check(d2, ws2, ws2_bytes, &w));
+    XG_TRY(check(d1, ws1, ws1_bytes, &b));
+    if (!p || !x2 || !run || !seq || !seq_logp || !n_steps || !x2->pos_feats || d2->T < 2) return XG_EINVAL;
+    if (n_sample <= 0 || n_sample >= d2->B || n_sample != d1->B || !uniforms || !(temperature > 0.f)) return XG_EINVAL;
+    w.gm = (run->gemm_mode == 1 || run->gemm_mode == 3) ? run->gemm_mode : 0;
+    attach_packed(w, *d2, run);
+    bool used_alt = false;
+    XG_TRY(rollout_impl((hipStream_t)stream, d2, p, bn, x2, run, XG_ROLLOUT_SAMPLE, uniforms, nullptr, temperature, w, seq, seq_logp,
+                        n_steps, n_sample, b.LOGITS, &used_alt));
+    return compact_impl((hipStream_t)stream, d2, w, d1, b, used_alt);
 }
 
 extern "C" int xg_rollout_bwd(void* stream, const XgDims* d, const XgParams* p, const XgParams* g, const XgBatch* x,

@@ -744,15 +744,20 @@ class _RolloutPairFunction(torch.autograd.Function):
             uniforms = torch.rand(T, B, device=dev, dtype=torch.float32)
         uniforms = uniforms.detach().contiguous().float()
         ps, bn, run = model._params_struct(), model._bn_struct(), model._run(need_grad)
-        nv.check(nv.lib().xg_rollout_pair(_stream(), C.byref(d2), C.byref(ps), C.byref(bn), C.byref(b2), C.byref(run), B,
-                                          nv.ptr(uniforms), temperature, wp2, wn2, nv.ptr(seq), nv.ptr(slp), nv.ptr(n)),
-                 "xg_rollout_pair")
-        model._bump_bn()
         ws1 = None
         if need_grad:
+            # rollout + compaction of the sampled half into an m-row workspace (what the backward reads) as one call: the sampled
+            # rows' logits -- two thirds of the compaction's bytes -- are written there by the rollout itself
             ws1 = model._pool.take(d1, dev)
             wp1, wn1 = _ws_ptr(ws1)
-            nv.check(nv.lib().xg_rollout_compact(_stream(), C.byref(d2), wp2, wn2, C.byref(d1), wp1, wn1), "xg_rollout_compact")
+            nv.check(nv.lib().xg_rollout_pair_compact(_stream(), C.byref(d2), C.byref(ps), C.byref(bn), C.byref(b2), C.byref(run), B,
+                                                      nv.ptr(uniforms), temperature, wp2, wn2, C.byref(d1), wp1, wn1, nv.ptr(seq),
+                                                      nv.ptr(slp), nv.ptr(n)), "xg_rollout_pair_compact")
+        else:
+            nv.check(nv.lib().xg_rollout_pair(_stream(), C.byref(d2), C.byref(ps), C.byref(bn), C.byref(b2), C.byref(run), B,
+                                              nv.ptr(uniforms), temperature, wp2, wn2, nv.ptr(seq), nv.ptr(slp), nv.ptr(n)),
+                     "xg_rollout_pair")
+        model._bump_bn()
         ctx.model, ctx.d, ctx.ws, ctx.run, ctx.need_grad = model, d1, ws1, run, need_grad
         ctx.keep = (feats_rgb, feats_opfl, feat_mask, pos_feats)
         gen, greedy = seq[:B], seq[B:]

@@ -40,8 +40,9 @@
 extern "C" {
 #endif
 
-#define XG_VERSION 202   /* 200: XgRun gained packed/aux/event fields, xg_set_grad_event removed, xg_vproj takes XgRun;
-                            201: + xg_clip_adam_zero; 202: XgRun.prof_event0/1, xg_adam_tick, xg_clip_adam_dev */
+#define XG_VERSION 203   /* 200: XgRun gained packed/aux/event fields, xg_set_grad_event removed, xg_vproj takes XgRun;
+                            201: + xg_clip_adam_zero; 202: XgRun.prof_event0/1, xg_adam_tick, xg_clip_adam_dev;
+                            203: + xg_rollout_pair_compact */
 
 enum {
     XG_OK = 0,
@@ -264,6 +265,13 @@ int xg_rollout_pair(void *stream, const XgDims *d2, const XgParams *p, const XgB
  * backward of the sampled part alone. */
 int xg_rollout_compact(void *stream, const XgDims *d2, const void *ws2, size_t ws2_bytes,
                        const XgDims *d1, void *ws1, size_t ws1_bytes);
+/* xg_rollout_pair followed by xg_rollout_compact(d1 = the n_sample sampled rows) as ONE call: same outputs, same contents of
+ * ws1 -- but the sampled rows' raw logits (two thirds of the bytes a compaction copies) are written into ws1 by the rollout
+ * itself whenever its token choice runs over tile statistics (<= 128 rows, gemm_mode 0); d1->B must equal n_sample. */
+int xg_rollout_pair_compact(void *stream, const XgDims *d2, const XgParams *p, const XgBnState *bn,
+                            const XgBatch *x2, const XgRun *run, int n_sample, const float *uniforms,
+                            float temperature, void *ws2, size_t ws2_bytes, const XgDims *d1, void *ws1,
+                            size_t ws1_bytes, int64_t *seq, float *seq_logp, int32_t *n_steps);
 /* Backward of a rollout run with run->save = 1, given d(seq_logp) (B,T-1)
  * (RewardCriterion, caption_src/SAModel.py:259-267; caption_src/starttrain.py:131-134). */
 int xg_rollout_bwd(void *stream, const XgDims *d, const XgParams *p, const XgParams *g,
