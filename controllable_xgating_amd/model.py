@@ -392,9 +392,10 @@ class SAModel(nn.Module):
 
     def _bump_bn(self):
         if self.training:
-            for m in (self.two_spatial_encoder.visual_emb_rgb[1], self.two_spatial_encoder.visual_emb_opfl[1]):
-                if m.num_batches_tracked is not None:
-                    m.num_batches_tracked += 1
+            ts = [m.num_batches_tracked for m in (self.two_spatial_encoder.visual_emb_rgb[1], self.two_spatial_encoder.visual_emb_opfl[1])
+                  if m.num_batches_tracked is not None]
+            if ts:
+                torch._foreach_add_(ts, 1)          # (one launch for both counters)
 
     # ------------------------------------------------------------------ reference surface
     def forward(self, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask):
