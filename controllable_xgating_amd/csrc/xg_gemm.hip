@@ -797,6 +797,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
     __syncthreads();
     PK_STAMP(1);
     int item_no = 0;
+    (void)item_no;                               // (read by the -DPK_TRACE stamps only)
 
     auto slab_mfma = [&](int buf) {
         const float* as = smem + buf * STAGE;
@@ -939,7 +940,7 @@ int launch_pk(hipStream_t st, const GemmArgs& a, long min_units_default) {
     // 8-wave (or two 4-wave) skinny workgroups, and costs the product itself ~10 %.
     static const int bg_off = xg_diag_env("XG_GEMM_NO_BG") ? 1 : 0;
     static const int bg_all = xg_diag_env("XG_GEMM_FORCE_BG") ? 1 : 0;     // tests: every product takes the background form
-    const bool bg = (a.bg || bg_all) && !bg_off;
+    const bool bg = (a.bg + bg_all > 0) && !bg_off;
     const int GMAX = env_g > 0 ? env_g : (bg ? 256 : 512);
     int G;
     const bool split = !a.relu && g.nslab >= 2 && env_split;

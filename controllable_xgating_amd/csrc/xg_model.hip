@@ -839,7 +839,7 @@ int decoder_tokens_xe(hipStream_t sx, const XgDims& d, const XgParams& p, const 
 int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatch& x, const XgRun& run, Ws& w,
                    int* logit_rows_done, bool early_loss = false) {
     hipStream_t st = ss.main;
-    const int B = d.B, R = d.R, A = d.A, E = d.E, T = d.T, N = B * d.K;
+    const int B = d.B, R = d.R, A = d.A, E = d.E, T = d.T;
     const size_t BR = (size_t)B * R;
     XG_TRY(init_and_vproj(ss, d, p, x.feat_mask, w));
     XG_TRY(zero_dsync(st, w));
@@ -1487,7 +1487,7 @@ extern "C" int xg_forward_ss(void* stream, const XgDims* d, const XgParams* p, c
     w.gm = (run->gemm_mode == 1 || run->gemm_mode == 3) ? run->gemm_mode : 0;
     attach_packed(w, *d, run);
     hipStream_t st = (hipStream_t)stream;
-    const int B = d->B, R = d->R, E = d->E, A = d->A, T = d->T, TB = T * B, N = B * d->K;
+    const int B = d->B, R = d->R, E = d->E, A = d->A, T = d->T, TB = T * B;
     const size_t BR = (size_t)B * R;
     Streams es(st, run);
     XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w, &es));
@@ -1608,7 +1608,7 @@ static int rollout_impl(hipStream_t st, const XgDims* d, const XgParams* p, cons
                         const XgRun* run, int mode, const float* uniforms, const int64_t* forced, float temperature, Ws& w,
                         int64_t* seq, float* seq_logp, int32_t* n_steps, int split, float* logits_alt = nullptr,
                         bool* used_alt = nullptr) {
-    const int B = d->B, R = d->R, E = d->E, A = d->A, T = d->T, N = B * d->K;
+    const int B = d->B, R = d->R, E = d->E, A = d->A, T = d->T;
     const size_t BR = (size_t)B * R;
     Streams es(st, run);
     XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w, &es));

@@ -878,7 +878,7 @@ extern "C" int xg_debug_sk_trace(long long* out, int n) {
 
 int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
     if (a.njobs <= 0 || a.njobs > SK_MAX_JOBS) return XG_EINVAL;
-    bool vec = true, generic = false, packed = true, special = false, has_attn = false;
+    bool vec = true, generic = false, packed = true, special = false;
     int tiles = 0, max_tiles = 0, max_k = 0;
     for (int j = 0; j < a.njobs; ++j) {
         SkJob& jb = a.job[j];
@@ -898,7 +898,6 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
                 if (jb.attn_A % 4 || jb.attn_A > 256 * 8 || jb.attn_K < 1 || jb.attn_K > 128 || jb.R < 2 || jb.R % 2) return XG_EINVAL;
                 if ((((uintptr_t)jb.attn_p | (uintptr_t)jb.attn_q | (uintptr_t)jb.attn_w) % 16) || ((uintptr_t)jb.attn_v % 8)) return XG_EINVAL;
                 nt = 2 * jb.M;
-                has_attn = true;
             }
             special = true;
             if (jb.epi == SK_EPI_ATTN) tiles += nt;              // (ZERO tiles are over at once: they do not count as occupancy)
