@@ -14,6 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("XG_LIBRARY") or os.path.join(_HERE, "lib", "libxgate_hip.so")
 LIB_DIAG_PATH = os.path.join(_HERE, "lib", "libxgate_hip_diag.so")
 
+XG_VERSION = 204                      # include/xgate.h
 XG_ROLLOUT_GREEDY, XG_ROLLOUT_SAMPLE, XG_ROLLOUT_REPLAY = 0, 1, 2
 
 
@@ -114,6 +115,11 @@ def lib():
         fn = getattr(L, name)
         fn.restype = C.c_int
         fn.argtypes = args
+    L.xg_abi_check.restype = C.c_int
+    L.xg_abi_check.argtypes = [C.c_int] + [C.c_size_t] * 5
+    if L.xg_abi_check(XG_VERSION, C.sizeof(XgDims), C.sizeof(_XgParams), C.sizeof(XgBnState), C.sizeof(XgBatch), C.sizeof(XgRun)):
+        raise XgError("%s has ABI version %d / other struct layouts than this binding (XG_VERSION %d): rebuild it with "
+                      "`python __graft_entry__.py --force`" % (LIB_PATH, L.xg_version(), XG_VERSION))
     _lib = L
     return L
 

@@ -552,7 +552,7 @@ extern "C" int xg_debug_ds_trace(long long* out, int n) {
 }
 #endif
 
-size_t xgk_dstep_sync_bytes() { return sizeof(int) * DC_WORDS; }
+static_assert(sizeof(int) * DC_WORDS <= XGK_DSTEP_SYNC_BYTES, "sync words exceed the workspace reservation");
 
 bool xgk_dstep_ok(const XgDims& d) {
     return d.R % 8 == 0 && d.E % 4 == 0 && d.A % 4 == 0 && d.A <= 1536 && d.K <= 128 && (d.B + 31) / 32 <= DS_MAXTM &&

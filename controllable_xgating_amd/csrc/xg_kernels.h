@@ -209,7 +209,7 @@ struct DStepArgs {
     XgDrop drop_gate, drop_l1, drop_l2;
     int t0_p, t0_att, t0_c1, t0_c2, total;       // first block of each job after the gate tiles (filled in by xgk_dstep)
 };
-size_t xgk_dstep_sync_bytes();
+constexpr size_t XGK_DSTEP_SYNC_BYTES = 1024;   // reserved in every workspace; the kernel itself exists in the -DXG_DIAG build only
 bool xgk_dstep_ok(const XgDims& d);              // shapes the dataflow kernel takes
 int xgk_dstep(hipStream_t st, DStepArgs& a, int gemm_mode);
 

@@ -181,7 +181,7 @@ Ws carve(const XgDims& d, void* base) {
     w.alive = c.take<int32_t>(4);
     c.off = (c.off + 15) & ~(size_t)15;
     w.VPART = c.take<float>(B * ((V + 31) / 32) * 4);         // per-tile row statistics of a rollout step's vocabulary product
-    w.dsync = c.take<int32_t>(xgk_dstep_sync_bytes() / sizeof(int32_t));
+    w.dsync = c.take<int32_t>(XGK_DSTEP_SYNC_BYTES / sizeof(int32_t));
     {   // the zero block
         c.off = (c.off + 255) & ~(size_t)255;
         const size_t z0 = c.off;
@@ -286,7 +286,12 @@ inline int zero_tickets(hipStream_t st, const Ws& w, int njobs) {
 // single-step entry point (xg_step_fwd) relies on the invariant alone: the workspace contract asks for a zero-filled
 // workspace at first use (include/xgate.h).
 inline int zero_dsync(hipStream_t st, const Ws& w) {
-    return hipMemsetAsync(w.dsync, 0, xgk_dstep_sync_bytes(), st) == hipSuccess ? XG_OK : XG_EHIP;
+#ifdef XG_DIAG
+    return hipMemsetAsync(w.dsync, 0, XGK_DSTEP_SYNC_BYTES, st) == hipSuccess ? XG_OK : XG_EHIP;
+#else
+    (void)st; (void)w;               // the dataflow kernel is not part of the product library
+    return XG_OK;
+#endif
 }
 // (the tile element type must fit the arithmetic: bf16 tiles for gemm_mode 1, fp32 tiles otherwise)
 inline void attach_packed(Ws& w, const XgDims& d, const XgRun* run) {
@@ -596,6 +601,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
     // The step as ONE dataflow launch (xg_dstep.hip) exists for measurement only (-DXG_DIAG build, XG_DSTEP=1): at 128 rows it
     // takes 77 us against 46 us for the three launches below (DESIGN.md 4.3 has the in-kernel timeline); it is ahead only
     // below ~16 rows (30 vs 34 us at 8 rows).
+#ifdef XG_DIAG
     static const bool use_dstep = xg_diag_env("XG_DSTEP") != nullptr;
     if (use_dstep && step_packed(w, d) && xgk_dstep_ok(d) && ((uintptr_t)V % 16 == 0) && ((uintptr_t)vproj % 16 == 0) &&
         ((uintptr_t)p.a2w_w % 16 == 0)) {
@@ -620,6 +626,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         a2.drop_gate = xg_make_drop(&run, XG_SITE_DGATE, s.t); a2.drop_l1 = a.drop; a2.drop_l2 = c.drop;
         return xgk_dstep(st, a2, w.gm);
     }
+#endif
     if (step_packed(w, d)) {
         // xt as a matrix operand: the materialised rows, or embed.weight gathered by token
         auto xt_seg = [&](int which, const float* W) {
@@ -1217,6 +1224,10 @@ static_assert(sizeof(kParamNames) / sizeof(kParamNames[0]) == sizeof(XgParams) /
               "XgParams field count must match the state_dict name table");
 
 extern "C" int xg_version(void) { return XG_VERSION; }
+extern "C" int xg_abi_check(int version, size_t sz_dims, size_t sz_params, size_t sz_bn, size_t sz_batch, size_t sz_run) {
+    return (version == XG_VERSION && sz_dims == sizeof(XgDims) && sz_params == sizeof(XgParams) && sz_bn == sizeof(XgBnState) &&
+            sz_batch == sizeof(XgBatch) && sz_run == sizeof(XgRun)) ? XG_OK : XG_EINVAL;
+}
 extern "C" const char* xg_strerror(int code) {
     switch (code) {
         case XG_OK: return "ok";

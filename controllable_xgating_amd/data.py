@@ -76,7 +76,9 @@ def open_feature_store(path):
     return h5py.File(path, "r")
 
 
-# POS tag -> category id (data_io.py:60-100); every tag not listed is category 1; ids 0 / 1 are <EOS> / unknown
+# POS tag -> category id (data_io.py:60-100); every tag not listed is category 1; ids 0 / 1 are <EOS> / unknown.
+# 'WRR' is the reference's own spelling in caption_src/data_io.py:64 (pos_src/ has 'WRB'): words tagged WRB are category 1 on
+# the training path, and parity with caption_src is the contract (tests/test_data_cpu.py pins the table tag by tag).
 _CATEGORY_OF_TAG = {}
 for _cid, _tags in ((2, "VB VBD VBP VBG VBN VBZ"), (3, "NN NNS NNP"), (4, "JJ JJR JJS"), (5, "RB RBS RBR WRR EX"), (6, "CC"),
                     (7, "PRP PRP$ WP POS WP$"), (8, "IN TO"), (9, "DT WDT PDT"), (10, "RP MD"), (11, "CD"), (12, "SYM : `` # $"),

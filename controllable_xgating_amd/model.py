@@ -838,8 +838,11 @@ class _RewardFunction(torch.autograd.Function):
         reward = reward.float() if reward.dtype != torch.float32 else reward
         if reward.dim() == 0:                  # one scalar for every element (broadcast like the reference's input * reward)
             reward = reward.reshape(1, 1)
-        if reward.dim() == 1:                  # (m,): one value per video;  (L,) with L != m: one value per position
-            reward = reward.unsqueeze(1) if reward.shape[0] == m or reward.shape[0] == 1 else reward.unsqueeze(0)
+        if reward.dim() == 1:
+            # the reference's `input * reward` (SAModel.py:263) broadcasts a 1-D tensor along the LAST axis: (L,) is one value
+            # per position -- also when m == L.  (m,) with m != L, which the reference rejects, is taken as one value per
+            # video (an extension; pass (m, 1) to say so explicitly).
+            reward = reward.unsqueeze(0) if reward.shape[0] == L or reward.shape[0] == 1 else reward.unsqueeze(1)
         if reward.shape[0] not in (1, m):
             raise nv.XgError("reward must broadcast against the (m, L) log-probs")
         if reward.shape[1] == 1:

@@ -40,9 +40,9 @@
 extern "C" {
 #endif
 
-#define XG_VERSION 203   /* 200: XgRun gained packed/aux/event fields, xg_set_grad_event removed, xg_vproj takes XgRun;
+#define XG_VERSION 204   /* 200: XgRun gained packed/aux/event fields, xg_set_grad_event removed, xg_vproj takes XgRun;
                             201: + xg_clip_adam_zero; 202: XgRun.prof_event0/1, xg_adam_tick, xg_clip_adam_dev;
-                            203: + xg_rollout_pair_compact */
+                            203: + xg_rollout_pair_compact; 204: + xg_abi_check */
 
 enum {
     XG_OK = 0,
@@ -134,6 +134,11 @@ enum { XG_ROLLOUT_GREEDY = 0, XG_ROLLOUT_SAMPLE = 1, XG_ROLLOUT_REPLAY = 2 };
 
 /* ---- library / ABI introspection ------------------------------------------------- */
 int xg_version(void);
+/* A binding checks ITS struct layouts against the library's before the first real call: pass XG_VERSION as compiled into the
+ * binding and sizeof of its XgDims, XgParams, XgBnState, XgBatch, XgRun.  XG_OK if all six agree with the library, XG_EINVAL
+ * otherwise (a stale stub -- e.g. an XgRun without the newest trailing fields -- would make the library read past the
+ * caller's struct).  Needs no GPU. */
+int xg_abi_check(int version, size_t sz_dims, size_t sz_params, size_t sz_bn, size_t sz_batch, size_t sz_run);
 const char *xg_strerror(int code);
 int xg_param_count(void);
 const char *xg_param_name(int index);                 /* state_dict key of XgParams field `index` */

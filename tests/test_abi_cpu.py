@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(built):
 def test_version_strerror_and_param_table(built):
     from controllable_xgating_amd import _native as nv
     L = nv.lib()
-    assert L.xg_version() == 203
+    assert L.xg_version() == 204 == nv.XG_VERSION
     assert L.xg_strerror(0) == b"ok"
     assert b"workspace" in L.xg_strerror(-4)
     d = pg.make_dims(**CFG["c1"])
@@ -101,3 +101,55 @@ def test_product_does_not_import_oracle():
             if f.endswith(".py"):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "oracle" not in txt.replace("# oracle", ""), f
+
+
+_STRUCTS = ("XgDims", "XgParams", "XgBnState", "XgBatch", "XgRun")
+
+
+def _header_sizes(tmp_path):
+    """sizeof of the five ABI structs (and XG_VERSION) as a C99 compiler sees include/xgate.h."""
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "xgate.h"\nint main(void) {\n' +
+                   "".join('  printf("%s %%zu\\n", sizeof(%s));\n' % (n, n) for n in _STRUCTS) +
+                   '  printf("XG_VERSION %d\\n", XG_VERSION);\n  return 0;\n}\n')
+    exe = tmp_path / "sizes"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)],
+                   check=True)
+    out = subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.split()
+    return {out[i]: int(out[i + 1]) for i in range(0, len(out), 2)}
+
+
+def _integration_stub():
+    """The struct mirror a maintainer is told to paste, executed without loading any library."""
+    txt = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    a = txt.index("# --- struct mirror of include/xgate.h")
+    b = txt.index("# --- end of the struct mirror ---")
+    ns = {"C": ctypes}
+    exec(txt[a:b], ns)
+    return ns
+
+
+def test_struct_sizes_agree_between_header_binding_and_integration_stub(built, tmp_path):
+    from controllable_xgating_amd import _native as nv
+    L = nv.lib()
+    hdr = _header_sizes(tmp_path)
+    assert hdr["XG_VERSION"] == nv.XG_VERSION == L.xg_version()
+    mine = {"XgDims": nv.XgDims, "XgParams": nv.XgParams, "XgBnState": nv.XgBnState, "XgBatch": nv.XgBatch, "XgRun": nv.XgRun}
+    stub = _integration_stub()
+    theirs = {"XgDims": stub["XgDims"], "XgParams": stub["XgParams"], "XgBnState": stub["XgBn"], "XgBatch": stub["XgBatch"],
+              "XgRun": stub["XgRun"]}
+    for n in _STRUCTS:
+        assert ctypes.sizeof(mine[n]) == hdr[n], (n, ctypes.sizeof(mine[n]), hdr[n])
+        assert ctypes.sizeof(theirs[n]) == hdr[n], ("INTEGRATION.md stub", n, ctypes.sizeof(theirs[n]), hdr[n])
+    assert stub["XG_VERSION"] == hdr["XG_VERSION"] and stub["N_PARAMS"] == L.xg_param_count()
+    # field names and order of the stub's XgRun == the binding's (same header fields, in order)
+    assert [f[0] for f in stub["XgRun"]._fields_] == [f[0] for f in nv.XgRun._fields_]
+    hdr_txt = open(os.path.join(ROOT, "include", "xgate.h")).read()
+    run_body = hdr_txt[hdr_txt.index("typedef struct XgRun {"):hdr_txt.index("} XgRun;")]
+    pos = [run_body.index(f[0]) for f in nv.XgRun._fields_]
+    assert pos == sorted(pos)
+    # the library's own check: right sizes pass, a stale (12-field, 64-byte) XgRun or an old version number does not
+    sz = [hdr[n] for n in _STRUCTS]
+    assert L.xg_abi_check(hdr["XG_VERSION"], *sz) == 0
+    assert L.xg_abi_check(hdr["XG_VERSION"], *sz[:4], 64) == -1
+    assert L.xg_abi_check(hdr["XG_VERSION"] - 1, *sz) == -1

@@ -127,6 +127,30 @@ def test_dataset_against_reference_classes(tmp_path):
             assert np.array_equal(gts, it["gts"])
 
 
+@pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
+def test_every_pos_tag_maps_like_the_reference_table(tmp_path):
+    """caption_src/data_io.py:60-100, tag by tag -- including the reference's own 'WRR' (sic, :64; pos_src/ spells it 'WRB',
+    but the training path is caption_src): a word tagged WRB is category 1 in the reference, and here."""
+    import pickle
+    sys.modules.setdefault("h5py", types.ModuleType("h5py"))
+    sys.path.insert(0, REF)
+    sys.argv = ["x"]
+    import data_io as ref
+    tags = ("FW -LRB- -RRB- LS VB VBD VBP VBG VBN VBZ NN NNS NNP NNPS JJ JJR JJS RB RBS RBR WRR WRB EX CC PRP PRP$ WP POS WP$ IN TO "
+            "DT WDT PDT RP MD CD SYM : `` # $ UH , . ''").split()
+    category = {t: ["w%d" % i] for i, t in enumerate(tags)}
+    words = ["w%d" % i for i in range(len(tags))] + ["untagged"]
+    path = str(tmp_path / "cate.pkl")
+    with open(path, "wb") as f:
+        pickle.dump(category, f)
+    theirs = ref.filt_word_category(path, {w: i + 2 for i, w in enumerate(words)})[0]
+    mine = word_categories(category, words)
+    for i, t in enumerate(tags):
+        assert mine["w%d" % i] == theirs["w%d" % i], (t, mine["w%d" % i], theirs["w%d" % i])
+    assert mine["untagged"] == theirs.get("untagged", 1) == 1
+    assert mine["w%d" % tags.index("WRB")] == 1 and mine["w%d" % tags.index("WRR")] == 5 and mine["w%d" % tags.index("RB")] == 5
+
+
 def test_hdf5_feature_store_roundtrip(tmp_path):
     h5py = pytest.importorskip("h5py")
     if not hasattr(h5py, "File"):                 # (the stand-in module the reference-import tests register, not the real package)

@@ -104,9 +104,19 @@ def test_config5_b128_hidden1024_bf16_and_split_bf16_vs_oracle():
         for name, prm in model.named_parameters():
             if name in ZERO_GRAD_PARAMS:
                 continue
-            gn, rn = float(prm.grad.double().norm()), float(np.linalg.norm(g_o[name].astype(np.float64)))
+            gd, rd = prm.grad.double().cpu().reshape(-1), torch.from_numpy(g_o[name].astype(np.float64)).reshape(-1)
+            gn, rn = float(gd.norm()), float(rd.norm())
+            # direction as well as length: a wrong-signed or permuted block keeps its norm but not its cosine
+            cos = float(torch.dot(gd, rd)) / max(gn * rn, 1e-300)
             if not abs(gn - rn) <= (5e-2 if precision == "bf16" else 2e-3) * rn + 1e-6:
-                bad.append((name, gn, rn))
+                bad.append((name, "norm", gn, rn))
+            if rn > 1e-9 and not cos >= (0.999 if precision == "bf16" else 0.999999):
+                bad.append((name, "cosine", cos))
+            # and a sample of elements (every 9973rd), to the bf16 / fp32 class of the product chains
+            idx = torch.arange(0, gd.numel(), 9973)
+            tol_e = (3e-2 if precision == "bf16" else 2e-3) * float(rd.abs().max()) + 1e-7
+            if float((gd[idx] - rd[idx]).abs().max()) > tol_e:
+                bad.append((name, "elements", float((gd[idx] - rd[idx]).abs().max()), tol_e))
         assert not bad, (precision, bad)
         del model
         torch.cuda.empty_cache()

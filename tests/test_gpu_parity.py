@@ -1114,6 +1114,14 @@ def test_reward_criterion_scalar_and_per_position_rewards():
         loss = crit(slp, seq, reward)
         assert abs(loss.item() - ref(full).item()) < 1e-6
         loss.backward()
+    # a 1-D reward of length L is one value per POSITION (torch's trailing-axis broadcast in the reference) -- also when m == L
+    per_pos = torch.rand(L, generator=g).cuda()
+    assert abs(crit(slp, seq, per_pos).item() - ref(per_pos[None, :].expand(m, L)).item()) < 1e-6
+    sq = slp.detach()[:, :m].contiguous().requires_grad_(True)
+    seq_sq, pp = seq[:, :m].contiguous(), per_pos[:m].contiguous()
+    mask = torch.cat([torch.ones(m, 1, device="cuda"), (seq_sq[:, :-1] > 0).float()], 1)
+    want = -(sq.detach() * pp * mask).sum() / mask.sum()            # literally the reference's expression
+    assert abs(crit(sq, seq_sq, pp).item() - want.item()) < 1e-6
 
 
 def test_repeated_iterations_are_reproducible_across_streams():
