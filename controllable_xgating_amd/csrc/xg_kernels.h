@@ -184,6 +184,8 @@ struct SkJob {
     // atomics; for LSTMB the last part to arrive (tickets: one zero-initialised int per tile, left at zero again) reads the
     // completed dh back and runs the pointwise backward.  ksplit is filled in by xgk_skinny.
     int ksplit_ok, ksplit; int* tickets;
+    int ksplit_cap;                    // > 0: upper bound of the cross-workgroup split of THIS launch (a side chain that must not crowd the main one)
+    int low_prio;                      // 1: the job's waves drop back to default wave priority (off-critical-path side chains)
     XgDrop drop;
 };
 struct SkArgs { int njobs; int tile0[SK_MAX_JOBS]; SkJob job[SK_MAX_JOBS]; };

@@ -14,6 +14,7 @@
 
 #include <new>
 #include <cstdlib>
+#include <functional>
 
 namespace {
 
@@ -43,6 +44,9 @@ struct Streams {
     int dh_split_step = 0, dh_mark = -1;      // heads_bwd -> decoder_bwd_core hand-off (see heads_bwd)
     hipEvent_t grad_event = nullptr;          // XgRun.grad_event: recorded when every gradient but the encoder's is final
     hipEvent_t grad_event_head = nullptr;     // XgRun.grad_event_head: recorded when the logit.* gradients are final
+    // parameter-gradient work of the decoder backward that nothing downstream waits for, handed to the encoder backward, which
+    // enqueues it when its own latency-bound recurrence starts (decoder_bwd_core -> encoder_bwd)
+    std::function<int()> deferred;
     Streams(hipStream_t m, const XgRun* run) : main(m), aux(m), aux2(m), a(aux_of(run)) {
         if (a) { aux = a->s; aux2 = a->s2; }
         if (run) { grad_event = static_cast<hipEvent_t>(run->grad_event); grad_event_head = static_cast<hipEvent_t>(run->grad_event_head); }
@@ -367,6 +371,11 @@ int encoder_fwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgBnSt
     }
     if (side) XG_TRY(ss->join2());
     ZERO(w.zeroBR, (size_t)B * R);
+    if (ss && ss->deferred) {                   // side work the caller wants under this latency-bound recurrence
+        std::function<int()> f = std::move(ss->deferred);
+        ss->deferred = nullptr;
+        XG_TRY(f());
+    }
     XgRun nodrop = run; nodrop.drop_p = 0.f;
     for (int i = 0; i < K; ++i) {                                                                  // sub_modules.py:132-148
         SkArgs sk{};
@@ -479,6 +488,11 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
         return a;
     };
     const bool fuse = R % 4 == 0;
+    if (ss.deferred) {                          // the decoder backward's leftover parameter gradients: under this recurrence
+        std::function<int()> f = std::move(ss.deferred);
+        ss.deferred = nullptr;
+        XG_TRY(f());
+    }
     for (int i = K - 1; i >= 0; --i) {                          // both modalities per launch
         if (!fuse || i == K - 1) XG_TRY(xgk_lstm_bwd2(st, enc_cell_bwd(0, i, curc, false), enc_cell_bwd(1, i, curc, false)));
         curc ^= 1;
@@ -983,6 +997,14 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
             j.nseg = 2;
         }
         allow_split(sk, 0, w); j.tickets = w.tickets + 2 * 1024;       // chain 1 runs beside chain 2 / the encoder: own counters
+        // Chain 1 has slack (one launch per step against chain 2's three) and only feeds parameter gradients: it must not crowd
+        // chain 2.  Launched one step behind with the full 8-way split (512 workgroups) it took the wave slots the attention
+        // backward needed beside a background product (attention 40 us in situ against 12.7 alone).  So: at most a 2-way split
+        // (128 workgroups), default wave priority, and its launches in batches of c1_lag steps (measured on MI355X,
+        // tools/ubench/c1_sweep.sh: 6.08 -> 5.93 ms per iteration).
+        static const int c1_ks = xg_diag_env("XG_C1_KS") ? atoi(xg_diag_env("XG_C1_KS")) : 2;
+        static const int c1_lowprio = xg_diag_env("XG_C1_LOWPRIO") ? atoi(xg_diag_env("XG_C1_LOWPRIO")) : 1;
+        j.ksplit_cap = c1_ks; j.low_prio = c1_lowprio;
         XG_TRY(xgk_skinny(s1, sk, w.gm));
         cur1 ^= 1;
         return XG_OK;
@@ -992,7 +1014,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     // the reverse-time loop has already left are done BESIDE the loop on the auxiliary stream, behind the vocabulary
     // head's products: the loop alone leaves most of the chip idle, and whatever runs under it does not compete with
     // the encoder's backward afterwards.
-    auto wgrads_chain2 = [&](hipStream_t sq, int t0, int t1) -> int {
+    auto wgrads_chain2 = [=, &w](hipStream_t sq, int t0, int t1) -> int {
         const int rows = (t1 - t0) * B;
         if (rows <= 0) return XG_OK;
         const size_t r0 = (size_t)t0 * B;
@@ -1009,7 +1031,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         XG_TRY(tn16(sq, w.gm, rows, A, R, dp, m16(w, dp), A, h2, m16(w, h2), R, g.h2a_w + R, 2 * R));
         return XG_OK;
     };
-    auto wgrads_chain1 = [&](hipStream_t sq, int t0, int t1) -> int {
+    auto wgrads_chain1 = [=, &w](hipStream_t sq, int t0, int t1) -> int {
         const int rows = (t1 - t0) * B;
         if (rows <= 0) return XG_OK;
         const size_t r0 = (size_t)t0 * B;
@@ -1028,6 +1050,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     // (fp32 products only: beside the bf16 GEMMs the loop loses more than the products gain, hidden-1024 iteration 8.50 -> 8.72 ms)
     const int wg_chunks = (ss.overlap() && T >= 8 && w.gm == 0) ? (wg_chunks_env < 1 ? 1 : (wg_chunks_env > 4 ? 4 : wg_chunks_env)) : 1;
     int wg_hi = T, wg_mark = -1;                 // steps [wg_hi, T) already have their weight gradients enqueued
+    int c1_next = T - 1;                         // the next step chain 1 has to do
     for (int t = T - 1; t >= 0; --t) {
         // dH of the early steps comes from the auxiliary stream; fused, step t-1's cell backward runs inside step t
         if (t == ss.dh_split_step - (fuse ? 0 : 1)) XG_TRY(ss.wait_mark(ss.dh_mark));
@@ -1057,10 +1080,17 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
             XG_TRY(xgk_skinny(st, sk, w.gm));
         }
         cur ^= 1;
-        XG_TRY(ss.fork2());                   // chain 2 has finished step t ...
-        XG_TRY(chain1_step(t));               // ... chain 1 may do it
+        // chain 2 has finished step t: chain 1 may do it.  One event per c1_lag steps (an event record between two dependent
+        // launches of the main chain costs it ~6 us; chain 1 has slack: its launch is shorter than chain 2's three)
+        static const int c1_lag = xg_diag_env("XG_C1_LAG") ? atoi(xg_diag_env("XG_C1_LAG")) : 7;
         bool boundary = false;                // t == ceil(k T / chunks) for some k in 1 .. chunks - 1
         for (int k = 1; k < wg_chunks; ++k) boundary = boundary || t == (k * T + wg_chunks - 1) / wg_chunks;
+        const int lag = c1_lag < 1 ? 1 : c1_lag;
+        if (t == 0 || (boundary && t < wg_hi) || (T - 1 - t) % lag == lag - 1) {
+            XG_TRY(ss.fork2());
+            for (int tt = c1_next; tt >= t; --tt) XG_TRY(chain1_step(tt));
+            c1_next = t - 1;
+        }
         if (boundary && t > 0 && t < wg_hi) {
             // DS2 / DP rows of steps >= t exist on main, DS1 rows of steps >= t on the second side chain
             XG_TRY(ss.fork());
@@ -1083,6 +1113,9 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     XG_TRY(cvt16(st, w, w.DVPROJ, (size_t)N * A));
     XG_TRY(nn16(st, w.gm, N, R, A, w.DVPROJ, m16(w, w.DVPROJ), A, p.v2a_w, w16(w, W16_V2A), R, w.DV, R, true));
     // gradients wrt the initial state -> img_embed_* (init_hidden; vbar is detached: SAModel.py:59-62)
+    const int cur1_end = cur1, wg_hi_end = wg_hi, wg_mark_end = wg_mark;
+    auto tail = [=, &w, &ss]() -> int {
+    const int cur1 = cur1_end, wg_hi = wg_hi_end, wg_mark = wg_mark_end;
     {
         float* gst[4] = {w.dst[cur1][0], w.dst[cur1][1], w.dst[cur2][2], w.dst[cur2][3]};
         float* gw[4] = {g.ih1_w, g.ic1_w, g.ih2_w, g.ic2_w};
@@ -1108,6 +1141,10 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     // everything but two_spatial_encoder.* is final once the auxiliary stream gets here (it has waited for main above)
     if (ss.grad_event && hipEventRecord(ss.grad_event, sx) != hipSuccess) return XG_EHIP;
     return XG_OK;
+    };
+    static const int defer_env = xg_diag_env("XG_DEFER_WG") ? atoi(xg_diag_env("XG_DEFER_WG")) : 0;
+    if (defer_env && ss.overlap()) { ss.deferred = tail; return XG_OK; }
+    return tail();
 }
 
 // heads backward from dlogits (rows,V) in w.LOGITS and dcl (rows,C) in w.DCL -> DH2OUT, head param grads
@@ -1572,8 +1609,15 @@ extern "C" int xg_xe_loss_fwd(void* stream, const XgDims* d, const XgParams* p, 
     Streams ss(st, run);
     int rows_done = 0;
     ZERO(w.sums, 2);                           // both halves of the cross-entropy add into it
-    XG_TRY(ss.fork());
-    XG_TRY(decoder_tokens_xe(ss.aux, *d, *p, *x, *run, w));
+    static const int tok_late = xg_diag_env("XG_TOK_LATE") ? atoi(xg_diag_env("XG_TOK_LATE")) : 0;
+    if (tok_late && ss.overlap()) {
+        // the token-side products (nothing before the decoder loop waits for them) under the encoder's recurrence instead of
+        // beside its input-side products
+        ss.deferred = [&ss, d, p, x, run, &w]() -> int { XG_TRY(ss.fork()); return decoder_tokens_xe(ss.aux, *d, *p, *x, *run, w); };
+    } else {
+        XG_TRY(ss.fork());
+        XG_TRY(decoder_tokens_xe(ss.aux, *d, *p, *x, *run, w));
+    }
     XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w, &ss));
     XG_TRY(decoder_fwd_xe(ss, *d, *p, *x, *run, w, &rows_done, true));
     XG_TRY(heads_fwd_logits(ss, *d, *p, *run, w, TB, rows_done));       // (joins the auxiliary stream)

@@ -615,6 +615,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
         }
         return;
     }
+    if (job.low_prio) __builtin_amdgcn_s_setprio(0);
     const int ntm = (job.M + 31) >> 5;
     const bool lstm = job.epi == SK_EPI_LSTM || job.cell_cols;      // cell tiling of the weight rows
     const int ntn = lstm ? job.R >> 3 : (job.N + 31) >> 5;
@@ -946,7 +947,9 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
                  xg_cdiv(jb.M, 32) * xg_cdiv(jb.N, 32) <= 1024;
             for (int s = 0; s < jb.nseg; ++s) min_chunks = jb.seg[s].nck < min_chunks ? jb.seg[s].nck : min_chunks;
         }
-        if (ok) while (ks < 8 && tiles * ks * 2 <= 512 && min_chunks / (ks * 2) >= 4) ks *= 2;
+        int cap = 8;
+        for (int j = 0; j < a.njobs; ++j) if (a.job[j].ksplit_cap > 0 && a.job[j].ksplit_cap < cap) cap = a.job[j].ksplit_cap;
+        if (ok) while (ks < cap && tiles * ks * 2 <= 512 && min_chunks / (ks * 2) >= 4) ks *= 2;
         for (int j = 0; j < a.njobs; ++j) a.job[j].ksplit = ks;
         tiles *= ks; max_tiles *= ks;
     }
