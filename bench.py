@@ -565,6 +565,28 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
     return out, parity_fail
 
 
+def step_group_by_arithmetic(args, ctx):
+    """The stand-alone decoder-step launch group (xg_step_fwd, 128 rows, hidden 512 -- the roofline kernel of the headline line)
+    in each arithmetic mode of the per-step products: exact fp32 MFMA, split-bf16 (three planes, six bf16 MFMAs per 16-deep
+    block: fp32-class results) and plain bf16.  Same weights, same inputs; microseconds per launch group."""
+    from controllable_xgating_amd import SAModel, make_opt
+    cfg = dict(B=128, K=26, R=512, A=1536, E=468, V=20000, C=14, L=20, F1=1536, F2=1024)
+    x = synth_inputs(cfg["B"], cfg["K"], cfg["L"], cfg["V"], cfg["R"], cfg["F1"], cfg["F2"], cfg["C"], 0, ctx["dev"])
+    out = {}
+    for precision in ("fp32", "bf16x3", "bf16"):
+        torch.manual_seed(0)
+        opt = make_opt(None, vocab_size=cfg["V"], seq_length=cfg["L"], precision=precision, rnn_size=cfg["R"], att_size=cfg["A"],
+                       input_encoding_size=cfg["E"], feat_size=cfg["F1"], feat_size2=cfg["F2"])
+        model = SAModel(opt).to(ctx["dev"])
+        model.eval()
+        out[precision] = round(measure_step_group(model, x) * 1e6, 2)
+        del model
+    out["what"] = ("xg_step_fwd stand-alone, 128 rows, hidden 512, 200 back-to-back calls; fp32 = v_mfma_f32_32x32x2_f32 on packed fp32 "
+                   "tiles; bf16x3 = the same tiles split into three bf16 planes in registers, 6 x v_mfma_f32_32x32x16_bf16 per 16-deep "
+                   "block (0.375 of the fp32 matrix time); bf16 = packed bf16 tiles, 1 MFMA per block")
+    return out
+
+
 def main():
     # stdout carries exactly ONE line, the JSON: everything else that writes to file descriptor 1 (RCCL prints a version banner
     # through C stdio when a communicator comes up, rocprofv3 children, ...) is sent to stderr
@@ -634,7 +656,7 @@ def main():
     if (not args.no_secondary and world == 1 and not use_dist and args.workload == "xe" and args.precision == "fp32"
             and args.batch == 128 and args.path == "fused"):
         sec = {}
-        for key, (wl_, prec_) in {"scst": ("scst", "fp32"), "xe5_bf16": ("xe5", "bf16")}.items():
+        for key, (wl_, prec_) in {"scst": ("scst", "fp32"), "xe5_bf16": ("xe5", "bf16"), "xe_bf16x3": ("xe", "bf16x3")}.items():
             try:
                 o, f = run_workload(args, wl_, prec_, 10, 5, ctx, pmc=False, comm_diag=False)
                 sec[key] = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "host_enqueue_ms_per_step", "dtype", "config",
@@ -647,6 +669,11 @@ def main():
                 sec[key] = {"error": repr(e)}
                 fails.append("secondary %s failed: %r" % (key, e))
         out["secondary"] = sec
+        # one shape, three arithmetic modes: the decoder-step launch group of the headline config (128 rows, hidden 512)
+        try:
+            out["roofline"]["step_us_by_arithmetic"] = step_group_by_arithmetic(args, ctx)
+        except Exception as e:
+            out["roofline"]["step_us_by_arithmetic"] = {"error": repr(e)}
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:

@@ -105,6 +105,49 @@ __device__ __forceinline__ void st_chunk_bf16(unsigned short* __restrict__ lds, 
     }
 }
 
+// ---- split-bf16 arithmetic (XgRun.gemm_mode = 3): an fp32 value is the EXACT sum of three bf16 planes (8 significand bits
+// each: hi = x truncated, mid = (x - hi) truncated, lo = the rest, rounded), and a product keeps the six plane products whose
+// weight is above fp32 round-off (hi*hi, hi*mid, mid*hi, mid*mid, hi*lo, lo*hi) on v_mfma_f32_32x32x16_bf16: 12 MFMAs of 32
+// cycles per 32-deep chunk instead of 16 of 64 -- 0.375 of the exact-fp32 matrix time at fp32-class accuracy.  The weights stay
+// the fp32 packed tiles (split in registers as they arrive); the activations are split while they are staged into three LDS
+// plane images.  Accumulation, reductions and every epilogue are fp32 as in the other modes.
+__device__ __forceinline__ void split3_pair(float a, float b, unsigned& p0, unsigned& p1, unsigned& p2) {
+    const unsigned ua = __float_as_uint(a), ub = __float_as_uint(b);
+    p0 = __builtin_amdgcn_perm(ub, ua, 0x07060302u);                      // {hi16(a), hi16(b)}: two bf16, a in the low half
+    const float ra = a - __uint_as_float(ua & 0xFFFF0000u), rb = b - __uint_as_float(ub & 0xFFFF0000u);      // exact
+    const unsigned va = __float_as_uint(ra), vb = __float_as_uint(rb);
+    p1 = __builtin_amdgcn_perm(vb, va, 0x07060302u);
+    const float sa = ra - __uint_as_float(va & 0xFFFF0000u), sb = rb - __uint_as_float(vb & 0xFFFF0000u);    // exact
+    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+    bf16x2_t lo;
+    lo[0] = (__bf16)sa; lo[1] = (__bf16)sb;                                // v_cvt_pk_bf16_f32 (round to nearest even)
+    p2 = __builtin_bit_cast(unsigned, lo);
+}
+constexpr int PLH = 32 * LDH;     // bf16 elements of one staged plane image
+// A chunk -> three plane images [3][32][LDH] (same index map as st_chunk_bf16)
+__device__ __forceinline__ void st_chunk_split3(unsigned short* __restrict__ lds, int lane, const f32x4 (&v)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        unsigned a0, a1, a2, b0, b1, b2;
+        split3_pair(v[i][0], v[i][1], a0, a1, a2);
+        split3_pair(v[i][2], v[i][3], b0, b1, b2);
+        unsigned short* q = lds + (i * 8 + (lane >> 3)) * LDH + ((lane & 7) << 2);
+        *reinterpret_cast<uint2*>(q) = make_uint2(a0, b0);
+        *reinterpret_cast<uint2*>(q + PLH) = make_uint2(a1, b1);
+        *reinterpret_cast<uint2*>(q + 2 * PLH) = make_uint2(a2, b2);
+    }
+}
+// the 8 fp32 weights a lane holds for one 16-deep MFMA block (two f32x4 pieces) -> three bf16x8 operands
+__device__ __forceinline__ void split3_b(const f32x4& x, const f32x4& y, bf16x8 (&pl)[3]) {
+    unsigned w[3][4];
+    split3_pair(x[0], x[1], w[0][0], w[1][0], w[2][0]);
+    split3_pair(x[2], x[3], w[0][1], w[1][1], w[2][1]);
+    split3_pair(y[0], y[1], w[0][2], w[1][2], w[2][2]);
+    split3_pair(y[2], y[3], w[0][3], w[1][3], w[2][3]);
+#pragma unroll
+    for (int p = 0; p < 3; ++p) { const uint4 u = {w[p][0], w[p][1], w[p][2], w[p][3]}; pl[p] = __builtin_bit_cast(bf16x8, u); }
+}
+
 // ---- epilogues shared by the two kernels.  red = [SKW][32][RS] partial tiles in LDS.
 // LSTM cell epilogue operands: every load is unconditional (absent operands read a valid dummy address and are dropped by
 // a select in the epilogue): a load under a branch makes the compiler wait for it on the spot, and 19 serialized L2 round
@@ -493,12 +536,16 @@ __device__ __forceinline__ void copy_tile(const SkJob& job, int tile) {
     }
 }
 
-// ---- ATTN job (256-thread workgroups): see SK_EPI_ATTN in xg_kernels.h.  Reference: caption_src/sub_modules.py:678-680.
-//   wave w scores rows k0 + w, k0 + w + 4, ... of this half (whole q rows, lane = 16 B); both halves use e_0 as the
+// ---- ATTN job: see SK_EPI_ATTN in xg_kernels.h.  Reference: caption_src/sub_modules.py:678-680.
+//   EVERY wave of the workgroup takes part (NWV = 4 or 8).  Round 4: the 8-wave launches used to let waves 4..7 return before
+//   the first workgroup barrier; beside split-bf16 cell tiles in the same launch that form produced run-to-run differences in
+//   the accumulated context (one video's row, ~1e-4, 4 of 5 runs; tools/step_mode_check.py) -- never seen with the fp32 tiles,
+//   but nothing in the code tied it to the arithmetic, so no wave leaves a workgroup ahead of a barrier any more.
+//   wave w scores rows k0 + w, k0 + w + NWV, ... of this half (whole q rows, lane = 16 B); both halves use e_0 as the
 //   softmax shift (the second half scores frame 0 once more: same arithmetic, same bits), so their unnormalised sums simply
 //   add.  exp argument clamped at 80 (only reachable when a frame outweighs the first by e^80; keeps that finite).
 constexpr int ATT_ROWS = 64;       // rows per half <= 64 (K <= 128)
-template <int NI>                  // float4 groups of A per lane: A <= 256 NI
+template <int NI, int NWV>         // float4 groups of A per lane: A <= 256 NI; waves of the workgroup (all of them take part)
 __device__ __forceinline__ void attn_part(const SkJob& job, int tile, float* smem) {
     const int b = tile >> 1, part = tile & 1;
     const int K = job.attn_K, A = job.attn_A, R = job.R;
@@ -518,11 +565,11 @@ __device__ __forceinline__ void attn_part(const SkJob& job, int tile, float* sme
         wr[i] = a < A ? *reinterpret_cast<const f32x4*>(job.attn_w + a) : z;
     }
     // the second half's reference row (frame 0) rides on its last wave, which has the fewest rows of its own
-    const bool ref_here = part == 1 && wave == 3;
-    const int own = k0 + wave < k1 ? (k1 - k0 - wave + 3) >> 2 : 0;
+    const bool ref_here = part == 1 && wave == NWV - 1;
+    const int own = k0 + wave < k1 ? (k1 - k0 - wave + NWV - 1) / NWV : 0;
     const int cnt = own + (ref_here ? 1 : 0);
     for (int j = 0; j < cnt; ++j) {
-        const float* qk = qb + (size_t)(j < own ? k0 + wave + 4 * j : 0) * A;
+        const float* qk = qb + (size_t)(j < own ? k0 + wave + NWV * j : 0) * A;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int a = lane * 4 + 256 * i;
@@ -534,7 +581,7 @@ __device__ __forceinline__ void attn_part(const SkJob& job, int tile, float* sme
             acc += wr[i][0] * xg_tanh(pr[i][0] + q[i][0]) + wr[i][1] * xg_tanh(pr[i][1] + q[i][1]) +
                    wr[i][2] * xg_tanh(pr[i][2] + q[i][2]) + wr[i][3] * xg_tanh(pr[i][3] + q[i][3]);
         acc = wave_sum(acc);
-        if (lane == 0) se[j < own ? wave + 4 * j : ATT_ROWS] = acc;
+        if (lane == 0) se[j < own ? wave + NWV * j : ATT_ROWS] = acc;
     }
     __syncthreads();
     const float eref = part == 0 ? se[0] : se[ATT_ROWS];
@@ -546,7 +593,7 @@ __device__ __forceinline__ void attn_part(const SkJob& job, int tile, float* sme
     }
     __syncthreads();
     // unnormalised context of this half: thread -> two adjacent columns
-    for (int c = threadIdx.x * 2; c < R; c += 512) {
+    for (int c = threadIdx.x * 2; c < R; c += NWV * 128) {
         float ax = 0.f, ay = 0.f;
 #pragma unroll 4
         for (int r = 0; r < nrow; ++r) {
@@ -598,7 +645,10 @@ template <int NW, int PREC, bool SCALE>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SCALE ? 2 : 4, SCALE ? 2 : 4))) skf_kernel(SkArgs args) {
     XG_CHAIN_PRIO();
     SK_STAMP(0);
-    __shared__ __attribute__((aligned(16))) float smem[NW * 32 * RSF > NW * OPF ? NW * 32 * RSF : NW * OPF];
+    // per wave: the staged activation chunk (fp32 image, one bf16 image, or three bf16 plane images), later the wave's partial tile
+    constexpr int WSM = PREC == 2 ? (3 * PLH) / 2 : (32 * RSF > OPF ? 32 * RSF : OPF);      // floats per wave
+    static_assert(WSM >= 32 * RSF, "the reduction buffer must fit the staging area");
+    __shared__ __attribute__((aligned(16))) float smem[NW * WSM + (SCALE ? 32 : 0)];
     const SkJob& job = args.job[blockIdx.y];
     if (job.epi == SK_EPI_ZERO) {
         if ((size_t)blockIdx.x * 4096 < (size_t)job.M * job.N) zero_tile<NW>(job, blockIdx.x);
@@ -609,9 +659,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
         return;
     }
     if (job.epi == SK_EPI_ATTN) {
-        if (NW == 8 && threadIdx.x >= 256) return;      // (written for 4 waves; the upper four leave before its first barrier)
-        if ((int)blockIdx.x < 2 * job.M) {
-            if (job.attn_A <= 1536) attn_part<6>(job, blockIdx.x, smem); else attn_part<8>(job, blockIdx.x, smem);
+        if ((int)blockIdx.x < 2 * job.M) {           // (every wave of the workgroup scores its share of the rows)
+            if (job.attn_A <= 1536) attn_part<6, NW>(job, blockIdx.x, smem); else attn_part<8, NW>(job, blockIdx.x, smem);
         }
         return;
     }
@@ -630,20 +679,23 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
     const int tm = bid % ntm, kp = (bid / ntm) % ks, tn = bid / (ntm * ks);
     const int m0 = tm * 32, n0 = tn * 32;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
-    float* As = smem + wave * OPF;
+    float* As = smem + wave * WSM;
     const int lrow = lane >> 3, lcol = (lane & 7) << 2;
 
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-    const LstmPre pre = lstm_prefetch<NW>(job, m0, tn);
+    // (split-bf16: the plane registers leave no room for 19 prefetched values across the K loop at 128 VGPRs -- they would go
+    //  to scratch, which costs more than it hides -- so that mode requests the cell operands behind the loop, under the reduction)
+    LstmPre pre;
+    if (PREC != 2) pre = lstm_prefetch<NW>(job, m0, tn);
     // A scaled operand (the unnormalised attention context): the reciprocal row scales go to LDS behind the staging images;
     // the workgroup meets at a barrier in front of the first scaled segment, i.e. after every wave has done its share of the
     // segments before it -- the scale's load latency hides there (registers would be simpler, but four more live values
     // push the K loop into scratch: measured 47.8 -> 52.9 us per step).  The unnormalised attention weights of this m-tile's
     // videos are normalised by ALL its n-tiles, a slice each: loads now, multiply + store at the very end.
-    float* rsc_lds = smem + NW * OPF;
+    float* rsc_lds = smem + NW * WSM;
     int scaled_seg = -1;
     if (SCALE) {
 #pragma unroll
@@ -799,13 +851,32 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
                 }
             }
             if (PREC == 1) st_chunk_bf16(reinterpret_cast<unsigned short*>(As), lane, ra);
+            else if (PREC == 2) st_chunk_split3(reinterpret_cast<unsigned short*>(As), lane, ra);
             else st_chunk(As, lane, ra);
             if (s == 0 && c == c0) SK_STAMP(2);
             if (c + DB < c1) ldB(c + DB, nxt);
             if (c + DA < c1) ldAc(c + DA, ra);
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (PREC == 1) {
+            if (PREC == 2) {
+                // lane (column l31, half h) holds the weights of k = 16 h + 4 i + kk in piece i: block j = pieces 2j, 2j + 1 =
+                // k in [16 h + 8 j, + 8), and the activation fragment is read at the same k (any k order does, if both sides agree)
+                const unsigned short* Ah = reinterpret_cast<const unsigned short*>(As);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    bf16x8 bp3[3], ap3[3];
+                    split3_b(cur[2 * j], cur[2 * j + 1], bp3);
+#pragma unroll
+                    for (int q = 0; q < 3; ++q) ap3[q] = *reinterpret_cast<const bf16x8*>(Ah + q * PLH + l31 * LDH + half * 16 + j * 8);
+                    // smallest terms first
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap3[0], bp3[2], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap3[2], bp3[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap3[1], bp3[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap3[0], bp3[1], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap3[1], bp3[0], acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ap3[0], bp3[0], acc, 0, 0, 0);
+                }
+            } else if (PREC == 1) {
                 const unsigned short* Ah = reinterpret_cast<const unsigned short*>(As);
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
@@ -843,6 +914,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
     }
 #endif
     SK_STAMP(3);
+    if (PREC == 2) pre = lstm_prefetch<NW>(job, m0, tn);
     __syncthreads();
     float (*red)[32][RSF] = reinterpret_cast<float (*)[32][RSF]>(smem);
 #pragma unroll
@@ -933,6 +1005,7 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         return XG_OK;
     }
     const bool bf16 = gemm_mode == 1;      // plain-bf16 mode covers the recurrent products too
+    const bool bf16x3 = gemm_mode == 3;    // split-bf16: fp32 packed tiles, three bf16 planes, 6 MFMAs per 16-deep block (fast kernel only)
     static const bool no_packed = xg_diag_env("XG_NO_PACKED") != nullptr;
     const bool fast = vec && packed && !no_packed;       // (the caller attaches bf16 tiles iff gemm_mode is 1: attach_packed)
     // cross-workgroup split-K for launches that would leave most CUs idle (every job must allow it)
@@ -965,25 +1038,34 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
     }
     if (fast) {
         static const int force_nw = xg_diag_env("XG_SK_NW") ? atoi(xg_diag_env("XG_SK_NW")) : 0;      // diagnosis
-        // A launch that carries the attention: its workgroups are written for 4 waves.  When everything fits the chip in one
-        // round as 8-wave workgroups (<= 512: batches of <= 64 rows) the products keep their 8-way K split and the attention
-        // runs on the first four waves of its workgroups (36.7 vs 38.6 us per step at 64 rows); beyond that 4-wave workgroups
-        // for all, which are all resident (49.4 vs 52.5 us at 128 rows).
+        // A launch that carries the attention: when everything fits the chip in one round as 8-wave workgroups (<= 512) the
+        // products keep their 8-way K split and the attention's rows are scored by all eight waves (36.7 vs 38.6 us per step at
+        // 64 rows); beyond that 4-wave workgroups for all, which are all resident (49.4 vs 52.5 us at 128 rows).
         // (bf16 tiles, hidden 1024: 4-wave workgroups throughout -- half the register footprint per workgroup is easier to place
         //  beside the bf16 GEMMs of the other streams: 8.20 -> 8.14 ms; at hidden 512 the rule above stands: fp32 6.08 vs 6.09,
         //  bf16 4.59 vs 4.66 ms)
-        const bool nw4 = ks > 1 || (force_nw ? force_nw == 4 : ((bf16 && max_k >= 1024) || tiles > 2 * 256));
+        const bool nw4_rule = ks > 1 || (force_nw ? force_nw == 4 : ((bf16 && max_k >= 1024) || tiles > 2 * 256));
         const dim3 grid((max_tiles + 7) & ~7, a.njobs);
         bool scaled = false;
         for (int j = 0; j < a.njobs; ++j)
             for (int q = 0; q < a.job[j].nseg; ++q) scaled = scaled || a.job[j].seg[q].row_scale != nullptr;
+        bool has_attn = false, has_zero = false;
+        for (int j = 0; j < a.njobs; ++j) { has_attn = has_attn || a.job[j].epi == SK_EPI_ATTN; has_zero = has_zero || a.job[j].epi == SK_EPI_ZERO; }
+        static const bool dbg_nw4_scaled = xg_diag_env("XG_SK_NW4_SCALED") != nullptr, dbg_nw4_attn = xg_diag_env("XG_SK_NW4_ATTN") != nullptr,
+                          dbg_nw4_zero = xg_diag_env("XG_SK_NW4_ZERO") != nullptr;
+        const bool nw4 = nw4_rule || (dbg_nw4_scaled && scaled) || (dbg_nw4_attn && has_attn) || (dbg_nw4_zero && has_zero);
 #define XG_SKF(NW_, PREC_) do { \
             if (scaled) hipLaunchKernelGGL((skf_kernel<NW_, PREC_, true>), grid, dim3(NW_ * 64), 0, st, a); \
             else hipLaunchKernelGGL((skf_kernel<NW_, PREC_, false>), grid, dim3(NW_ * 64), 0, st, a); } while (0)
-        if (bf16) { if (nw4) XG_SKF(4, 1); else XG_SKF(8, 1); }
-        else      { if (nw4) XG_SKF(4, 0); else XG_SKF(8, 0); }
+        if (bf16)        { if (nw4) XG_SKF(4, 1); else XG_SKF(8, 1); }
+        else if (bf16x3) { if (nw4) XG_SKF(4, 2); else XG_SKF(8, 2); }
+        else             { if (nw4) XG_SKF(4, 0); else XG_SKF(8, 0); }
 #undef XG_SKF
         XG_CHECK_LAUNCH();
+#ifdef XG_DIAG
+        static const bool dbg_sync = xg_diag_env("XG_SYNC_LAUNCH") != nullptr;
+        if (dbg_sync) (void)hipStreamSynchronize(st);
+#endif
         return XG_OK;
     }
     for (int j = 0; j < a.njobs; ++j)

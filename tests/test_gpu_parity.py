@@ -223,9 +223,9 @@ def run_oracle_xe(d, ragged, p=0.0, seed=0, train=True, weight_class=WEIGHT_CLAS
     return P, logp.detach().numpy(), cat.detach().numpy(), l_xe.item(), l_cls.item(), running
 
 
-def run_hip_xe(d, ragged, p=0.0, seed=None, weight_class=WEIGHT_CLASS):
+def run_hip_xe(d, ragged, p=0.0, seed=None, weight_class=WEIGHT_CLASS, precision="fp32"):
     from controllable_xgating_amd import ClassiferCriterion, LanguageModelCriterion
-    model = make_model(d, p_drop=p)
+    model = make_model(d, p_drop=p, precision=precision)
     x = to_dev(pg.make_inputs(d, seed=0, ragged=ragged))
     if seed is not None:
         model._run_seed_override = seed
@@ -1491,3 +1491,77 @@ def test_single_step_backward_vs_oracle_autograd():
             continue
         want = P[name].grad if P[name].grad is not None else torch.zeros_like(P[name])
         close(prm.grad, want, name)
+
+
+# ---------------------------------------------------------------- split-bf16 arithmetic of the per-step products (gemm_mode 3)
+@pytest.mark.parametrize("tag,ragged", [("tiny", True), ("mid", True), ("c1", False), ("c1", True)])
+def test_split_bf16_step_products_xe_vs_oracle(tag, ragged):
+    """precision='bf16x3' (XgRun.gemm_mode 3): the large products AND the per-step products (xg_step.hip, PREC 2: three bf16
+    planes of the packed fp32 weights and of the staged activations, six plane products per 16-deep block) are fp32-class:
+    the same tolerances as the exact-fp32 path -- loss within 1e-4 (north_star), log-probs, every gradient."""
+    d = pg.make_dims(**CFG[tag])
+    P, lo, co, lxe_o, lcls_o, running = run_oracle_xe(d, ragged)
+    model, lh, ch, lxe_h, lcls_h = run_hip_xe(d, ragged, precision="bf16x3")
+    assert abs(lxe_h - lxe_o) < 1e-4, (lxe_h, lxe_o)
+    assert abs(lcls_h - lcls_o) < 1e-4
+    np.testing.assert_allclose(lh, lo, atol=3e-4, rtol=0)
+    np.testing.assert_allclose(ch, co, atol=1e-4, rtol=0)
+    assert_grads_close(model, oracle_grads(P))
+
+
+@pytest.mark.parametrize("name,tag,ragged", [("greedy_tiny.npz", "tiny", False), ("greedy_c1.npz", "c1", False),
+                                              ("greedy_c1_ragged.npz", "c1", True), ("greedy_c1_eos.npz", "c1", False),
+                                              ("beam_c1.npz", "c1", False)])
+def test_split_bf16_greedy_token_for_token_vs_reference(name, tag, ragged):
+    """Every greedy golden of the reference (and the beam-size-1 decode of the beam golden's inputs against the exact-fp32 HIP
+    path), decoded with the split-bf16 step products: the same tokens."""
+    from tests.util import EOS_CASE, eos_params
+    d = pg.make_dims(**CFG[tag])
+    eos = name == "greedy_c1_eos.npz"
+    Pn = eos_params(d) if eos else None
+    x = to_dev(pg.make_inputs(d, seed=EOS_CASE["input_seed"] if eos else 0, ragged=ragged))
+    model = make_model(d, P=Pn, train=False, precision="bf16x3")
+    with torch.no_grad():
+        seq, slp = model.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"sample_max": 1})
+    if name.startswith("beam"):
+        ref_model = make_model(d, P=Pn, train=False)
+        with torch.no_grad():
+            rs, rl = ref_model.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"sample_max": 1})
+        want_seq, want_lp = rs.cpu().numpy(), rl.cpu().numpy()
+    else:
+        g = load_golden(name)
+        want_seq, want_lp = g["seq"], g["seqLogprobs"]
+    seq, slp = seq.cpu().numpy(), slp.cpu().numpy()
+    assert seq.shape == want_seq.shape
+    assert np.array_equal(seq, want_seq), np.argwhere(seq != want_seq)
+    np.testing.assert_allclose(slp, want_lp, atol=3e-4)
+
+
+def test_split_bf16_raw_step_equals_exact_fp32_step():
+    """xg_step_fwd at 128 rows (the benchmarked launch group) in gemm_mode 3 against gemm_mode 0: new state within 2e-6."""
+    from controllable_xgating_amd import _native as nv
+    from controllable_xgating_amd.model import _stream, _ws_ptr
+    import ctypes as C
+    d = pg.make_dims(**dict(CFG["c1"], B=128))
+    Pn = pg.make_params(d)
+    x = to_dev(pg.make_inputs(d, seed=0))
+    outs = []
+    for precision in ("fp32", "bf16x3"):
+        model = make_model(d, P=Pn, train=False, precision=precision)
+        with torch.no_grad():
+            V = model.encode(x["feats_rgb"], x["feats_opfl"], x["feat_mask"])
+            st = model.init_hidden(V, x["feat_mask"])
+            state = torch.cat([st[0][0], st[0][1], st[1][0], st[1][1]], 0).contiguous()
+            dd = model._dims(d.B, d.K, 1)
+            ps, run = model._params_struct(), model._run(False)
+            vproj = torch.empty(d.B, d.K, model.att_size, device="cuda")
+            nv.check(nv.lib().xg_vproj(_stream(), C.byref(dd), C.byref(ps), nv.ptr(V), nv.ptr(vproj), C.byref(run)), "xg_vproj")
+            ws = model._pool.shared(dd, V.device)
+            wp, wn = _ws_ptr(ws)
+            tok = x["seq"][:, 1].contiguous()
+            for _ in range(3):
+                nv.check(nv.lib().xg_step_fwd(_stream(), C.byref(dd), C.byref(ps), nv.ptr(tok), None, nv.ptr(V), nv.ptr(vproj),
+                                              nv.ptr(x["pos_feats"]), C.byref(run), 0, wp, wn, nv.ptr(state), None, None), "xg_step_fwd")
+            torch.cuda.synchronize()
+        outs.append(state.cpu().numpy())
+    np.testing.assert_allclose(outs[1], outs[0], atol=5e-6, rtol=0)

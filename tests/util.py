@@ -47,9 +47,9 @@ def header_symbols():
     return sorted(set(re.findall(r"\b(xg_[a-z_0-9]+)\s*\(", txt)))
 
 
-def make_model(d, P=None, device="cuda", p_drop=0.0, train=True):
+def make_model(d, P=None, device="cuda", p_drop=0.0, train=True, precision="fp32"):
     from controllable_xgating_amd import SAModel, make_opt
-    model = SAModel(make_opt(d, drop_prob_lm=p_drop))
+    model = SAModel(make_opt(d, drop_prob_lm=p_drop, precision=precision))
     if P is None:
         P = pg.make_params(d)
     missing = model.load_state_dict({k: torch.from_numpy(v) for k, v in P.items()}, strict=False)
