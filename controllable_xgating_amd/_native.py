@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("XG_LIBRARY") or os.path.join(_HERE, "lib", "libxgate_hip.so")
 LIB_DIAG_PATH = os.path.join(_HERE, "lib", "libxgate_hip_diag.so")
 
-XG_VERSION = 204                      # include/xgate.h
+XG_VERSION = 205                      # include/xgate.h
 XG_ROLLOUT_GREEDY, XG_ROLLOUT_SAMPLE, XG_ROLLOUT_REPLAY = 0, 1, 2
 
 
@@ -100,6 +100,7 @@ def lib():
         "xg_rollout_pair": [vp, PD, PP, PB, PX, PR, i32, vp, f32, vp, C.c_size_t, vp, vp, vp],
         "xg_rollout_compact": [vp, PD, vp, C.c_size_t, PD, vp, C.c_size_t],
         "xg_rollout_pair_compact": [vp, PD, PP, PB, PX, PR, i32, vp, f32, vp, C.c_size_t, PD, vp, C.c_size_t, vp, vp, vp],
+        "xg_rollout_pair_videos": [vp, PD, PP, PB, PX, PR, vp, f32, vp, C.c_size_t, PD, vp, C.c_size_t, i32, vp, vp, vp],
         "xg_nll_fwd": [vp, vp, vp, vp, vp, i32, i32, i32, i32, vp],
         "xg_nll_bwd": [vp, vp, vp, vp, i32, i32, i32, i32, vp, f32, vp, vp],
         "xg_clip_adam": [vp, i64, vp, vp, vp, vp, f32, f32, f32, f32, f32, i32, f32],

@@ -1659,15 +1659,41 @@ extern "C" int xg_xe_loss_bwd(void* stream, const XgDims* d, const XgParams* p, 
 // logits_alt (paired rollout whose sampled half will be compacted for the backward): the raw logits of rows [0, split) go there,
 // (T - 1) blocks of `split` rows, instead of into this workspace -- they are two thirds of what a compaction would copy.  Only the
 // tile-statistics path writes row subsets: *used_alt tells the caller whether it happened.
+// shared (paired rollout over the SAME videos, xg_rollout_pair_videos): `x` holds the d1->B = B / 2 videos once; the encoder,
+// v2a(V) and the initial state are computed ONCE, in the workspace `enc` of the un-repeated batch (where the backward of the
+// sampled half reads them), and row-repeated into this workspace for the 2m-row decoder loop -- half the encoder work of the
+// repeated batch, no repeated inputs, and BatchNorm sees the m-row batch exactly as the reference's two sample() calls do
+// (two running-statistics updates with the same batch statistics, SAModel.py:169 called twice: starttrain.py:131, myutils.py:45).
 static int rollout_impl(hipStream_t st, const XgDims* d, const XgParams* p, const XgBnState* bn, const XgBatch* x,
                         const XgRun* run, int mode, const float* uniforms, const int64_t* forced, float temperature, Ws& w,
                         int64_t* seq, float* seq_logp, int32_t* n_steps, int split, float* logits_alt = nullptr,
-                        bool* used_alt = nullptr) {
+                        bool* used_alt = nullptr, const XgDims* d1 = nullptr, Ws* enc = nullptr) {
     const int B = d->B, R = d->R, E = d->E, A = d->A, T = d->T;
     const size_t BR = (size_t)B * R;
     Streams es(st, run);
-    XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w, &es));
-    XG_TRY(init_and_vproj(es, *d, *p, x->feat_mask, w));
+    const float* pos_rows = x->pos_feats;
+    if (enc) {
+        const size_t B1 = d1->B, N1 = B1 * d->K;
+        XG_TRY(encoder_fwd(st, *d1, *p, bn, *x, *run, *enc, &es));
+        if (run->train && bn && bn->rgb_mean && bn->rgb_var && bn->opfl_mean && bn->opfl_var) {      // the second sample() call's update
+            XG_TRY(xgk_bn_running(st, enc->bn_mean[0], enc->bn_var[0], bn->rgb_mean, bn->rgb_var, (int)N1, R, run->bn_momentum));
+            XG_TRY(xgk_bn_running(st, enc->bn_mean[1], enc->bn_var[1], bn->opfl_mean, bn->opfl_var, (int)N1, R, run->bn_momentum));
+        }
+        XG_TRY(init_and_vproj(es, *d1, *p, x->feat_mask, *enc));
+        CompactArgs ca{};
+        auto twice = [&](float* dst, const float* src, size_t n) {
+            ca.e[ca.n++] = CompactEntry{dst, src, (int64_t)n, (int64_t)n, (int64_t)n};
+            ca.e[ca.n++] = CompactEntry{dst + n, src, (int64_t)n, (int64_t)n, (int64_t)n};
+        };
+        twice(w.Venc, enc->Venc, N1 * R); twice(w.vproj, enc->vproj, N1 * A);
+        twice(w.H1, enc->H1, B1 * R); twice(w.C1, enc->C1, B1 * R); twice(w.H2, enc->H2, B1 * R); twice(w.C2, enc->C2, B1 * R);
+        twice(w.DPOSG, x->pos_feats, B1 * R);          // (a backward-only buffer: this workspace never runs a backward)
+        XG_TRY(xgk_compact(st, ca));
+        pos_rows = w.DPOSG;
+    } else {
+        XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w, &es));
+        XG_TRY(init_and_vproj(es, *d, *p, x->feat_mask, w));
+    }
     XG_TRY(zero_dsync(st, w));
     if (hipMemsetAsync(w.alive, 0, sizeof(int32_t) * 4, st) != hipSuccess) return XG_EHIP;   // alive[i] = running max finishing step
     if (run->prof_event0 && hipEventRecord(static_cast<hipEvent_t>(run->prof_event0), st) != hipSuccess) return XG_EHIP;
@@ -1701,7 +1727,7 @@ static int rollout_impl(hipStream_t st, const XgDims* d, const XgParams* p, cons
         float* gp = w.GP + t * BR;
         float* posg = w.POSG + t * BR;
         StepIO s{};
-        s.xt = xt; s.pos = x->pos_feats; s.gp = gp; s.posg = posg; s.pre1 = nullptr; s.mask = unf; s.ldm = 1;
+        s.xt = xt; s.pos = pos_rows; s.gp = gp; s.posg = posg; s.pre1 = nullptr; s.mask = unf; s.ldm = 1;
         s.h1 = w.H1 + t * BR; s.c1 = w.C1 + t * BR; s.h2 = w.H2 + t * BR; s.c2 = w.C2 + t * BR;
         s.h1o = w.H1 + (t + 1) * BR; s.c1o = w.C1 + (t + 1) * BR; s.h2o = w.H2 + (t + 1) * BR; s.c2o = w.C2 + (t + 1) * BR;
         s.P = w.P + (size_t)t * B * A; s.alpha = w.ALPHA + (size_t)t * B * d->K; s.af = w.AF + t * BR;
@@ -1746,7 +1772,7 @@ extern "C" int xg_rollout_pair(void* stream, const XgDims* d2, const XgParams* p
 
 // Everything xg_rollout_bwd reads, for the FIRST d1->B rows of a rollout that ran over d2->B >= d1->B rows: encoder-side
 // tensors are row prefixes, decoder-side tensors are per-step blocks (pitch B2 -> B1).
-static int compact_impl(hipStream_t st, const XgDims* d2, const Ws& a, const XgDims* d1, Ws& b, bool skip_logits) {
+static int compact_impl(hipStream_t st, const XgDims* d2, const Ws& a, const XgDims* d1, Ws& b, bool skip_logits, bool skip_encoder = false) {
     if (d1->B > d2->B || d1->K != d2->K || d1->R != d2->R || d1->A != d2->A || d1->E != d2->E || d1->V != d2->V ||
         d1->T != d2->T || d1->F1 != d2->F1 || d1->F2 != d2->F2 || d1->C != d2->C || d1->H != d2->H) return XG_EINVAL;
     const size_t B1 = d1->B, B2 = d2->B, K = d1->K, R = d1->R, A = d1->A, E = d1->E, V = d1->V, T = d1->T, N1 = B1 * K;
@@ -1762,14 +1788,16 @@ static int compact_impl(hipStream_t st, const XgDims* d2, const Ws& a, const XgD
                                     (int64_t)(B2 * width_floats), (int64_t)(B1 * width_floats * nblocks)};
         return XG_OK;
     };
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < 2 && !skip_encoder; ++m) {    // (skip_encoder: the encoder ran in `b` itself, xg_rollout_pair_videos)
         XG_TRY(prefix(b.Z[m], a.Z[m], N1 * R)); XG_TRY(prefix(b.X[m], a.X[m], N1 * R)); XG_TRY(prefix(b.PRE[m], a.PRE[m], N1 * 4 * R));
         XG_TRY(prefix(b.Hs[m], a.Hs[m], N1 * R)); XG_TRY(prefix(b.Cs[m], a.Cs[m], N1 * R)); XG_TRY(prefix(b.G[m], a.G[m], N1 * 4 * R));
         XG_TRY(prefix(b.GG[m], a.GG[m], N1 * R)); XG_TRY(prefix(b.Hprev[m], a.Hprev[m], N1 * R));
         XG_TRY(prefix(b.bn_mean[m], a.bn_mean[m], R)); XG_TRY(prefix(b.bn_var[m], a.bn_var[m], R));
     }
-    XG_TRY(prefix(b.Y, a.Y, N1 * 2 * R)); XG_TRY(prefix(b.Venc, a.Venc, N1 * R)); XG_TRY(prefix(b.vbar, a.vbar, B1 * R));
-    XG_TRY(prefix(b.vproj, a.vproj, N1 * A));
+    if (!skip_encoder) {
+        XG_TRY(prefix(b.Y, a.Y, N1 * 2 * R)); XG_TRY(prefix(b.Venc, a.Venc, N1 * R)); XG_TRY(prefix(b.vbar, a.vbar, B1 * R));
+        XG_TRY(prefix(b.vproj, a.vproj, N1 * A));
+    }
     XG_TRY(blocks(b.Xe, a.Xe, E, T)); XG_TRY(blocks(b.GP, a.GP, R, T)); XG_TRY(blocks(b.POSG, a.POSG, R, T));
     XG_TRY(blocks(b.H1, a.H1, R, T + 1)); XG_TRY(blocks(b.C1, a.C1, R, T + 1));
     XG_TRY(blocks(b.H2, a.H2, R, T + 1)); XG_TRY(blocks(b.C2, a.C2, R, T + 1));
@@ -1810,6 +1838,29 @@ extern "C" int xg_rollout_pair_compact(void* stream, const XgDims* d2, const XgP
     XG_TRY(rollout_impl((hipStream_t)stream, d2, p, bn, x2, run, XG_ROLLOUT_SAMPLE, uniforms, nullptr, temperature, w, seq, seq_logp,
                         n_steps, n_sample, b.LOGITS, &used_alt));
     return compact_impl((hipStream_t)stream, d2, w, d1, b, used_alt);
+}
+
+extern "C" int xg_rollout_pair_videos(void* stream, const XgDims* d2, const XgParams* p, const XgBnState* bn, const XgBatch* x1,
+                                      const XgRun* run, const float* uniforms, float temperature, void* ws2, size_t ws2_bytes,
+                                      const XgDims* d1, void* ws1, size_t ws1_bytes, int compact, int64_t* seq, float* seq_logp,
+                                      int32_t* n_steps) {
+    Ws w, b;
+    XG_TRY(check(d2, ws2, ws2_bytes, &w));
+    XG_TRY(check(d1, ws1, ws1_bytes, &b));
+    if (!p || !x1 || !run || !seq || !seq_logp || !n_steps || !x1->pos_feats || !x1->feats_rgb || !x1->feats_opfl || !x1->feat_mask ||
+        d2->T < 2) return XG_EINVAL;
+    if (d2->B != 2 * d1->B || !uniforms || !(temperature > 0.f) || ws1 == ws2) return XG_EINVAL;
+    if (d1->K != d2->K || d1->R != d2->R || d1->A != d2->A || d1->E != d2->E || d1->V != d2->V || d1->T != d2->T ||
+        d1->F1 != d2->F1 || d1->F2 != d2->F2 || d1->C != d2->C || d1->H != d2->H) return XG_EINVAL;
+    w.gm = (run->gemm_mode == 1 || run->gemm_mode == 3) ? run->gemm_mode : 0;
+    b.gm = w.gm;
+    attach_packed(w, *d2, run);
+    attach_packed(b, *d1, run);
+    bool used_alt = false;
+    XG_TRY(rollout_impl((hipStream_t)stream, d2, p, bn, x1, run, XG_ROLLOUT_SAMPLE, uniforms, nullptr, temperature, w, seq, seq_logp,
+                        n_steps, d1->B, compact ? b.LOGITS : nullptr, &used_alt, d1, &b));
+    if (!compact) return XG_OK;
+    return compact_impl((hipStream_t)stream, d2, w, d1, b, used_alt, true);
 }
 
 extern "C" int xg_rollout_bwd(void* stream, const XgDims* d, const XgParams* p, const XgParams* g, const XgBatch* x,

@@ -390,12 +390,12 @@ class SAModel(nn.Module):
         b.seq_mask = keep[5].data_ptr() if keep[5] is not None else None
         return b, keep
 
-    def _bump_bn(self):
+    def _bump_bn(self, n=1):
         if self.training:
             ts = [m.num_batches_tracked for m in (self.two_spatial_encoder.visual_emb_rgb[1], self.two_spatial_encoder.visual_emb_opfl[1])
                   if m.num_batches_tracked is not None]
             if ts:
-                torch._foreach_add_(ts, 1)          # (one launch for both counters)
+                torch._foreach_add_(ts, n)          # (one launch for both counters)
 
     # ------------------------------------------------------------------ reference surface
     def forward(self, feats_rgb, feats_opfl, feat_mask, pos_feats, seq, seq_mask):
@@ -433,30 +433,8 @@ class SAModel(nn.Module):
         temperature = float(opt.get("temperature", 1.0))
         params = self._param_list()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
-        bns = [self.two_spatial_encoder.visual_emb_rgb[1], self.two_spatial_encoder.visual_emb_opfl[1]]
-        r0 = [(m.running_mean.clone(), m.running_var.clone()) for m in bns] if self.training else None
-        out = _RolloutPairFunction.apply(self, feats_rgb, feats_opfl, feat_mask, pos_feats, opt.get("uniforms", None),
-                                         temperature, need_grad, *params)
-        if r0 is not None:
-            # the library saw ONE batch of 2N repeated rows: same mean and biased variance as the N-row batch, but its
-            # running_var took the unbiased factor 2N/(2N-1) instead of N/(N-1), and only one momentum update was made
-            rows = feats_rgb.shape[0] * feats_rgb.shape[1]
-            with torch.no_grad():
-                keep = 1.0 - bns[0].momentum
-                if rows > 1:
-                    c = (2.0 * rows - 1.0) / (2.0 * rows - 2.0)
-                    rv, rv0 = [m.running_var for m in bns], [pair[1] for pair in r0]
-                    torch._foreach_mul_(rv, c)                              # (rv - keep rv0) c + keep rv0
-                    torch._foreach_add_(rv, rv0, alpha=keep * (1.0 - c))
-                # second update with the same batch statistics s:  r2 = keep r1 + momentum s = (1 + keep) r1 - keep r0
-                cur = [t for m in bns for t in (m.running_mean, m.running_var)]
-                old = [t for pair in r0 for t in pair]
-                torch._foreach_mul_(cur, 1.0 + keep)
-                torch._foreach_add_(cur, old, alpha=-keep)
-                for m in bns:
-                    if m.num_batches_tracked is not None:
-                        m.num_batches_tracked += 1
-        return out
+        return _RolloutPairFunction.apply(self, feats_rgb, feats_opfl, feat_mask, pos_feats, opt.get("uniforms", None),
+                                          temperature, need_grad, *params)
 
     def init_hidden(self, feat, feat_mask):
         """SAModel.init_hidden (SAModel.py:58-65) -> [(h1,c1),(h2,c2)], each (1,m,R)."""
@@ -733,11 +711,12 @@ class _RolloutPairFunction(torch.autograd.Function):
         d1, d2 = model._dims(B, K, T), model._dims(2 * B, K, T)
         ws2 = model._pool.shared(d2, dev)
         wp2, wn2 = _ws_ptr(ws2)
+        # the videos are handed over ONCE: the library runs the encoder on the m-row batch and repeats V / v2a(V) / the
+        # initial state on the device (xg_rollout_pair_videos) -- no torch.cat of the inputs, half the encoder work
         fm = feat_mask
         if fm.dim() == 1:
             fm = fm.unsqueeze(0).expand(B, K)
-        b2, keep2 = model._batch(torch.cat([feats_rgb, feats_rgb]), torch.cat([feats_opfl, feats_opfl]), torch.cat([fm, fm]),
-                                 torch.cat([pos_feats, pos_feats]))
+        b1, keep1 = model._batch(feats_rgb, feats_opfl, fm, pos_feats)
         seq = torch.zeros(2 * B, T - 1, dtype=torch.int64, device=dev)
         slp = torch.zeros(2 * B, T - 1, dtype=torch.float32, device=dev)
         n = torch.zeros(2, dtype=torch.int32, device=dev)
@@ -745,20 +724,16 @@ class _RolloutPairFunction(torch.autograd.Function):
             uniforms = torch.rand(T, B, device=dev, dtype=torch.float32)
         uniforms = uniforms.detach().contiguous().float()
         ps, bn, run = model._params_struct(), model._bn_struct(), model._run(need_grad)
-        ws1 = None
-        if need_grad:
-            # rollout + compaction of the sampled half into an m-row workspace (what the backward reads) as one call: the sampled
-            # rows' logits -- two thirds of the compaction's bytes -- are written there by the rollout itself
-            ws1 = model._pool.take(d1, dev)
-            wp1, wn1 = _ws_ptr(ws1)
-            nv.check(nv.lib().xg_rollout_pair_compact(_stream(), C.byref(d2), C.byref(ps), C.byref(bn), C.byref(b2), C.byref(run), B,
-                                                      nv.ptr(uniforms), temperature, wp2, wn2, C.byref(d1), wp1, wn1, nv.ptr(seq),
-                                                      nv.ptr(slp), nv.ptr(n)), "xg_rollout_pair_compact")
-        else:
-            nv.check(nv.lib().xg_rollout_pair(_stream(), C.byref(d2), C.byref(ps), C.byref(bn), C.byref(b2), C.byref(run), B,
-                                              nv.ptr(uniforms), temperature, wp2, wn2, nv.ptr(seq), nv.ptr(slp), nv.ptr(n)),
-                     "xg_rollout_pair")
-        model._bump_bn()
+        # rollout + compaction of the sampled half into the m-row workspace (what the backward reads) as one call: the encoder
+        # runs there in the first place, and the sampled rows' logits are written there by the rollout itself
+        ws1 = model._pool.take(d1, dev) if need_grad else model._pool.shared(d1, dev)
+        wp1, wn1 = _ws_ptr(ws1)
+        nv.check(nv.lib().xg_rollout_pair_videos(_stream(), C.byref(d2), C.byref(ps), C.byref(bn), C.byref(b1), C.byref(run),
+                                                 nv.ptr(uniforms), temperature, wp2, wn2, C.byref(d1), wp1, wn1, 1 if need_grad else 0,
+                                                 nv.ptr(seq), nv.ptr(slp), nv.ptr(n)), "xg_rollout_pair_videos")
+        if not need_grad:
+            ws1 = None
+        model._bump_bn(2)                         # two sample() calls of the reference: two running-statistics updates (in the library)
         ctx.model, ctx.d, ctx.ws, ctx.run, ctx.need_grad = model, d1, ws1, run, need_grad
         ctx.keep = (feats_rgb, feats_opfl, feat_mask, pos_feats)
         gen, greedy = seq[:B], seq[B:]

@@ -40,9 +40,10 @@
 extern "C" {
 #endif
 
-#define XG_VERSION 204   /* 200: XgRun gained packed/aux/event fields, xg_set_grad_event removed, xg_vproj takes XgRun;
+#define XG_VERSION 205   /* 200: XgRun gained packed/aux/event fields, xg_set_grad_event removed, xg_vproj takes XgRun;
                             201: + xg_clip_adam_zero; 202: XgRun.prof_event0/1, xg_adam_tick, xg_clip_adam_dev;
-                            203: + xg_rollout_pair_compact; 204: + xg_abi_check */
+                            203: + xg_rollout_pair_compact; 204: + xg_abi_check;
+                            205: + xg_rollout_pair_videos */
 
 enum {
     XG_OK = 0,
@@ -277,6 +278,16 @@ int xg_rollout_pair_compact(void *stream, const XgDims *d2, const XgParams *p, c
                             const XgBatch *x2, const XgRun *run, int n_sample, const float *uniforms,
                             float temperature, void *ws2, size_t ws2_bytes, const XgDims *d1, void *ws1,
                             size_t ws1_bytes, int64_t *seq, float *seq_logp, int32_t *n_steps);
+/* The same SCST pair over the SAME videos without repeating them: x1 holds the m = d1->B videos once (d2->B = 2 m; rows
+ * [0, m) of the outputs sample, rows [m, 2m) decode greedily).  The CG encoder, v2a(V) and the initial state are computed once,
+ * in ws1 (the workspace of the un-repeated batch), and row-repeated on the device for the 2m-row decoder loop; in train mode
+ * the BatchNorm running statistics receive the reference's TWO updates with the m-row batch statistics (one per sample()
+ * call: caption_src/starttrain.py:131, caption_src/myutils.py:45).  compact != 0: ws1 is left as xg_rollout_pair_compact
+ * leaves it (xg_rollout_bwd(d1, ws1) is the backward of the sampled rollout); compact = 0: ws1 only hosts the encoder. */
+int xg_rollout_pair_videos(void *stream, const XgDims *d2, const XgParams *p, const XgBnState *bn, const XgBatch *x1,
+                           const XgRun *run, const float *uniforms, float temperature, void *ws2, size_t ws2_bytes,
+                           const XgDims *d1, void *ws1, size_t ws1_bytes, int compact, int64_t *seq, float *seq_logp,
+                           int32_t *n_steps);
 /* Backward of a rollout run with run->save = 1, given d(seq_logp) (B,T-1)
  * (RewardCriterion, caption_src/SAModel.py:259-267; caption_src/starttrain.py:131-134). */
 int xg_rollout_bwd(void *stream, const XgDims *d, const XgParams *p, const XgParams *g,

@@ -1565,3 +1565,37 @@ def test_split_bf16_raw_step_equals_exact_fp32_step():
             torch.cuda.synchronize()
         outs.append(state.cpu().numpy())
     np.testing.assert_allclose(outs[1], outs[0], atol=5e-6, rtol=0)
+
+
+def test_paired_rollout_over_videos_equals_the_repeated_batch_entry_point():
+    """xg_rollout_pair_videos (the m videos handed over once, encoder run once, BatchNorm updated twice in the library) against
+    xg_rollout_pair on the caller-repeated 2m-row batch: same tokens, same log-probs, same early-exit widths."""
+    import ctypes as C
+    from controllable_xgating_amd import _native as nv
+    from controllable_xgating_amd.model import _stream, _ws_ptr
+    d = pg.make_dims(**CFG["mid"])
+    Pn = pg.make_params(d, logit_gain=1.0)
+    x = to_dev(pg.make_inputs(d, seed=0, ragged=True))
+    u = torch.from_numpy(pg.uniform("uni2", (d.L + 1, d.B), 78)).cuda()
+    model = make_model(d, P=Pn, train=True)
+    with torch.no_grad():
+        gen, slp, greedy, n = model.sample_pair(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"uniforms": u})
+    torch.cuda.synchronize()
+    ref = make_model(d, P=Pn, train=True)
+    B, T = d.B, d.L + 1
+    d2 = ref._dims(2 * B, d.K, T)
+    ws2 = ref._pool.shared(d2, x["feats_rgb"].device)
+    wp2, wn2 = _ws_ptr(ws2)
+    b2, keep = ref._batch(torch.cat([x["feats_rgb"]] * 2), torch.cat([x["feats_opfl"]] * 2), torch.cat([x["feat_mask"]] * 2),
+                          torch.cat([x["pos_feats"]] * 2))
+    seq = torch.zeros(2 * B, T - 1, dtype=torch.int64, device="cuda")
+    lp = torch.zeros(2 * B, T - 1, dtype=torch.float32, device="cuda")
+    nn_ = torch.zeros(2, dtype=torch.int32, device="cuda")
+    ps, run = ref._params_struct(), ref._run(False)
+    nv.check(nv.lib().xg_rollout_pair(_stream(), C.byref(d2), C.byref(ps), C.byref(nv.XgBnState()), C.byref(b2), C.byref(run), B,
+                                      nv.ptr(u), 1.0, wp2, wn2, nv.ptr(seq), nv.ptr(lp), nv.ptr(nn_)), "xg_rollout_pair")
+    torch.cuda.synchronize()
+    assert torch.equal(n.cpu(), nn_.cpu())
+    w = int(n[0]), int(n[1])
+    assert torch.equal(seq[:B, :w[0]].cpu(), gen[:, :w[0]].cpu()) and torch.equal(seq[B:, :w[1]].cpu(), greedy[:, :w[1]].cpu())
+    np.testing.assert_allclose(lp[:B, :w[0]].cpu().numpy(), slp[:, :w[0]].cpu().numpy(), atol=2e-6)
