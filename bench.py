@@ -219,6 +219,50 @@ def _cpu_baseline_once(cfg, d, Pn, budget_s):
                 ms_per_step=round(dt * 1e3, 1), loss=loss0)
 
 
+def pin_host_thread(local_rank, world):
+    """One training process enqueues ~350 launches per iteration (2 ms of host time); eight of them on one host must not share
+    cores.  Pin this rank's process to its own slice of the cores it may use (os.sched_setaffinity by LOCAL_RANK), unless the
+    launcher already narrowed the affinity (then keep it).  Returns the core list in use (reported per rank in comm.per_rank)."""
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        if os.environ.get("XG_NO_PIN") is not None or len(allowed) < 2 * max(world, 1):
+            return allowed
+        per = max(2, len(allowed) // max(world, 1))
+        mine = allowed[local_rank * per:(local_rank + 1) * per] or allowed
+        os.sched_setaffinity(0, mine)
+        torch.set_num_threads(max(1, min(len(mine), 8)))
+        return mine
+    except Exception:                            # (not Linux / not permitted: run unpinned)
+        return None
+
+
+def core_ranges(cores):
+    """[0, 1, 2, 3, 8, 9] -> '0-3,8-9' (None stays None)."""
+    if not cores:
+        return None
+    cores = sorted(cores)
+    out, a, b = [], cores[0], cores[0]
+    for c in cores[1:]:
+        if c == b + 1:
+            b = c
+            continue
+        out.append("%d-%d" % (a, b) if b > a else str(a))
+        a = b = c
+    out.append("%d-%d" % (a, b) if b > a else str(a))
+    return ",".join(out)
+
+
+def cap_rccl_channels():
+    """RCCL's collectives run as kernels that need CUs; during the backward every CU also hosts one workgroup of a persistent
+    background product and the latency-bound chain kernels.  A ring all-reduce over xGMI is link-bound (7 links x ~153 GB/s per
+    GPU), not CU-bound: 16 channels (= 16 workgroups) are enough to keep the links busy and leave the rest of the chip to the
+    backward.  Only set when the user has not chosen (NCCL_MAX_NCHANNELS); reported with the scaling line."""
+    if "NCCL_MAX_NCHANNELS" not in os.environ and os.environ.get("XG_NO_RCCL_CAP") is None:
+        os.environ["NCCL_MAX_NCHANNELS"] = "16"
+        return {"NCCL_MAX_NCHANNELS": "16", "set_by": "bench.py (XG_NO_RCCL_CAP=1 leaves RCCL's default)"}
+    return {"NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"), "set_by": "environment"}
+
+
 def rccl_debug_setup(rank):
     """Ask RCCL for its INIT log in a private file (unless the user already directs NCCL_DEBUG somewhere) so that the channel
     count of the communicator can be reported with the scaling line."""
@@ -420,14 +464,27 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
             finally:
                 tr._SKIP_COLLECTIVE = False
             broadcast_parameters(model)           # (replicas diverged without the collective: back to rank 0's)
+            # host side of THIS rank: the loop's wall time per iteration (enqueue + queue back-pressure) and the enqueue cost of one
+            # iteration against an idle GPU -- with N ranks on one host these show at once whether a rank is host-bound
+            enq_r = []
+            for _ in range(3):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                step()
+                enq_r.append(time.perf_counter() - t1)
+            torch.cuda.synchronize()
             mine = {"rank": rank, "ms_per_step": round(dt_own / steps * 1e3, 3), "ms_per_step_no_collective": round(dt_nc / steps * 1e3, 3),
-                    "exposed_comm_ms": round((dt_own - dt_nc) / steps * 1e3, 3)}
+                    "exposed_comm_ms": round((dt_own - dt_nc) / steps * 1e3, 3),
+                    "host_loop_ms_per_step": round(t_enq * 1e3 / steps, 3),
+                    "host_enqueue_ms_per_step": round(sorted(enq_r)[1] * 1e3, 3),
+                    "host_cores": core_ranges(ctx.get("cores"))}
             allr = [None] * world
             dist.all_gather_object(allr, mine)
             comm = {"per_rank": allr, "gradient_bytes": int(model.flat_grads().numel() * 4), "schedule": comm_choice,
                     "buckets": "logit | lstmcore+embed+img_embed | classifer | two_spatial_encoder (train.GradSync)"
                                if (sync is not None and state["overlap_comm"]) else "one",
                     "rccl_channels": rccl_channels(ctx.get("rccl_log")) if ctx.get("rccl_log") else None,
+                    "rccl_channel_cap": ctx.get("rccl_cap"),
                     "rccl_version": ".".join(str(v) for v in torch.cuda.nccl.version())}
         except Exception as e:                    # never lose the scaling line over the diagnosis
             comm = {"error": repr(e)}
@@ -635,7 +692,10 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     use_dist = world > 1 or os.environ.get("XG_FORCE_DIST") in ("1", "2")    # XG_FORCE_DIST: exercise the RCCL path on one GPU
-    ctx = dict(world=world, rank=rank, dev=dev, use_dist=use_dist, rccl_log=None)
+    ctx = dict(world=world, rank=rank, dev=dev, use_dist=use_dist, rccl_log=None, cores=None, rccl_cap=None)
+    if use_dist:
+        ctx["cores"] = pin_host_thread(local, world)
+        ctx["rccl_cap"] = cap_rccl_channels()
     if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
