@@ -1128,8 +1128,7 @@ int xgk_gemm_cs(hipStream_t st, int mode, bool transA, bool transB, int M, int N
     mode &= ~XGK_GEMM_BG;
     // large products may run on the bf16 matrix cores (split-bf16 or plain bf16); skinny / tiny ones stay fp32
     if ((mode == 1 || mode == 3) && M >= 256 && N >= 64 && K >= 64) {
-        XG_TRY(xgk_gemm_bf16(st, mode, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate));
-        return want_cs ? xgk_colsum3(st, A, lda, K, M, cs1, cs2, cs3) : XG_OK;
+        return xgk_gemm_bf16(st, mode, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, cs1, cs2, cs3);
     }
     GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1, 0, 1, bg, {nullptr, nullptr, nullptr}};
     const bool akc = !transA;   // A (M,K) row-major -> k contiguous
@@ -1157,8 +1156,7 @@ int xgk_gemm_x(hipStream_t st, int mode, bool transA, bool transB, int M, int N,
                bool accumulate, float* cs1, float* cs2, float* cs3) {
     if ((mode & ~XGK_GEMM_BG) == 1 && (A16 || B16) && M >= 256 && N >= 64 && K >= 64) {
         if (cs1 && !transA) return XG_EINVAL;
-        XG_TRY(xgk_gemm_bf16x(st, 1, transA, transB, M, N, K, A, A16, lda, B, B16, ldb, C, ldc, bias, relu, accumulate));
-        return cs1 ? xgk_colsum3(st, A, lda, K, M, cs1, cs2, cs3) : XG_OK;
+        return xgk_gemm_bf16x(st, 1, transA, transB, M, N, K, A, A16, lda, B, B16, ldb, C, ldc, bias, relu, accumulate, cs1, cs2, cs3);
     }
     return xgk_gemm_cs(st, mode, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, cs1, cs2, cs3);
 }

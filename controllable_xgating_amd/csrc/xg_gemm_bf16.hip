@@ -38,6 +38,10 @@ struct BArgs {
     // operands that ALREADY ARE bf16 in memory (same shape / layout, lda / ldb in elements): loaded 16 bytes = 8 elements at a
     // time and stored into the LDS image as they are -- half the operand bytes from L2, no convert (NP = 1 kernels only)
     const unsigned short* A16; const unsigned short* B16;
+    // weight-gradient layout only (A m-contiguous = dY^T): csum[q][m] += sum_k A(k, m) for up to three accumulators -- the bias
+    // gradient(s) of the same dY, formed by the tn == 0 tiles from the A slabs they stream anyway (as xg_gemm.hip's fp32
+    // kernels do; round 4: no separate column-reduction pass over dY in the bf16 / split-bf16 modes either)
+    float* csum[3];
 };
 
 constexpr int LDMC = BM + 16;      // [k][m] image of an m-contiguous operand: row stride in bf16 (288 B: the 4 k rows of a
@@ -299,15 +303,55 @@ __global__ void __launch_bounds__(256) gemm_bs_kernel(BArgs g) {
                 }
         }
     };
+    // column sums of the A slabs (see BArgs::csum): per thread the rows it loads -- 8 (bf16 operand), 4 (16-byte fp32 loads) or 1
+    constexpr int CSN = AKC ? 1 : (A16 ? 8 : (VEC ? 4 : 1));
+    const bool cs_on = !AKC && g.csum[0] != nullptr && tn == 0;
+    float csv[CSN];
+#pragma unroll
+    for (int e = 0; e < CSN; ++e) csv[e] = 0.f;
     {
     f32x4 ra[A16 ? 1 : 4], rb[B16 ? 1 : 4];
     uint4 ha[2], hb[2];
+    auto cs_add = [&](int s, bool edge) {        // (loads are clamped at the edges: duplicates there are masked out here)
+        if constexpr (!AKC) {
+            const int t = threadIdx.x;
+            if constexpr (A16) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int f = t + 256 * i, k = f >> 4, r = (f & 15) << 3;
+                    const unsigned wds[4] = {ha[i].x, ha[i].y, ha[i].z, ha[i].w};
+                    const bool kok = !edge || s * BK + k < g.K;
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float v = __uint_as_float((j & 1) ? (wds[j >> 1] & 0xFFFF0000u) : (wds[j >> 1] << 16));
+                        if (kok && (!edge || m0 + r + j < g.M)) csv[j] += v;
+                    }
+                }
+            } else if constexpr (VEC) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const int f = t + 256 * i, k = f >> 5, r = (f & 31) << 2;
+                    const bool kok = !edge || s * BK + k < g.K;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (kok && (!edge || m0 + r + j < g.M)) csv[j] += ra[i][j];
+                }
+            } else {
+                const int kb = (t >> 7) << 4;
+                const bool rok = m0 + (t & 127) < g.M;
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (rok && s * BK + kb + 4 * i + j < g.K) csv[0] += ra[i][j];
+            }
+        }
+    };
     auto loadA = [&](int s) { if constexpr (A16) load_tile16<AKC>(g.A16, g.lda, m0, s * BK, g.M, g.K, ha); else load_tile<AKC, VEC>(g.A, g.lda, m0, s * BK, g.M, g.K, ra); };
     auto loadB = [&](int s) { if constexpr (B16) load_tile16<BKC>(g.B16, g.ldb, n0, s * BK, g.N, g.K, hb); else load_tile<BKC, VEC>(g.B, g.ldb, n0, s * BK, g.N, g.K, rb); };
     loadA(s_begin); loadB(s_begin);
     for (int s = s_begin; s < s_end; ++s) {
         const bool ktail = (s + 1) * BK > g.K;
         __syncthreads();                                   // everyone is done reading the previous slab
+        if (cs_on) cs_add(s, edge_a || ktail);
         if constexpr (A16) store_tile16<AKC>(As, ha, m0, s * BK, g.M, g.K, edge_a || ktail);
         else store_tile<NP, AKC, VEC>(As, ra, m0, s * BK, g.M, g.K, edge_a || ktail);
         if constexpr (B16) store_tile16<BKC>(Bs, hb, n0, s * BK, g.N, g.K, edge_b || ktail);
@@ -316,6 +360,24 @@ __global__ void __launch_bounds__(256) gemm_bs_kernel(BArgs g) {
         if (s + 1 < s_end) { loadA(s + 1); loadB(s + 1); }   // next slab's loads fly under this slab's MFMAs
         slab_mfma(As, Bs);
     }
+    }
+    if constexpr (!AKC) {
+        if (cs_on) {                                       // (wave-uniform: the whole workgroup is in tile column 0 or not)
+            __syncthreads();                               // the staging area is free: [256][CSN] partial sums
+            float* red = reinterpret_cast<float*>(smem_bs);
+#pragma unroll
+            for (int e = 0; e < CSN; ++e) red[threadIdx.x * CSN + e] = csv[e];
+            __syncthreads();
+            const int r = threadIdx.x;
+            if (r < BM && m0 + r < g.M) {
+                float v = 0.f;
+                if constexpr (A16) { for (int j = 0; j < 16; ++j) v += red[((r >> 3) + 16 * j) * CSN + (r & 7)]; }
+                else if constexpr (VEC) { for (int j = 0; j < 8; ++j) v += red[((r >> 2) + 32 * j) * CSN + (r & 3)]; }
+                else { v = red[r] + red[r + 128]; }
+#pragma unroll
+                for (int o = 0; o < 3; ++o) if (g.csum[o]) unsafeAtomicAdd(g.csum[o] + m0 + r, v);
+            }
+        }
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -572,21 +634,24 @@ extern "C" int xg_gemm_bf16_operands(void* stream, int transA, int transB, int M
     if (M <= 0 || N <= 0) return XG_OK;
     if (K < 0 || !A || !B || !C) return XG_EINVAL;
     return xgk_gemm_bf16x((hipStream_t)stream, 1, transA != 0, transB != 0, M, N, K, A, static_cast<const unsigned short*>(A16), lda, B,
-                          static_cast<const unsigned short*>(B16), ldb, C, ldc, bias, relu != 0, accumulate != 0);
+                          static_cast<const unsigned short*>(B16), ldb, C, ldc, bias, relu != 0, accumulate != 0, nullptr, nullptr, nullptr);
 }
 
 // planes: 1 = bf16 compute, 3 = split-bf16 (fp32-class accuracy).  Only called for products large enough to tile.
 int xgk_gemm_bf16(hipStream_t st, int planes, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
-                  const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate) {
-    return xgk_gemm_bf16x(st, planes, transA, transB, M, N, K, A, nullptr, lda, B, nullptr, ldb, C, ldc, bias, relu, accumulate);
+                  const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate, float* cs1, float* cs2,
+                  float* cs3) {
+    return xgk_gemm_bf16x(st, planes, transA, transB, M, N, K, A, nullptr, lda, B, nullptr, ldb, C, ldc, bias, relu, accumulate, cs1, cs2, cs3);
 }
 
 // the same with optional bf16 copies of the operands (A16 / B16: same shape, layout and leading dimension as A / B, or null):
 // where one exists and is 16-byte loadable the kernel reads it instead of converting the fp32 operand on the fly
 int xgk_gemm_bf16x(hipStream_t st, int planes, bool transA, bool transB, int M, int N, int K, const float* A, const unsigned short* A16,
                    int lda, const float* B, const unsigned short* B16, int ldb, float* C, int ldc, const float* bias, bool relu,
-                   bool accumulate) {
-    BArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1, 1, nullptr, nullptr};
+                   bool accumulate, float* cs1, float* cs2, float* cs3) {
+    // (column sums are a side output of the weight-gradient layout only: transA)
+    if (cs1 && !transA) return XG_EINVAL;
+    BArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1, 1, nullptr, nullptr, {cs1, cs2, cs3}};
     const bool akc = !transA, bkc = transB;
     bool vec = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && (lda % 4 == 0) && (ldb % 4 == 0);
     vec = vec && ((akc ? K : M) % 4 == 0) && ((bkc ? K : N) % 4 == 0);

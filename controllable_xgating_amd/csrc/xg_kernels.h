@@ -29,11 +29,13 @@ int xgk_gemm_x(hipStream_t st, int mode, bool transA, bool transB, int M, int N,
                int lda, const float* B, const unsigned short* B16, int ldb, float* C, int ldc, const float* bias, bool relu,
                bool accumulate, float* cs1 = nullptr, float* cs2 = nullptr, float* cs3 = nullptr);
 // xg_gemm_bf16.hip: split-bf16 / bf16 arithmetic for large products (planes = 3 or 1)
+// cs1..cs3 (optional, weight-gradient layout transA only): column sums of A = the bias gradient(s) of the same dY, a side output
 int xgk_gemm_bf16(hipStream_t st, int planes, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
-                  const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate);
+                  const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate, float* cs1 = nullptr,
+                  float* cs2 = nullptr, float* cs3 = nullptr);
 int xgk_gemm_bf16x(hipStream_t st, int planes, bool transA, bool transB, int M, int N, int K, const float* A, const unsigned short* A16,
                    int lda, const float* B, const unsigned short* B16, int ldb, float* C, int ldc, const float* bias, bool relu,
-                   bool accumulate);
+                   bool accumulate, float* cs1 = nullptr, float* cs2 = nullptr, float* cs3 = nullptr);
 int xgk_cvt_bf16(hipStream_t st, const float* src, unsigned short* dst, size_t n);      // fp32 -> bf16 (RNE), both 16-byte aligned
 // Y[M,N] (+)= X[M,K] W[N,K]^T + bias   (nn.Linear forward)
 static inline int xgk_linear(hipStream_t st, int mode, int M, int N, int K, const float* X, int ldx, const float* W,
