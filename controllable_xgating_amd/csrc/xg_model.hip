@@ -873,6 +873,109 @@ int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatc
     const bool fwd_bg = fwd_bg_env && th > 0 && w.gm == 0;
     *logit_rows_done = 0;
     if (run.prof_event0 && hipEventRecord(static_cast<hipEvent_t>(run.prof_event0), st) != hipSuccess) return XG_EHIP;
+    // ---- form F (round 4): cell 1 runs AHEAD.  Under teacher forcing cell 1 is a recurrence of its own -- h1(t) depends on
+    // h1(t-1) and the tokens only (sub_modules.py:683: its inputs xt and pos' are hoisted) -- and everything of a step that reads
+    // h1 alone (cell 1 itself, the h1 half of the attention query, the h1' and h2 segments of cell 2) can be computed before the
+    // step's own chain needs it.  Per step the chain keeps three launches, but each carries only what truly waits:
+    //   L1  p(t) += h2(t-1) W_h2a[:, R:]            (K = R; the h1 half and the bias were stored a step earlier) | zero the accumulators
+    //   L2  attention(t)  ||  cell 1(t+1)  ||  p(t+1) = h1(t) W_h2a[:, :R] + b  ||  S2(t) = h1(t) W_i2h2 + h2(t-1) W_h2h2 + biases
+    //   L3  cell 2(t) = (c / s) W_a2h2 + S2(t)      (K = R)
+    // instead of p (K = 2R) || cell 1, attention, cell 2 (K = 3R): the chain's launches shrink to a third of their reduction depth
+    // and the rest of the step's products ride beside the attention.  Same arithmetic per product (the sums of a cell's segments
+    // are formed in a different order: fp32 round-off only); parity suite green.  MEASURED AND NOT THE DEFAULT (XG_XE_FORM=F in
+    // the -DXG_DIAG build): 54.7 vs 50.5 us per step in situ, 6.00 vs 5.93 ms per iteration (hidden 1024 bf16: 7.85 either way) --
+    // a launch costs its fixed ~6 us plus its share of the step's 14 us of matrix time wherever that share sits, and the
+    // attention (VALU-bound: tanh) does not hide matrix time on the same SIMDs: moving work between the three launches does
+    // not shorten their sum.
+    static const char xe_env = xg_diag_env("XG_XE_FORM") ? xg_diag_env("XG_XE_FORM")[0] : 0;
+    const bool ahead = xe_env == 'F' && step_packed(w, d) && A <= 2048 && d.K <= 128 && ((uintptr_t)w.Venc % 8 == 0) &&
+                       ((uintptr_t)w.vproj % 16 == 0) && ((uintptr_t)p.a2w_w % 16 == 0);
+    if (ahead) {
+        const int K = d.K;
+        auto cell1 = [&](int t) {                    // cell 1 of step t: H1[t] -> H1[t + 1]
+            LstmFwdArgs a{};
+            a.add = w.PRE1 + (size_t)t * B * 4 * R; a.ldadd = 4 * R;
+            a.c_prev = w.C1 + t * BR; a.ldcp = R; a.h_prev = w.H1 + t * BR; a.ldhp = R; a.mask = x.seq_mask + t; a.ldm = T;
+            a.gates = w.G1 + (size_t)t * B * 4 * R; a.ldg = 4 * R; a.c_out = w.C1 + (t + 1) * BR; a.ldco = R;
+            a.h_out = w.H1 + (t + 1) * BR; a.ldho = R;
+            a.B = B; a.R = R; a.order = XG_ORDER_IFOG; a.mask_mode = XG_MASK_HOLD;
+            a.drop = xg_make_drop(&run, XG_SITE_L1, t);
+            SkJob j = job_lstm(a);
+            j.nseg = 1;
+            j.seg[0] = seg_nt(w, PK_L1_H2H, w.H1 + t * BR, R, p.l1_h2h_w, R, R); j.bias[0] = p.l1_h2h_b;
+            return j;
+        };
+        auto p_h1 = [&](int t) {                     // P[t] = H1[t] W_h2a[:, :R] + b   (the h1 half of step t's query)
+            SkJob j = job_store(B, A, w.P + (size_t)t * B * A, A, false);
+            j.nseg = 1;
+            j.seg[0] = seg_nt(w, PK_H2A1, w.H1 + t * BR, R, p.h2a_w, 2 * R, R);
+            j.bias[0] = p.h2a_b;
+            return j;
+        };
+        {   // ahead of the loop: cell 1(0) || the h1 half of p(0)
+            SkArgs k0{};
+            k0.njobs = 2; k0.job[0] = cell1(0); k0.job[1] = p_h1(0);
+            XG_TRY(xgk_skinny(st, k0, w.gm));
+        }
+        for (int t = 0; t < T; ++t) {
+            {   // L1
+                SkArgs k1{};
+                k1.njobs = 2;
+                k1.job[0] = job_store(B, A, w.P + (size_t)t * B * A, A, true);
+                k1.job[0].nseg = 1;
+                k1.job[0].seg[0] = seg_nt(w, PK_H2A2, w.H2 + t * BR, R, p.h2a_w + R, 2 * R, R);
+                k1.job[1] = SkJob{};
+                k1.job[1].epi = SK_EPI_ZERO; k1.job[1].M = 1; k1.job[1].N = B * R + ((B + 3) & ~3); k1.job[1].C = w.AFU;
+                XG_TRY(xgk_skinny(st, k1, w.gm));
+            }
+            {   // L2
+                SkArgs k2{};
+                int n2 = 0;
+                SkJob& ja = k2.job[n2++];
+                ja = SkJob{};
+                ja.epi = SK_EPI_ATTN; ja.M = B; ja.R = R; ja.attn_K = K; ja.attn_A = A;
+                ja.attn_p = w.P + (size_t)t * B * A; ja.attn_q = w.vproj; ja.attn_v = w.Venc; ja.attn_w = p.a2w_w;
+                ja.attn_ex = w.ALPHA + (size_t)t * B * K; ja.attn_s = w.ATS; ja.attn_c = w.AFU;
+                if (t + 1 < T) { k2.job[n2++] = cell1(t + 1); k2.job[n2++] = p_h1(t + 1); }
+                SkJob& js = k2.job[n2++];               // S2(t): everything of cell 2 that does not wait for the attention
+                js = job_store(B, 4 * R, w.S2, 4 * R, false);
+                js.cell_cols = 1; js.R = R; js.nseg = 2;
+                js.seg[0] = seg_nt(w, PK_L2_I2H, w.H1 + (t + 1) * BR, R, p.l2_i2h_w, R, R); js.bias[0] = p.l2_i2h_b;
+                js.seg[1] = seg_nt(w, PK_L2_H2H, w.H2 + t * BR, R, p.l2_h2h_w, R, R); js.bias[1] = p.l2_h2h_b;
+                k2.njobs = n2;
+                XG_TRY(xgk_skinny(st, k2, w.gm));
+            }
+            {   // L3
+                LstmFwdArgs c{};
+                c.add = w.S2; c.ldadd = 4 * R;
+                c.c_prev = w.C2 + t * BR; c.ldcp = R; c.h_prev = w.H2 + t * BR; c.ldhp = R; c.mask = x.seq_mask + t; c.ldm = T;
+                c.gates = w.G2 + (size_t)t * B * 4 * R; c.ldg = 4 * R; c.c_out = w.C2 + (t + 1) * BR; c.ldco = R;
+                c.h_out = w.H2 + (t + 1) * BR; c.ldho = R;
+                c.B = B; c.R = R; c.order = XG_ORDER_IFOG; c.mask_mode = XG_MASK_HOLD;
+                c.drop = xg_make_drop(&run, XG_SITE_L2, t);
+                SkArgs k3{};
+                k3.njobs = 1;
+                SkJob& j = k3.job[0];
+                j = job_lstm(c);
+                j.nseg = 1;
+                j.seg[0] = seg_nt(w, PK_L2_A2H, w.AFU, R, p.l2_a2h_w, R, R); j.bias[0] = p.l2_a2h_b;
+                SkSeg& g = j.seg[0];
+                g.row_scale = w.ATS; g.scaled_out = w.AF + t * BR; g.ld_out = R; g.ex = w.ALPHA + (size_t)t * B * K; g.ex_ld = K; g.ex_K = K;
+                XG_TRY(xgk_skinny(st, k3, w.gm));
+            }
+            if (th > 0 && t == th - 1) {
+                XG_TRY(ss.fork());
+                XG_TRY(cvt16(ss.aux, w, w.H2 + BR, (size_t)th * B * R));
+                XG_TRY(lin16(ss.aux, w.gm | (fwd_bg ? XGK_GEMM_BG : 0), th * B, d.V, R, w.H2 + BR, m16(w, w.H2 + BR), R, p.logit_w,
+                             w16(w, W16_LOGIT), p.logit_b, w.LOGITS, d.V));
+                *logit_rows_done = th * B;
+                if (early_loss)
+                    XG_TRY(xgk_xent_fwd(ss.aux, w.LOGITS, d.V, x.seq, x.seq_mask, nullptr, B, T, d.V, 1, w.LSE, w.sums, 0, th * B, false));
+            }
+        }
+        if (run.prof_event1 && hipEventRecord(static_cast<hipEvent_t>(run.prof_event1), st) != hipSuccess) return XG_EHIP;
+        return XG_OK;
+    }
     for (int t = 0; t < T; ++t) {
         StepIO s{};
         s.xt = w.Xe + (size_t)t * B * E; s.posg = w.POSG + t * BR; s.pre1 = w.PRE1 + (size_t)t * B * 4 * R;
