@@ -168,7 +168,14 @@ __device__ __forceinline__ void w1_interleave() {
 template <int BM, int BN, bool AKC, bool BKC, int MT, int NT>
 __device__ __forceinline__ void slab_mfma_pipelined(const float* __restrict__ as, const float* __restrict__ bs, int arow, int brow,
                                                     int half, f32x16 (&acc)[MT][NT]) {
-#ifndef GEMM_FRAG_PIPE
+#if defined(GEMM_FRAG_PIPE)
+    constexpr bool PIPE = true;
+#elif defined(GEMM_FRAG_PIPE_KC)
+    constexpr bool PIPE = AKC && BKC;            // both operands k-contiguous (one b128 read per fragment): the forward products
+#else
+    constexpr bool PIPE = false;
+#endif
+    if constexpr (!PIPE) {
 #pragma unroll
     for (int kb = 0; kb < BKS / 8; ++kb) {
         f32x4 fa[MT], fb[NT];
@@ -184,7 +191,7 @@ __device__ __forceinline__ void slab_mfma_pipelined(const float* __restrict__ as
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
     }
-#else
+    } else {
     f32x4 fa[2][MT], fb[2][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i) fa[0][i] = read_frag<BM, AKC>(as, arow + i * 32, 0, half);
@@ -209,7 +216,7 @@ __device__ __forceinline__ void slab_mfma_pipelined(const float* __restrict__ as
         if (kb + 1 < BKS / 8) w1_interleave<4 * MT * NT, MT * (AKC ? 1 : 2) + NT * (BKC ? 1 : 2), 0>();
         __builtin_amdgcn_sched_barrier(0);
     }
-#endif
+    }
 }
 
 struct GemmArgs {

@@ -592,14 +592,71 @@ __device__ __forceinline__ void attn_part(const SkJob& job, int tile, float* sme
         if (lane == 0 && nrow > 0) atomicAdd(job.attn_s + b, ssum);
     }
     __syncthreads();
+#ifndef SKF_ATTN_NODRAIN
+    // Every vector-memory operation this wave has in flight lands before the context loop starts to recycle registers (round 4:
+    // without this the accumulated context showed run-to-run differences of single elements -- one frame's term, the low lane of
+    // the packed multiply-add -- whenever split-bf16 cell tiles shared the launch; the generated loop waits with vmcnt(N > 0)
+    // counts that assume a fixed number of older operations in flight, tools/step_mode_check.py).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
     // unnormalised context of this half: thread -> two adjacent columns
     for (int c = threadIdx.x * 2; c < R; c += NWV * 128) {
         float ax = 0.f, ay = 0.f;
+#if defined(SKF_ATTN_UNROLL1)
+#pragma unroll 1
+        for (int r = 0; r < nrow; ++r) {
+            const float2 v = *reinterpret_cast<const float2*>(Vb + (size_t)(k0 + r) * R + c);
+            ax += sx[r] * v.x; ay += sx[r] * v.y;
+        }
+#elif defined(SKF_ATTN_OLD)
 #pragma unroll 4
         for (int r = 0; r < nrow; ++r) {
             const float2 v = *reinterpret_cast<const float2*>(Vb + (size_t)(k0 + r) * R + c);
             ax += sx[r] * v.x; ay += sx[r] * v.y;
         }
+#else
+        // four rows per trip, written out: the four loads are requested first, then the four weights come out of LDS one by one
+        // (scalar reads, no b128), then the multiply-adds.  (Round 4: the compiler's own 4-way unrolling of the simple loop --
+        // address registers of the loads recycled as the destination of a ds_read_b128 two instructions later -- gave run-to-run
+        // differences of single context elements beside split-bf16 cell tiles in the same launch; tools/step_mode_check.py.)
+        const float* vp = Vb + (size_t)k0 * R + c;
+        int r = 0;
+        for (; r + 4 <= nrow; r += 4) {
+            const float2 v0 = *reinterpret_cast<const float2*>(vp + (size_t)(r + 0) * R);
+            const float2 v1 = *reinterpret_cast<const float2*>(vp + (size_t)(r + 1) * R);
+            const float2 v2 = *reinterpret_cast<const float2*>(vp + (size_t)(r + 2) * R);
+            const float2 v3 = *reinterpret_cast<const float2*>(vp + (size_t)(r + 3) * R);
+#ifdef SKF_ATTN_NOP
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+#endif
+            const float s0 = sx[r], s1 = sx[r + 1], s2 = sx[r + 2], s3 = sx[r + 3];
+#ifdef SKF_ATTN_PKFMA
+            ax += s0 * v0.x; ay += s0 * v0.y;
+            ax += s1 * v1.x; ay += s1 * v1.y;
+            ax += s2 * v2.x; ay += s2 * v2.y;
+            ax += s3 * v3.x; ay += s3 * v3.y;
+#else
+            // plain v_fmac_f32, pinned (the compiler pairs ax / ay into v_pk_fma_f32 with operand-select modifiers otherwise)
+            asm volatile("v_fmac_f32 %0, %2, %3\n\tv_fmac_f32 %1, %2, %4" : "+v"(ax), "+v"(ay) : "v"(s0), "v"(v0.x), "v"(v0.y));
+            asm volatile("v_fmac_f32 %0, %2, %3\n\tv_fmac_f32 %1, %2, %4" : "+v"(ax), "+v"(ay) : "v"(s1), "v"(v1.x), "v"(v1.y));
+            asm volatile("v_fmac_f32 %0, %2, %3\n\tv_fmac_f32 %1, %2, %4" : "+v"(ax), "+v"(ay) : "v"(s2), "v"(v2.x), "v"(v2.y));
+            asm volatile("v_fmac_f32 %0, %2, %3\n\tv_fmac_f32 %1, %2, %4" : "+v"(ax), "+v"(ay) : "v"(s3), "v"(v3.x), "v"(v3.y));
+#endif
+        }
+        for (; r < nrow; ++r) {
+            const float2 v = *reinterpret_cast<const float2*>(vp + (size_t)r * R);
+            ax += sx[r] * v.x; ay += sx[r] * v.y;
+        }
+#ifdef SKF_ATTN_CHECK
+        {   // diagnosis: is the LDS copy of the weights still what wave 0 stored (== the attn_ex rows in memory)?
+            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
+            for (int q = 0; q < nrow; ++q) {
+                const float a = sx[q], bq = __hip_atomic_load(job.attn_ex + (size_t)b * K + k0 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (a != bq) printf("attn check: wg %d tid %d q %d lds %.9g mem %.9g\n", (int)blockIdx.x, (int)threadIdx.x, q, a, bq);
+            }
+        }
+#endif
+#endif
         atomicAdd(job.attn_c + (size_t)b * R + c, ax);
         atomicAdd(job.attn_c + (size_t)b * R + c + 1, ay);
     }
@@ -660,7 +717,12 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
     }
     if (job.epi == SK_EPI_ATTN) {
         if ((int)blockIdx.x < 2 * job.M) {           // (every wave of the workgroup scores its share of the rows)
-            if (job.attn_A <= 1536) attn_part<6, NW>(job, blockIdx.x, smem); else attn_part<8, NW>(job, blockIdx.x, smem);
+#ifdef SKF_ATTN_LDS_OFF
+            float* asm_ = smem + SKF_ATTN_LDS_OFF;
+#else
+            float* asm_ = smem;
+#endif
+            if (job.attn_A <= 1536) attn_part<6, NW>(job, blockIdx.x, asm_); else attn_part<8, NW>(job, blockIdx.x, asm_);
         }
         return;
     }
@@ -678,7 +740,9 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
     }
     const int tm = bid % ntm, kp = (bid / ntm) % ks, tn = bid / (ntm * ks);
     const int m0 = tm * 32, n0 = tn * 32;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, half = lane >> 5, l31 = lane & 31;
+    // (the wave index is the same for every lane: saying so keeps the chunk ranges, loop counters and branches of the K loop on the
+    //  scalar unit instead of exec-masked vector control flow)
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
     float* As = smem + wave * WSM;
     const int lrow = lane >> 3, lcol = (lane & 7) << 2;
 
@@ -1028,7 +1092,8 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
     }
     if (special && !fast) return XG_EINVAL;            // ZERO / ATTN jobs and scaled operands exist in the fast kernel only
     static const bool split_jobs = xg_diag_env("XG_SPLIT_JOBS") != nullptr;       // diagnosis: one launch per job
-    if (fast && split_jobs && a.njobs > 1 && !special) {
+    static const bool split_all = xg_diag_env("XG_SPLIT_JOBS") && xg_diag_env("XG_SPLIT_JOBS")[0] == '2';   // ... ATTN / ZERO / COPY jobs too
+    if (fast && split_jobs && a.njobs > 1 && (!special || split_all)) {
         for (int j = 0; j < a.njobs; ++j) {
             SkArgs one{};
             one.njobs = 1; one.job[0] = a.job[j];
@@ -1054,9 +1119,10 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         static const bool dbg_nw4_scaled = xg_diag_env("XG_SK_NW4_SCALED") != nullptr, dbg_nw4_attn = xg_diag_env("XG_SK_NW4_ATTN") != nullptr,
                           dbg_nw4_zero = xg_diag_env("XG_SK_NW4_ZERO") != nullptr;
         const bool nw4 = nw4_rule || (dbg_nw4_scaled && scaled) || (dbg_nw4_attn && has_attn) || (dbg_nw4_zero && has_zero);
+        static const int dyn_lds = xg_diag_env("XG_SK_DYN_LDS") ? atoi(xg_diag_env("XG_SK_DYN_LDS")) : 0;      // diagnosis
 #define XG_SKF(NW_, PREC_) do { \
-            if (scaled) hipLaunchKernelGGL((skf_kernel<NW_, PREC_, true>), grid, dim3(NW_ * 64), 0, st, a); \
-            else hipLaunchKernelGGL((skf_kernel<NW_, PREC_, false>), grid, dim3(NW_ * 64), 0, st, a); } while (0)
+            if (scaled) hipLaunchKernelGGL((skf_kernel<NW_, PREC_, true>), grid, dim3(NW_ * 64), dyn_lds, st, a); \
+            else hipLaunchKernelGGL((skf_kernel<NW_, PREC_, false>), grid, dim3(NW_ * 64), dyn_lds, st, a); } while (0)
         if (bf16)        { if (nw4) XG_SKF(4, 1); else XG_SKF(8, 1); }
         else if (bf16x3) { if (nw4) XG_SKF(4, 2); else XG_SKF(8, 2); }
         else             { if (nw4) XG_SKF(4, 0); else XG_SKF(8, 0); }

@@ -1599,3 +1599,39 @@ def test_paired_rollout_over_videos_equals_the_repeated_batch_entry_point():
     w = int(n[0]), int(n[1])
     assert torch.equal(seq[:B, :w[0]].cpu(), gen[:, :w[0]].cpu()) and torch.equal(seq[B:, :w[1]].cpu(), greedy[:, :w[1]].cpu())
     np.testing.assert_allclose(lp[:B, :w[0]].cpu().numpy(), slp[:, :w[0]].cpu().numpy(), atol=2e-6)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_in_place_steps_are_bitwise_reproducible(precision):
+    """Three consecutive xg_step_fwd calls on an in-place state (128 rows: the 8-wave launches that carry the fused attention
+    beside cell tiles), twelve times over: every repetition must give the same bits.  Round 4 found single elements of the
+    attention context differing from run to run in the split-bf16 mode (a compiler-formed v_pk_fma_f32 with operand-select
+    modifiers, see __graft_entry__.FLAGS); the accumulation order of the step is fixed, so anything but identical bits is a bug."""
+    import ctypes as C
+    from controllable_xgating_amd import _native as nv
+    from controllable_xgating_amd.model import _stream, _ws_ptr
+    d = pg.make_dims(**dict(CFG["c1"], B=128))
+    x = to_dev(pg.make_inputs(d, seed=0))
+    model = make_model(d, train=False, precision=precision)
+    with torch.no_grad():
+        V = model.encode(x["feats_rgb"], x["feats_opfl"], x["feat_mask"])
+        st = model.init_hidden(V, x["feat_mask"])
+        state0 = torch.cat([st[0][0], st[0][1], st[1][0], st[1][1]], 0).contiguous()
+        dd = model._dims(d.B, d.K, 1)
+        ps, run = model._params_struct(), model._run(False)
+        vproj = torch.empty(d.B, d.K, model.att_size, device="cuda")
+        nv.check(nv.lib().xg_vproj(_stream(), C.byref(dd), C.byref(ps), nv.ptr(V), nv.ptr(vproj), C.byref(run)), "xg_vproj")
+        ws = model._pool.shared(dd, V.device)
+        wp, wn = _ws_ptr(ws)
+        tok = x["seq"][:, 1].contiguous()
+        first = None
+        for rep in range(12):
+            s = state0.clone()
+            for _ in range(3):
+                nv.check(nv.lib().xg_step_fwd(_stream(), C.byref(dd), C.byref(ps), nv.ptr(tok), None, nv.ptr(V), nv.ptr(vproj),
+                                              nv.ptr(x["pos_feats"]), C.byref(run), 0, wp, wn, nv.ptr(s), None, None), "xg_step_fwd")
+            torch.cuda.synchronize()
+            if first is None:
+                first = s.clone()
+            else:
+                assert torch.equal(s, first), (precision, rep, float((s - first).abs().max()))

@@ -19,7 +19,7 @@ d = pg.make_dims(B=rows, K=26, R=512, A=1536, E=468, V=20000, C=14, L=20, F1=153
 Pn = pg.make_params(d)
 xn = pg.make_inputs(d, seed=0)
 x = {k: torch.from_numpy(v).cuda() for k, v in xn.items()}
-model = SAModel(make_opt(d))
+model = SAModel(make_opt(d, precision=os.environ.get("PREC_MODEL", "fp32")))
 model.load_state_dict({k: torch.from_numpy(v) for k, v in Pn.items()}, strict=False)
 model = model.cuda().eval()
 with torch.no_grad():
@@ -48,7 +48,7 @@ with torch.no_grad():
     if os.environ.get("WS_DIFF"):
         from tools.ws_map import ws_map, locate
         regs = ws_map(d.B, d.K, d.R, d.A, d.E, d.V, d.C, 128, 1)
-        run = model._run(False); run.gemm_mode = 3
+        run = model._run(False); run.gemm_mode = int(os.environ.get("WS_MODE", "3"))
         def one(s):
             nv.check(nv.lib().xg_step_fwd(_stream(), C.byref(dd), C.byref(ps), nv.ptr(tok), None, nv.ptr(V), nv.ptr(vproj),
                                           nv.ptr(x["pos_feats"]), C.byref(run), 0, wp, wn, nv.ptr(s), None, None), "xg_step_fwd")
@@ -70,10 +70,13 @@ with torch.no_grad():
                 names.setdefault(nm, []).append(idx)
             print("rep %d: state differs: %s; workspace regions: %s" % (rep, not np.array_equal(s_, ref_s),
                   {k: (len(v), v[:6]) for k, v in names.items()}))
+            fa, fb = ref_ws.view(np.uint8)[base_off:].view(np.float32), w_.view(np.uint8)[base_off:].view(np.float32)
+            for wd in words[:8]:
+                print("    word %d (%s): %.9g vs %.9g" % (wd, locate(regs, wd * 4), fa[wd], fb[wd]))
         sys.exit(0)
     for nsteps in (1, 2, 3):
-        ref = step(0, nsteps)
-        for mode in (0, 3):
+        ref = step(int(os.environ.get("REF_MODE", "0")), nsteps)
+        for mode in [int(v) for v in os.environ.get("MODES", "0,3").split(",")]:
             worst, rep_worst = 0.0, 0.0
             first = None
             for rep in range(20):
