@@ -65,6 +65,8 @@ def lib():
     L.xg_param_numel.argtypes = [C.POINTER(XgDims), C.c_int, C.POINTER(C.c_int64)]
     L.xg_workspace_bytes.restype = C.c_size_t
     L.xg_workspace_bytes.argtypes = [C.POINTER(XgDims)]
+    L.xg_workspace_bytes_mode.restype = C.c_size_t
+    L.xg_workspace_bytes_mode.argtypes = [C.POINTER(XgDims), C.c_int]
     L.xg_packed_bytes.restype = C.c_size_t
     L.xg_packed_bytes.argtypes = [C.POINTER(XgDims), C.c_int]
     n = L.xg_param_count()

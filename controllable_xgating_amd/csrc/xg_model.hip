@@ -127,7 +127,7 @@ struct Ws {
     // everything a backward pass needs ZERO on entry is one contiguous block (dst[0][*], DAF, the encoder's carried
     // gradients, the BatchNorm sums, the tickets): one memset on a side stream instead of a dozen on the critical path
     char* zblock; size_t zbytes; bool zeroed;
-    size_t bytes;
+    size_t bytes, core_bytes;
     // ---- packed recurrent weights (XgRun.packed; not part of the workspace)
     PackedView pk; bool packed;
     int gm;                            // XgRun.gemm_mode of this call (0 / 1 / 3), handed to every product explicitly
@@ -203,6 +203,7 @@ Ws carve(const XgDims& d, void* base) {
     w.base_f = reinterpret_cast<const float*>(c.base);
     w.end_f = c.base ? reinterpret_cast<const float*>(c.base + w.bytes) : nullptr;
     w.sh16 = c.base ? reinterpret_cast<unsigned short*>(c.base + w.bytes) : nullptr;
+    w.core_bytes = w.bytes;                      // everything but the bf16 mirror region (only gemm_mode 1 reads mirrors)
     w.bytes += (w.bytes / 2 + 255) & ~(size_t)255;
     return w;
 }
@@ -238,6 +239,7 @@ inline const unsigned short* m16(const Ws& w, const float* p) {
 }
 inline int cvt16(hipStream_t st, const Ws& w, const float* p, size_t n) {          // refresh the mirror of p[0 .. n)
     if (w.gm != 1 || n == 0) return XG_OK;
+    if (!w.sh16) return XG_OK;                   // workspace without a mirror region: the consumers convert on the fly
     const unsigned short* dst = m16(w, p);
     if (!dst) return XG_EINVAL;
     return xgk_cvt_bf16(st, p, const_cast<unsigned short*>(dst), n);
@@ -1337,7 +1339,13 @@ __global__ void losses_kernel(const float* s, float wc, float* out) {
 int check(const XgDims* d, const void* ws, size_t ws_bytes, Ws* w) {
     if (!dims_ok(d) || !ws) return XG_EINVAL;
     *w = carve(*d, const_cast<void*>(ws));
-    if (ws_bytes < w->bytes) return XG_EWORKSPACE;
+    if (ws_bytes < w->bytes) {
+        // a workspace sized by xg_workspace_bytes_mode for an arithmetic mode without bf16 mirrors: no mirror region (the bf16
+        // mode then converts every operand on the fly, as it does wherever a mirror is not valid)
+        if (ws_bytes < w->core_bytes) return XG_EWORKSPACE;
+        w->sh16 = nullptr;
+        w->bytes = w->core_bytes;
+    }
     if ((uintptr_t)ws % 256 != 0) return XG_EINVAL;
     return XG_OK;
 }
@@ -1403,6 +1411,11 @@ extern "C" int xg_param_numel(const XgDims* d, int i, int64_t* numel) {
     static_assert(sizeof(n) / sizeof(n[0]) == sizeof(XgParams) / sizeof(float*), "numel table size");
     *numel = n[i];
     return XG_OK;
+}
+extern "C" size_t xg_workspace_bytes_mode(const XgDims* d, int gemm_mode) {
+    if (!dims_ok(d)) return 0;
+    const Ws w = carve(*d, nullptr);
+    return gemm_mode == 1 ? w.bytes : w.core_bytes;
 }
 extern "C" size_t xg_workspace_bytes(const XgDims* d) {
     if (!dims_ok(d)) return 0;

@@ -70,18 +70,19 @@ class _WorkspacePool:
     """Caller-owned workspaces (xg_workspace_bytes).  A forward that saves activations for a
     backward keeps its workspace until the backward has run; everything else shares scratch."""
 
-    def __init__(self):
+    def __init__(self, gemm_mode=0):
         self.free = {}
         self.scratch = {}
+        self.gemm_mode = gemm_mode            # sizes the workspaces: only the bf16 mode carries the bf16 mirror region (+50 %)
 
     @staticmethod
     def _key(dims, device):
         return (tuple(getattr(dims, f[0]) for f in dims._fields_), str(device))
 
     def _alloc(self, dims, device):
-        n = nv.lib().xg_workspace_bytes(C.byref(dims))
+        n = nv.lib().xg_workspace_bytes_mode(C.byref(dims), self.gemm_mode)
         if n == 0:
-            raise nv.XgError("xg_workspace_bytes: invalid dims")
+            raise nv.XgError("xg_workspace_bytes_mode: invalid dims")
         return torch.zeros(n + 256, dtype=torch.uint8, device=device)     # zero-filled at first use: include/xgate.h
 
     def take(self, dims, device):
@@ -173,7 +174,7 @@ class SAModel(nn.Module):
         self.init_weights()
         if getattr(opt, "fusion_activity", "ReLU") != "ReLU":
             raise ValueError("only fusion_activity='ReLU' (the shipped recipe) is implemented in HIP")
-        self._pool = _WorkspacePool()
+        self._pool = _WorkspacePool({"fp32": 0, "bf16": 1, "bf16x3": 3}.get(getattr(opt, "precision", "fp32"), 1))
         self._flat = None
         self._ps_cache = None
         self._gs_cache = None
@@ -184,7 +185,7 @@ class SAModel(nn.Module):
         self._packed_epoch = 0
         # arithmetic of the large GEMMs: 'fp32' (exact fp32 MFMA), 'bf16x3' (split-bf16, fp32-class accuracy, faster),
         # 'bf16' (bf16 operands / fp32 accumulate, for the large AND the per-step products: BASELINE.json configs[4]).
-        # The per-step products are exact fp32 in the other two modes.
+        # 'bf16x3' splits the per-step products too (three bf16 planes of the packed fp32 tiles, xg_step.hip PREC 2).
         self.precision = getattr(opt, "precision", "fp32")
         if self.precision not in ("fp32", "bf16", "bf16x3"):
             raise ValueError("precision must be 'fp32', 'bf16x3' or 'bf16'")

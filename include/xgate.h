@@ -43,7 +43,7 @@ extern "C" {
 #define XG_VERSION 205   /* 200: XgRun gained packed/aux/event fields, xg_set_grad_event removed, xg_vproj takes XgRun;
                             201: + xg_clip_adam_zero; 202: XgRun.prof_event0/1, xg_adam_tick, xg_clip_adam_dev;
                             203: + xg_rollout_pair_compact; 204: + xg_abi_check;
-                            205: + xg_rollout_pair_videos */
+                            205: + xg_rollout_pair_videos, xg_workspace_bytes_mode */
 
 enum {
     XG_OK = 0,
@@ -104,8 +104,8 @@ typedef struct XgRun {
     int32_t save;         /* 1: keep activations in the workspace for a following *_bwd */
     float bn_momentum;    /* 0.1 */
     float bn_eps;         /* 1e-5 */
-    int32_t gemm_mode;    /* arithmetic of the products: 0 = fp32 MFMA, exact fp32 (default); 3 = split-bf16 for the LARGE
-                             products (three bf16 planes, 6 MFMAs, fp32-class accuracy), per-step products fp32;
+    int32_t gemm_mode;    /* arithmetic of the products: 0 = fp32 MFMA, exact fp32 (default); 3 = split-bf16 (three bf16 planes,
+                             6 MFMAs per 16-deep block, fp32-class accuracy) for the large AND the per-step products;
                              1 = bf16 operands, fp32 accumulate, for the large AND the per-step products
                              (BASELINE.json configs[4], tolerance 1e-2).  Accumulation, the cell arithmetic, the
                              attention and every reduction are fp32 in all modes. */
@@ -144,7 +144,10 @@ const char *xg_strerror(int code);
 int xg_param_count(void);
 const char *xg_param_name(int index);                 /* state_dict key of XgParams field `index` */
 int xg_param_numel(const XgDims *d, int index, int64_t *numel);
-size_t xg_workspace_bytes(const XgDims *d);           /* covers every entry point below for dims d */
+size_t xg_workspace_bytes(const XgDims *d);           /* covers every entry point below for dims d, in every gemm_mode */
+/* the same for ONE arithmetic mode: only gemm_mode 1 (bf16) uses the bf16 mirror region, a third of xg_workspace_bytes; a
+ * workspace of this size is accepted by every entry point (gemm_mode 1 on a mirror-less workspace converts operands on the fly) */
+size_t xg_workspace_bytes_mode(const XgDims *d, int gemm_mode);
 /* zero-fills a freshly allocated workspace (the one-time initialisation the conventions above ask for; a hipMemsetAsync) */
 int xg_workspace_init(void *stream, void *ws, size_t ws_bytes);
 

@@ -47,7 +47,12 @@ def test_version_strerror_and_param_table(built):
         assert k.value == int(np.prod(shapes[n])), n
         tot += k.value
     assert tot == 36122159                                  # parameter count at V = 20000
-    assert L.xg_workspace_bytes(ctypes.byref(dims)) > 0
+    full = L.xg_workspace_bytes(ctypes.byref(dims))
+    assert full > 0
+    # only the bf16 mode carries the bf16 mirror region (a third of the full size)
+    assert L.xg_workspace_bytes_mode(ctypes.byref(dims), 1) == full
+    core = L.xg_workspace_bytes_mode(ctypes.byref(dims), 0)
+    assert core == L.xg_workspace_bytes_mode(ctypes.byref(dims), 3) and 0.60 * full < core < 0.70 * full
     bad = nv.XgDims(0, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1)
     assert L.xg_workspace_bytes(ctypes.byref(bad)) == 0
 

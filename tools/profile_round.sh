@@ -11,6 +11,7 @@ cd $GRAFT_REPO_ROOT
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/bench -- python bench.py --no-cpu-baseline --no-pmc --no-secondary --steps 10 --warmup 3 > $OUT/bench.log 2>&1
 python tools/prof_summary.py $OUT/bench $OUT/${R}_bench_kernel_stats.txt 23 > /dev/null
 python tools/timeline.py $OUT/bench > $OUT/${R}_bench_timeline.txt 2>&1
+python tools/timeline.py $OUT/bench 1 2950 3300 2>&1 | sed -n '/^detail/,$p' >> $OUT/${R}_bench_timeline.txt
 # 2. decoder-step launch group: kernel stats, per-launch durations, PMC passes
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/step -- python tools/step_group_run.py 200 > $OUT/step.log 2>&1
 python tools/prof_summary.py $OUT/step $OUT/${R}_step_group_kernel_stats.txt 210 > /dev/null
@@ -40,13 +41,20 @@ python tools/select_check.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Libr\|a
 python tools/dstep_trace.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Libr\|amdgpu.ids" > $OUT/${R}_dstep_timeline.txt
 for b in 8 32 64 128 256; do echo "rows $b: $(DS_B=$b timeout 300 python tools/dstep_check.py 2>&1 | grep 'us per step')"; done > $OUT/${R}_dstep_vs_three_launches.txt
 python tools/graph_probe.py 2>&1 | grep -v "^RCCL\|^HIP\|^ROCm\|^Host\|^Libr\|amdgpu.ids" > $OUT/${R}_graph_probe.txt
+# 4c. round 4: CU-masked streams probe, chain-1 / scheduling / split-point sweeps, arithmetic-mode reproducibility of the step
+(cd tools/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/cumask_probe cumask_probe.hip 2>/dev/null; { echo "# tools/ubench/cumask_probe.hip: hipExtStreamCreateWithCUMask -- which mask bit is which (XCD, SE, CU); a latency-bound chain beside an MFMA background kernel, shared CUs vs complementary masks"; timeout 120 /tmp/cumask_probe; }) > $OUT/${R}_cumask_probe.txt 2>&1
+{ echo "# tools/ubench/c1_sweep.sh (diag library): chain 1 of the decoder backward -- split cap / wave priority / steps per event: ms per iteration, in-situ us per forward step"; bash tools/ubench/c1_sweep.sh 2>&1 | grep " : "; } > $OUT/${R}_c1_sweep.txt
+{ echo "# tools/ubench/sched_sweep.sh (diag library): deferred decoder weight gradients (XG_DEFER_WG), late token side (XG_TOK_LATE), chain-1 knobs"; bash tools/ubench/sched_sweep.sh 2>&1 | grep " : "; } > $OUT/${R}_sched_sweep.txt
+{ echo "# tools/ubench/th_sweep.sh (diag library): split point of dH = dlogits W (XG_BWD_TH) and of the forward logits (XG_FWD_TH)"; bash tools/ubench/th_sweep.sh 2>&1 | grep " : "; } > $OUT/${R}_th_sweep.txt
+{ echo "# tools/step_mode_check.py: xg_step_fwd x 1/2/3 in place, gemm_mode 3 (split-bf16 step products) against gemm_mode 0; 20 repetitions each"; python tools/step_mode_check.py 2>&1 | grep "^steps"; } > $OUT/${R}_step_mode_check.txt
+{ echo "# XG_XE_FORM=F (cell 1 one step ahead) against the default teacher-forced step form (diag library): ms per iteration, in-situ us per step"; for f in D F D F; do XG_LIBRARY=$GRAFT_REPO_ROOT/controllable_xgating_amd/lib/libxgate_hip_diag.so XG_XE_FORM=$f python bench.py --no-secondary --no-cpu-baseline --no-pmc --steps 30 --warmup 8 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('form $f :', d['ms_per_step'], d['roofline'].get('in_situ_us_per_step'))"; done; } > $OUT/${R}_xe_form_f.txt
 # 5. the bench lines themselves (un-profiled)
 python bench.py > $OUT/${R}_bench_line.json 2> $OUT/bench_line.err
 python bench.py --no-cpu-baseline --workload scst > $OUT/${R}_bench_line_scst.json 2>/dev/null
 python bench.py --no-cpu-baseline --workload xe5 --precision bf16 > $OUT/${R}_bench_line_xe5_bf16.json 2>/dev/null
 python bench.py --no-cpu-baseline --precision bf16x3 > $OUT/${R}_bench_line_bf16x3.json 2>/dev/null
 python bench.py --no-cpu-baseline --no-pmc --no-secondary --graph > $OUT/${R}_bench_line_graph.json 2>/dev/null
-XG_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-pmc > $OUT/${R}_bench_line_one_rank_rccl.json 2>/dev/null
+XG_FORCE_DIST=2 python bench.py --no-cpu-baseline --no-pmc --no-secondary > $OUT/${R}_bench_line_one_rank_rccl.json 2>/dev/null
 # keep the merge small: raw traces stay on the box
 rm -rf $OUT/bench $OUT/step $OUT/scst $OUT/xe5 $OUT/pmcF $OUT/pmcW $OUT/pmc1 $OUT/pmc2 $OUT/pmc3
 ls -la $OUT

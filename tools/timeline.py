@@ -76,6 +76,19 @@ def main():
     for r in sorted(runs, key=lambda r: r["s"]):
         print("%9.1f %9.1f %5d  %-3s %s" % ((r["s"] - t0) / 1e3, (r["e"] - r["s"]) / 1e3, r["n"], qs.index(r["q"]),
                                             ", ".join("%s x%d" % kv for kv in r["names"].items())))
+    # the two decoder recurrences as blocks: forward = first to last attention-forward launch (+ the skinny launch behind it),
+    # reverse-time = the skinny launch in front of the first attention-backward launch to the one behind the last
+    main_q = qs[0]
+    mk = [r for r in it if r["q"] == main_q]
+    for tag, key in (("forward decoder loop", "attn_fwd"), ("reverse-time decoder loop", "attn_bwd_split")):
+        idx = [i for i, r in enumerate(mk) if r["name"].startswith(key)]
+        if len(idx) >= 2:
+            a = mk[max(idx[0] - 1, 0)]["s"]
+            b = mk[min(idx[-1] + 1, len(mk) - 1)]["e"]
+            gaps = [(mk[i + 1]["s"] - mk[i]["e"]) / 1e3 for i in range(max(idx[0] - 1, 0), min(idx[-1] + 1, len(mk) - 1))]
+            big = [g for g in gaps if g > 20]
+            print("\n%s (main stream): %d steps in %.1f us = %.1f us per step; idle gaps > 20 us inside the block: %s"
+                  % (tag, len(idx), (b - a) / 1e3, (b - a) / 1e3 / len(idx), ["%.0f" % g for g in big] or "none"))
 
 
 if __name__ == "__main__":
