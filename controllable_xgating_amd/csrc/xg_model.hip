@@ -679,6 +679,16 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         float* h1_new = h1_alias ? w.state_tmp : s.h1o;
         // ---- launch 1: what the attention and cell 1 wait for (jobs that gather come first: the index load is one more
         // dependent round trip)
+        // Job order is dispatch order, and with two workgroups per CU resident at once a CU ends up with tile c of the first 256
+        // and tile c of the next 256: the 256 S2' tiles (K = R) go FIRST so that every heavy p tile (K = 2R) is paired with a light
+        // one instead of with another p tile (round 4: 45.3 -> 44.5 us per step at 128 rows; XG_L1_ORDER=0: the old order)
+        static const int l1_order = xg_diag_env("XG_L1_ORDER") ? atoi(xg_diag_env("XG_L1_ORDER")) : 1;
+        auto s2_job_early = [&](SkJob& j) {
+            j = job_store(B, 4 * R, w.S2, 4 * R, false);
+            j.cell_cols = 1; j.R = R; j.nseg = 1;
+            j.seg[0] = seg_nt(w, PK_L2_H2H, s.h2, R, p.l2_h2h_w, R, R); j.bias[0] = p.l2_h2h_b;
+        };
+        if (l1_order == 1 && s2_first) s2_job_early(k1.job[n1++]);
         if (!s.pre1) {  // POS gate: pos' = dropout(relu(W_g xt + b)) * pos + pos                          :682
             SkJob& j = k1.job[n1++];
             j = job_store(B, R, s.gp, R, false);
@@ -707,7 +717,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
             j.nseg = 1;
             j.seg[0] = seg_nt(w, PK_L2_H2H, s.h2, R, p.l2_h2h_w, R, R); j.bias[0] = p.l2_h2h_b;
         };
-        if (s2_first) s2_job(k1.job[n1++]);
+        if (s2_first && l1_order != 1) s2_job(k1.job[n1++]);
         if (s1_first) {     // S1' (gate-major, cell tiling) -> w.S
             SkJob& j = k1.job[n1++];
             j = job_store(B, 4 * R, w.S, 4 * R, false);

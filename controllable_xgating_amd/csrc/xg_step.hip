@@ -707,6 +707,17 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
     static_assert(WSM >= 32 * RSF, "the reduction buffer must fit the staging area");
     __shared__ __attribute__((aligned(16))) float smem[NW * WSM + (SCALE ? 32 : 0)];
     const SkJob& job = args.job[blockIdx.y];
+#ifndef SKF_NO_DESC_WARM
+    {   // The job descriptor (664 bytes of kernel arguments) is read field by field where each field is first needed -- behind
+        // branches, i.e. as a chain of dependent scalar-cache misses when a workgroup is the first on its CU.  One independent
+        // load per 64-byte line up front turns the chain into one miss and a row of hits.
+        const int* jd = reinterpret_cast<const int*>(&job);
+        int warm = 0;
+#pragma unroll
+        for (int i = 0; i < (int)((sizeof(SkJob) + 63) / 64); ++i) warm |= jd[i * 16 < (int)(sizeof(SkJob) / 4) ? i * 16 : (int)(sizeof(SkJob) / 4) - 1];
+        asm volatile("" ::"s"(warm));
+    }
+#endif
     if (job.epi == SK_EPI_ZERO) {
         if ((size_t)blockIdx.x * 4096 < (size_t)job.M * job.N) zero_tile<NW>(job, blockIdx.x);
         return;
