@@ -517,7 +517,7 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
     for _ in range(5):
         eager_step()                             # (events inside a replayed graph cannot be read: eager launches here)
         torch.cuda.synchronize()
-        insitu.append(e0.elapsed_time(e1) * 1e3 / T)
+        insitu.append(e0.elapsed_time(e1) * 1e3 / (T - 1 if workload == "scst" else T))   # (a rollout runs L core steps: the reference's L + 1st is dead)
     model._prof_events = None
     in_situ_us = sorted(insitu)[len(insitu) // 2]
 
@@ -529,7 +529,7 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
         x2 = {k: torch.cat([v, v]) for k, v in x.items()}
         t_step = measure_step_group(model, x2)
     ms = dt / steps * 1e3
-    value = world * cfg["B"] * T * steps / dt * (2 if workload == "scst" else 1)
+    value = world * cfg["B"] * (2 * (T - 1) if workload == "scst" else T) * steps / dt     # scst: L core steps per row actually run, two rollouts
     bf16 = precision == "bf16"
     bytes_step = step_bytes(step_rows, cfg["K"], cfg["R"], cfg["A"], cfg["E"], save=False, elem=2 if bf16 else 4)
     bytes_step_saved = step_bytes(step_rows, cfg["K"], cfg["R"], cfg["A"], cfg["E"], save=True, elem=2 if bf16 else 4)
@@ -566,7 +566,7 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
         "config": {"workload": wl,
                    "global_batch": world * cfg["B"], "per_gpu_batch": cfg["B"], "parallelism": "dp%d" % world,
                    "path": args.path, "drop_prob_lm": args.drop, "gemm_precision": precision,
-                   "timed_region": ("zero_grad + sampled + greedy rollouts (31 steps, one 2m-row batch) + reward criterion + backward"
+                   "timed_region": ("zero_grad + sampled + greedy rollouts (30 core steps, one 2m-row batch) + reward criterion + backward"
                                     if workload == "scst" else
                                     "zero_grad + encoder fwd + 21 decoder steps + heads/loss + full backward")
                                    + (" + RCCL grad all-reduce" if world > 1 else "") + " + clip + Adam",

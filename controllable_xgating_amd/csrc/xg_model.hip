@@ -1866,8 +1866,11 @@ static int rollout_impl(hipStream_t st, const XgDims* d, const XgParams* p, cons
         s.h1o = w.H1 + (t + 1) * BR; s.c1o = w.C1 + (t + 1) * BR; s.h2o = w.H2 + (t + 1) * BR; s.c2o = w.C2 + (t + 1) * BR;
         s.P = w.P + (size_t)t * B * A; s.alpha = w.ALPHA + (size_t)t * B * d->K; s.af = w.AF + t * BR;
         s.g1 = w.G1 + (size_t)t * B * 4 * R; s.g2 = w.G2 + (size_t)t * B * 4 * R; s.t = t;
+        // The reference runs the core once more at t = L and discards what it computes (SAModel.py:182,217: the loop ends before
+        // those logits are ever read, and no state is returned): that step feeds neither an output nor a gradient and is not run.
+        if (t + 1 == T) break;
         XG_TRY(core_step(st, *d, *p, *run, w, w.Venc, w.vproj, s));
-        if (t + 1 < T) {   // the step at t = L is computed and its logits discarded in the reference (:182,:217)
+        if (t + 1 < T) {
             if (fused_select)
                 XG_TRY(xgk_vocab_part(st, B, R, d->V, s.h2o, R, p->logit_w, p->logit_b, logits_of(t), wr_rows,
                                       w.VPART, temperature > 0.f ? temperature : 1.0f));
@@ -2015,8 +2018,12 @@ extern "C" int xg_rollout_bwd(void* stream, const XgDims* d, const XgParams* p, 
         XG_TRY(cvt16(st, w, w.Y, 2 * NR)); XG_TRY(cvt16(st, w, w.Venc, NR));
     }
     Streams ss(st, run);
-    XG_TRY(heads_bwd(ss, *d, *p, *g, *run, w, (T - 1) * B, false));
-    XG_TRY(decoder_bwd_core(ss, *d, *p, *g, *x, *run, w, w.UNF, 1, B, w.TOK, 1, B));
+    // the rollout ran T - 1 core steps (the reference's last one is dead, rollout_impl): the reverse-time pass covers those.
+    // All per-step buffers are time-major, so the first T - 1 blocks of the T-step workspace are the (T - 1)-step problem.
+    XgDims dT = *d;
+    dT.T = T - 1;
+    XG_TRY(heads_bwd(ss, dT, *p, *g, *run, w, (T - 1) * B, false));
+    XG_TRY(decoder_bwd_core(ss, dT, *p, *g, *x, *run, w, w.UNF, 1, B, w.TOK, 1, B));
     XG_TRY(encoder_bwd(ss, *d, *p, *g, *x, *run, w, w.DV));
     return ss.join();
 }
