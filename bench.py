@@ -363,7 +363,11 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
     rl_crit = RewardCriterion()
     reward_b = torch.randn(cfg["B"], 1, generator=torch.Generator().manual_seed(7)).to(dev)   # CIDEr stubbed (configs[2])
 
+    sleep_cycles_box = [int(float(os.environ.get("XG_BENCH_SLEEP_MS", "0")) * 2.4e6)]     # diagnosis (see `step` below)
+
     def step_scst():
+        if sleep_cycles_box[0]:
+            torch.cuda._sleep(sleep_cycles_box[0])
         optim.zero_grad()
         if os.environ.get("XG_SCST_MODE") in (None, "batched"):      # no host sync anywhere in the iteration
             gen, slp, greedy, n = scst_rollouts(model, x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], trim=False)
