@@ -1180,6 +1180,8 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
             sk.job[0] = job_store(B, R, daf, R, true);   sk.job[0].nseg = 1; sk.job[0].seg[0] = seg_nn(w, PKB_L2_A2H, ds2, 4 * R, p.l2_a2h_w, R, 4 * R);
             sk.job[1] = job_store(B, R, dh2p, R, true);  sk.job[1].nseg = 1; sk.job[1].seg[0] = seg_nn(w, PKB_L2_H2H, ds2, 4 * R, p.l2_h2h_w, R, 4 * R);
             allow_split(sk, 0, w); allow_split(sk, 1, w);
+            static const int a_ks = xg_diag_env("XG_A_KS") ? atoi(xg_diag_env("XG_A_KS")) : 0;      // experiment: split cap of launch A
+            sk.job[0].ksplit_cap = a_ks;
             XG_TRY(xgk_skinny(st, sk, w.gm));
         }
         XG_TRY(xgk_attn_bwd(st, daf, R, w.P + (size_t)t * B * A, w.vproj, w.Venc, p.a2w_w, w.ALPHA + (size_t)t * B * K,
@@ -1192,6 +1194,8 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
             sk.job[0].nseg = 1;
             sk.job[0].seg[0] = seg_nn(w, PKB_H2A2, dp, A, p.h2a_w + R, 2 * R, A);
             allow_split(sk, 0, w);
+            static const int b_ks = xg_diag_env("XG_B_KS") ? atoi(xg_diag_env("XG_B_KS")) : 0;      // experiment: split cap of launch B
+            sk.job[0].ksplit_cap = b_ks;
             XG_TRY(xgk_skinny(st, sk, w.gm));
         }
         cur ^= 1;

@@ -763,8 +763,10 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
 
     // (split-bf16: the plane registers leave no room for 19 prefetched values across the K loop at 128 VGPRs -- they would go
     //  to scratch, which costs more than it hides -- so that mode requests the cell operands behind the loop, under the reduction)
+    // (the same when the activations are requested two chunks ahead: SKF_DEPTH_A = 2)
+    constexpr bool LATE_PRE = PREC == 2 || SKF_DEPTH_A(PREC, SCALE) == 2;
     LstmPre pre;
-    if (PREC != 2) pre = lstm_prefetch<NW>(job, m0, tn);
+    if (!LATE_PRE) pre = lstm_prefetch<NW>(job, m0, tn);
     // A scaled operand (the unnormalised attention context): the reciprocal row scales go to LDS behind the staging images;
     // the workgroup meets at a barrier in front of the first scaled segment, i.e. after every wave has done its share of the
     // segments before it -- the scale's load latency hides there (registers would be simpler, but four more live values
@@ -989,7 +991,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
     }
 #endif
     SK_STAMP(3);
-    if (PREC == 2) pre = lstm_prefetch<NW>(job, m0, tn);
+    if (LATE_PRE) pre = lstm_prefetch<NW>(job, m0, tn);
     __syncthreads();
     float (*red)[32][RSF] = reinterpret_cast<float (*)[32][RSF]>(smem);
 #pragma unroll
