@@ -254,13 +254,17 @@ def core_ranges(cores):
 
 def cap_rccl_channels():
     """RCCL's collectives run as kernels that need CUs; during the backward every CU also hosts one workgroup of a persistent
-    background product and the latency-bound chain kernels.  A ring all-reduce over xGMI is link-bound (7 links x ~153 GB/s per
-    GPU), not CU-bound: 16 channels (= 16 workgroups) are enough to keep the links busy and leave the rest of the chip to the
-    backward.  Only set when the user has not chosen (NCCL_MAX_NCHANNELS); reported with the scaling line."""
-    if "NCCL_MAX_NCHANNELS" not in os.environ and os.environ.get("XG_NO_RCCL_CAP") is None:
-        os.environ["NCCL_MAX_NCHANNELS"] = "16"
-        return {"NCCL_MAX_NCHANNELS": "16", "set_by": "bench.py (XG_NO_RCCL_CAP=1 leaves RCCL's default)"}
-    return {"NCCL_MAX_NCHANNELS": os.environ.get("NCCL_MAX_NCHANNELS"), "set_by": "environment"}
+    background product and the latency-bound chain kernels.  Whether fewer channels (= fewer RCCL workgroups) help or starve the
+    ring over xGMI (7 links x ~153 GB/s per GPU) cannot be decided without an N > 1 run, and none has happened: RCCL's own choice
+    stands unless the launcher sets NCCL_MAX_NCHANNELS or XG_RCCL_CAP=<n> (which this sets before the communicator comes up).
+    Either way the setting is reported with the scaling line (comm.rccl_channel_cap) next to the channel count RCCL logs."""
+    if "NCCL_MAX_NCHANNELS" in os.environ:
+        return {"NCCL_MAX_NCHANNELS": os.environ["NCCL_MAX_NCHANNELS"], "set_by": "environment"}
+    cap = os.environ.get("XG_RCCL_CAP")
+    if cap:
+        os.environ["NCCL_MAX_NCHANNELS"] = str(int(cap))
+        return {"NCCL_MAX_NCHANNELS": str(int(cap)), "set_by": "XG_RCCL_CAP"}
+    return {"NCCL_MAX_NCHANNELS": None, "set_by": "RCCL default (XG_RCCL_CAP=<n> to cap)"}
 
 
 def rccl_debug_setup(rank):
