@@ -109,13 +109,13 @@ __global__ void __launch_bounds__(ATPB) attn_bwd_kernel(const float* __restrict_
 //   dq[b,k,a] = w_a sum_t de_t[b,k] (1 - th_t^2),  dw[a] += sum_{t,b,k} de_t[b,k] th_t,  th_t = tanh(p_t[b,a] + q[b,k,a])
 // grid (ceil(A/256), B); thread = one a, loops k and t.
 template <int TMAX>
-__global__ void __launch_bounds__(256) attn_bwd_post_kernel(const float* __restrict__ P, const float* __restrict__ vproj,
-                                                              const float* __restrict__ w, const float* __restrict__ DE,
-                                                              float* __restrict__ dvproj, float* __restrict__ dw, int T,
-                                                              int B, int K, int A) {
+__device__ __forceinline__ void attn_bwd_post_body(const float* __restrict__ P, const float* __restrict__ vproj,
+                                                   const float* __restrict__ w, const float* __restrict__ DE,
+                                                   float* __restrict__ dvproj, float* __restrict__ dw, int T,
+                                                   int B, int K, int A, int bx) {
     extern __shared__ float sde[];         // DE[:, b, :]  (T*K)
     const int b = blockIdx.y;
-    const int a = blockIdx.x * 256 + threadIdx.x;
+    const int a = bx * 256 + threadIdx.x;
     for (int i = threadIdx.x; i < T * K; i += 256) sde[i] = DE[((size_t)(i / K) * B + b) * K + (i % K)];
     __syncthreads();
     if (a >= A) return;
@@ -152,6 +152,13 @@ __global__ void __launch_bounds__(256) attn_bwd_post_kernel(const float* __restr
     }
     atomicAdd(dw + a, dwa);
 }
+template <int TMAX>
+__global__ void __launch_bounds__(256) attn_bwd_post_kernel(const float* __restrict__ P, const float* __restrict__ vproj,
+                                                              const float* __restrict__ w, const float* __restrict__ DE,
+                                                              float* __restrict__ dvproj, float* __restrict__ dw, int T,
+                                                              int B, int K, int A) {
+    attn_bwd_post_body<TMAX>(P, vproj, w, DE, dvproj, dw, T, B, K, A, (int)blockIdx.x);
+}
 
 // dV[b,k,r] (+)= sum_t ALPHA[t,b,k] * DAF[t,b,r]
 __global__ void attn_dV_kernel(const float* __restrict__ ALPHA, const float* __restrict__ DAF, int lddaf,
@@ -170,11 +177,11 @@ __global__ void attn_dV_kernel(const float* __restrict__ ALPHA, const float* __r
 // (the kernel above re-reads them for each of the K frames: 143 MB through L2 at config 2, 84 us on the path between the
 // reverse-time loop and the encoder backward); alpha[:, b, :] sits in LDS.  grid (ceil(R / 256), B).
 template <int TMAX>
-__global__ void __launch_bounds__(256) attn_dV_reg_kernel(const float* __restrict__ ALPHA, const float* __restrict__ DAF,
-                                                            int lddaf, int64_t tstride, float* __restrict__ dV, int T, int B,
-                                                            int K, int R, int acc) {
+__device__ __forceinline__ void attn_dV_reg_body(const float* __restrict__ ALPHA, const float* __restrict__ DAF,
+                                                 int lddaf, int64_t tstride, float* __restrict__ dV, int T, int B,
+                                                 int K, int R, int acc, int bx) {
     const int b = blockIdx.y;
-    const int r = blockIdx.x * 256 + threadIdx.x;
+    const int r = bx * 256 + threadIdx.x;
     float d[TMAX];
 #pragma unroll
     for (int t = 0; t < TMAX; ++t) d[t] = (t < T && r < R) ? DAF[(size_t)t * tstride + (size_t)b * lddaf + r] : 0.f;
@@ -202,6 +209,25 @@ __global__ void __launch_bounds__(256) attn_dV_reg_kernel(const float* __restric
         for (int j = 0; j < 8; ++j)
             if (k0 + j < K) dV[((size_t)b * K + k0 + j) * R + r] = old[j] + s[j];
     }
+}
+template <int TMAX>
+__global__ void __launch_bounds__(256) attn_dV_reg_kernel(const float* __restrict__ ALPHA, const float* __restrict__ DAF,
+                                                            int lddaf, int64_t tstride, float* __restrict__ dV, int T, int B,
+                                                            int K, int R, int acc) {
+    attn_dV_reg_body<TMAX>(ALPHA, DAF, lddaf, tstride, dV, T, B, K, R, acc, (int)blockIdx.x);
+}
+// Both passes that follow the reverse-time loop as ONE launch (round 4): dV = sum_t alpha_t dAF_t (latency-bound: 256 workgroups,
+// 35 us alone) in the shadow of dq / dw (VALU-bound: 768 workgroups of tanh, 67 us): grid (nxa + nxr, B), the first nxa blocks of
+// a row take the attention columns, the rest the context columns.  Same arithmetic as the two kernels above.
+template <int TMAX>
+__global__ void __launch_bounds__(256) attn_post_dV_kernel(const float* __restrict__ P, const float* __restrict__ vproj,
+                                                             const float* __restrict__ w, const float* __restrict__ DE,
+                                                             float* __restrict__ dvproj, float* __restrict__ dw,
+                                                             const float* __restrict__ ALPHA, const float* __restrict__ DAF, int lddaf,
+                                                             int64_t tstride, float* __restrict__ dV, int T, int B, int K, int A,
+                                                             int R, int nxa) {
+    if ((int)blockIdx.x < nxa) attn_bwd_post_body<TMAX>(P, vproj, w, DE, dvproj, dw, T, B, K, A, (int)blockIdx.x);
+    else attn_dV_reg_body<TMAX>(ALPHA, DAF, lddaf, tstride, dV, T, B, K, R, 0, (int)blockIdx.x - nxa);
 }
 
 
@@ -628,6 +654,22 @@ int xgk_attn_bwd_post(hipStream_t st, const float* P, const float* vproj, const 
     else if (T <= 24) hipLaunchKernelGGL((attn_bwd_post_kernel<24>), grid, dim3(256), lds, st, P, vproj, w, DE, dvproj, dw, T, B, K, A);
     else if (T <= 32) hipLaunchKernelGGL((attn_bwd_post_kernel<32>), grid, dim3(256), lds, st, P, vproj, w, DE, dvproj, dw, T, B, K, A);
     else hipLaunchKernelGGL((attn_bwd_post_kernel<0>), grid, dim3(256), lds, st, P, vproj, w, DE, dvproj, dw, T, B, K, A);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+int xgk_attn_post_dV(hipStream_t st, const float* P, const float* vproj, const float* w, const float* DE, float* dvproj, float* dw,
+                     const float* ALPHA, const float* DAF, int lddaf, int64_t daf_tstride, float* dV, int T, int B, int K, int A, int R) {
+    if (T > 32 || (size_t)T * K * sizeof(float) > 60000) {           // long sequences: the two separate passes
+        XG_TRY(xgk_attn_dV(st, ALPHA, DAF, lddaf, daf_tstride, dV, T, B, K, R, false));
+        return xgk_attn_bwd_post(st, P, vproj, w, DE, dvproj, dw, T, B, K, A);
+    }
+    const int nxa = xg_cdiv(A, 256), nxr = xg_cdiv(R, 256);
+    const dim3 grid(nxa + nxr, B);
+    const size_t lds = (size_t)T * K * sizeof(float);
+#define XG_PDV(TM) hipLaunchKernelGGL((attn_post_dV_kernel<TM>), grid, dim3(256), lds, st, P, vproj, w, DE, dvproj, dw, ALPHA, DAF, lddaf, \
+                                      daf_tstride, dV, T, B, K, A, R, nxa)
+    if (T <= 8) XG_PDV(8); else if (T <= 24) XG_PDV(24); else XG_PDV(32);
+#undef XG_PDV
     XG_CHECK_LAUNCH();
     return XG_OK;
 }

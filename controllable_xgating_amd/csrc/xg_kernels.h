@@ -240,6 +240,9 @@ int xgk_attn_bwd(hipStream_t st, const float* daf, int lddaf, const float* p, co
 // after the time loop: dvproj[b][k][a] = w_a sum_t de_t (1-th^2) ; dw[a] += sum de_t th ; dV[b][k][r] (+)= sum_t alpha_t daf_t
 int xgk_attn_bwd_post(hipStream_t st, const float* P /*(T,B,A)*/, const float* vproj, const float* w,
                       const float* DE /*(T,B,K)*/, float* dvproj, float* dw, int T, int B, int K, int A);
+// dV = sum_t alpha_t dAF_t (plain store) and dq / dw of the hoisted projection as ONE launch (T <= 32; otherwise the two passes)
+int xgk_attn_post_dV(hipStream_t st, const float* P, const float* vproj, const float* w, const float* DE, float* dvproj, float* dw,
+                     const float* ALPHA, const float* DAF, int lddaf, int64_t daf_tstride, float* dV, int T, int B, int K, int A, int R);
 int xgk_attn_dV(hipStream_t st, const float* ALPHA /*(T,B,K)*/, const float* DAF /*(T,B,ldaf)*/, int lddaf,
                 int64_t daf_tstride, float* dV, int T, int B, int K, int R, bool accumulate);
 

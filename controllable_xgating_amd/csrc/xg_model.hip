@@ -1227,8 +1227,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     // ---- after the loop.  Main chain (the encoder backward waits for it): dVproj -> dV.  Everything else is a
     // parameter gradient and goes to the auxiliary stream, under the encoder's recurrent backward.
     // (dV first, as a plain store: accumulating on top of the product below it would read every element back)
-    XG_TRY(xgk_attn_dV(st, w.ALPHA, w.DAF, R, (int64_t)BR, w.DV, T, B, K, R, false));
-    XG_TRY(xgk_attn_bwd_post(st, w.P, w.vproj, p.a2w_w, w.DE, w.DVPROJ, g.a2w_w, T, B, K, A));
+    XG_TRY(xgk_attn_post_dV(st, w.P, w.vproj, p.a2w_w, w.DE, w.DVPROJ, g.a2w_w, w.ALPHA, w.DAF, R, (int64_t)BR, w.DV, T, B, K, A, R));
     XG_TRY(cvt16(st, w, w.DVPROJ, (size_t)N * A));
     XG_TRY(nn16(st, w.gm, N, R, A, w.DVPROJ, m16(w, w.DVPROJ), A, p.v2a_w, w16(w, W16_V2A), R, w.DV, R, true));
     // gradients wrt the initial state -> img_embed_* (init_hidden; vbar is detached: SAModel.py:59-62)
