@@ -554,6 +554,8 @@ extern "C" int xg_debug_ds_trace(long long* out, int n) {
 
 static_assert(sizeof(int) * DC_WORDS <= XGK_DSTEP_SYNC_BYTES, "sync words exceed the workspace reservation");
 
+int xgk_dstep_err_word() { return DC_ERR; }      // index of the time-out flag among the sync words (diagnosis entry point below)
+
 bool xgk_dstep_ok(const XgDims& d) {
     return d.R % 8 == 0 && d.E % 4 == 0 && d.A % 4 == 0 && d.A <= 1536 && d.K <= 128 && (d.B + 31) / 32 <= DS_MAXTM &&
            d.R <= 2048;      // (the attention's partial contexts: 4 R floats of LDS)

@@ -214,6 +214,7 @@ struct DStepArgs {
     int t0_p, t0_att, t0_c1, t0_c2, total;       // first block of each job after the gate tiles (filled in by xgk_dstep)
 };
 constexpr size_t XGK_DSTEP_SYNC_BYTES = 1024;   // reserved in every workspace; the kernel itself exists in the -DXG_DIAG build only
+int xgk_dstep_err_word();
 bool xgk_dstep_ok(const XgDims& d);              // shapes the dataflow kernel takes
 int xgk_dstep(hipStream_t st, DStepArgs& a, int gemm_mode);
 

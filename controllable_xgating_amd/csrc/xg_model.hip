@@ -1425,6 +1425,19 @@ extern "C" int xg_param_numel(const XgDims* d, int i, int64_t* numel) {
     *numel = n[i];
     return XG_OK;
 }
+#ifdef XG_DIAG
+// diag library only: reads AND clears the dataflow step kernel's time-out flag (a bounded spin that gave up: the step's results are
+// wrong); host-synchronous.  tools/dstep_check.py fails on a non-zero value.
+extern "C" int xg_debug_dstep_err(void* stream, const XgDims* d, void* ws, size_t ws_bytes, int* out) {
+    Ws w; XG_TRY(check(d, ws, ws_bytes, &w));
+    if (!out) return XG_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    int32_t* word = w.dsync + xgk_dstep_err_word();
+    if (hipMemcpyAsync(out, word, sizeof(int), hipMemcpyDeviceToHost, st) != hipSuccess) return XG_EHIP;
+    if (hipMemsetAsync(word, 0, sizeof(int), st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess) return XG_EHIP;
+    return XG_OK;
+}
+#endif
 extern "C" size_t xg_workspace_bytes_mode(const XgDims* d, int gemm_mode) {
     if (!dims_ok(d)) return 0;
     const Ws w = carve(*d, nullptr);

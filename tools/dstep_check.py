@@ -46,6 +46,11 @@ def run(nrep):
                                  C.byref(run_), 0, wp, wn, nv.ptr(state), None, None)
         e1.record(); torch.cuda.synchronize()
         us = e0.elapsed_time(e1) * 1e3 / nrep
+        if hasattr(nv.lib(), "xg_debug_dstep_err"):        # (diag library) a consumer's bounded spin gave up somewhere: wrong results
+            flag = C.c_int(0)
+            rc = nv.lib().xg_debug_dstep_err(_stream(), C.byref(d), wp, wn, C.byref(flag))
+            if rc != 0 or flag.value != 0:
+                raise SystemExit("dataflow step kernel: time-out flag %d (rc %d)" % (flag.value, rc))
     return outs, us
 
 
