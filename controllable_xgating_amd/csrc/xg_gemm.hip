@@ -29,10 +29,14 @@ namespace {
 
 constexpr int BKS = 32;          // slab depth
 constexpr int LDK = BKS + 4;     // row stride of a k-contiguous LDS image
+#ifndef GEMM_MC_PAD
+#define GEMM_MC_PAD 4
+#endif
+constexpr int MCP = GEMM_MC_PAD;  // padding of a k-row of an m-contiguous LDS image
 
 template <int ROWS, bool KC>
 struct TileGeom {
-    static constexpr int lds_floats = KC ? ROWS * LDK : BKS * (ROWS + 4);
+    static constexpr int lds_floats = KC ? ROWS * LDK : BKS * (ROWS + MCP);
     static constexpr int nvec = ROWS * BKS / 4 / 256;   // float4 per thread per slab
 };
 
@@ -114,7 +118,7 @@ __device__ __forceinline__ void store_tile(float* __restrict__ lds, const f32x4 
             *reinterpret_cast<f32x4*>(lds + r * LDK + k) = regs[i];
         } else {
             const int k = f / (ROWS / 4), r = (f % (ROWS / 4)) << 2;
-            *reinterpret_cast<f32x4*>(lds + k * (ROWS + 4) + r) = regs[i];
+            *reinterpret_cast<f32x4*>(lds + k * (ROWS + MCP) + r) = regs[i];
         }
     }
 }
@@ -125,12 +129,12 @@ __device__ __forceinline__ f32x4 read_frag(const float* __restrict__ lds, int ro
     if (KC) {
         return *reinterpret_cast<const f32x4*>(lds + row * LDK + kb * 8 + half * 4);
     } else {
-        const float* p = lds + (kb * 8 + half * 4) * (ROWS + 4) + row;
+        const float* p = lds + (kb * 8 + half * 4) * (ROWS + MCP) + row;
         f32x4 v;
         v[0] = p[0];
-        v[1] = p[ROWS + 4];
-        v[2] = p[2 * (ROWS + 4)];
-        v[3] = p[3 * (ROWS + 4)];
+        v[1] = p[ROWS + MCP];
+        v[2] = p[2 * (ROWS + MCP)];
+        v[3] = p[3 * (ROWS + MCP)];
         return v;
     }
 }
@@ -402,8 +406,8 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
 // k-contiguous images have a row stride of BK + 4 floats (an odd number of 16-byte slots: ds_read_b128 fragments are conflict-free).
 template <int ROWS, int BK, bool KC>
 struct TileW {
-    static constexpr int ld = KC ? BK + 4 : ROWS + 4;
-    static constexpr int lds_floats = KC ? ROWS * (BK + 4) : BK * (ROWS + 4);
+    static constexpr int ld = KC ? BK + 4 : ROWS + MCP;
+    static constexpr int lds_floats = KC ? ROWS * (BK + 4) : BK * (ROWS + MCP);
     static constexpr int nvec = ROWS * BK / 4 / 256;        // float4 per thread per slab
     static_assert(ROWS * BK % 1024 == 0, "tile must divide over 256 threads");
 };
@@ -430,15 +434,15 @@ __device__ __forceinline__ void w1_store_one(float* __restrict__ lds, int i, con
         *reinterpret_cast<f32x4*>(lds + r * (BK + 4) + k) = v;
     } else {
         const int k = f / (ROWS / 4), r = (f % (ROWS / 4)) << 2;
-        *reinterpret_cast<f32x4*>(lds + k * (ROWS + 4) + r) = v;
+        *reinterpret_cast<f32x4*>(lds + k * (ROWS + MCP) + r) = v;
     }
 }
 template <int ROWS, int BK, bool KC>
 __device__ __forceinline__ f32x4 w1_frag(const float* __restrict__ lds, int row, int kb, int half) {
     if (KC) return *reinterpret_cast<const f32x4*>(lds + row * (BK + 4) + kb * 8 + half * 4);
-    const float* p = lds + (kb * 8 + half * 4) * (ROWS + 4) + row;
+    const float* p = lds + (kb * 8 + half * 4) * (ROWS + MCP) + row;
     f32x4 v;
-    v[0] = p[0]; v[1] = p[ROWS + 4]; v[2] = p[2 * (ROWS + 4)]; v[3] = p[3 * (ROWS + 4)];
+    v[0] = p[0]; v[1] = p[ROWS + MCP]; v[2] = p[2 * (ROWS + MCP)]; v[3] = p[3 * (ROWS + MCP)];
     return v;
 }
 
@@ -936,7 +940,11 @@ int launch_pk(hipStream_t st, const GemmArgs& a, long min_units_default) {
     // measured (tools/ubench/gemm_bench.py): the persistent form wins 3-6 % when every workgroup has >= ~40 slabs of work
     // (vocabulary head: logits, dW_logit, dH) and loses 10-15 % to 64x64 tiles + split-K on the mid-size products
     static const long min_units_env = xg_diag_env("XG_PK_MIN") ? atol(xg_diag_env("XG_PK_MIN")) : -1;
-    const long min_units = min_units_env >= 0 ? min_units_env : min_units_default;
+    // (experiment, XG_BG_MIN: a BACKGROUND product takes the persistent form from that many slabs per workgroup on -- beside a
+    //  launch chain the one-workgroup-per-CU form is about not crowding the chain, not about the product's own time)
+    static const long bg_min_env = xg_diag_env("XG_BG_MIN") ? atol(xg_diag_env("XG_BG_MIN")) : -1;
+    const bool bg_req = a.bg && !xg_diag_env("XG_GEMM_NO_BG");
+    const long min_units = (bg_req && bg_min_env >= 0) ? bg_min_env : (min_units_env >= 0 ? min_units_env : min_units_default);
     if (units < 512L * min_units) return 1;
     static const int env_g = xg_diag_env("XG_PK_G") ? atoi(xg_diag_env("XG_PK_G")) : 0;
     static const int env_split = xg_diag_env("XG_PK_SPLIT") ? atoi(xg_diag_env("XG_PK_SPLIT")) : 1;

@@ -1129,6 +1129,8 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     // the reverse-time loop has already left are done BESIDE the loop on the auxiliary stream, behind the vocabulary
     // head's products: the loop alone leaves most of the chip idle, and whatever runs under it does not compete with
     // the encoder's backward afterwards.
+    static const int wg_bg = xg_diag_env("XG_WG_BG") ? atoi(xg_diag_env("XG_WG_BG")) : 0;   // experiment: weight gradients as background products
+    const int wgm = w.gm | ((wg_bg && ss.overlap()) ? XGK_GEMM_BG : 0);
     auto wgrads_chain2 = [=, &w](hipStream_t sq, int t0, int t1) -> int {
         const int rows = (t1 - t0) * B;
         if (rows <= 0) return XG_OK;
@@ -1139,11 +1141,11 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         // (bf16 mode: mirrors of this range's operands -- each is read by two or three of the products below)
         XG_TRY(cvt16(sq, w, ds2, (size_t)rows * 4 * R)); XG_TRY(cvt16(sq, w, dp, (size_t)rows * A));
         XG_TRY(cvt16(sq, w, h1, (size_t)(rows + B) * R)); XG_TRY(cvt16(sq, w, h2, (size_t)rows * R)); XG_TRY(cvt16(sq, w, af, (size_t)rows * R));
-        XG_TRY(tn16(sq, w.gm, rows, 4 * R, R, ds2, m16(w, ds2), 4 * R, h1n, m16(w, h1n), R, g.l2_i2h_w, R, g.l2_i2h_b, g.l2_a2h_b, g.l2_h2h_b));
-        XG_TRY(tn16(sq, w.gm, rows, 4 * R, R, ds2, m16(w, ds2), 4 * R, af, m16(w, af), R, g.l2_a2h_w, R));
-        XG_TRY(tn16(sq, w.gm, rows, 4 * R, R, ds2, m16(w, ds2), 4 * R, h2, m16(w, h2), R, g.l2_h2h_w, R));
-        XG_TRY(tn16(sq, w.gm, rows, A, R, dp, m16(w, dp), A, h1, m16(w, h1), R, g.h2a_w, 2 * R, g.h2a_b));
-        XG_TRY(tn16(sq, w.gm, rows, A, R, dp, m16(w, dp), A, h2, m16(w, h2), R, g.h2a_w + R, 2 * R));
+        XG_TRY(tn16(sq, wgm, rows, 4 * R, R, ds2, m16(w, ds2), 4 * R, h1n, m16(w, h1n), R, g.l2_i2h_w, R, g.l2_i2h_b, g.l2_a2h_b, g.l2_h2h_b));
+        XG_TRY(tn16(sq, wgm, rows, 4 * R, R, ds2, m16(w, ds2), 4 * R, af, m16(w, af), R, g.l2_a2h_w, R));
+        XG_TRY(tn16(sq, wgm, rows, 4 * R, R, ds2, m16(w, ds2), 4 * R, h2, m16(w, h2), R, g.l2_h2h_w, R));
+        XG_TRY(tn16(sq, wgm, rows, A, R, dp, m16(w, dp), A, h1, m16(w, h1), R, g.h2a_w, 2 * R, g.h2a_b));
+        XG_TRY(tn16(sq, wgm, rows, A, R, dp, m16(w, dp), A, h2, m16(w, h2), R, g.h2a_w + R, 2 * R));
         return XG_OK;
     };
     auto wgrads_chain1 = [=, &w](hipStream_t sq, int t0, int t1) -> int {
@@ -1153,12 +1155,12 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         const float* ds1 = w.DS1 + r0 * 4 * R;
         const float *h1 = w.H1 + r0 * R, *posg = w.POSG + r0 * R;
         XG_TRY(cvt16(sq, w, ds1, (size_t)rows * 4 * R)); XG_TRY(cvt16(sq, w, h1, (size_t)rows * R)); XG_TRY(cvt16(sq, w, posg, (size_t)rows * R));
-        XG_TRY(tn16(sq, w.gm, rows, 4 * R, R, ds1, m16(w, ds1), 4 * R, h1, m16(w, h1), R, g.l1_h2h_w, R, g.l1_i2h_b, g.l1_a2h_b, g.l1_h2h_b));
-        XG_TRY(tn16(sq, w.gm, rows, 4 * R, E, ds1, m16(w, ds1), 4 * R, w.Xe + r0 * E, nullptr, E, g.l1_i2h_w, E));
-        XG_TRY(tn16(sq, w.gm, rows, 4 * R, R, ds1, m16(w, ds1), 4 * R, posg, m16(w, posg), R, g.l1_a2h_w, R));
+        XG_TRY(tn16(sq, wgm, rows, 4 * R, R, ds1, m16(w, ds1), 4 * R, h1, m16(w, h1), R, g.l1_h2h_w, R, g.l1_i2h_b, g.l1_a2h_b, g.l1_h2h_b));
+        XG_TRY(tn16(sq, wgm, rows, 4 * R, E, ds1, m16(w, ds1), 4 * R, w.Xe + r0 * E, nullptr, E, g.l1_i2h_w, E));
+        XG_TRY(tn16(sq, wgm, rows, 4 * R, R, ds1, m16(w, ds1), 4 * R, posg, m16(w, posg), R, g.l1_a2h_w, R));
         // input side of cell 1: pos' gate, embedding
-        XG_TRY(nn16(sq, w.gm, rows, R, 4 * R, ds1, m16(w, ds1), 4 * R, p.l1_a2h_w, w16(w, W16_L1_A2H), R, w.DPOSG + r0 * R, R, false));
-        XG_TRY(nn16(sq, w.gm, rows, E, 4 * R, ds1, m16(w, ds1), 4 * R, p.l1_i2h_w, w16(w, W16_L1_I2H), E, w.DXe + r0 * E, E, false));
+        XG_TRY(nn16(sq, wgm, rows, R, 4 * R, ds1, m16(w, ds1), 4 * R, p.l1_a2h_w, w16(w, W16_L1_A2H), R, w.DPOSG + r0 * R, R, false));
+        XG_TRY(nn16(sq, wgm, rows, E, 4 * R, ds1, m16(w, ds1), 4 * R, p.l1_i2h_w, w16(w, W16_L1_I2H), E, w.DXe + r0 * E, E, false));
         return XG_OK;
     };
     static const int wg_chunks_env = xg_diag_env("XG_WG_CHUNKS") ? atoi(xg_diag_env("XG_WG_CHUNKS")) : 2;
