@@ -1020,6 +1020,208 @@ int launch(hipStream_t st, const GemmArgs& g) {
     return XG_OK;
 }
 
+// ---- weight-gradient layout straight from memory ("td": transposed-direct) -------------------------------------------
+// C[M,N] (+)= A^T B with A stored (K, M) and B stored (K, N), both row-major: the layout of every weight gradient dW = dY^T X.
+// Here the operand layout of v_mfma_f32_16x16x4_f32 IS the memory layout: the instruction wants A[i = lane % 16][k = lane / 16]
+// and B[k = lane / 16][j = lane % 16], i.e. for a fixed k one value per consecutive m (n) -- a row of the stored matrix.  A lane
+// loads 16 bytes = 4 consecutive m of row k = 4 s + lane / 16 and uses the four values as the A operand of FOUR tiles whose rows
+// interleave (tile i holds rows m0 + 4 a + i): one global_load_dwordx4 per operand per 4-deep step feeds 16 MFMAs of a 64 x 64
+// wave tile.  No LDS image, no barrier and no ds_read in the K loop; 16-lane groups read 256 contiguous bytes.  The four waves of
+// a workgroup take interleaved k-steps of the SAME tile (16 consecutive k-rows per round) and add their tiles through LDS at the
+// end; a ring of D steps of operands per wave is in flight.  Measured against the LDS-staged kernels on the weight-gradient
+// shapes in tools/ubench/gemm_bench.py.
+struct TdArgs {
+    const float* A; const float* B; float* C;
+    int M, N, K, lda, ldb, ldc, accumulate;
+    int ntm, ntn, ksplit, nrounds;   // nrounds = K / 16
+    float* csum[3];
+};
+constexpr int TD_LDW = 68;           // row pitch of a wave's partial tile in LDS (floats)
+
+template <int D>
+__global__ void __launch_bounds__(256) gemm_td_kernel(TdArgs g) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];       // 4 x 64 x TD_LDW partial tiles + 4 x 64 column sums
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int a16 = lane & 15, kq = lane >> 4;
+    const int G = gridDim.x;
+    const int xq = G >> 3, xr = G & 7, xcd = blockIdx.x & 7, idx = blockIdx.x >> 3;
+    const int pos = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + idx;     // XCD x owns contiguous positions
+    const int nitems = g.ntm * g.ntn * g.ksplit;
+    const bool want_cs = g.csum[0] != nullptr;
+    const size_t stepA = (size_t)16 * g.lda * sizeof(float), stepB = (size_t)16 * g.ldb * sizeof(float);
+    float* red = smem + 4 * 64 * TD_LDW;
+    for (int item = pos; item < nitems; item += G) {
+        const int part = item % g.ksplit, tile = item / g.ksplit;
+        const int tn = tile % g.ntn, tm = tile / g.ntn;
+        const int m0 = tm * 64, n0 = tn * 64;
+        const int i0 = (int)(((long)part * g.nrounds) / g.ksplit), i1 = (int)(((long)(part + 1) * g.nrounds) / g.ksplit);
+        const bool cs_on = want_cs && tn == 0;
+        // this lane's 16 bytes of a k-row: columns clamped into the matrix (whole groups of 4: M % 4 == N % 4 == 0)
+        const uint32_t offA = (uint32_t)(((size_t)kq * g.lda + min(m0 + 4 * a16, g.M - 4)) * sizeof(float));
+        const uint32_t offB = (uint32_t)(((size_t)kq * g.ldb + min(n0 + 4 * a16, g.N - 4)) * sizeof(float));
+        const char* pa = reinterpret_cast<const char*>(g.A) + (size_t)4 * wave * g.lda * sizeof(float);
+        const char* pb = reinterpret_cast<const char*>(g.B) + (size_t)4 * wave * g.ldb * sizeof(float);
+        f32x4 acc[4][4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+        // ring of D steps: slot u holds step it + u; a slot is requested again (step + D) right after it is consumed.  The order
+        // [16 MFMAs][2 loads] per step is pinned (sched_barrier): left alone the scheduler sinks all of a ring's loads behind its
+        // last MFMA, which makes the ring one step deep.  (launcher: every part has at least D steps)
+        f32x4 ra[D], rb[D];
+        const char* qa = pa + (size_t)i0 * stepA;
+        const char* qb = pb + (size_t)i0 * stepB;
+#pragma unroll
+        for (int u = 0; u < D; ++u) {
+            ra[u] = *reinterpret_cast<const f32x4*>(qa + u * stepA + offA);
+            rb[u] = *reinterpret_cast<const f32x4*>(qb + u * stepB + offB);
+        }
+        qa += D * stepA; qb += D * stepB;            // -> step it + D of slot 0
+        auto step = [&](int u, bool reload) {         // (the reload goes into the registers the MFMAs have just read: no second name)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ra[u][i], rb[u][j], acc[i][j], 0, 0, 0);
+            if (cs_on) cs += ra[u];
+            __builtin_amdgcn_sched_barrier(0);
+            if (reload) {
+                ra[u] = *reinterpret_cast<const f32x4*>(qa + u * stepA + offA);
+                rb[u] = *reinterpret_cast<const f32x4*>(qb + u * stepB + offB);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        int it = i0;
+        for (; it + 2 * D <= i1; it += D) {          // every reload of this ring is a step of this part
+#pragma unroll
+            for (int u = 0; u < D; ++u) step(u, true);
+            qa += D * stepA; qb += D * stepB;
+        }
+        {   // the last D .. 2 D - 1 steps
+            const int left = i1 - it - D;           // steps behind the ring that is in registers: 0 .. D - 1
+#pragma unroll
+            for (int u = 0; u < D; ++u) step(u, u < left);
+#pragma unroll
+            for (int u = 0; u < D; ++u) if (u < left) step(u, false);
+        }
+        // ---- the four waves' tiles meet in LDS.  D layout of the instruction: lane l, register r = element (4 (l / 16) + r, l % 16)
+        // of the 16 x 16 tile; tile (i, j) holds rows m0 + 4 a + i, columns n0 + 4 c + j: a lane's (i, r) is a row, its j = 0..3
+        // four consecutive columns.
+        float* mine = smem + wave * 64 * TD_LDW;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = 16 * kq + 4 * r + i;
+                *reinterpret_cast<f32x4*>(mine + row * TD_LDW + 4 * a16) = f32x4{acc[i][0][r], acc[i][1][r], acc[i][2][r], acc[i][3][r]};
+            }
+        if (cs_on) {
+            // the four k-quarters of the wave (lanes l, l + 16, l + 32, l + 48), then one row of 64 sums per wave
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float v = cs[q];
+                v += __shfl_xor(v, 16);
+                v += __shfl_xor(v, 32);
+                if (kq == 0) red[wave * 64 + 4 * a16 + q] = v;
+            }
+        }
+        __syncthreads();
+        {
+            const bool atom = g.ksplit > 1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int q = lane + 64 * u;
+                const int row = 16 * wave + (q >> 4), col = (q & 15) << 2;
+                f32x4 v = *reinterpret_cast<const f32x4*>(smem + row * TD_LDW + col);
+#pragma unroll
+                for (int w2 = 1; w2 < 4; ++w2) v += *reinterpret_cast<const f32x4*>(smem + (w2 * 64 + row) * TD_LDW + col);
+                const int gr = m0 + row, gc = n0 + col;
+                if (gr < g.M && gc < g.N) {
+                    float* dst = g.C + (size_t)gr * g.ldc + gc;
+                    if (atom) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) unsafeAtomicAdd(dst + e, v[e]);
+                    } else if (g.accumulate) {
+                        *reinterpret_cast<f32x4*>(dst) = *reinterpret_cast<const f32x4*>(dst) + v;
+                    } else {
+                        *reinterpret_cast<f32x4*>(dst) = v;
+                    }
+                }
+            }
+            if (cs_on && threadIdx.x < 64) {
+                const int m = m0 + (int)threadIdx.x;
+                if (m < g.M) {
+                    const float v = (red[threadIdx.x] + red[64 + threadIdx.x]) + (red[128 + threadIdx.x] + red[192 + threadIdx.x]);
+#pragma unroll
+                    for (int o = 0; o < 3; ++o) if (g.csum[o]) unsafeAtomicAdd(g.csum[o] + m, v);
+                }
+            }
+        }
+        __syncthreads();                          // the partial tiles are free again
+    }
+}
+
+// returns 1 when the product is not this kernel's kind
+int launch_td(hipStream_t st, const GemmArgs& a) {
+    static const int off = xg_diag_env("XG_GEMM_NO_TD") ? 1 : 0;
+    if (off || !a.fast || a.relu || a.bias || a.M % 4 || a.N % 4 || a.K % 16 || a.ldc % 4 || ((uintptr_t)a.C % 16) != 0) return 1;
+    if (a.M < 64 || a.N < 64 || a.K < 16 * 16) return 1;      // (>= 2 rings of 8 steps)
+    TdArgs g{a.A, a.B, a.C, a.M, a.N, a.K, a.lda, a.ldb, a.ldc, a.accumulate, 0, 0, 1, a.K / 16, {a.csum[0], a.csum[1], a.csum[2]}};
+    g.ntm = xg_cdiv(a.M, 64); g.ntn = xg_cdiv(a.N, 64);
+    const long tiles = (long)g.ntm * g.ntn;
+    if (tiles < 32) return 1;
+    static const long tmin = xg_diag_env("XG_TD_TILES_MIN") ? atol(xg_diag_env("XG_TD_TILES_MIN")) : 0;
+    static const long tmax = xg_diag_env("XG_TD_TILES_MAX") ? atol(xg_diag_env("XG_TD_TILES_MAX")) : (1L << 40);
+    static const int only_bg = xg_diag_env("XG_TD_ONLY_BG") ? atoi(xg_diag_env("XG_TD_ONLY_BG")) : 0;     // 1: background products only, 2: the others only
+    if (tiles < tmin || tiles > tmax || (only_bg == 1 && !a.bg) || (only_bg == 2 && a.bg)) return 1;
+    // Production rule: the vocabulary head's weight gradient (a background product, or >= 1024 tiles).  The mid-size weight
+    // gradients are 18 % faster here when they run ALONE (51.6 vs 61.0 us at 2048 x 512 x 2688) but the iteration is 1 % slower
+    // with them (5.95-5.99 vs 5.88-5.91 ms, three runs each way, tools/ubench/td_iter*.sh): they run beside the recurrent launch
+    // chains, which are the critical path, and a product that keeps 16 wide loads per wave in flight lengthens every round trip of
+    // the chain next to it.  XG_TD_ALL=1 (diag library) sends every eligible product here.
+    static const int td_all = xg_diag_env("XG_TD_ALL") ? atoi(xg_diag_env("XG_TD_ALL")) : 0;
+    if (!td_all && !only_bg && tmin == 0 && !a.bg && tiles < 1024) return 1;
+    static const int ks_env = xg_diag_env("XG_TD_KS") ? atoi(xg_diag_env("XG_TD_KS")) : 0;
+    int ks = 1;
+    if (tiles < 192) { ks = (int)(256 / tiles); if (ks > g.nrounds / 16) ks = g.nrounds / 16; if (ks < 1) ks = 1; }
+    if (ks_env > 0) ks = ks_env;
+    if (ks > g.nrounds / 8) ks = g.nrounds / 8;      // every part: at least one ring
+    g.ksplit = ks;
+    if (ks > 1 && !a.accumulate) {
+        if (a.ldc == a.N) { if (hipMemsetAsync(a.C, 0, sizeof(float) * (size_t)a.M * a.N, st) != hipSuccess) return XG_EHIP; }
+        else if (hipMemset2DAsync(a.C, sizeof(float) * a.ldc, 0, sizeof(float) * a.N, a.M, st) != hipSuccess) return XG_EHIP;
+    }
+    static const int bg_off = xg_diag_env("XG_GEMM_NO_BG") ? 1 : 0;
+    static const int pad_all = xg_diag_env("XG_TD_PAD") ? atoi(xg_diag_env("XG_TD_PAD")) : 0;      // experiment: every td launch one workgroup per CU
+    const bool bg = (a.bg && !bg_off) || (pad_all && tiles <= 512);
+    const long items = tiles * ks;
+    const int GMAX = bg ? 256 : 512;
+    const long rounds = xg_cdiv64(items, GMAX);
+    const int G = (int)xg_cdiv64(items, rounds);      // the fewest rounds, evened out over the workgroups
+    size_t lds = (4 * 64 * TD_LDW + 256) * sizeof(float);
+    if (bg && lds < 82 * 1024) lds = 82 * 1024;      // one workgroup per CU beside a launch chain (see launch_pk)
+    static const int depth_all = xg_diag_env("XG_TD_DEPTH") ? atoi(xg_diag_env("XG_TD_DEPTH")) : 8;
+    static const int depth_bg = xg_diag_env("XG_TD_BG_DEPTH") ? atoi(xg_diag_env("XG_TD_BG_DEPTH")) : depth_all;
+    const int depth_env = bg ? depth_bg : depth_all;
+    if (depth_env == 4) {
+        static std::atomic<unsigned> optin4{0};
+        XG_TRY(xg_lds_optin(optin4, reinterpret_cast<const void*>(&gemm_td_kernel<4>), 84 * 1024));
+        hipLaunchKernelGGL((gemm_td_kernel<4>), dim3(G), dim3(256), lds, st, g);
+    } else if (depth_env == 12 && g.nrounds / ks >= 12) {
+        static std::atomic<unsigned> optin12{0};
+        XG_TRY(xg_lds_optin(optin12, reinterpret_cast<const void*>(&gemm_td_kernel<12>), 84 * 1024));
+        hipLaunchKernelGGL((gemm_td_kernel<12>), dim3(G), dim3(256), lds, st, g);
+    } else {
+        static std::atomic<unsigned> optin{0};
+        XG_TRY(xg_lds_optin(optin, reinterpret_cast<const void*>(&gemm_td_kernel<8>), 84 * 1024));
+        hipLaunchKernelGGL((gemm_td_kernel<8>), dim3(G), dim3(256), lds, st, g);
+    }
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+
 // launcher of the one-workgroup-per-CU kernel: picks the tile (wave grid 2 x 2 of 32 x 32 MFMA tiles) whose ONE round over the 256 CUs
 // wastes the least, returns 1 when no candidate covers the chip well enough (or the shape is not its kind)
 template <int BM, int BN, int BK, bool AKC, bool BKC>
@@ -1104,6 +1306,12 @@ int dispatch(hipStream_t st, GemmArgs g, bool vec) {
         if (sscanf(force, "%d,%d", &t, &sk) == 2) { big = t == 128; g.splitk = g.relu ? 1 : (sk < 1 ? 1 : sk); }
     }
     g.gm = xgk_group_rows(g.K);                     // the persistent kernel walks whole reductions
+    if constexpr (!AKC && !BKC) {
+        if (vec && !force) {                        // the weight-gradient layout: operands straight from memory
+            const int rct = launch_td(st, g);
+            if (rct != 1) return rct;
+        }
+    }
     if (vec && !force) {
         const int rc1 = dispatch_w1<AKC, BKC>(st, g);
         if (rc1 != 1) return rc1;

@@ -195,6 +195,54 @@ def test_dataflow_step_kernel_equals_three_launch_step(rows):
     assert r.returncode == 0 and "us per step" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
+_GEMM_TD = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from controllable_xgating_amd import _native as nv
+L = nv.lib()
+bad = []
+for (M, N, K) in ((2048, 512, 2688), (20000, 512, 2688), (512, 512, 3328), (516, 468, 1040), (1536, 512, 2688), (2048, 468, 2688),
+                  (512, 1024, 3328), (4100, 260, 272)):
+    g = torch.Generator(device="cuda").manual_seed(M + 3 * N + 5 * K)
+    A = torch.randn(K, M, generator=g, device="cuda")
+    B = torch.randn(K, N, generator=g, device="cuda")
+    C0 = torch.randn(M, N, generator=g, device="cuda")
+    ref = A.t().double() @ B.double()
+    scale = float(ref.abs().max())
+    for acc in (0, 1):
+        Cd = C0.clone()
+        rc = L.xg_gemm(None, 1, 0, M, N, K, nv.ptr(A), M, nv.ptr(B), N, nv.ptr(Cd), N, None, 0, acc)
+        want = ref + (C0.double() if acc else 0)
+        err = float((Cd.double() - want).abs().max()) / scale
+        if rc != 0 or not err < 4e-6 * max(1.0, np.sqrt(K / 4096.0)): bad.append((M, N, K, acc, rc, err))
+print("bad", bad)
+sys.exit(1 if bad else 0)
+"""
+
+
+@pytest.mark.parametrize("rule", ["production", "every_eligible_product", "split_2", "depth_4"])
+def test_gemm_weight_gradient_layout_from_memory(rule):
+    """C (+)= A^T B with both operands stored (K, .): xg_gemm.hip's gemm_td_kernel (v_mfma_f32_16x16x4_f32 fed by 16-byte global loads
+    in the instruction's own operand layout, no LDS image; four waves per 64 x 64 tile on interleaved k-steps, added through LDS;
+    a cross-workgroup split of the reduction with atomics when there are few tiles; persistent rounds when there are many).
+    Ragged edges (extents that are multiples of 4 but not of 64), plain store and += C, every element against fp64.  The
+    production rule sends only the vocabulary head's weight gradient there (20000 x 512: see launch_td); the -DXG_DIAG library's
+    XG_TD_ALL=1 every eligible product (few tiles: split reductions; XG_TD_KS / XG_TD_DEPTH force the split and the ring depth)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from controllable_xgating_amd import _native as nv
+    env = dict(os.environ)
+    if rule != "production":
+        env.update(XG_LIBRARY=nv.LIB_DIAG_PATH, XG_TD_ALL="1")
+    if rule == "split_2":
+        env["XG_TD_KS"] = "2"
+    if rule == "depth_4":
+        env["XG_TD_DEPTH"] = "4"
+    r = subprocess.run([sys.executable, "-c", _GEMM_TD % root], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_gemm_strided_submatrix():
     """W[:, R:2R] column block of h2a.weight as B operand (ldb = 2R) and accumulate, as the step uses it."""
     from controllable_xgating_amd import _native as nv
