@@ -90,7 +90,7 @@ int xgk_gate_bwd(hipStream_t st, const float* dy, int lddy, const float* g, int 
 
 // y = dropout(x) (x already ReLU'd) in place ; backward: dx = dy*keep*(y>0) in place
 int xgk_relu_drop_fwd(hipStream_t st, float* x, int64_t n, XgDrop drop);
-int xgk_relu_drop_bwd(hipStream_t st, float* dy, const float* y, int64_t n, XgDrop drop);
+int xgk_relu_drop_bwd(hipStream_t st, float* dy, const float* y, int64_t n, XgDrop drop, const float* src = nullptr /* dy = f(src): out of place */);
 
 // column reductions over rows of X (N,Cn) ld: out[c] += sum_r X[r][c]  (atomic accumulate; caller zeroes)
 int xgk_colsum(hipStream_t st, const float* X, int ld, int N, int Cn, float* out);
@@ -100,7 +100,12 @@ int xgk_colsum3(hipStream_t st, const float* X, int ld, int N, int Cn, float* ou
 int xgk_colsum_prod(hipStream_t st, const float* X, int ldx, const float* Y, int ldy, int N, int Cn, float* out);
 
 // BatchNorm1d over rows of Z (N,R): statistics, apply (+ReLU, dropout, row mask), backward
-int xgk_bn_stats(hipStream_t st, const float* Z, int N, int R, float* mean, float* var /*biased*/, float* scratch);
+// train-mode BatchNorm forward in one launch: batch statistics (+ running statistics when rmean / rvar are given) and, when X is
+// given, X = dropout(relu(bn(Z))) * rowmask.  Returns 1 when the shape is not the fused kernel's kind (R % 16, N <= 5120).
+int xgk_bn_train_fwd(hipStream_t st, const float* Z, int N, int R, float* mean, float* var, float* rmean, float* rvar, float momentum,
+                     const float* gamma, const float* beta, const float* rowmask, float* X, float eps, XgDrop drop);
+int xgk_bn_stats(hipStream_t st, const float* Z, int N, int R, float* mean, float* var /*biased*/, float* rmean = nullptr,
+                 float* rvar = nullptr, float momentum = 0.f /* running statistics updated in the same launch when given */);
 int xgk_bn_running(hipStream_t st, const float* mean, const float* var, float* rmean, float* rvar, int N, int R,
                    float momentum);
 // X[r][c] = dropout(relu((Z-mean)*rsqrt(var+eps)*gamma+beta)) * rowmask[r]
@@ -112,7 +117,7 @@ int xgk_bn_bwd_reduce(hipStream_t st, float* dX, const float* X, const float* Z,
 // dZ = gamma*invstd*(dY - sum_dy/N - xhat*sum_dyxhat/N) (train) or gamma*invstd*dY (eval), in place on dY
 int xgk_bn_bwd_apply(hipStream_t st, float* dY, const float* Z, const float* mean, const float* var,
                      const float* gamma, const float* sum_dy, const float* sum_dyxhat, int N, int R, float eps,
-                     bool train);
+                     bool train, float* g_beta = nullptr, float* g_gamma = nullptr /* += sum_dy, += sum_dyxhat in the same launch */);
 
 // row i uses token tok[(i % inner) * s_inner + (i / inner) * s_outer]
 int xgk_step_prep(hipStream_t st, const float* table, int E, const int64_t* tok, int V, float* xt, int B,

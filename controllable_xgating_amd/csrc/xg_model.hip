@@ -356,23 +356,30 @@ int encoder_fwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgBnSt
         hipStream_t st = (m == 1 && side) ? ss->aux2 : st_main;
         XG_TRY(lin16(st, w.gm, N, R, F[m], feats[m], nullptr, F[m], emb_w[m], w16(w, m == 0 ? W16_EMB_RGB : W16_EMB_OPFL), emb_b[m],
                      w.Z[m], R));                                                                           // sub_modules.py:121,126
+        const XgDrop emb_drop = xg_make_drop(&run, m == 0 ? XG_SITE_EMB_RGB : XG_SITE_EMB_OPFL, 0);
+        bool applied = false;
         if (run.train) {
-            XG_TRY(xgk_bn_stats(st, w.Z[m], N, R, w.bn_mean[m], w.bn_var[m], nullptr));
-            if (rmean[m] && rvar[m])
-                XG_TRY(xgk_bn_running(st, w.bn_mean[m], w.bn_var[m], rmean[m], rvar[m], N, R, run.bn_momentum));
+            const bool upd = rmean[m] && rvar[m];                  // (running statistics: updated by the same launch)
+            // statistics + running statistics + the layer's output in ONE launch when the shape allows
+            const int rc = xgk_bn_train_fwd(st, w.Z[m], N, R, w.bn_mean[m], w.bn_var[m], upd ? rmean[m] : nullptr, upd ? rvar[m] : nullptr,
+                                            run.bn_momentum, bn_g[m], bn_b[m], x.feat_mask, w.X[m], run.bn_eps, emb_drop);
+            if (rc == XG_OK) applied = true;
+            else if (rc != 1) return rc;
+            else XG_TRY(xgk_bn_stats(st, w.Z[m], N, R, w.bn_mean[m], w.bn_var[m], upd ? rmean[m] : nullptr, upd ? rvar[m] : nullptr,
+                                     run.bn_momentum));
         } else {
             if (!rmean[m] || !rvar[m]) return XG_EINVAL;
             if (hipMemcpyAsync(w.bn_mean[m], rmean[m], sizeof(float) * R, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
             if (hipMemcpyAsync(w.bn_var[m], rvar[m], sizeof(float) * R, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
         }
-        XG_TRY(xgk_bn_apply(st, w.Z[m], w.bn_mean[m], w.bn_var[m], bn_g[m], bn_b[m], x.feat_mask, w.X[m], N, R,
-                            run.bn_eps, xg_make_drop(&run, m == 0 ? XG_SITE_EMB_RGB : XG_SITE_EMB_OPFL, 0)));
+        if (!applied)
+            XG_TRY(xgk_bn_apply(st, w.Z[m], w.bn_mean[m], w.bn_var[m], bn_g[m], bn_b[m], x.feat_mask, w.X[m], N, R, run.bn_eps, emb_drop));
         XG_TRY(cvt16(st, w, w.X[m], (size_t)N * R));
         XG_TRY(lin16(st, w.gm, N, 4 * R, R, w.X[m], m16(w, w.X[m]), R, wih[m], w16(w, m == 0 ? W16_WIH_RGB : W16_WIH_OPFL), bih[m],
                      w.PRE[m], 4 * R));                                                                     // hoisted over all K frames
     }
+    if (hipMemsetAsync(w.zeroBR, 0, sizeof(float) * (size_t)B * R, (side ? ss->aux2 : st_main)) != hipSuccess) return XG_EHIP;   // (off the main chain)
     if (side) XG_TRY(ss->join2());
-    ZERO(w.zeroBR, (size_t)B * R);
     if (ss && ss->deferred) {                   // side work the caller wants under this latency-bound recurrence
         std::function<int()> f = std::move(ss->deferred);
         ss->deferred = nullptr;
@@ -446,8 +453,7 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
     float* g_emb_w[2] = {g.emb_rgb_w, g.emb_opfl_w};
     float* g_emb_b[2] = {g.emb_rgb_b, g.emb_opfl_b};
 
-    if (hipMemcpyAsync(w.dVw, dV_in, sizeof(float) * (size_t)N * R, hipMemcpyDeviceToDevice, st) != hipSuccess) return XG_EHIP;
-    XG_TRY(xgk_relu_drop_bwd(st, w.dVw, w.Venc, (int64_t)N * R, xg_make_drop(&run, XG_SITE_FUSION, 0)));
+    XG_TRY(xgk_relu_drop_bwd(st, w.dVw, w.Venc, (int64_t)N * R, xg_make_drop(&run, XG_SITE_FUSION, 0), dV_in));   // dVw = f(dV_in)
     XG_TRY(cvt16(st, w, w.dVw, (size_t)N * R));
     XG_TRY(ss.fork());
     XG_TRY(tn16(sx, w.gm, N, R, 2 * R, w.dVw, m16(w, w.dVw), R, w.Y, m16(w, w.Y), 2 * R, g.fusion_w, 2 * R, g.fusion_b));
@@ -532,10 +538,8 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
         if (!w.zeroed) { ZERO(w.bn_s1[m], R); ZERO(w.bn_s2[m], R); }
         XG_TRY(xgk_bn_bwd_reduce(st, w.dX[m], w.X[m], w.Z[m], w.bn_mean[m], w.bn_var[m], x.feat_mask, N, R, run.bn_eps,
                                  xg_make_drop(&run, m == 0 ? XG_SITE_EMB_RGB : XG_SITE_EMB_OPFL, 0), w.bn_s1[m], w.bn_s2[m]));
-        XG_TRY(xgk_axpy(st, g_bn_b[m], w.bn_s1[m], 1.f, R));
-        XG_TRY(xgk_axpy(st, g_bn_g[m], w.bn_s2[m], 1.f, R));
         XG_TRY(xgk_bn_bwd_apply(st, w.dX[m], w.Z[m], w.bn_mean[m], w.bn_var[m], bn_g[m], w.bn_s1[m], w.bn_s2[m], N, R,
-                                run.bn_eps, run.train != 0));
+                                run.bn_eps, run.train != 0, g_bn_b[m], g_bn_g[m]));     // (+ the two parameter gradients)
         XG_TRY(gemm_tn_cs(st, w.gm, N, R, F[m], w.dX[m], R, feats[m], F[m], g_emb_w[m], F[m], g_emb_b[m]));
     }
     return ss.chain2_into_aux();              // the caller's join() of aux then covers the second side chain too

@@ -158,9 +158,9 @@ __global__ void relu_drop_fwd_kernel(float* x, int64_t n, XgDrop drop) {
     const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
     if (i < n) x[i] *= xg_keep(drop, (uint32_t)i);
 }
-__global__ void relu_drop_bwd_kernel(float* dy, const float* y, int64_t n, XgDrop drop) {
+__global__ void relu_drop_bwd_kernel(float* dy, const float* src, const float* y, int64_t n, XgDrop drop) {
     const int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x;
-    if (i < n) dy[i] = y[i] > 0.f ? dy[i] * drop.scale : 0.f;
+    if (i < n) dy[i] = y[i] > 0.f ? src[i] * drop.scale : 0.f;
 }
 
 // ------------------------------------------------------------------ column reductions
@@ -282,13 +282,17 @@ template <int NV>
 __global__ void bn_bwd_apply_kernel(float* __restrict__ dY, const float* __restrict__ Z, const float* __restrict__ mean,
                                     const float* __restrict__ var, const float* __restrict__ gamma,
                                     const float* __restrict__ sum_dy, const float* __restrict__ sum_dyxhat, int N, int R,
-                                    float eps, int train) {
+                                    float eps, int train, float* g_beta, float* g_gamma) {
     const int64_t idx = ((int64_t)blockIdx.x * TPB + threadIdx.x) * NV;
     if (idx >= (int64_t)N * R) return;
     const int c = (int)(idx % R);
     float d[NV], z[NV], mu[NV], vr[NV], ga[NV], s1[NV], s2[NV];
     ldv<NV>(dY + idx, d); ldv<NV>(Z + idx, z); ldv<NV>(mean + c, mu); ldv<NV>(var + c, vr); ldv<NV>(gamma + c, ga);
     ldv<NV>(sum_dy + c, s1); ldv<NV>(sum_dyxhat + c, s2);
+    if (g_beta && idx < R) {                         // row 0's threads: d(beta) += sum dy, d(gamma) += sum dy xhat (two axpy launches less)
+#pragma unroll
+        for (int q = 0; q < NV; ++q) { g_beta[c + q] += s1[q]; g_gamma[c + q] += s2[q]; }
+    }
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
         const float is = 1.0f / sqrtf(vr[q] + eps);
@@ -432,9 +436,9 @@ int xgk_relu_drop_fwd(hipStream_t st, float* x, int64_t n, XgDrop drop) {
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
-int xgk_relu_drop_bwd(hipStream_t st, float* dy, const float* y, int64_t n, XgDrop drop) {
+int xgk_relu_drop_bwd(hipStream_t st, float* dy, const float* y, int64_t n, XgDrop drop, const float* src) {
     if (n <= 0) return XG_OK;
-    hipLaunchKernelGGL(relu_drop_bwd_kernel, grid1(n), dim3(TPB), 0, st, dy, y, n, drop);
+    hipLaunchKernelGGL(relu_drop_bwd_kernel, grid1(n), dim3(TPB), 0, st, dy, src ? src : dy, y, n, drop);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
@@ -447,60 +451,113 @@ int xgk_colsum3(hipStream_t st, const float* X, int ld, int N, int Cn, float* ou
 int xgk_colsum_prod(hipStream_t st, const float* X, int ldx, const float* Y, int ldy, int N, int Cn, float* out) {
     return colreduce<1>(st, X, ldx, Y, ldy, N, Cn, out);
 }
-// Batch statistics of 4 columns per workgroup with the column strip held in registers: one read of Z, the exact two-pass form
-// (mean, then sum of squared deviations), a fixed summation order -- one launch where the column reductions below take six
-// (2 fills, 2 reductions with atomics, 2 scalings: 65 us of launches on the encoder's critical path at N = 3328, this 6-8 us).
+// Train-mode BatchNorm forward of 16 columns per workgroup with the column strip held in registers: one read of Z, the exact
+// two-pass statistics (mean, then the sum of squared deviations) in a fixed summation order, the running statistics' update and
+// -- when X is given -- the normalised, ReLU'd, dropped and row-masked output, all in ONE launch.  The column reductions it
+// replaces took six launches (2 fills, 2 reductions with atomics, 2 scalings) + bn_running + bn_apply: ~110 us of launch chain in
+// front of the encoder's recurrence at N = 3328.  Four lanes cover a row's 64 bytes (whole sectors; a first form with 4 columns
+// per workgroup read 16 bytes per row and took 47 us).
 template <int NV>
-__global__ void __launch_bounds__(512) bn_stats_reg_kernel(const float* __restrict__ Z, int N, int R, float* __restrict__ mean,
-                                                             float* __restrict__ var) {
-    __shared__ float4 red[8];
-    const int c0 = blockIdx.x * 4, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ void __launch_bounds__(1024) bn_train_fwd_kernel(const float* __restrict__ Z, int N, int R, float* __restrict__ mean,
+                                                              float* __restrict__ var, float* rmean, float* rvar, float mom,
+                                                              const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                              const float* __restrict__ rowmask, float* __restrict__ X, float eps,
+                                                              XgDrop drop) {
+    __shared__ float4 red[16][4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int rl = threadIdx.x >> 2, cq = threadIdx.x & 3, c = blockIdx.x * 16 + 4 * cq;
     float4 x[NV];
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        const int r = (int)threadIdx.x + 512 * i;
-        x[i] = r < N ? *reinterpret_cast<const float4*>(Z + (size_t)r * R + c0) : float4{0.f, 0.f, 0.f, 0.f};
+        const int r = rl + 256 * i;
+        x[i] = r < N ? *reinterpret_cast<const float4*>(Z + (size_t)r * R + c) : float4{0.f, 0.f, 0.f, 0.f};
     }
-    auto block4 = [&](float4 v) -> float4 {
-        v.x = wave_sum(v.x); v.y = wave_sum(v.y); v.z = wave_sum(v.z); v.w = wave_sum(v.w);
-        __syncthreads();                             // (red is read by everyone below and written again on the second call)
-        if (lane == 0) red[wave] = v;
-        __syncthreads();
-        float4 t = red[0];
+    auto colsum = [&](float4 v) -> float4 {          // over all threads of this column quad
 #pragma unroll
-        for (int w = 1; w < 8; ++w) { t.x += red[w].x; t.y += red[w].y; t.z += red[w].z; t.w += red[w].w; }
+        for (int o = 4; o < 64; o <<= 1) {
+            v.x += __shfl_xor(v.x, o); v.y += __shfl_xor(v.y, o); v.z += __shfl_xor(v.z, o); v.w += __shfl_xor(v.w, o);
+        }
+        __syncthreads();                             // (red is reused by the second call)
+        if (lane < 4) red[wave][lane] = v;           // lane == cq here
+        __syncthreads();
+        float4 t = red[0][cq];
+#pragma unroll
+        for (int w = 1; w < 16; ++w) { const float4 u = red[w][cq]; t.x += u.x; t.y += u.y; t.z += u.z; t.w += u.w; }
         return t;
     };
     float4 s = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NV; ++i) { s.x += x[i].x; s.y += x[i].y; s.z += x[i].z; s.w += x[i].w; }
-    s = block4(s);
+    s = colsum(s);
     const float inv = 1.0f / (float)N;
     const float4 mu = {s.x * inv, s.y * inv, s.z * inv, s.w * inv};
     float4 q = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
-        if ((int)threadIdx.x + 512 * i < N) {
+        if (rl + 256 * i < N) {
             const float dx = x[i].x - mu.x, dy = x[i].y - mu.y, dz = x[i].z - mu.z, dw = x[i].w - mu.w;
             q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
         }
     }
-    q = block4(q);
-    if (threadIdx.x == 0) {
-        *reinterpret_cast<float4*>(mean + c0) = mu;
-        *reinterpret_cast<float4*>(var + c0) = float4{q.x * inv, q.y * inv, q.z * inv, q.w * inv};
+    q = colsum(q);
+    const float4 vb = {q.x * inv, q.y * inv, q.z * inv, q.w * inv};
+    if (rl == 0) {
+        *reinterpret_cast<float4*>(mean + c) = mu;
+        *reinterpret_cast<float4*>(var + c) = vb;
+        if (rmean) {                                 // the running statistics' update (bn_running_kernel's arithmetic)
+            const float ub = (float)N / (float)max(N - 1, 1);
+            const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, v4[4] = {vb.x, vb.y, vb.z, vb.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                rmean[c + j] = (1.f - mom) * rmean[c + j] + mom * m4[j];
+                rvar[c + j] = (1.f - mom) * rvar[c + j] + mom * (v4[j] * ub);
+            }
+        }
+    }
+    if (!X) return;
+    // the output of the layer (bn_apply_kernel's arithmetic, element for element)
+    const float4 ga = *reinterpret_cast<const float4*>(gamma + c), be = *reinterpret_cast<const float4*>(beta + c);
+    const float sd[4] = {sqrtf(vb.x + eps), sqrtf(vb.y + eps), sqrtf(vb.z + eps), sqrtf(vb.w + eps)};
+    const float m4[4] = {mu.x, mu.y, mu.z, mu.w}, g4[4] = {ga.x, ga.y, ga.z, ga.w}, b4[4] = {be.x, be.y, be.z, be.w};
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int r = rl + 256 * i;
+        if (r < N) {
+            const float rm = rowmask[r];
+            const float z4[4] = {x[i].x, x[i].y, x[i].z, x[i].w};
+            float o[4];
+            const size_t idx = (size_t)r * R + c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (z4[j] - m4[j]) / sd[j];
+                o[j] = fmaxf(xh * g4[j] + b4[j], 0.f) * xg_keep(drop, (uint32_t)(idx + j)) * rm;
+            }
+            *reinterpret_cast<float4*>(X + idx) = float4{o[0], o[1], o[2], o[3]};
+        }
     }
 }
 
-int xgk_bn_stats(hipStream_t st, const float* Z, int N, int R, float* mean, float* var, float* scratch) {
-    (void)scratch;
-    if (R % 4 == 0 && N >= 1 && N <= 16 * 512 && ((uintptr_t)Z % 16 == 0) && ((uintptr_t)mean % 16 == 0) && ((uintptr_t)var % 16 == 0)) {
-        const int nv = xg_cdiv(N, 512);
-        if (nv <= 4) hipLaunchKernelGGL((bn_stats_reg_kernel<4>), dim3(R / 4), dim3(512), 0, st, Z, N, R, mean, var);
-        else if (nv <= 8) hipLaunchKernelGGL((bn_stats_reg_kernel<8>), dim3(R / 4), dim3(512), 0, st, Z, N, R, mean, var);
-        else hipLaunchKernelGGL((bn_stats_reg_kernel<16>), dim3(R / 4), dim3(512), 0, st, Z, N, R, mean, var);
-        XG_CHECK_LAUNCH();
-        return XG_OK;
+// returns 1 when the shape is not this kernel's kind (the caller takes xgk_bn_stats + xgk_bn_apply)
+int xgk_bn_train_fwd(hipStream_t st, const float* Z, int N, int R, float* mean, float* var, float* rmean, float* rvar, float momentum,
+                     const float* gamma, const float* beta, const float* rowmask, float* X, float eps, XgDrop drop) {
+    if (rmean && !rvar) return XG_EINVAL;
+    const bool al = ((uintptr_t)Z % 16 == 0) && ((uintptr_t)mean % 16 == 0) && ((uintptr_t)var % 16 == 0) &&
+                    (!X || (((uintptr_t)X % 16 == 0) && ((uintptr_t)gamma % 16 == 0) && ((uintptr_t)beta % 16 == 0) && rowmask));
+    if (R % 16 != 0 || N < 1 || N > 20 * 256 || !al) return 1;      // (20 x 16 bytes per thread: the register budget of 16 waves per CU)
+    if (N <= 16 * 256) hipLaunchKernelGGL((bn_train_fwd_kernel<16>), dim3(R / 16), dim3(1024), 0, st, Z, N, R, mean, var, rmean, rvar, momentum,
+                                          gamma, beta, rowmask, X, eps, drop);
+    else hipLaunchKernelGGL((bn_train_fwd_kernel<20>), dim3(R / 16), dim3(1024), 0, st, Z, N, R, mean, var, rmean, rvar, momentum,
+                            gamma, beta, rowmask, X, eps, drop);
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
+
+int xgk_bn_stats(hipStream_t st, const float* Z, int N, int R, float* mean, float* var, float* rmean, float* rvar, float momentum) {
+    if (rmean && !rvar) return XG_EINVAL;
+    {
+        XgDrop nodrop{};
+        const int rc = xgk_bn_train_fwd(st, Z, N, R, mean, var, rmean, rvar, momentum, nullptr, nullptr, nullptr, nullptr, 0.f, nodrop);
+        if (rc != 1) return rc;
     }
     if (hipMemsetAsync(mean, 0, sizeof(float) * R, st) != hipSuccess) return XG_EHIP;
     if (hipMemsetAsync(var, 0, sizeof(float) * R, st) != hipSuccess) return XG_EHIP;
@@ -509,6 +566,7 @@ int xgk_bn_stats(hipStream_t st, const float* Z, int N, int R, float* mean, floa
     XG_TRY(colreduce<2>(st, Z, R, mean, 0, N, R, var));
     hipLaunchKernelGGL(scale_kernel, grid1(R), dim3(TPB), 0, st, var, 1.0f / (float)N, R);
     XG_CHECK_LAUNCH();
+    if (rmean) return xgk_bn_running(st, mean, var, rmean, rvar, N, R, momentum);
     return XG_OK;
 }
 int xgk_bn_running(hipStream_t st, const float* mean, const float* var, float* rmean, float* rvar, int N, int R,
@@ -539,14 +597,15 @@ int xgk_bn_bwd_reduce(hipStream_t st, float* dX, const float* X, const float* Z,
 }
 int xgk_bn_bwd_apply(hipStream_t st, float* dY, const float* Z, const float* mean, const float* var,
                      const float* gamma, const float* sum_dy, const float* sum_dyxhat, int N, int R, float eps,
-                     bool train) {
+                     bool train, float* g_beta, float* g_gamma) {
+    if ((g_beta == nullptr) != (g_gamma == nullptr)) return XG_EINVAL;
     const bool v4 = R % 4 == 0 && ((uintptr_t)dY % 16 == 0) && ((uintptr_t)Z % 16 == 0) && ((uintptr_t)mean % 16 == 0) &&
                     ((uintptr_t)var % 16 == 0) && ((uintptr_t)gamma % 16 == 0) && ((uintptr_t)sum_dy % 16 == 0) &&
                     ((uintptr_t)sum_dyxhat % 16 == 0);
     if (v4) hipLaunchKernelGGL((bn_bwd_apply_kernel<4>), grid1((int64_t)N * R / 4), dim3(TPB), 0, st, dY, Z, mean, var, gamma,
-                               sum_dy, sum_dyxhat, N, R, eps, train ? 1 : 0);
+                               sum_dy, sum_dyxhat, N, R, eps, train ? 1 : 0, g_beta, g_gamma);
     else hipLaunchKernelGGL((bn_bwd_apply_kernel<1>), grid1((int64_t)N * R), dim3(TPB), 0, st, dY, Z, mean, var, gamma, sum_dy,
-                            sum_dyxhat, N, R, eps, train ? 1 : 0);
+                            sum_dyxhat, N, R, eps, train ? 1 : 0, g_beta, g_gamma);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
