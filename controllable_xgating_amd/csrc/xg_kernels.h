@@ -88,6 +88,13 @@ int xgk_gate_fwd(hipStream_t st, float* pre_g, int ldp, const float* t, int ldt,
 int xgk_gate_bwd(hipStream_t st, const float* dy, int lddy, const float* g, int ldg, const float* t, int ldt, int t_mod,
                  float* dpre, int lddp, float* dt, int lddt, bool dt_accumulate, int rows, int R, XgDrop drop);
 
+// two gates of the same shape in ONE launch (the encoder's cross gates: forward, and backward with plain stores)
+int xgk_gate_fwd2(hipStream_t st, float* pre_g0, float* pre_g1, int ldp, const float* t0, const float* t1, int ldt, int t_mod, float* y0,
+                  float* y1, int ldy, int rows, int R, XgDrop drop0, XgDrop drop1, int s_div, int s_mod, int b_div, int b_mod);
+int xgk_gate_bwd2(hipStream_t st, const float* dy0, const float* dy1, int lddy, const float* g0, const float* g1, int ldg, const float* t0,
+                  const float* t1, int ldt, float* dpre0, float* dpre1, int lddp, float* dt0, float* dt1, int lddt, int rows, int R,
+                  XgDrop drop0, XgDrop drop1);
+
 // y = dropout(x) (x already ReLU'd) in place ; backward: dx = dy*keep*(y>0) in place
 int xgk_relu_drop_fwd(hipStream_t st, float* x, int64_t n, XgDrop drop);
 int xgk_relu_drop_bwd(hipStream_t st, float* dy, const float* y, int64_t n, XgDrop drop, const float* src = nullptr /* dy = f(src): out of place */);

@@ -420,11 +420,9 @@ int encoder_fwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgBnSt
     XG_TRY(cvt16(st, w, w.Hs[1], (size_t)N * R));
     XG_TRY(lin16(st, w.gm, N, R, R, w.Hs[1], m16(w, w.Hs[1]), R, p.gate_rgb_w, w16(w, W16_GATE_RGB), p.gate_rgb_b, w.GG[0], R, true));
     XG_TRY(lin16(st, w.gm, N, R, R, w.Hs[0], m16(w, w.Hs[0]), R, p.gate_opfl_w, w16(w, W16_GATE_OPFL), p.gate_opfl_b, w.GG[1], R, true));
-    for (int m = 0; m < 2; ++m) {
-        XgDrop dr = xg_make_drop(&run, m == 0 ? XG_SITE_GATE_RGB : XG_SITE_GATE_OPFL, 0);
-        XG_TRY(xgk_gate_fwd(st, w.GG[m], R, w.Hs[m], R, 0, w.Y + (size_t)m * R, 2 * R, N, R, dr, /*step=row%K*/ 1, K,
-                            /*b=row/K*/ K, 1 << 30));
-    }
+    XG_TRY(xgk_gate_fwd2(st, w.GG[0], w.GG[1], R, w.Hs[0], w.Hs[1], R, 0, w.Y, w.Y + R, 2 * R, N, R,
+                         xg_make_drop(&run, XG_SITE_GATE_RGB, 0), xg_make_drop(&run, XG_SITE_GATE_OPFL, 0), /*step=row%K*/ 1, K,
+                         /*b=row/K*/ K, 1 << 30));                                        // (both gates: one launch)
     XG_TRY(cvt16(st, w, w.Y, (size_t)N * 2 * R));
     XG_TRY(lin16(st, w.gm, N, R, 2 * R, w.Y, m16(w, w.Y), 2 * R, p.fusion_w, w16(w, W16_FUSION), p.fusion_b, w.Venc, R, true));   // :69-70
     XG_TRY(xgk_relu_drop_fwd(st, w.Venc, (int64_t)N * R, xg_make_drop(&run, XG_SITE_FUSION, 0)));
@@ -458,11 +456,9 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
     XG_TRY(ss.fork());
     XG_TRY(tn16(sx, w.gm, N, R, 2 * R, w.dVw, m16(w, w.dVw), R, w.Y, m16(w, w.Y), 2 * R, g.fusion_w, 2 * R, g.fusion_b));
     XG_TRY(nn16(st, w.gm, N, 2 * R, R, w.dVw, m16(w, w.dVw), R, p.fusion_w, w16(w, W16_FUSION), 2 * R, w.dY, 2 * R, false));
-    for (int m = 0; m < 2; ++m) {   // y = g*h + h : dpre -> dGG, dh -> dHs (overwrite)
-        XgDrop dr = xg_make_drop(&run, m == 0 ? XG_SITE_GATE_RGB : XG_SITE_GATE_OPFL, 0);
-        XG_TRY(xgk_gate_bwd(st, w.dY + (size_t)m * R, 2 * R, w.GG[m], R, w.Hs[m], R, 0, w.dGG[m], R, w.dHs[m], R, false,
-                            N, R, dr));
-    }
+    // y = g*h + h : dpre -> dGG, dh -> dHs (overwrite); both gates in one launch
+    XG_TRY(xgk_gate_bwd2(st, w.dY, w.dY + R, 2 * R, w.GG[0], w.GG[1], R, w.Hs[0], w.Hs[1], R, w.dGG[0], w.dGG[1], R, w.dHs[0], w.dHs[1], R,
+                         N, R, xg_make_drop(&run, XG_SITE_GATE_RGB, 0), xg_make_drop(&run, XG_SITE_GATE_OPFL, 0)));
     for (int m = 0; m < 2; ++m) XG_TRY(cvt16(st, w, w.dGG[m], (size_t)N * R));
     XG_TRY(ss.fork());
     for (int m = 0; m < 2; ++m) {   // gate m takes source = hidden of the OTHER modality

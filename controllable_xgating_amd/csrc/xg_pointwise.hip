@@ -107,49 +107,51 @@ template <int NV> __device__ __forceinline__ void stv(float* p, const float (&v)
     if (NV == 4) *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
     else p[0] = v[0];
 }
+// (both gate kernels take TWO parameter sets, blockIdx.y picks one: the encoder's two cross gates are one launch)
+struct GateFwdP { float* pre_g; int ldp; const float* t; int ldt; int t_mod; float* y; int ldy; XgDrop drop; };
 template <int NV>
-__global__ void gate_fwd_kernel(float* __restrict__ pre_g, int ldp, const float* __restrict__ t, int ldt, int t_mod,
-                                float* __restrict__ y, int ldy, int rows, int R, XgDrop drop, int s_div, int s_mod,
-                                int b_div, int b_mod) {
+__global__ void gate_fwd_kernel(GateFwdP pa, GateFwdP pb, int rows, int R, int s_div, int s_mod, int b_div, int b_mod) {
+    const GateFwdP& p = blockIdx.y ? pb : pa;
     const int64_t idx = ((int64_t)blockIdx.x * TPB + threadIdx.x) * NV;
     if (idx >= (int64_t)rows * R) return;
     const int r = (int)(idx / R), j = (int)(idx % R);
-    XgDrop dr = drop;
-    dr.step = drop.step + (uint32_t)((r / s_div) % s_mod);
+    XgDrop dr = p.drop;
+    dr.step = p.drop.step + (uint32_t)((r / s_div) % s_mod);
     const uint32_t e = (uint32_t)((r / b_div) % b_mod) * (uint32_t)R + (uint32_t)j;
     float g[NV], tv[NV], yv[NV];
-    ldv<NV>(pre_g + (size_t)r * ldp + j, g);
-    if (y) ldv<NV>(t + (size_t)(t_mod > 0 ? r % t_mod : r) * ldt + j, tv);
+    ldv<NV>(p.pre_g + (size_t)r * p.ldp + j, g);
+    if (p.y) ldv<NV>(p.t + (size_t)(p.t_mod > 0 ? r % p.t_mod : r) * p.ldt + j, tv);
 #pragma unroll
     for (int q = 0; q < NV; ++q) g[q] *= xg_keep(dr, e + q);
-    stv<NV>(pre_g + (size_t)r * ldp + j, g);
-    if (y) {
+    stv<NV>(p.pre_g + (size_t)r * p.ldp + j, g);
+    if (p.y) {
 #pragma unroll
         for (int q = 0; q < NV; ++q) yv[q] = g[q] * tv[q] + tv[q];                // sub_modules.py:45
-        stv<NV>(y + (size_t)r * ldy + j, yv);
+        stv<NV>(p.y + (size_t)r * p.ldy + j, yv);
     }
 }
+struct GateBwdP { const float* dy; int lddy; const float* g; int ldg; const float* t; int ldt; int t_mod; float* dpre; int lddp;
+                  float* dt; int lddt; int dt_acc; XgDrop drop; };
 template <int NV>
-__global__ void gate_bwd_kernel(const float* __restrict__ dy, int lddy, const float* __restrict__ g, int ldg,
-                                const float* __restrict__ t, int ldt, int t_mod, float* __restrict__ dpre, int lddp,
-                                float* __restrict__ dt, int lddt, int dt_acc, int rows, int R, XgDrop drop) {
+__global__ void gate_bwd_kernel(GateBwdP pa, GateBwdP pb, int rows, int R) {
+    const GateBwdP& p = blockIdx.y ? pb : pa;
     const int64_t idx = ((int64_t)blockIdx.x * TPB + threadIdx.x) * NV;
     if (idx >= (int64_t)rows * R) return;
     const int r = (int)(idx / R), j = (int)(idx % R);
     float d[NV], gv[NV], tv[NV], o[NV];
-    ldv<NV>(dy + (size_t)r * lddy + j, d);
-    ldv<NV>(g + (size_t)r * ldg + j, gv);
-    ldv<NV>(t + (size_t)(t_mod > 0 ? r % t_mod : r) * ldt + j, tv);
-    if (dpre) {
+    ldv<NV>(p.dy + (size_t)r * p.lddy + j, d);
+    ldv<NV>(p.g + (size_t)r * p.ldg + j, gv);
+    ldv<NV>(p.t + (size_t)(p.t_mod > 0 ? r % p.t_mod : r) * p.ldt + j, tv);
+    if (p.dpre) {
 #pragma unroll
-        for (int q = 0; q < NV; ++q) o[q] = gv[q] > 0.f ? d[q] * tv[q] * drop.scale : 0.f;   // g>0 <=> relu active & kept
-        stv<NV>(dpre + (size_t)r * lddp + j, o);
+        for (int q = 0; q < NV; ++q) o[q] = gv[q] > 0.f ? d[q] * tv[q] * p.drop.scale : 0.f;   // g>0 <=> relu active & kept
+        stv<NV>(p.dpre + (size_t)r * p.lddp + j, o);
     }
-    if (dt) {
-        float* qd = dt + (size_t)r * lddt + j;
-        if (dt_acc) ldv<NV>(qd, o);
+    if (p.dt) {
+        float* qd = p.dt + (size_t)r * p.lddt + j;
+        if (p.dt_acc) ldv<NV>(qd, o);
 #pragma unroll
-        for (int q = 0; q < NV; ++q) o[q] = (dt_acc ? o[q] : 0.f) + d[q] * (gv[q] + 1.0f);
+        for (int q = 0; q < NV; ++q) o[q] = (p.dt_acc ? o[q] : 0.f) + d[q] * (gv[q] + 1.0f);
         stv<NV>(qd, o);
     }
 }
@@ -406,29 +408,53 @@ int xgk_lstm_bwd2(hipStream_t st, const LstmBwdArgs& a, const LstmBwdArgs& b) {
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
+static bool gate_fwd_v4(const GateFwdP& p, int R) {
+    return R % 4 == 0 && p.ldp % 4 == 0 && (!p.y || (p.ldt % 4 == 0 && p.ldy % 4 == 0)) && ((uintptr_t)p.pre_g % 16 == 0) &&
+           ((uintptr_t)p.t % 16 == 0) && ((uintptr_t)p.y % 16 == 0);
+}
+static int gate_fwd_launch(hipStream_t st, const GateFwdP& a, const GateFwdP& b, int n, int rows, int R, int s_div, int s_mod, int b_div,
+                           int b_mod) {
+    const bool v4 = gate_fwd_v4(a, R) && (n < 2 || gate_fwd_v4(b, R));
+    if (v4) { dim3 g = grid1((int64_t)rows * R / 4); g.y = n;
+              hipLaunchKernelGGL((gate_fwd_kernel<4>), g, dim3(TPB), 0, st, a, b, rows, R, s_div, s_mod, b_div, b_mod); }
+    else { dim3 g = grid1((int64_t)rows * R); g.y = n;
+           hipLaunchKernelGGL((gate_fwd_kernel<1>), g, dim3(TPB), 0, st, a, b, rows, R, s_div, s_mod, b_div, b_mod); }
+    XG_CHECK_LAUNCH();
+    return XG_OK;
+}
 int xgk_gate_fwd(hipStream_t st, float* pre_g, int ldp, const float* t, int ldt, int t_mod, float* y, int ldy,
                  int rows, int R, XgDrop drop, int s_div, int s_mod, int b_div, int b_mod) {
     if (!y && drop.thresh == 0u) return XG_OK;   // pure dropout with p = 0: nothing to do
-    const bool v4 = R % 4 == 0 && ldp % 4 == 0 && (!y || (ldt % 4 == 0 && ldy % 4 == 0)) && ((uintptr_t)pre_g % 16 == 0) &&
-                    ((uintptr_t)t % 16 == 0) && ((uintptr_t)y % 16 == 0);
-    if (v4) hipLaunchKernelGGL((gate_fwd_kernel<4>), grid1((int64_t)rows * R / 4), dim3(TPB), 0, st, pre_g, ldp, t, ldt, t_mod, y,
-                               ldy, rows, R, drop, s_div, s_mod, b_div, b_mod);
-    else hipLaunchKernelGGL((gate_fwd_kernel<1>), grid1((int64_t)rows * R), dim3(TPB), 0, st, pre_g, ldp, t, ldt, t_mod, y, ldy,
-                            rows, R, drop, s_div, s_mod, b_div, b_mod);
+    const GateFwdP a{pre_g, ldp, t, ldt, t_mod, y, ldy, drop};
+    return gate_fwd_launch(st, a, a, 1, rows, R, s_div, s_mod, b_div, b_mod);
+}
+int xgk_gate_fwd2(hipStream_t st, float* pre_g0, float* pre_g1, int ldp, const float* t0, const float* t1, int ldt, int t_mod, float* y0,
+                  float* y1, int ldy, int rows, int R, XgDrop drop0, XgDrop drop1, int s_div, int s_mod, int b_div, int b_mod) {
+    const GateFwdP a{pre_g0, ldp, t0, ldt, t_mod, y0, ldy, drop0}, b{pre_g1, ldp, t1, ldt, t_mod, y1, ldy, drop1};
+    return gate_fwd_launch(st, a, b, 2, rows, R, s_div, s_mod, b_div, b_mod);
+}
+static bool gate_bwd_v4(const GateBwdP& p, int R) {
+    return R % 4 == 0 && p.lddy % 4 == 0 && p.ldg % 4 == 0 && p.ldt % 4 == 0 && (!p.dpre || p.lddp % 4 == 0) &&
+           (!p.dt || p.lddt % 4 == 0) && ((uintptr_t)p.dy % 16 == 0) && ((uintptr_t)p.g % 16 == 0) && ((uintptr_t)p.t % 16 == 0) &&
+           ((uintptr_t)p.dpre % 16 == 0) && ((uintptr_t)p.dt % 16 == 0);
+}
+static int gate_bwd_launch(hipStream_t st, const GateBwdP& a, const GateBwdP& b, int n, int rows, int R) {
+    const bool v4 = gate_bwd_v4(a, R) && (n < 2 || gate_bwd_v4(b, R));
+    if (v4) { dim3 g = grid1((int64_t)rows * R / 4); g.y = n; hipLaunchKernelGGL((gate_bwd_kernel<4>), g, dim3(TPB), 0, st, a, b, rows, R); }
+    else { dim3 g = grid1((int64_t)rows * R); g.y = n; hipLaunchKernelGGL((gate_bwd_kernel<1>), g, dim3(TPB), 0, st, a, b, rows, R); }
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
 int xgk_gate_bwd(hipStream_t st, const float* dy, int lddy, const float* g, int ldg, const float* t, int ldt, int t_mod,
                  float* dpre, int lddp, float* dt, int lddt, bool dt_accumulate, int rows, int R, XgDrop drop) {
-    const bool v4 = R % 4 == 0 && lddy % 4 == 0 && ldg % 4 == 0 && ldt % 4 == 0 && (!dpre || lddp % 4 == 0) &&
-                    (!dt || lddt % 4 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)g % 16 == 0) && ((uintptr_t)t % 16 == 0) &&
-                    ((uintptr_t)dpre % 16 == 0) && ((uintptr_t)dt % 16 == 0);
-    if (v4) hipLaunchKernelGGL((gate_bwd_kernel<4>), grid1((int64_t)rows * R / 4), dim3(TPB), 0, st, dy, lddy, g, ldg, t, ldt, t_mod,
-                               dpre, lddp, dt, lddt, dt_accumulate ? 1 : 0, rows, R, drop);
-    else hipLaunchKernelGGL((gate_bwd_kernel<1>), grid1((int64_t)rows * R), dim3(TPB), 0, st, dy, lddy, g, ldg, t, ldt, t_mod, dpre,
-                            lddp, dt, lddt, dt_accumulate ? 1 : 0, rows, R, drop);
-    XG_CHECK_LAUNCH();
-    return XG_OK;
+    const GateBwdP a{dy, lddy, g, ldg, t, ldt, t_mod, dpre, lddp, dt, lddt, dt_accumulate ? 1 : 0, drop};
+    return gate_bwd_launch(st, a, a, 1, rows, R);
+}
+int xgk_gate_bwd2(hipStream_t st, const float* dy0, const float* dy1, int lddy, const float* g0, const float* g1, int ldg, const float* t0,
+                  const float* t1, int ldt, float* dpre0, float* dpre1, int lddp, float* dt0, float* dt1, int lddt, int rows, int R,
+                  XgDrop drop0, XgDrop drop1) {
+    const GateBwdP a{dy0, lddy, g0, ldg, t0, ldt, 0, dpre0, lddp, dt0, lddt, 0, drop0}, b{dy1, lddy, g1, ldg, t1, ldt, 0, dpre1, lddp, dt1, lddt, 0, drop1};
+    return gate_bwd_launch(st, a, b, 2, rows, R);
 }
 int xgk_relu_drop_fwd(hipStream_t st, float* x, int64_t n, XgDrop drop) {
     if (drop.thresh == 0u || n <= 0) return XG_OK;
