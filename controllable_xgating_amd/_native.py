@@ -55,6 +55,13 @@ def lib():
         raise XgError("libxgate_hip.so not found at %s -- build it with `python __graft_entry__.py` "
                       "(hipcc --offload-arch=gfx950); there is no CPU / PyTorch fallback." % LIB_PATH)
     L = C.CDLL(LIB_PATH)
+    # a stale build (older ABI) may lack entry points this binding declares: say so, instead of an AttributeError from ctypes
+    need = ("xg_version", "xg_abi_check", "xg_strerror", "xg_param_count", "xg_param_name", "xg_param_numel", "xg_workspace_bytes",
+            "xg_workspace_bytes_mode", "xg_packed_bytes")
+    missing = [n for n in need if not hasattr(L, n)]
+    if missing:
+        raise XgError("%s lacks %s: a stale build of another ABI version -- rebuild it with `python __graft_entry__.py --force`"
+                      % (LIB_PATH, ", ".join(missing)))
     L.xg_version.restype = C.c_int
     L.xg_strerror.restype = C.c_char_p
     L.xg_strerror.argtypes = [C.c_int]
@@ -114,6 +121,10 @@ def lib():
         "xg_reward_fwd": [vp, vp, i32, vp, i32, vp, i32, i32, vp, i32, i32, vp],
         "xg_reward_bwd": [vp, vp, i32, vp, i32, i32, vp, i32, i32, vp, vp, vp, i32],
     }
+    missing = [n for n in sigs if not hasattr(L, n)]
+    if missing:
+        raise XgError("%s (xg_version %d) lacks %s: rebuild it with `python __graft_entry__.py --force`"
+                      % (LIB_PATH, L.xg_version(), ", ".join(missing)))
     for name, args in sigs.items():
         fn = getattr(L, name)
         fn.restype = C.c_int

@@ -1,6 +1,7 @@
 // Internal launcher prototypes (host side).  Every launcher enqueues on `st` and returns XG_OK / XG_EHIP.
 #pragma once
 #include "xg_common.h"
+#include <cstddef>
 
 // ---- xg_gemm.hip
 // `mode` = arithmetic of the product (XgRun.gemm_mode): 0 exact fp32 MFMA, 3 split-bf16, 1 bf16 operands; modes 1 / 3 apply
@@ -158,37 +159,56 @@ enum { SK_EPI_STORE = 0, SK_EPI_LSTM = 1, SK_EPI_GATE = 2,
        //   The cell-2 job of the NEXT launch normalises while it stages af (SkSeg.row_scale) -- no merge launch.
        SK_EPI_ATTN = 5 };
 constexpr int SK_MAX_JOBS = 5;
+// Field ORDER matters to the fast kernel (xg_step.hip: skf_kernel): it reads a job's 64-byte head and the first 48 bytes of each
+// segment with ONE round of wide scalar loads at kernel entry (s_load_dwordx16 / x8 / x4) instead of field by field behind
+// branches -- a chain of ~15 dependent scalar-cache round trips in front of the first operand request before round 5.
 struct SkSeg {
-    const float* A; const float* B;   // A (M,K) row-major lda ; B (N,K) row-major ldb, or (K,N) when b_ncontig
-    int lda, ldb, K, b_ncontig;
+    // ---- hot (48 B: what it takes to request the segment's first operands)
+    const float* A;                    // A (M,K) row-major lda (rows gathered through `gather` when set)
     // packed form of B (xg_pack.hip: 32 x 32 tiles in MFMA-fragment order, nck tiles per 32-column slice) or null: when
     // every segment of a launch has one, the launch takes the fast kernel (B operand global -> VGPR, no LDS)
-    const float* Bp; int nck;          // (bf16 tiles when the launch runs with gemm_mode 1: xgk_skinny's argument)
+    const float* Bp;                   // (bf16 tiles when the launch runs with gemm_mode 1: xgk_skinny's argument)
     // optional row gather on A: row m of the operand is A + clamp(gather[m * gstride], 0, gather_max) * lda
     // (embedding lookup folded into the product: caption_src/SAModel.py:105,198)
-    const int64_t* gather; int gstride, gather_max;
+    const int64_t* gather;
+    int lda, K, nck, gstride, gather_max;
+    int sflags;                        // filled by xgk_skinny: SKS_SCALED | SKS_WRITEBACK | SKS_EX
+    // ---- cold
+    const float* B; int ldb, b_ncontig;   // B (N,K) row-major ldb, or (K,N) when b_ncontig (LDS-staged kernel, fallbacks)
     // optional per-row scale of A: row m is multiplied by 1 / row_scale[m] while it is staged (the attention context
     // arrives unnormalised: af = c / s).  scaled_out (lda_out): the scaled rows are written back by the tn == 0 tiles
     // (the normalised context is a saved tensor); ex / ex_ld / ex_K: those tiles also normalise the (M, ex_K) unnormalised
     // attention weights in place.
-    const float* row_scale; float* scaled_out; int ld_out; float* ex; int ex_ld, ex_K;
+    const float* row_scale; float* scaled_out; float* ex; int ld_out, ex_ld, ex_K, pad_;
 };
-struct SkJob {
-    SkSeg seg[3];
-    const float* bias[3];
+enum { SKS_SCALED = 1, SKS_WRITEBACK = 2, SKS_EX = 4 };
+enum { SKH_CELL_TILES = 1 /* weight rows in the cell tiling (LSTM epilogue or cell_cols) */, SKH_LOW_PRIO = 2, SKH_HAS_SCALED = 4,
+       SKH_GATHER_SHIFT = 4 /* bits 4-5: 1 + index of the first gathered segment (0 = none) */ };
+struct alignas(64) SkJob {
+    // ---- head (64 B).  ntm / ntn / ntiles / hflags / ksplit / tile0 are filled in by xgk_skinny.
+    int epi, M, N, R;
+    int nseg, ksplit, ntm, ntn;
+    int ntiles, hflags, ldc, tile0;
     float* C;                          // STORE epilogue output (M,N) ldc
+    int* tickets;                      // cross-workgroup split-K: one zero-initialised int per tile (see ksplit_ok)
+    SkSeg seg[3];
+    // ---- epilogue INPUTS, contiguous (requested before the K loop so that their latency hides under it)
+    const float* bias[3];
     // LSTM epilogue (N must be 4R; weight rows / bias / add columns in gate-major order like the reference)
     const float* add; const float* c_prev; const float* h_prev; const float* mask;
-    float* gates; float* c_out; float* h_out;
-    int ldadd, ldcp, ldhp, ldm, ldg, ldco, ldho;
+    int ldadd, ldcp, ldhp, ldm;
+    int accumulate, relu, order, mask_mode;
     // GATE epilogue (sub_modules.py:42-47): g = dropout(relu(.)) -> C ; y = g*t + t
-    const float* gate_t; float* gate_y; int ldt, ldy;
-    // LSTMB epilogue (reads gates / c_prev / c_out / mask / add from the LSTM fields above)
-    const float* dc_in; float* ds; float* dc_prev; float* dh_hold; int lddci, ldds, lddcp, lddhh;
-    int nseg, M, N, ldc, accumulate, relu, epi, R, order, mask_mode, tile0;
+    const float* gate_t; int ldt, ldy; float* gate_y;
+    // ---- epilogue OUTPUTS
+    float* gates; float* c_out; float* h_out;
+    int ldg, ldco, ldho;
     // STORE epilogue over a (M,4R) gate-major pre-activation with the CELL tiling of the weight rows (tile tn = hidden units
     // 8 tn .. 8 tn + 7 of all four gates, like the LSTM epilogue): a partial cell product another launch finishes
     int cell_cols;
+    XgDrop drop;
+    // LSTMB epilogue (reads gates / c_prev / c_out / mask / add from the LSTM fields above)
+    const float* dc_in; float* ds; float* dc_prev; float* dh_hold; int lddci, ldds, lddcp, lddhh;
     // ATTN job: p (M,A) at attn_p, q = v2a(V) (M,K,A) at attn_q, V (M,K,R) at attn_v, w_a (A) at attn_w; outputs
     // attn_ex (M,K) unnormalised weights, attn_s (M) and attn_c (M,R) accumulated with atomics
     const float *attn_p, *attn_q, *attn_v, *attn_w; float *attn_ex, *attn_s, *attn_c; int attn_K, attn_A;
@@ -197,12 +217,15 @@ struct SkJob {
     // chains' dh = ds W products are 64-128 tiles, K = 1536-2048 deep).  Each part adds its partial tile into C with fp32
     // atomics; for LSTMB the last part to arrive (tickets: one zero-initialised int per tile, left at zero again) reads the
     // completed dh back and runs the pointwise backward.  ksplit is filled in by xgk_skinny.
-    int ksplit_ok, ksplit; int* tickets;
+    int ksplit_ok;
     int ksplit_cap;                    // > 0: upper bound of the cross-workgroup split of THIS launch (a side chain that must not crowd the main one)
     int low_prio;                      // 1: the job's waves drop back to default wave priority (off-critical-path side chains)
-    XgDrop drop;
+    int pad_;
 };
-struct SkArgs { int njobs; int tile0[SK_MAX_JOBS]; SkJob job[SK_MAX_JOBS]; };
+static_assert(offsetof(SkJob, seg) == 64 && sizeof(SkSeg) == 104, "skf_kernel reads the head and the segments' hot parts by offset");
+static_assert(sizeof(SkJob) % 64 == 0 && sizeof(SkJob) * SK_MAX_JOBS + 64 <= 4096, "SkJob array stride / kernel-argument budget");
+struct SkArgs { int njobs; int tile0[SK_MAX_JOBS]; int pad_[10]; SkJob job[SK_MAX_JOBS]; };
+static_assert(offsetof(SkArgs, job) == 64, "descriptor lines");
 // gemm_mode 1 (plain bf16) rounds the staged chunks to bf16 (LDS-staged kernel); 0 / 3: exact fp32
 int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode);
 

@@ -734,13 +734,15 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         k1.njobs = n1;
         XG_TRY(xgk_skinny(st, k1, w.gm));
         // ---- launch 2: attention || rollout: cell 1 = h1 W_h2h + pos' W_a2h + xt W_i2h || S2'
-        if (fused_attn) {
-            SkJob& j = k2.job[n2++];
+        // (XG_L2_ORDER=1 of the diag build: cell 1's tiles dispatched in front of the attention's workgroups)
+        static const int l2_order = xg_diag_env("XG_L2_ORDER") ? atoi(xg_diag_env("XG_L2_ORDER")) : 0;
+        auto attn_job = [&](SkJob& j) {
             j = SkJob{};
             j.epi = SK_EPI_ATTN; j.M = B; j.R = R; j.attn_K = d.K; j.attn_A = A;
             j.attn_p = s.P; j.attn_q = vproj; j.attn_v = V; j.attn_w = p.a2w_w;
             j.attn_ex = s.alpha; j.attn_s = w.ATS; j.attn_c = w.AFU;
-        }
+        };
+        if (fused_attn && l2_order == 0) attn_job(k2.job[n2++]);
         if (!s.pre1) {
             SkJob& j = k2.job[n2++];
             a.h_out = h1_new;
@@ -757,6 +759,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
             }
         }
         if (!s2_first && !s2_in_cell2) s2_job(k2.job[n2++]);
+        if (fused_attn && l2_order != 0) attn_job(k2.job[n2++]);
         k2.njobs = n2;
         if (n2 > 0) XG_TRY(xgk_skinny(st, k2, w.gm));
         if (!fused_attn) XG_TRY(xgk_attn_fwd(st, s.P, vproj, V, p.a2w_w, s.alpha, s.af, B, d.K, R, A, s.half_attn));
@@ -2038,6 +2041,10 @@ extern "C" int xg_rollout_bwd(void* stream, const XgDims* d, const XgParams* p, 
     Streams ss(st, run);
     // the rollout ran T - 1 core steps (the reference's last one is dead, rollout_impl): the reverse-time pass covers those.
     // All per-step buffers are time-major, so the first T - 1 blocks of the T-step workspace are the (T - 1)-step problem.
+    // (What that relies on: LOGITS / H2 / the saved gates, states, p, alpha, af, xt and the gate values are (T, B, .) blocks with
+    //  t outermost -- carve_workspace -- so rows [0, (T - 1) B) of each are exactly what a (T - 1)-step workspace would hold, and
+    //  heads_bwd's split of dH into an early and a late half plus its background product see rows == dT.T * B as in the
+    //  teacher-forced backward: the same code path, covered by the SCST gradient tests at configs[2]'s full size.)
     XgDims dT = *d;
     dT.T = T - 1;
     XG_TRY(heads_bwd(ss, dT, *p, *g, *run, w, (T - 1) * B, false));

@@ -71,16 +71,16 @@ __device__ __forceinline__ void st_chunk(float* __restrict__ lds, int lane, cons
 }
 
 #ifdef SK_TRACE
-#ifndef SK_TRACE_NJOBS
-#define SK_TRACE_NJOBS 1
-#endif
+// In-kernel phase stamps (tools/sk_trace_run.py): 8 slots per workgroup of the launches whose grid matches the filter set through
+// xg_debug_sk_trace_filter (jobs, grid x).  Slot 7 = the LAST wave's end of the K loop (atomic max), the others are wave 0's view.
 __device__ long long sk_trace_buf[4096 * 8];
-#ifndef SK_TRACE_GX
-#define SK_TRACE_GX gridDim.x
-#endif
-#define SK_STAMP(i) do { if (threadIdx.x == 0 && gridDim.y == SK_TRACE_NJOBS && gridDim.x == SK_TRACE_GX) sk_trace_buf[(blockIdx.x + blockIdx.y * gridDim.x) * 8 + (i)] = wall_clock64(); } while (0)
+__device__ int sk_trace_sel[2] = {1, 256};
+#define SK_TRACE_ON() ((int)gridDim.y == sk_trace_sel[0] && (int)gridDim.x == sk_trace_sel[1])
+#define SK_STAMP(i) do { if (threadIdx.x == 0 && SK_TRACE_ON()) sk_trace_buf[(blockIdx.x + blockIdx.y * gridDim.x) * 8 + (i)] = wall_clock64(); } while (0)
+#define SK_STAMP_MAX(i) do { if ((threadIdx.x & 63) == 0 && SK_TRACE_ON()) atomicMax((unsigned long long*)&sk_trace_buf[(blockIdx.x + blockIdx.y * gridDim.x) * 8 + (i)], (unsigned long long)wall_clock64()); } while (0)
 #else
 #define SK_STAMP(i) do {} while (0)
+#define SK_STAMP_MAX(i) do {} while (0)
 #endif
 
 // ---- bf16 arithmetic (XgRun.gemm_mode = 1, BASELINE.json configs[4]): the staged chunk is rounded to bf16 on its way
@@ -669,15 +669,48 @@ __device__ __forceinline__ void attn_part(const SkJob& job, int tile, float* sme
 //     it feeds: with no global loads at all its K loop is 64 % MFMA-busy.
 //   * A (the activations: 32 rows of this m-tile) still goes through the wave-private LDS image; the k order inside a
 //     32-deep chunk is the packed one (lane half h owns k in [16 h, 16 h + 16)).  Optional row gather (embedding lookup).
-//   * the job is blockIdx.y: everything the prologue needs comes from ONE round of scalar loads.
+//   * the job is blockIdx.y.  Round 5: the job's 64-byte head and the 48-byte hot part of each segment arrive through ONE
+//     round of wide scalar loads at kernel entry (s_load_dwordx16 + 3 x (x8 + x4)), the gathered segment's row indices are
+//     requested right behind them, the epilogue's input block (bias / cell-state pointers, 112 B) behind the first operand
+//     request, its output block behind the K loop.  Before, every field was read where it was first used -- ~15 dependent
+//     scalar-cache round trips between kernel entry and the first operand request (in-kernel stamps: 2.1-7.6 us per tile,
+//     profiles/r05_sk_trace_before.txt), more when the CU was already busy.
+//   * epilogue operands of EVERY job type (bias rows, the accumulate / gate operand, the cell state) are requested before the
+//     K loop with unconditional loads; the epilogue itself issues no dependent load.
 //   * reduction buffer rows are 40 floats apart: conflict-free for the column-wise reads of the cell epilogue.
 constexpr int RSF = 40;
-#ifndef SKF_DEPTH_A
-#define SKF_DEPTH_A(PREC, SCALE) 1
-#endif
-#ifndef SKF_DEPTH_B
-#define SKF_DEPTH_B(PREC, SCALE) 1
-#endif
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+struct SkHeadBlk { int epi, M, N, R, nseg, ksplit, ntm, ntn, ntiles, hflags, ldc, tile0; float* C; int* tickets; };
+struct SkSegHot { const float* A; const float* Bp; const int64_t* gather; int lda, K, nck, gstride, gather_max, sflags; };
+struct SkEpiIn { const float* bias[3]; const float* add; const float* c_prev; const float* h_prev; const float* mask;
+                 int ldadd, ldcp, ldhp, ldm, accumulate, relu, order, mask_mode; const float* gate_t; int ldt, ldy; float* gate_y; };
+struct SkEpiOut { float* gates; float* c_out; float* h_out; int ldg, ldco, ldho, cell_cols; XgDrop drop; int pad_; };
+static_assert(sizeof(SkHeadBlk) == 64 && sizeof(SkSegHot) == 48 && sizeof(SkEpiIn) == 112 && sizeof(SkEpiOut) == 64, "descriptor blocks");
+static_assert(offsetof(SkJob, tickets) == 56 && offsetof(SkSeg, sflags) == 44 && offsetof(SkJob, bias) + 112 == offsetof(SkJob, gates) &&
+              offsetof(SkJob, gate_y) + 8 == offsetof(SkJob, gates) && offsetof(SkJob, drop) + 20 <= offsetof(SkJob, gates) + 64,
+              "descriptor blocks mirror SkJob's layout (xg_kernels.h)");
+// The blocks are read as typed struct copies (pointer fields stay kernel-argument pointers to the compiler, i.e. global memory;
+// adjacent scalar loads of one basic block are merged into s_load_dwordx8 / x4) and PINNED right behind the copy: every field has
+// to sit in a scalar register at that point, so all of the block's loads are issued together, in front of one wait.
+__device__ __forceinline__ void sk_pin(const SkHeadBlk& h) {
+    asm volatile("" ::"s"(h.epi), "s"(h.M), "s"(h.N), "s"(h.R), "s"(h.nseg), "s"(h.ksplit), "s"(h.ntm), "s"(h.ntn), "s"(h.ntiles),
+                 "s"(h.hflags), "s"(h.ldc), "s"(h.C), "s"(h.tickets));
+}
+__device__ __forceinline__ void sk_pin(const SkSegHot& g) {
+    asm volatile("" ::"s"(g.A), "s"(g.Bp), "s"(g.gather), "s"(g.lda), "s"(g.K), "s"(g.nck), "s"(g.gstride), "s"(g.gather_max), "s"(g.sflags));
+}
+__device__ __forceinline__ void sk_pin(const SkEpiIn& e) {
+    asm volatile("" ::"s"(e.bias[0]), "s"(e.bias[1]), "s"(e.bias[2]), "s"(e.add), "s"(e.c_prev), "s"(e.h_prev), "s"(e.mask), "s"(e.ldadd),
+                 "s"(e.ldcp), "s"(e.ldhp), "s"(e.ldm), "s"(e.accumulate), "s"(e.relu), "s"(e.order), "s"(e.mask_mode), "s"(e.gate_t),
+                 "s"(e.ldt), "s"(e.ldy), "s"(e.gate_y));
+}
+__device__ __forceinline__ void sk_pin(const SkEpiOut& e) {
+    asm volatile("" ::"s"(e.gates), "s"(e.c_out), "s"(e.h_out), "s"(e.ldg), "s"(e.ldco), "s"(e.ldho), "s"(e.cell_cols), "s"(e.drop.seed),
+                 "s"(e.drop.site), "s"(e.drop.step), "s"(e.drop.thresh), "s"(e.drop.scale));
+}
+
 template <bool HAS_TAIL>
 __device__ __forceinline__ void ldA(const float* const (&ap)[4], int c, int kleft /* K - c*32 - lcol */, f32x4 (&v)[4]) {
 #pragma unroll
@@ -685,6 +718,163 @@ __device__ __forceinline__ void ldA(const float* const (&ap)[4], int c, int klef
         const f32x4 t = *reinterpret_cast<const f32x4*>(ap[i] + (size_t)c * CK);
         if (HAS_TAIL) { const f32x4 z = {0.f, 0.f, 0.f, 0.f}; v[i] = kleft > 0 ? t : z; }
         else v[i] = t;
+    }
+}
+
+// Epilogue operands requested before the K loop.  LSTM jobs: the four gates' bias / add terms of this thread's (row, unit) and
+// the cell state.  STORE / GATE jobs: per output element e of this thread (2 with 8 waves, 4 with 4) a[4e .. 4e+2] = the three
+// bias terms of its column, a[4e+3] = what the result is added to (accumulate) or gated with (GATE).  Every load is
+// unconditional (absent operands read a valid dummy address and are dropped by a select in the epilogue): a load under a
+// branch makes the compiler wait for it on the spot.
+struct EpiPre { float a[16]; float st[3]; };       // st: c_prev, h_prev, mask of the LSTM epilogue
+enum { EP_CP = 0, EP_HP = 1, EP_MK = 2 };
+// (p arrives zero-filled from the top of the kernel, i.e. from before any load was in flight: an initialisation HERE would have to
+//  wait for whatever pending load targets the same registers on some other path through the kernel)
+template <int NW>
+__device__ __forceinline__ void epi_prefetch(EpiPre& p, const SkHeadBlk& hd, const SkEpiIn& ei, bool cell_tiles, int m0, int n0, int tn) {
+    const int M = hd.M, N = hd.N, R = hd.R;
+    if (hd.epi == SK_EPI_LSTM) {
+        // (every thread loads -- with 8 waves the upper four read what the lower four read: no exec-masked region, and no
+        //  register of the result is written by anything but a load, so nothing here has to wait for the operands in flight)
+        const int em = (threadIdx.x >> 3) & 31, eu = threadIdx.x & 7;
+        const int eb = min(m0 + em, M - 1), ej = min(tn * 8 + eu, R - 1);
+        const float* dummy = ei.c_prev + (size_t)eb * ei.ldcp + ej;
+        const float* mkp = ei.mask ? ei.mask + (size_t)eb * ei.ldm : dummy;
+        const float* hpp = ei.mask_mode == XG_MASK_HOLD ? ei.h_prev + (size_t)eb * ei.ldhp + ej : dummy;
+#pragma unroll
+        for (int gi = 0; gi < 4; ++gi) {
+            const int col = gi * R + ej;
+            p.a[gi] = *(ei.bias[0] ? ei.bias[0] + col : dummy);
+            p.a[4 + gi] = *(ei.bias[1] ? ei.bias[1] + col : dummy);
+            p.a[8 + gi] = *(ei.bias[2] ? ei.bias[2] + col : dummy);
+            p.a[12 + gi] = *(ei.add ? ei.add + (size_t)eb * ei.ldadd + col : dummy);
+        }
+        p.st[EP_CP] = *dummy;
+        p.st[EP_MK] = *mkp;
+        p.st[EP_HP] = *hpp;
+        // (two different empty statements at the two branch ends: the optimiser otherwise merges the branches' last stores into one
+        //  store through a pointer phi, which keeps part of `p` in scratch memory -- with a wait for the load in front of the store)
+        asm volatile("; cell operands requested");
+    } else if (hd.ksplit <= 1 && (hd.epi == SK_EPI_STORE || hd.epi == SK_EPI_GATE)) {
+        const float* dummy = hd.C;
+#pragma unroll
+        for (int e = 0; e < 1024 / (NW * 64); ++e) {
+            const int idx = threadIdx.x + NW * 64 * e;
+            const int m = idx >> 5, c = idx & 31;
+            const int row = min(m0 + m, M - 1);
+            const int unit = min((n0 >> 2) + (c & 7), R - 1);
+            const int col = cell_tiles ? (c >> 3) * R + unit : min(n0 + c, N - 1);
+            p.a[4 * e] = *(ei.bias[0] ? ei.bias[0] + col : dummy);
+            p.a[4 * e + 1] = *(ei.bias[1] ? ei.bias[1] + col : dummy);
+            p.a[4 * e + 2] = *(ei.bias[2] ? ei.bias[2] + col : dummy);
+            const float* xp = hd.epi == SK_EPI_GATE ? ei.gate_t + (size_t)row * ei.ldt + col
+                                                    : (ei.accumulate ? hd.C + (size_t)row * hd.ldc + col : dummy);
+            p.a[4 * e + 3] = *xp;
+        }
+        asm volatile("; store operands requested");
+    }
+}
+
+// epilogue of the fast kernel (un-split tiles): red = [NW][32][RSF] partial tiles in LDS.  Same arithmetic, in the same order,
+// as sk_epilogue above.
+// ef: which optional operands exist / which variant runs, folded into one scalar at the top of the kernel (the pointers themselves
+// are dead once their loads are requested: fewer scalar registers live across the K loop).
+enum { EF_B0 = 1, EF_B1 = 2, EF_B2 = 4, EF_ADD = 8, EF_MASK = 16, EF_ACC = 32, EF_RELU = 64, EF_IFOG = 128, EF_HOLD = 256 };
+template <int NW>
+__device__ __forceinline__ void skf_epilogue(const SkJob& job, const SkHeadBlk& hd, int ef, float* gate_y, int ldy, const SkEpiOut& eo,
+                                             bool cell_tiles, const float* __restrict__ redp, int m0, int n0, int tn, const EpiPre& pre) {
+    const float (*red)[32][RSF] = reinterpret_cast<const float (*)[32][RSF]>(redp);
+    const int R = hd.R, M = hd.M, N = hd.N;
+    if (hd.epi == SK_EPI_STORE) {
+#pragma unroll
+        for (int e = 0; e < 1024 / (NW * 64); ++e) {
+            const int idx = threadIdx.x + NW * 64 * e;
+            const int m = idx >> 5, c = idx & 31;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += red[w][m][c];
+            const int row = m0 + m;
+            // n0 = 32 tn; cell tiling: column = gate (c / 8) of hidden unit 8 tn + c % 8
+            const int unit = (n0 >> 2) + (c & 7);
+            const int col = cell_tiles ? (unit < R ? (c >> 3) * R + unit : N) : n0 + c;
+            if (row < M && col < N) {
+                if (ef & EF_B0) v += pre.a[4 * e];
+                if (ef & EF_B1) v += pre.a[4 * e + 1];
+                if (ef & EF_B2) v += pre.a[4 * e + 2];
+                if (ef & EF_ACC) v += pre.a[4 * e + 3];
+                if (ef & EF_RELU) v = fmaxf(v, 0.f);
+                hd.C[(size_t)row * hd.ldc + col] = v;
+            }
+        }
+    } else if (hd.epi == SK_EPI_LSTMB) {
+        // pointwise LSTM backward of the step whose dh this product completes (same arithmetic as lstm_bwd_body)
+#pragma unroll
+        for (int e = 0; e < 1024 / (NW * 64); ++e) {
+            const int idx = threadIdx.x + NW * 64 * e;
+            const int m = idx >> 5, c = idx & 31;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += red[w][m][c];
+            const int b = m0 + m, j = n0 + c;
+            if (b < M && j < N) {
+                if (ef & EF_ACC) v += hd.C[(size_t)b * hd.ldc + j];
+                lstmb_point(job, b, j, v);
+            }
+        }
+    } else if (hd.epi == SK_EPI_GATE) {
+#pragma unroll
+        for (int e = 0; e < 1024 / (NW * 64); ++e) {
+            const int idx = threadIdx.x + NW * 64 * e;
+            const int m = idx >> 5, c = idx & 31;
+            float v = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) v += red[w][m][c];
+            const int row = m0 + m, col = n0 + c;
+            if (row < M && col < N) {
+                if (ef & EF_B0) v += pre.a[4 * e];
+                const float g = fmaxf(v, 0.f) * xg_keep(eo.drop, (uint32_t)(row * N + col));
+                hd.C[(size_t)row * hd.ldc + col] = g;
+                const float tv = pre.a[4 * e + 3];
+                gate_y[(size_t)row * ldy + col] = g * tv + tv;
+            }
+        }
+    } else {
+        // LSTM cell epilogue: thread -> (row em, unit eu); its four gate pre-activations sit at columns eu + 8*gate
+        const int em_ = threadIdx.x >> 3, eu_ = threadIdx.x & 7;
+        const int b = m0 + em_, j = tn * 8 + eu_;
+        if (threadIdx.x < 256 && b < M && j < R) {
+            float s4[4];
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) {
+                float v = ((ef & EF_B0) ? pre.a[gi] : 0.f) + ((ef & EF_B1) ? pre.a[4 + gi] : 0.f) + ((ef & EF_B2) ? pre.a[8 + gi] : 0.f) +
+                          ((ef & EF_ADD) ? pre.a[12 + gi] : 0.f);
+#pragma unroll
+                for (int w = 0; w < NW; ++w) v += red[w][em_][gi * 8 + eu_];
+                s4[gi] = v;
+            }
+            const float so = (ef & EF_IFOG) ? s4[2] : s4[3];
+            const float sg_ = (ef & EF_IFOG) ? s4[3] : s4[2];
+            const float ig = xg_sigmoid(s4[0]), fg = xg_sigmoid(s4[1]), og = xg_sigmoid(so), gg = xg_tanh(sg_);
+            const float cp = pre.st[EP_CP], mk = (ef & EF_MASK) ? pre.st[EP_MK] : 1.0f;
+            float cn = fg * cp + ig * gg, hn;
+            if (ef & EF_HOLD) {
+                cn = cn * mk + cp * (1.0f - mk);
+                hn = og * xg_tanh(cn);
+                hn = hn * mk + pre.st[EP_HP] * (1.0f - mk);
+            } else {
+                hn = og * xg_tanh(cn) * mk;
+                cn = cn * mk;
+            }
+            hn *= xg_keep(eo.drop, (uint32_t)(b * R + j));
+            if (eo.gates) {
+                float* g = eo.gates + (size_t)b * eo.ldg;
+                g[j] = ig; g[R + j] = fg;
+                if (ef & EF_IFOG) { g[2 * R + j] = og; g[3 * R + j] = gg; }
+                else                           { g[2 * R + j] = gg; g[3 * R + j] = og; }
+            }
+            eo.c_out[(size_t)b * eo.ldco + j] = cn;
+            eo.h_out[(size_t)b * eo.ldho + j] = hn;
+        }
     }
 }
 
@@ -707,26 +897,42 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
     static_assert(WSM >= 32 * RSF, "the reduction buffer must fit the staging area");
     __shared__ __attribute__((aligned(16))) float smem[NW * WSM + (SCALE ? 32 : 0)];
     const SkJob& job = args.job[blockIdx.y];
-#ifndef SKF_NO_DESC_WARM
-    {   // The job descriptor (664 bytes of kernel arguments) is read field by field where each field is first needed -- behind
-        // branches, i.e. as a chain of dependent scalar-cache misses when a workgroup is the first on its CU.  One independent
-        // load per 64-byte line up front turns the chain into one miss and a row of hits.
-        const int* jd = reinterpret_cast<const int*>(&job);
+    const char* jb = reinterpret_cast<const char*>(&job);
+#ifdef SKF_WARM_NEXT
+    if (blockIdx.y + 1 < SK_MAX_JOBS) {
+        // (experiment, round 5, NOT the default: every workgroup of job j touches the cache lines of job j + 1's descriptor in the
+        //  same round as its own, so that they are in the scalar cache when the next job's workgroups land on this CU.  Measured:
+        //  the later jobs' descriptor round stays at 2.3-3.1 us and the step is 0.6 us slower -- that round is not a cache miss,
+        //  it is instruction issue: docs/EXPERIMENTS.md.)
+        const int* nb = reinterpret_cast<const int*>(jb + sizeof(SkJob));
         int warm = 0;
 #pragma unroll
-        for (int i = 0; i < (int)((sizeof(SkJob) + 63) / 64); ++i) warm |= jd[i * 16 < (int)(sizeof(SkJob) / 4) ? i * 16 : (int)(sizeof(SkJob) / 4) - 1];
+        for (int i = 0; i < (int)sizeof(SkJob) / 64; ++i) warm |= nb[i * 16];
         asm volatile("" ::"s"(warm));
     }
 #endif
-    if (job.epi == SK_EPI_ZERO) {
+    // ---- ONE round of wide scalar loads: the head and the three segments' hot parts
+    const SkHeadBlk hd = *reinterpret_cast<const SkHeadBlk*>(jb);
+    const SkSegHot sh0 = *reinterpret_cast<const SkSegHot*>(jb + offsetof(SkJob, seg));
+    const SkSegHot sh1 = *reinterpret_cast<const SkSegHot*>(jb + offsetof(SkJob, seg) + sizeof(SkSeg));
+    const SkSegHot sh2 = *reinterpret_cast<const SkSegHot*>(jb + offsetof(SkJob, seg) + 2 * sizeof(SkSeg));
+    // (round 5, measured: a scalar load issued once the launch's operand burst is under way takes 1-2.5 us to come back, so the
+    //  epilogue's two blocks ride in the same first round instead of behind the first operand request)
+    const SkEpiIn ei = *reinterpret_cast<const SkEpiIn*>(jb + offsetof(SkJob, bias));
+    const SkEpiOut eo = *reinterpret_cast<const SkEpiOut*>(jb + offsetof(SkJob, gates));
+    sk_pin(hd); sk_pin(sh0); sk_pin(sh1); sk_pin(sh2); sk_pin(ei); sk_pin(eo);
+    const int ef = (ei.bias[0] ? EF_B0 : 0) | (ei.bias[1] ? EF_B1 : 0) | (ei.bias[2] ? EF_B2 : 0) | (ei.add ? EF_ADD : 0) | (ei.mask ? EF_MASK : 0) |
+                   (ei.accumulate ? EF_ACC : 0) | (ei.relu ? EF_RELU : 0) | (ei.order == XG_ORDER_IFOG ? EF_IFOG : 0) |
+                   (ei.mask_mode == XG_MASK_HOLD ? EF_HOLD : 0);
+    if (hd.epi == SK_EPI_ZERO) {
         if ((size_t)blockIdx.x * 4096 < (size_t)job.M * job.N) zero_tile<NW>(job, blockIdx.x);
         return;
     }
-    if (job.epi == SK_EPI_COPY) {
+    if (hd.epi == SK_EPI_COPY) {
         if ((size_t)blockIdx.x * 4096 < (size_t)job.M * job.N) copy_tile<NW>(job, blockIdx.x);
         return;
     }
-    if (job.epi == SK_EPI_ATTN) {
+    if (hd.epi == SK_EPI_ATTN) {
         if ((int)blockIdx.x < 2 * job.M) {           // (every wave of the workgroup scores its share of the rows)
 #ifdef SKF_ATTN_LDS_OFF
             float* asm_ = smem + SKF_ATTN_LDS_OFF;
@@ -737,16 +943,13 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
         }
         return;
     }
-    if (job.low_prio) __builtin_amdgcn_s_setprio(0);
-    const int ntm = (job.M + 31) >> 5;
-    const bool lstm = job.epi == SK_EPI_LSTM || job.cell_cols;      // cell tiling of the weight rows
-    const int ntn = lstm ? job.R >> 3 : (job.N + 31) >> 5;
-    const int ks = job.ksplit > 1 ? job.ksplit : 1;             // cross-workgroup split of the reduction
-    const int ntiles = ntm * ntn * ks;
-    if ((int)blockIdx.x >= ntiles) return;
+    if ((int)blockIdx.x >= hd.ntiles) return;
+    if (hd.hflags & SKH_LOW_PRIO) __builtin_amdgcn_s_setprio(0);
+    const int ntm = hd.ntm, ntn = hd.ntn, ks = hd.ksplit;      // (ksplit >= 1: xgk_skinny)
+    const bool cell_tiles = (hd.hflags & SKH_CELL_TILES) != 0;
     int bid = blockIdx.x;
     {   // XCD-aware: the m-tiles that share a weight slice stay on one XCD's L2 (gridDim.x is a multiple of 8)
-        const int q = ntiles / 8, r = ntiles % 8, xcd = bid % 8, idx = bid / 8;
+        const int q = hd.ntiles / 8, r = hd.ntiles % 8, xcd = bid % 8, idx = bid / 8;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int tm = bid % ntm, kp = (bid / ntm) % ks, tn = bid / (ntm * ks);
@@ -757,16 +960,31 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
     float* As = smem + wave * WSM;
     const int lrow = lane >> 3, lcol = (lane & 7) << 2;
 
+    // ---- the gathered segment's row indices (embedding lookup inside the product): one more dependent round trip in front of
+    // that segment's operands, so they are requested first of all
+    const int gseg = ((hd.hflags >> SKH_GATHER_SHIFT) & 3) - 1;
+    // (the low dword of the int64 token only: a negative token is a negative int, and the clamp keeps the row inside the table
+    //  whatever the value -- four registers instead of eight across the earlier segments' K loops)
+    int gidx[4] = {0, 0, 0, 0};
+    if (gseg >= 0) {
+        const int64_t* gp = gseg == 0 ? sh0.gather : (gseg == 1 ? sh1.gather : sh2.gather);
+        const int gs = gseg == 0 ? sh0.gstride : (gseg == 1 ? sh1.gstride : sh2.gstride);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) gidx[i] = *reinterpret_cast<const int*>(gp + (size_t)min(m0 + i * 8 + lrow, hd.M - 1) * gs);
+    }
+    SK_STAMP(6);
+
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
     // (split-bf16: the plane registers leave no room for 19 prefetched values across the K loop at 128 VGPRs -- they would go
     //  to scratch, which costs more than it hides -- so that mode requests the cell operands behind the loop, under the reduction)
-    // (the same when the activations are requested two chunks ahead: SKF_DEPTH_A = 2)
-    constexpr bool LATE_PRE = PREC == 2 || SKF_DEPTH_A(PREC, SCALE) == 2;
-    LstmPre pre;
-    if (!LATE_PRE) pre = lstm_prefetch<NW>(job, m0, tn);
+    constexpr bool LATE_PRE = PREC == 2;
+    EpiPre pre;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) pre.a[i] = 0.f;
+    pre.st[EP_CP] = 0.f; pre.st[EP_HP] = 0.f; pre.st[EP_MK] = 1.f;
     // A scaled operand (the unnormalised attention context): the reciprocal row scales go to LDS behind the staging images;
     // the workgroup meets at a barrier in front of the first scaled segment, i.e. after every wave has done its share of the
     // segments before it -- the scale's load latency hides there (registers would be simpler, but four more live values
@@ -776,133 +994,69 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
     int scaled_seg = -1;
     if (SCALE) {
 #pragma unroll
-        for (int s = 0; s < 3; ++s) if (s < job.nseg && job.seg[s].row_scale && scaled_seg < 0) scaled_seg = s;
+        for (int s = 2; s >= 0; --s) if (s < hd.nseg && ((s == 0 ? sh0 : (s == 1 ? sh1 : sh2)).sflags & SKS_SCALED)) scaled_seg = s;
     }
-    float exv = 0.f, exs = 1.f;
+    float exv = 0.f, exs = 1.f, rsv = 1.f;
     float* exp_ = nullptr;
-    if (scaled_seg >= 0) {
-        const SkSeg& sg = job.seg[scaled_seg];
-        if (threadIdx.x < 32) rsc_lds[threadIdx.x] = 1.0f / sg.row_scale[min(m0 + (int)threadIdx.x, job.M - 1)];
-        if (sg.ex) {
-            const int per = (32 * sg.ex_K + ntn - 1) / ntn;              // elements of this tile's slice
-            const int idx = tn * per + (int)threadIdx.x;
-            const int row = m0 + idx / sg.ex_K;
-            if ((int)threadIdx.x < per && idx < 32 * sg.ex_K && row < job.M) {
-                exp_ = sg.ex + (size_t)row * sg.ex_ld + idx % sg.ex_K;
-                exv = *exp_;
-                exs = sg.row_scale[row];
+    auto scale_loads = [&]() {          // issued behind the first operand request; consumed at the scaled segment / at the very end
+        if (scaled_seg >= 0) {
+            const SkSeg& sgc = job.seg[scaled_seg];
+            if (threadIdx.x < 32) rsv = sgc.row_scale[min(m0 + (int)threadIdx.x, hd.M - 1)];
+            if (sgc.ex) {
+                const int per = (32 * sgc.ex_K + ntn - 1) / ntn;              // elements of this tile's slice
+                const int idx = tn * per + (int)threadIdx.x;
+                const int row = m0 + idx / sgc.ex_K;
+                if ((int)threadIdx.x < per && idx < 32 * sgc.ex_K && row < hd.M) {
+                    exp_ = sgc.ex + (size_t)row * sgc.ex_ld + idx % sgc.ex_K;
+                    exv = *exp_;
+                    exs = sgc.row_scale[row];
+                }
             }
         }
-    }
+    };
+    if (SCALE && scaled_seg == 0) scale_loads();       // (a scaled FIRST segment: nothing to hide the loads behind)
+    // ---- the epilogue's operands are requested now: they have the whole K loop to land
+    if (!LATE_PRE) epi_prefetch<NW>(pre, hd, ei, cell_tiles, m0, n0, tn);
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-        if (s >= job.nseg) break;
-        const SkSeg sg = job.seg[s];
+        if (s >= hd.nseg) break;
+        const SkSegHot& sg = s == 0 ? sh0 : (s == 1 ? sh1 : sh2);
         const int nc = sg.nck;
-        if (s == scaled_seg) __syncthreads();               // rsc_lds is complete (uniform: every wave passes here)
+        if (SCALE && s == scaled_seg) {
+            if (threadIdx.x < 32) rsc_lds[threadIdx.x] = 1.0f / rsv;
+            __syncthreads();               // rsc_lds is complete (uniform: every wave passes here)
+        }
         // every wave takes its share of EVERY segment, in order (a gathered or scaled operand comes last in its job, so the
         // index / scale loads have the earlier segments to land)
         const int p0 = (kp * nc) / ks, pn = ((kp + 1) * nc) / ks - p0;      // this workgroup's part of the segment
         const int c0 = p0 + (wave * pn) / NW, c1 = p0 + ((wave + 1) * pn) / NW;
-        if (c0 >= c1) continue;
+        const bool have = c0 < c1;
         // this lane's 16-byte piece of B tile (tn, chunk c), sub-piece i: bp + c * TILE + i * 256   (float units; a bf16
         // tile is 512 float-sized words: 2 pieces of 256, an fp32 tile 1024: 4 pieces)
         constexpr int TILE = PREC == 1 ? 512 : 1024, NPB = PREC == 1 ? 2 : 4;
         const float* bp = sg.Bp + ((size_t)tn * nc) * TILE + (size_t)(half * 32 + l31) * 4;
-#ifdef SKF_DIRECT_A
-        // ---- A straight from global memory in MFMA-fragment order (no LDS image, no wave barriers): lane (row l31, half h) owns
-        // k in [16 h, 16 h + 16) of a 32-deep chunk = 64 contiguous bytes of its row (bf16: two runs of 8 k = 32 bytes each).
-        // Costs coalescing (every load instruction touches 32 rows) -- measured against the staged form, see DESIGN 4.3.
-        {
-            int row = min(m0 + l31, job.M - 1);
-            if (sg.gather) {
-                const int64_t t = sg.gather[(size_t)row * sg.gstride];
-                row = (int)(t < 0 ? 0 : (t > sg.gather_max ? sg.gather_max : t));
-            }
-            const float* adp = sg.A + (size_t)row * sg.lda;
-            const int nfull = sg.K / CK;
-            const bool wb_seg = SCALE && sg.row_scale && sg.scaled_out;
-            const ptrdiff_t wb_delta = wb_seg ? sg.scaled_out - sg.A : 0;
-            const float rs = (SCALE && sg.row_scale) ? rsc_lds[l31] : 1.0f;
-            auto koff = [&](int i) { return PREC == 1 ? (i >> 1) * 16 + half * 8 + (i & 1) * 4 : half * 16 + i * 4; };
-            f32x4 da0[4], da1[4], rb0[NPB], rb1[NPB];
-            auto ldB = [&](int c, f32x4 (&b)[NPB]) {
-#pragma unroll
-                for (int i = 0; i < NPB; ++i) b[i] = *reinterpret_cast<const f32x4*>(bp + (size_t)c * TILE + i * 256);
-            };
-            auto ldD = [&](int c, f32x4 (&a)[4]) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const int k = c * CK + koff(i);
-                    const f32x4 t = *reinterpret_cast<const f32x4*>(adp + (c < nfull ? k : min(k, sg.K - 4)));
-                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                    a[i] = (c < nfull || k < sg.K) ? t : z;
-                }
-            };
-            if (s == 0) SK_STAMP(1);
-            ldB(c0, rb0); ldD(c0, da0);
-            auto chunk = [&](int c, f32x4 (&a)[4], f32x4 (&an)[4], const f32x4 (&cur)[NPB], f32x4 (&nxt)[NPB]) {
-                if (c + 1 < c1) { ldB(c + 1, nxt); ldD(c + 1, an); }
-                if (SCALE && sg.row_scale) {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        a[i] *= rs;
-                        const int k = c * CK + koff(i);
-                        if (wb_seg && c % ntn == tn && m0 + l31 < job.M && k < sg.K)
-                            *reinterpret_cast<f32x4*>(const_cast<float*>(adp) + wb_delta + k) = a[i];
-                    }
-                }
-                if (s == 0 && c == c0) SK_STAMP(2);
-                if (PREC == 1) {
-                    typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        unsigned w[4];
-#pragma unroll
-                        for (int q = 0; q < 2; ++q) {
-                            bf16x2_t lo, hi;
-                            lo[0] = (__bf16)a[2 * i + q][0]; lo[1] = (__bf16)a[2 * i + q][1];
-                            hi[0] = (__bf16)a[2 * i + q][2]; hi[1] = (__bf16)a[2 * i + q][3];
-                            w[2 * q] = __builtin_bit_cast(unsigned, lo); w[2 * q + 1] = __builtin_bit_cast(unsigned, hi);
-                        }
-                        const uint4 pk = {w[0], w[1], w[2], w[3]};
-                        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, pk), __builtin_bit_cast(bf16x8, cur[i]), acc, 0, 0, 0);
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 4; ++i)
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][kk], cur[i][kk], acc, 0, 0, 0);
-                }
-            };
-            for (int c = c0; c < c1; c += 2) {
-                chunk(c, da0, da1, rb0, rb1);
-                if (c + 1 < c1) chunk(c + 1, da1, da0, rb1, rb0);
-            }
-        }
-    }
-#else
         const float* ap[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int row = min(m0 + i * 8 + lrow, job.M - 1);
+            int row = min(m0 + i * 8 + lrow, hd.M - 1);
             if (sg.gather) {
-                const int64_t t = sg.gather[(size_t)row * sg.gstride];
-                row = (int)(t < 0 ? 0 : (t > sg.gather_max ? sg.gather_max : t));
+                int t;
+                if (s == gseg) t = gidx[i];
+                else t = *reinterpret_cast<const int*>(sg.gather + (size_t)row * sg.gstride);
+                row = t < 0 ? 0 : (t > sg.gather_max ? sg.gather_max : t);
             }
             ap[i] = sg.A + (size_t)row * sg.lda + lcol;
         }
         const int nfull = sg.K / CK;                 // chunks >= nfull are the (single) k tail: K % 4 == 0 on this path
         // unnormalised attention context as an operand: rows scaled by 1 / s while they are staged; the tn == 0 tiles write
         // the normalised rows back (scaled_out has A's row pitch: checked by the host)
-        const bool wb_seg = SCALE && sg.row_scale && sg.scaled_out;      // chunk c of the scaled rows is written back by n-tile c % ntn
-        const ptrdiff_t wb_delta = wb_seg ? sg.scaled_out - sg.A : 0;
-        // Operands are requested DA / DB chunks ahead of their MFMAs: 1 = ping-pong B sets, one A set (reloaded right behind its
-        // LDS store); 2 = three B sets / two A sets (-DSKF_DEPTH_A / -DSKF_DEPTH_B).  Depth 2 was measured and is NOT the default:
-        // it needs 10-12 registers beyond the 128 of four waves per SIMD (the cell epilogue's prefetched operands then live in
-        // scratch across the K loop) and the step got slower, 49.0 vs 46.2 us fp32, 8.49 vs 8.17 ms per hidden-1024 bf16 iteration.
-        constexpr int DA = SKF_DEPTH_A(PREC, SCALE), DB = SKF_DEPTH_B(PREC, SCALE);     // chunks ahead: activations / weights
-        f32x4 ra0[4], ra1[DA == 2 ? 4 : 1], rb0[NPB], rb1[NPB], rb2[DB == 2 ? NPB : 1];
+        const bool sc_seg = SCALE && (sg.sflags & SKS_SCALED);
+        const bool wb_seg = SCALE && (sg.sflags & SKS_WRITEBACK);      // chunk c of the scaled rows is written back by n-tile c % ntn
+        const ptrdiff_t wb_delta = wb_seg ? job.seg[s].scaled_out - sg.A : 0;
+        // Operands are requested one chunk ahead of their MFMAs: ping-pong B sets, one A set (reloaded right behind its LDS store).
+        // (Two chunks ahead was measured in round 3 and is not kept: it needs 10-12 registers beyond the 128 of four waves per
+        // SIMD and the step got slower, docs/EXPERIMENTS.md.)
+        f32x4 ra0[4], rb0[NPB], rb1[NPB];
         if (s == 0) SK_STAMP(1);
         auto ldB = [&](int c, f32x4 (&b)[NPB]) {
 #pragma unroll
@@ -911,19 +1065,17 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
         auto ldAc = [&](int c, f32x4 (&a)[4]) {
             if (c < nfull) ldA<false>(ap, c, 0, a); else ldA<true>(ap, c, sg.K - c * CK - lcol, a);
         };
-        ldB(c0, rb0); ldAc(c0, ra0);
-        if (c0 + 1 < c1) {
-            if constexpr (DB == 2) ldB(c0 + 1, rb1);
-            if constexpr (DA == 2) ldAc(c0 + 1, ra1);
-        }
-        // one chunk: stage A (scaled / written back when it is the attention context), request chunk `cn`'s operands (A into the
-        // registers just stored, B into a free set: no copies), then the 16 MFMAs of this chunk
+        if (have) { ldB(c0, rb0); ldAc(c0, ra0); }
+        if (s == 0 && SCALE && scaled_seg > 0) scale_loads();
+        if (!have) continue;
+        // one chunk: stage A (scaled / written back when it is the attention context), request the next chunk's operands (A into
+        // the registers just stored, B into the free set: no copies), then the 16 MFMAs of this chunk
         auto chunk = [&](int c, f32x4 (&ra)[4], const f32x4 (&cur)[NPB], f32x4 (&nxt)[NPB]) {
-            if (SCALE && sg.row_scale) {
+            if (sc_seg) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     ra[i] *= rsc_lds[i * 8 + lrow];
-                    if (wb_seg && c % ntn == tn && m0 + i * 8 + lrow < job.M && c * CK + lcol < sg.K)
+                    if (wb_seg && c % ntn == tn && m0 + i * 8 + lrow < hd.M && c * CK + lcol < sg.K)
                         *reinterpret_cast<f32x4*>(const_cast<float*>(ap[i]) + wb_delta + (size_t)c * CK) = ra[i];
                 }
             }
@@ -931,8 +1083,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
             else if (PREC == 2) st_chunk_split3(reinterpret_cast<unsigned short*>(As), lane, ra);
             else st_chunk(As, lane, ra);
             if (s == 0 && c == c0) SK_STAMP(2);
-            if (c + DB < c1) ldB(c + DB, nxt);
-            if (c + DA < c1) ldAc(c + DA, ra);
+            if (c + 1 < c1) { ldB(c + 1, nxt); ldAc(c + 1, ra); }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (PREC == 2) {
@@ -971,27 +1122,14 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         };
-        // register sets: A alternates (period 2) when DA == 2; B rotates over three sets (period 3) when DB == 2, ping-pongs otherwise
-        auto& A1 = *reinterpret_cast<f32x4 (*)[4]>(DA == 2 ? ra1 : ra0);
-        if constexpr (DB == 2) {
-            for (int c = c0; c < c1; c += 6) {
-                chunk(c, ra0, rb0, rb2);
-                if (c + 1 < c1) chunk(c + 1, A1, rb1, rb0);
-                if (c + 2 < c1) chunk(c + 2, ra0, rb2, rb1);
-                if (c + 3 < c1) chunk(c + 3, A1, rb0, rb2);
-                if (c + 4 < c1) chunk(c + 4, ra0, rb1, rb0);
-                if (c + 5 < c1) chunk(c + 5, A1, rb2, rb1);
-            }
-        } else {
-            for (int c = c0; c < c1; c += 2) {
-                chunk(c, ra0, rb0, rb1);
-                if (c + 1 < c1) chunk(c + 1, A1, rb1, rb0);
-            }
+        for (int c = c0; c < c1; c += 2) {
+            chunk(c, ra0, rb0, rb1);
+            if (c + 1 < c1) chunk(c + 1, ra0, rb1, rb0);
         }
     }
-#endif
     SK_STAMP(3);
-    if (LATE_PRE) pre = lstm_prefetch<NW>(job, m0, tn);
+    SK_STAMP_MAX(7);
+    if (LATE_PRE) epi_prefetch<NW>(pre, hd, ei, cell_tiles, m0, n0, tn);
     __syncthreads();
     float (*red)[32][RSF] = reinterpret_cast<float (*)[32][RSF]>(smem);
 #pragma unroll
@@ -999,7 +1137,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
     __syncthreads();
     SK_STAMP(4);
     if (ks > 1) sk_epilogue_split<RSF, NW>(job, smem, m0, n0, kp, tm + ntm * tn);
-    else sk_epilogue<RSF, NW>(job, smem, m0, n0, pre);
+    else skf_epilogue<NW>(job, hd, ef, ei.gate_y, ei.ldy, eo, cell_tiles, smem, m0, n0, tn, pre);
     if (exp_) *exp_ = exv * (1.0f / exs);
     SK_STAMP(5);
 }
@@ -1023,6 +1161,15 @@ static int skinny_fallback(hipStream_t st, const SkJob& jb, int gemm_mode) {
 #ifdef SK_TRACE
 extern "C" int xg_debug_sk_trace(long long* out, int n) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(sk_trace_buf), sizeof(long long) * (size_t)n) == hipSuccess ? 0 : -1;
+}
+extern "C" int xg_debug_sk_trace_filter(int njobs, int gx) {
+    const int sel[2] = {njobs, gx};
+    return hipMemcpyToSymbol(HIP_SYMBOL(sk_trace_sel), sel, sizeof(sel)) == hipSuccess ? 0 : -1;
+}
+extern "C" int xg_debug_sk_trace_clear(void) {
+    void* p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(sk_trace_buf)) != hipSuccess) return -1;
+    return hipMemset(p, 0, sizeof(long long) * 4096 * 8) == hipSuccess ? 0 : -1;
 }
 #endif
 
@@ -1102,6 +1249,23 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         if (ok) while (ks < cap && tiles * ks * 2 <= 512 && min_chunks / (ks * 2) >= 4) ks *= 2;
         for (int j = 0; j < a.njobs; ++j) a.job[j].ksplit = ks;
         tiles *= ks; max_tiles *= ks;
+    }
+    // derived fields of the job heads (what skf_kernel reads with its first round of scalar loads)
+    for (int j = 0; j < a.njobs; ++j) {
+        SkJob& jb = a.job[j];
+        const bool cells = jb.epi == SK_EPI_LSTM || jb.cell_cols;
+        jb.ntm = xg_cdiv(jb.M, 32);
+        jb.ntn = cells ? jb.R / 8 : xg_cdiv(jb.N, 32);
+        jb.ntiles = jb.ntm * jb.ntn * ks;
+        int gseg = 0;
+        bool any_scaled = false;
+        for (int q = jb.nseg - 1; q >= 0; --q) {
+            SkSeg& sg = jb.seg[q];
+            sg.sflags = (sg.row_scale ? SKS_SCALED : 0) | (sg.row_scale && sg.scaled_out ? SKS_WRITEBACK : 0) | (sg.row_scale && sg.ex ? SKS_EX : 0);
+            any_scaled = any_scaled || sg.row_scale;
+            if (sg.gather) gseg = q + 1;
+        }
+        jb.hflags = (cells ? SKH_CELL_TILES : 0) | (jb.low_prio ? SKH_LOW_PRIO : 0) | (any_scaled ? SKH_HAS_SCALED : 0) | (gseg << SKH_GATHER_SHIFT);
     }
     if (special && !fast) return XG_EINVAL;            // ZERO / ATTN jobs and scaled operands exist in the fast kernel only
     static const bool split_jobs = xg_diag_env("XG_SPLIT_JOBS") != nullptr;       // diagnosis: one launch per job

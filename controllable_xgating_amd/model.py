@@ -430,10 +430,23 @@ class SAModel(nn.Module):
         Returns (gen (m,L), sample_logprobs (m,L) [differentiable], greedy (m,L), n (2,) int32 device tensor: the
         reference's early-exit lengths of the two rollouts -- trim with them, or hand n[:1] to RewardCriterion).
         In train mode the BatchNorm running statistics end up exactly where the reference's TWO sample() calls leave
-        them (two momentum updates with the unbiased N/(N-1) variance of the un-repeated batch)."""
+        them (two momentum updates with the unbiased N/(N-1) variance of the un-repeated batch).  With train-mode dropout
+        (drop_prob_lm > 0) the two rollouts run as two calls with independent masks, like the reference's."""
         temperature = float(opt.get("temperature", 1.0))
         params = self._param_list()
         need_grad = torch.is_grad_enabled() and any(p.requires_grad for p in params)
+        if self.training and self.drop_prob_lm > 0.0:
+            # Train-mode dropout: the reference's two sample() calls (starttrain.py:131, myutils.py:45) draw INDEPENDENT masks,
+            # in the encoder and img_embed as well as in the decoder.  The one-batch form below runs the encoder once and would
+            # hand both halves the same encoder realisation, so this case takes the reference's own shape: two rollouts, two
+            # seeds (each with its BatchNorm update), the greedy one without saved activations.
+            uni = opt.get("uniforms", None)
+            gen, slp, n_s = _RolloutFunction.apply(self, feats_rgb, feats_opfl, feat_mask, pos_feats, nv.XG_ROLLOUT_SAMPLE, uni,
+                                                   None, temperature, need_grad, True, *params)
+            with torch.no_grad():
+                greedy, _, n_g = _RolloutFunction.apply(self, feats_rgb, feats_opfl, feat_mask, pos_feats, nv.XG_ROLLOUT_GREEDY,
+                                                        None, None, 1.0, False, True, *params)
+            return gen, slp, greedy, torch.cat([n_s.reshape(1), n_g.reshape(1)])
         return _RolloutPairFunction.apply(self, feats_rgb, feats_opfl, feat_mask, pos_feats, opt.get("uniforms", None),
                                           temperature, need_grad, *params)
 
@@ -815,10 +828,23 @@ class _RewardFunction(torch.autograd.Function):
         if reward.dim() == 0:                  # one scalar for every element (broadcast like the reference's input * reward)
             reward = reward.reshape(1, 1)
         if reward.dim() == 1:
-            # the reference's `input * reward` (SAModel.py:263) broadcasts a 1-D tensor along the LAST axis: (L,) is one value
-            # per position -- also when m == L.  (m,) with m != L, which the reference rejects, is taken as one value per
-            # video (an extension; pass (m, 1) to say so explicitly).
-            reward = reward.unsqueeze(0) if reward.shape[0] == L or reward.shape[0] == 1 else reward.unsqueeze(1)
+            # The reference flattens both tensors (SAModel.py:260-261: view(-1)) and never broadcasts, so a 1-D reward has no
+            # reference meaning unless it is the full m*L vector.  Extensions: (m*L,) is the flattened (m, L) matrix; (1,) one
+            # value for all; (m,) with m != L one value per video; (L,) with L != m one value per position.  m == L is ambiguous
+            # and rejected -- pass (m, 1) or (1, L).
+            k = reward.shape[0]
+            if k == m * L and m > 1 and L > 1:
+                reward = reward.reshape(m, L)
+            elif k == 1:
+                reward = reward.reshape(1, 1)
+            elif m == L and k == m:
+                raise nv.XgError("1-D reward of length m == L is ambiguous: pass (m, 1) per video or (1, L) per position")
+            elif k == m:
+                reward = reward.unsqueeze(1)
+            elif k == L:
+                reward = reward.unsqueeze(0)
+            else:
+                raise nv.XgError("1-D reward must have m, L or m*L elements")
         if reward.shape[0] not in (1, m):
             raise nv.XgError("reward must broadcast against the (m, L) log-probs")
         if reward.shape[1] == 1:
@@ -849,7 +875,8 @@ class RewardCriterion(nn.Module):
     mask[:, 0] = 1, mask[:, t] = seq[:, t-1] > 0, as ONE HIP launch forward and one backward (xg_reward_fwd/bwd).
     ``n`` (optional device int tensor: the rollout's early-exit width, e.g. from ``model.sample(..., {'async': True})`` or
     ``scst_rollouts(..., trim=False)``) lets the caller pass full-width (m, L) rollout outputs without ever syncing on n;
-    ``reward`` may be (m, n') or one value per video, (m,) / (m, 1)."""
+    ``reward`` may be (m, n'), one value per video (m, 1), one per position (1, L), a scalar, or 1-D of length m / L when
+    m != L (m == L is ambiguous and raises)."""
 
     def forward(self, input, seq, reward, n=None):
         reward = torch.as_tensor(reward, dtype=torch.float32, device=input.device)

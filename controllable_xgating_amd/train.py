@@ -303,6 +303,19 @@ def _segment_bounds(model):
     return split, (lw[0], lb[0] + (lb[1] + 63) // 64 * 64)
 
 
+def bucket_plan(split, head, numel):
+    """The collectives of one GradSync iteration, in issue order, as (first, last, event) element ranges of the flat gradient
+    buffer: event "head" = behind XgRun.grad_event_head, "rest" = behind XgRun.grad_event, "end" = behind the whole backward.
+    A pure function of the buffer layout, so every rank issues the same collectives in the same order with the same bounds
+    (tests/test_dp_gloo.py checks the partition and the order at world size 8)."""
+    a0, a1 = head
+    plan = [(a0, a1, "head"), (split, a0, "rest")]
+    if a1 < numel:
+        plan.append((a1, numel, "rest"))
+    plan.append((0, split, "end"))
+    return plan
+
+
 class GradSync:
     """Overlaps the gradient all-reduce with the backward pass.  The flat gradient buffer is in xg_param_name order:
     [two_spatial_encoder.* | img_embed / lstmcore / embed | logit.* | classifer.*], and the backward pass finishes it
@@ -336,26 +349,24 @@ class GradSync:
         world = dist.get_world_size(group)
         g = self.model.flat_grads()
         main = torch.cuda.current_stream()
-        a0, a1 = self.head
         # an overlapping optimizer (ClipAdam(overlap=True), armed) updates each segment right behind its all-reduce
         opt = getattr(self.model, "_overlap_optimizer", None)
         opt = opt if (opt is not None and opt._armed) else None
         if opt is not None:
             opt.begin_step()
         upd = (lambda a, b: opt.update_segment(a, b)) if opt is not None else (lambda a, b: None)
-        self.side.wait_event(self.event_head)    # the backward has been enqueued: these are the records it made
-        with torch.cuda.stream(self.side):
-            _reduce(g[a0:a1], world, group)
-            upd(a0, a1)
-        self.side.wait_event(self.event)
-        with torch.cuda.stream(self.side):
-            _reduce(g[self.split:a0], world, group)
-            upd(self.split, a0)
-            if a1 < g.numel():
-                _reduce(g[a1:], world, group)
-                upd(a1, g.numel())
-        _reduce(g[:self.split], world, group)    # after the whole backward (main stream order)
-        upd(0, self.split)
+        waited = None
+        for lo, hi, ev in bucket_plan(self.split, self.head, g.numel()):
+            if ev == "end":                          # after the whole backward (main stream order)
+                _reduce(g[lo:hi], world, group)
+                upd(lo, hi)
+                continue
+            if ev != waited:                         # the backward has been enqueued: these are the records it made
+                self.side.wait_event(self.event_head if ev == "head" else self.event)
+                waited = ev
+            with torch.cuda.stream(self.side):
+                _reduce(g[lo:hi], world, group)
+                upd(lo, hi)
         main.wait_stream(self.side)
         if opt is not None:
             opt._segments_done = True

@@ -91,3 +91,64 @@ def test_single_process_is_a_noop():
     g = torch.arange(5.0)
     allreduce_gradients(_FlatHolder(g, g))                         # no process group: must not touch anything
     assert torch.equal(g, torch.arange(5.0))
+
+
+# ---------------------------------------------------------------- world size 8 (BASELINE.json configs[3]: one node, 8 ranks)
+def _worker8(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from controllable_xgating_amd.train import _reduce, allreduce_gradients, bucket_plan, shard_batch
+    torch.set_num_threads(1)
+    d = pg.make_dims(**dict(CFG["tiny"], B=19))                 # 19 videos over 8 ranks: shards of 3, 3, 3, 2, 2, 2, 2, 2
+    x = xo.to_torch_inputs(pg.make_inputs(d, seed=0))
+    mine = shard_batch(x, rank, world)
+    np.save(os.path.join(out_dir, f"rows{rank}.npy"), mine["feats_rgb"].numpy())
+    # a flat "gradient" that depends on the rank, reduced (a) as ONE collective and (b) as GradSync's buckets in plan order
+    numel, split, head = 5000, 1300, (3100, 4420)
+    base = torch.from_numpy(pg.uniform("dp8.g", (numel,), 3, -1.0, 1.0))
+    g_one = base * (rank + 1)
+    g_bkt = g_one.clone()
+    allreduce_gradients(_FlatHolder(g_one, g_one))
+    plan = bucket_plan(split, head, numel)
+    for lo, hi, _ in plan:
+        _reduce(g_bkt[lo:hi], world, None)
+    np.save(os.path.join(out_dir, f"one{rank}.npy"), g_one.numpy())
+    np.save(os.path.join(out_dir, f"bkt{rank}.npy"), g_bkt.numpy())
+    with open(os.path.join(out_dir, f"plan{rank}.txt"), "w") as f:
+        f.write(repr(plan))
+    dist.destroy_process_group()
+
+
+def test_world8_shards_partition_the_batch_and_buckets_are_deterministic(tmp_path):
+    """Eight ranks (gloo): (1) shard_batch r::8 of a batch that does not divide by 8 is a partition, in rank-strided order;
+    (2) every rank derives the SAME bucket plan (bounds and order), the buckets tile the flat buffer exactly once, and reducing
+    bucket by bucket in plan order gives bit-identical results on all ranks, equal to the single-collective path."""
+    from controllable_xgating_amd.train import bucket_plan
+    world = 8
+    mp.spawn(_worker8, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    d = pg.make_dims(**dict(CFG["tiny"], B=19))
+    x = pg.make_inputs(d, seed=0)
+    rows = [np.load(tmp_path / f"rows{r}.npy") for r in range(world)]
+    assert [len(r) for r in rows] == [3, 3, 3, 2, 2, 2, 2, 2]
+    merged = np.empty_like(x["feats_rgb"])
+    for r in range(world):
+        merged[r::world] = rows[r]
+    assert np.array_equal(merged, x["feats_rgb"])
+    plans = [open(tmp_path / f"plan{r}.txt").read() for r in range(world)]
+    assert len(set(plans)) == 1
+    plan = bucket_plan(1300, (3100, 4420), 5000)
+    assert repr(plan) == plans[0] and [e for _, _, e in plan] == ["head", "rest", "rest", "end"]
+    cover = np.zeros(5000, np.int32)
+    for lo, hi, _ in plan:
+        assert 0 <= lo < hi <= 5000
+        cover[lo:hi] += 1
+    assert (cover == 1).all()
+    one = [np.load(tmp_path / f"one{r}.npy") for r in range(world)]
+    bkt = [np.load(tmp_path / f"bkt{r}.npy") for r in range(world)]
+    base = pg.uniform("dp8.g", (5000,), 3, -1.0, 1.0)
+    for r in range(world):
+        assert np.array_equal(one[r], one[0]) and np.array_equal(bkt[r], bkt[0])
+    # (gloo's ring sums in a rank-dependent association per chunk: the two paths agree to round-off, every rank bit-identically)
+    np.testing.assert_allclose(bkt[0], one[0], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(one[0], base * 4.5, rtol=0, atol=2e-6)        # mean of (r + 1) over 8 ranks

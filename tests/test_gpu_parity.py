@@ -415,7 +415,8 @@ def test_init_hidden_and_encoder_surface():
 def test_greedy_token_for_token_vs_reference(name, tag, ragged):
     g = load_golden(name)
     d = pg.make_dims(**CFG[tag])
-    model = make_model(d, train=False)
+    assert float(g["min_margin"]) >= 1e-3                  # the reference's own top-2 margins, recorded in the fixture
+    model = make_model(d, P=pg.make_params(d, logit_gain=float(g["logit_gain"])), train=False)
     x = to_dev(pg.make_inputs(d, seed=0, ragged=ragged))
     with torch.no_grad():
         seq, slp = model.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"sample_max": 1})
@@ -1162,14 +1163,23 @@ def test_reward_criterion_scalar_and_per_position_rewards():
         loss = crit(slp, seq, reward)
         assert abs(loss.item() - ref(full).item()) < 1e-6
         loss.backward()
-    # a 1-D reward of length L is one value per POSITION (torch's trailing-axis broadcast in the reference) -- also when m == L
+    # a 1-D reward of length L != m is one value per POSITION; the flattened (m*L,) vector is the reference's own view(-1) form
     per_pos = torch.rand(L, generator=g).cuda()
     assert abs(crit(slp, seq, per_pos).item() - ref(per_pos[None, :].expand(m, L)).item()) < 1e-6
+    full = torch.rand(m, L, generator=g).cuda()
+    assert abs(crit(slp, seq, full.reshape(-1)).item() - ref(full).item()) < 1e-6
+    # m == L: a 1-D reward of that length could mean either -- the reference never broadcasts (SAModel.py:260-261 flattens both
+    # tensors), so the ambiguous form is rejected and the two explicit ones are accepted
+    from controllable_xgating_amd._native import XgError
     sq = slp.detach()[:, :m].contiguous().requires_grad_(True)
     seq_sq, pp = seq[:, :m].contiguous(), per_pos[:m].contiguous()
+    with pytest.raises(XgError):
+        crit(sq, seq_sq, pp)
     mask = torch.cat([torch.ones(m, 1, device="cuda"), (seq_sq[:, :-1] > 0).float()], 1)
-    want = -(sq.detach() * pp * mask).sum() / mask.sum()            # literally the reference's expression
-    assert abs(crit(sq, seq_sq, pp).item() - want.item()) < 1e-6
+    want_pos = -(sq.detach() * pp[None, :] * mask).sum() / mask.sum()
+    want_vid = -(sq.detach() * pp[:, None] * mask).sum() / mask.sum()
+    assert abs(crit(sq, seq_sq, pp[None, :]).item() - want_pos.item()) < 1e-6
+    assert abs(crit(sq, seq_sq, pp[:, None]).item() - want_vid.item()) < 1e-6
 
 
 def test_repeated_iterations_are_reproducible_across_streams():
@@ -1473,6 +1483,49 @@ def test_sample_pair_leaves_reference_batchnorm_statistics():
         assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == 2
 
 
+def test_sample_pair_with_train_mode_dropout_equals_two_independent_sample_calls():
+    """Train mode with drop_prob_lm > 0 (the reference's default 0.5): the reference's two sample() calls (starttrain.py:131,
+    myutils.py:45) draw INDEPENDENT dropout masks, in the encoder too.  sample_pair then runs as two rollouts with two seeds:
+    tokens, log-probs, gradients and BatchNorm statistics equal those of sample(sample_max=0) followed by sample(sample_max=1)
+    on a model in the same state -- and the greedy half really saw other masks than the sampled one."""
+    from controllable_xgating_amd import RewardCriterion
+    d = pg.make_dims(**CFG["mid"])
+    Pn = pg.make_params(d, logit_gain=1.0)
+    x = to_dev(pg.make_inputs(d, seed=0))
+    u = torch.from_numpy(pg.uniform("uni2", (d.L + 1, d.B), 78)).cuda()
+    rew = torch.from_numpy(pg.uniform("rew.p", (d.B, 1), 5)).cuda() - 0.5
+    ma = make_model(d, P=Pn, train=True, p_drop=0.5)
+    mb = make_model(d, P=Pn, train=True, p_drop=0.5)
+    ma._call = mb._call = 100                                # same seed sequence for both models
+    gen_a, slp_a = ma.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"sample_max": 0, "uniforms": u})
+    with torch.no_grad():
+        greedy_a, _ = ma.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"sample_max": 1})
+    RewardCriterion()(slp_a, gen_a, rew.expand(-1, gen_a.shape[1])).backward()
+    gen_b, slp_b, greedy_b, n = mb.sample_pair(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"uniforms": u})
+    nb = int(n[0])
+    RewardCriterion()(slp_b[:, :nb], gen_b[:, :nb], rew.expand(-1, nb)).backward()
+    torch.cuda.synchronize()
+    na, ng = gen_a.shape[1], greedy_a.shape[1]
+    assert nb == na and int(n[1]) == ng
+    assert torch.equal(gen_a, gen_b[:, :na]) and torch.equal(greedy_a, greedy_b[:, :ng])
+    np.testing.assert_allclose(slp_b[:, :na].detach().cpu().numpy(), slp_a.detach().cpu().numpy(), atol=1e-6)
+    for (name, pa), (_, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        np.testing.assert_allclose(pb.grad.cpu().numpy(), pa.grad.cpu().numpy(), atol=1e-6 + 1e-4 * float(pa.grad.abs().max()), err_msg=name)
+    for mod in ("rgb", "opfl"):
+        a = getattr(ma.two_spatial_encoder, f"visual_emb_{mod}")[1]
+        b = getattr(mb.two_spatial_encoder, f"visual_emb_{mod}")[1]
+        np.testing.assert_allclose(b.running_var.cpu().numpy(), a.running_var.cpu().numpy(), atol=1e-6)
+        assert int(a.num_batches_tracked) == int(b.num_batches_tracked) == 2
+    # independent masks: with ONE shared encoder realisation the greedy rollout would be the argmax path of the sampled rollout's
+    # own encoder output; run it that way (same seed as the sampled call) and it must differ from what sample_pair returned
+    mc = make_model(d, P=Pn, train=True, p_drop=0.5)
+    mc._call = 100
+    with torch.no_grad():
+        greedy_shared, _ = mc.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"sample_max": 1})
+    w = min(greedy_shared.shape[1], ng)
+    assert not torch.equal(greedy_shared[:, :w], greedy_a[:, :w])
+
+
 def test_single_step_backward_vs_oracle_autograd():
     """xg_step_bwd (SURVEY.md 8b export list): gradients of one LSTMCore_two_layer_gate step (sub_modules.py:671-687) wrt
     the old state, V, v2a(V), pos and every lstmcore / embed parameter == autograd over the oracle's core_step, with a held
@@ -1567,6 +1620,8 @@ def test_split_bf16_greedy_token_for_token_vs_reference(name, tag, ragged):
     d = pg.make_dims(**CFG[tag])
     eos = name == "greedy_c1_eos.npz"
     Pn = eos_params(d) if eos else None
+    if name.startswith("greedy") and not eos:
+        Pn = pg.make_params(d, logit_gain=float(load_golden(name)["logit_gain"]))
     x = to_dev(pg.make_inputs(d, seed=EOS_CASE["input_seed"] if eos else 0, ragged=ragged))
     model = make_model(d, P=Pn, train=False, precision="bf16x3")
     with torch.no_grad():

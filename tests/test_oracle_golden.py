@@ -86,6 +86,8 @@ def test_unhoisted_equals_hoisted():
 def test_greedy_token_for_token(name, tag, ragged):
     g = load(name)
     d, P, x = setup(tag, ragged)
+    P = xo.to_torch_params(pg.make_params(d, logit_gain=float(g["logit_gain"])))      # the gain the fixture was recorded with
+    assert float(g["min_margin"]) >= 1e-3 and abs(float(g["min_margin"]) - g["margin"][: g["seq"].shape[1]].min()) < 1e-7
     with torch.no_grad():
         seq, slp = xo.sample(P, x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], d.L,
                              mode="greedy", train=False, running=xo.new_running(d))
