@@ -183,7 +183,9 @@ struct SkSeg {
 };
 enum { SKS_SCALED = 1, SKS_WRITEBACK = 2, SKS_EX = 4 };
 enum { SKH_CELL_TILES = 1 /* weight rows in the cell tiling (LSTM epilogue or cell_cols) */, SKH_LOW_PRIO = 2, SKH_HAS_SCALED = 4,
-       SKH_GATHER_SHIFT = 4 /* bits 4-5: 1 + index of the first gathered segment (0 = none) */ };
+       SKH_GATHER_SHIFT = 4 /* bits 4-5: 1 + index of the first gathered segment (0 = none) */,
+       SKH_POW2_NTM = 64 /* the m-tile count is a power of two: tile decode by shifts */, SKH_LGNTM_SHIFT = 8 /* bits 8-11 */,
+       SKH_LGKS_SHIFT = 12 /* bits 12-15: log2 of the cross-workgroup split */ };
 struct alignas(64) SkJob {
     // ---- head (64 B).  ntm / ntn / ntiles / hflags / ksplit / tile0 are filled in by xgk_skinny.
     int epi, M, N, R;

@@ -691,119 +691,150 @@ static_assert(sizeof(SkHeadBlk) == 64 && sizeof(SkSegHot) == 48 && sizeof(SkEpiI
 static_assert(offsetof(SkJob, tickets) == 56 && offsetof(SkSeg, sflags) == 44 && offsetof(SkJob, bias) + 112 == offsetof(SkJob, gates) &&
               offsetof(SkJob, gate_y) + 8 == offsetof(SkJob, gates) && offsetof(SkJob, drop) + 20 <= offsetof(SkJob, gates) + 64,
               "descriptor blocks mirror SkJob's layout (xg_kernels.h)");
-// The blocks are read as typed struct copies (pointer fields stay kernel-argument pointers to the compiler, i.e. global memory;
-// adjacent scalar loads of one basic block are merged into s_load_dwordx8 / x4) and PINNED right behind the copy: every field has
-// to sit in a scalar register at that point, so all of the block's loads are issued together, in front of one wait.
-__device__ __forceinline__ void sk_pin(const SkHeadBlk& h) {
-    asm volatile("" ::"s"(h.epi), "s"(h.M), "s"(h.N), "s"(h.R), "s"(h.nseg), "s"(h.ksplit), "s"(h.ntm), "s"(h.ntn), "s"(h.ntiles),
-                 "s"(h.hflags), "s"(h.ldc), "s"(h.C), "s"(h.tickets));
+// The blocks are read as typed struct copies (adjacent scalar loads of one basic block are merged into s_load_dwordx8 / x4) and
+// HELD right behind the copy: an empty asm statement takes every field as an in/out scalar-register operand.  Two effects: all of
+// the block's loads are issued together in front of one wait, and the values are no longer "loads from kernel-argument memory" to
+// the register allocator, which otherwise re-loads them wherever it runs short of scalar registers (measured: the 112-byte
+// epilogue block re-read ten times inside the operand-request code, each time with its own wait).  Blocks are loaded where their
+// latency hides and live only as long as they are needed: head + first segment + epilogue inputs at entry, the next segment's
+// hot part behind the current segment's first operand request, the epilogue's output block behind the last one.
+__device__ __forceinline__ void sk_hold(SkHeadBlk& h) {
+    asm volatile("" : "+s"(h.epi), "+s"(h.M), "+s"(h.N), "+s"(h.R), "+s"(h.nseg), "+s"(h.ksplit), "+s"(h.ntm), "+s"(h.ntn), "+s"(h.ntiles),
+                 "+s"(h.hflags), "+s"(h.ldc), "+s"(h.C), "+s"(h.tickets));
 }
-__device__ __forceinline__ void sk_pin(const SkSegHot& g) {
-    asm volatile("" ::"s"(g.A), "s"(g.Bp), "s"(g.gather), "s"(g.lda), "s"(g.K), "s"(g.nck), "s"(g.gstride), "s"(g.gather_max), "s"(g.sflags));
+__device__ __forceinline__ void sk_hold(SkSegHot& g) {
+    asm volatile("" : "+s"(g.A), "+s"(g.Bp), "+s"(g.gather), "+s"(g.lda), "+s"(g.K), "+s"(g.nck), "+s"(g.gstride), "+s"(g.gather_max), "+s"(g.sflags));
 }
-__device__ __forceinline__ void sk_pin(const SkEpiIn& e) {
-    asm volatile("" ::"s"(e.bias[0]), "s"(e.bias[1]), "s"(e.bias[2]), "s"(e.add), "s"(e.c_prev), "s"(e.h_prev), "s"(e.mask), "s"(e.ldadd),
-                 "s"(e.ldcp), "s"(e.ldhp), "s"(e.ldm), "s"(e.accumulate), "s"(e.relu), "s"(e.order), "s"(e.mask_mode), "s"(e.gate_t),
-                 "s"(e.ldt), "s"(e.ldy), "s"(e.gate_y));
+__device__ __forceinline__ void sk_hold(SkEpiIn& e) {
+    asm volatile("" : "+s"(e.bias[0]), "+s"(e.bias[1]), "+s"(e.bias[2]), "+s"(e.add), "+s"(e.c_prev), "+s"(e.h_prev), "+s"(e.mask));
+    asm volatile("" : "+s"(e.ldadd), "+s"(e.ldcp), "+s"(e.ldhp), "+s"(e.ldm), "+s"(e.accumulate), "+s"(e.relu), "+s"(e.order), "+s"(e.mask_mode),
+                 "+s"(e.gate_t), "+s"(e.ldt), "+s"(e.ldy), "+s"(e.gate_y));
 }
-__device__ __forceinline__ void sk_pin(const SkEpiOut& e) {
-    asm volatile("" ::"s"(e.gates), "s"(e.c_out), "s"(e.h_out), "s"(e.ldg), "s"(e.ldco), "s"(e.ldho), "s"(e.cell_cols), "s"(e.drop.seed),
-                 "s"(e.drop.site), "s"(e.drop.step), "s"(e.drop.thresh), "s"(e.drop.scale));
-}
-
-template <bool HAS_TAIL>
-__device__ __forceinline__ void ldA(const float* const (&ap)[4], int c, int kleft /* K - c*32 - lcol */, f32x4 (&v)[4]) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const f32x4 t = *reinterpret_cast<const f32x4*>(ap[i] + (size_t)c * CK);
-        if (HAS_TAIL) { const f32x4 z = {0.f, 0.f, 0.f, 0.f}; v[i] = kleft > 0 ? t : z; }
-        else v[i] = t;
-    }
+__device__ __forceinline__ void sk_hold(SkEpiOut& e) {
+    asm volatile("" : "+s"(e.gates), "+s"(e.c_out), "+s"(e.h_out), "+s"(e.ldg), "+s"(e.ldco), "+s"(e.ldho), "+s"(e.cell_cols), "+s"(e.drop.seed),
+                 "+s"(e.drop.site), "+s"(e.drop.step), "+s"(e.drop.thresh), "+s"(e.drop.scale));
 }
 
-// Epilogue operands requested before the K loop.  LSTM jobs: the four gates' bias / add terms of this thread's (row, unit) and
-// the cell state.  STORE / GATE jobs: per output element e of this thread (2 with 8 waves, 4 with 4) a[4e .. 4e+2] = the three
-// bias terms of its column, a[4e+3] = what the result is added to (accumulate) or gated with (GATE).  Every load is
-// unconditional (absent operands read a valid dummy address and are dropped by a select in the epilogue): a load under a
-// branch makes the compiler wait for it on the spot.
-struct EpiPre { float a[16]; float st[3]; };       // st: c_prev, h_prev, mask of the LSTM epilogue
+// ---- addressing of the fast kernel (round 5).  In-kernel stamps showed the launches' fixed parts to be INSTRUCTION-ISSUE bound: a
+// wave ran ~300 scalar + ~320 vector instructions around its ~42 MFMAs, four waves per SIMD take turns at one scalar and one
+// vector issue slot, and the later-dispatched tiles needed 4-5 us from entry to their first operand request (profiles/
+// r05_sk_trace_*.txt).  So the address arithmetic is kept off the vector unit and out of 64-bit: operands come through buffer
+// descriptors (uniform base in four scalar registers, per-lane 32-bit byte offset fixed for the whole segment, the chunk as the
+// scalar offset: a chunk costs one s_add per operand), epilogue operands through uniform base + 32-bit lane offset (the saddr form
+// of global_load / global_store), optional operands sit behind uniform branches instead of dummy-pointer selects, and the tile
+// decode uses shifts the launcher precomputed (power-of-two tile counts) instead of divisions.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sk_rsrc(const void* p) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFF, 0x00020000);
+}
+__device__ __forceinline__ f32x4 bld16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
+}
+__device__ __forceinline__ void bst16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff, const f32x4& v) {
+    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, (int)voff, (int)soff, 0);
+}
+// (explicit global address space: the descriptor values pass through opaque register barriers below, after which the compiler no
+//  longer knows that they came from kernel arguments and would use flat instructions, which count on the LDS counter too)
+#define SK_GLOBAL __attribute__((address_space(1)))
+__device__ __forceinline__ float ldf(const float* sbase, unsigned off) {
+    return *reinterpret_cast<const SK_GLOBAL float*>((const SK_GLOBAL char*)sbase + off);
+}
+__device__ __forceinline__ void stf(float* sbase, unsigned off, float v) {
+    *reinterpret_cast<SK_GLOBAL float*>((SK_GLOBAL char*)sbase + off) = v;
+}
+// Epilogue operands requested before the K loop (p arrives zero-filled from the top of the kernel, i.e. from before any load was
+// in flight).  LSTM jobs: a[0..3] / a[4..7] / a[8..11] = the four gates' bias terms of this thread's unit, a[12..15] = the add
+// term, st = c_prev / h_prev / mask.  STORE / GATE jobs: a[0..2] = the three bias terms of this thread's column (one column per
+// thread: the 2 or 4 elements it finishes are 16 or 8 rows apart), a[4 + e] = what element e is added to (accumulate) or gated with.
+struct EpiPre { float a[16]; float st[3]; };
 enum { EP_CP = 0, EP_HP = 1, EP_MK = 2 };
-// (p arrives zero-filled from the top of the kernel, i.e. from before any load was in flight: an initialisation HERE would have to
-//  wait for whatever pending load targets the same registers on some other path through the kernel)
+enum { EF_B0 = 1, EF_B1 = 2, EF_B2 = 4, EF_ADD = 8, EF_MASK = 16, EF_ACC = 32, EF_RELU = 64, EF_IFOG = 128, EF_HOLD = 256 };
 template <int NW>
-__device__ __forceinline__ void epi_prefetch(EpiPre& p, const SkHeadBlk& hd, const SkEpiIn& ei, bool cell_tiles, int m0, int n0, int tn) {
+__device__ __forceinline__ void epi_prefetch(EpiPre& p, const SkHeadBlk& hd, const SkEpiIn& ei, int ef, bool cell_tiles, int m0, int n0, int tn) {
     const int M = hd.M, N = hd.N, R = hd.R;
     if (hd.epi == SK_EPI_LSTM) {
-        // (every thread loads -- with 8 waves the upper four read what the lower four read: no exec-masked region, and no
-        //  register of the result is written by anything but a load, so nothing here has to wait for the operands in flight)
+        // (every thread loads -- with 8 waves the upper four read what the lower four read: no exec-masked region)
         const int em = (threadIdx.x >> 3) & 31, eu = threadIdx.x & 7;
-        const int eb = min(m0 + em, M - 1), ej = min(tn * 8 + eu, R - 1);
-        const float* dummy = ei.c_prev + (size_t)eb * ei.ldcp + ej;
-        const float* mkp = ei.mask ? ei.mask + (size_t)eb * ei.ldm : dummy;
-        const float* hpp = ei.mask_mode == XG_MASK_HOLD ? ei.h_prev + (size_t)eb * ei.ldhp + ej : dummy;
+        const unsigned eb = (unsigned)min(m0 + em, M - 1), cj = (unsigned)min(tn * 8 + eu, R - 1) * 4u, r4 = (unsigned)R * 4u;
+        if (ef & EF_B0) {
 #pragma unroll
-        for (int gi = 0; gi < 4; ++gi) {
-            const int col = gi * R + ej;
-            p.a[gi] = *(ei.bias[0] ? ei.bias[0] + col : dummy);
-            p.a[4 + gi] = *(ei.bias[1] ? ei.bias[1] + col : dummy);
-            p.a[8 + gi] = *(ei.bias[2] ? ei.bias[2] + col : dummy);
-            p.a[12 + gi] = *(ei.add ? ei.add + (size_t)eb * ei.ldadd + col : dummy);
+            for (int gi = 0; gi < 4; ++gi) p.a[gi] = ldf(ei.bias[0], cj + gi * r4);
         }
-        p.st[EP_CP] = *dummy;
-        p.st[EP_MK] = *mkp;
-        p.st[EP_HP] = *hpp;
+        if (ef & EF_B1) {
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) p.a[4 + gi] = ldf(ei.bias[1], cj + gi * r4);
+        }
+        if (ef & EF_B2) {
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) p.a[8 + gi] = ldf(ei.bias[2], cj + gi * r4);
+        }
+        if (ef & EF_ADD) {
+            const unsigned ro = eb * ((unsigned)ei.ldadd * 4u) + cj;
+#pragma unroll
+            for (int gi = 0; gi < 4; ++gi) p.a[12 + gi] = ldf(ei.add, ro + gi * r4);
+        }
+        p.st[EP_CP] = ldf(ei.c_prev, eb * ((unsigned)ei.ldcp * 4u) + cj);
+        if (ef & EF_MASK) p.st[EP_MK] = ldf(ei.mask, eb * ((unsigned)ei.ldm * 4u));
+        if (ef & EF_HOLD) p.st[EP_HP] = ldf(ei.h_prev, eb * ((unsigned)ei.ldhp * 4u) + cj);
         // (two different empty statements at the two branch ends: the optimiser otherwise merges the branches' last stores into one
         //  store through a pointer phi, which keeps part of `p` in scratch memory -- with a wait for the load in front of the store)
         asm volatile("; cell operands requested");
     } else if (hd.ksplit <= 1 && (hd.epi == SK_EPI_STORE || hd.epi == SK_EPI_GATE)) {
-        const float* dummy = hd.C;
+        const int c = threadIdx.x & 31;
+        const int unit = min((n0 >> 2) + (c & 7), R - 1);
+        const unsigned cb = (unsigned)(cell_tiles ? (c >> 3) * R + unit : min(n0 + c, N - 1)) * 4u;
+        if (ef & EF_B0) p.a[0] = ldf(ei.bias[0], cb);
+        if (ef & EF_B1) p.a[1] = ldf(ei.bias[1], cb);
+        if (ef & EF_B2) p.a[2] = ldf(ei.bias[2], cb);
+        if (hd.epi == SK_EPI_GATE || (ef & EF_ACC)) {
+            const float* xb = hd.epi == SK_EPI_GATE ? ei.gate_t : hd.C;                       // (uniform)
+            const unsigned ldx = (unsigned)(hd.epi == SK_EPI_GATE ? ei.ldt : hd.ldc) * 4u;
 #pragma unroll
-        for (int e = 0; e < 1024 / (NW * 64); ++e) {
-            const int idx = threadIdx.x + NW * 64 * e;
-            const int m = idx >> 5, c = idx & 31;
-            const int row = min(m0 + m, M - 1);
-            const int unit = min((n0 >> 2) + (c & 7), R - 1);
-            const int col = cell_tiles ? (c >> 3) * R + unit : min(n0 + c, N - 1);
-            p.a[4 * e] = *(ei.bias[0] ? ei.bias[0] + col : dummy);
-            p.a[4 * e + 1] = *(ei.bias[1] ? ei.bias[1] + col : dummy);
-            p.a[4 * e + 2] = *(ei.bias[2] ? ei.bias[2] + col : dummy);
-            const float* xp = hd.epi == SK_EPI_GATE ? ei.gate_t + (size_t)row * ei.ldt + col
-                                                    : (ei.accumulate ? hd.C + (size_t)row * hd.ldc + col : dummy);
-            p.a[4 * e + 3] = *xp;
+            for (int e = 0; e < 1024 / (NW * 64); ++e) {
+                const int m = (threadIdx.x >> 5) + NW * 2 * e;
+                p.a[4 + e] = ldf(xb, (unsigned)min(m0 + m, M - 1) * ldx + cb);
+            }
         }
         asm volatile("; store operands requested");
     }
 }
 
 // epilogue of the fast kernel (un-split tiles): red = [NW][32][RSF] partial tiles in LDS.  Same arithmetic, in the same order,
-// as sk_epilogue above.
-// ef: which optional operands exist / which variant runs, folded into one scalar at the top of the kernel (the pointers themselves
-// are dead once their loads are requested: fewer scalar registers live across the K loop).
-enum { EF_B0 = 1, EF_B1 = 2, EF_B2 = 4, EF_ADD = 8, EF_MASK = 16, EF_ACC = 32, EF_RELU = 64, EF_IFOG = 128, EF_HOLD = 256 };
+// as sk_epilogue above.  ef: which optional operands exist / which variant runs, folded into one scalar at the top of the kernel
+// (the pointers themselves are dead once their loads are requested: fewer scalar registers live across the K loop).
 template <int NW>
 __device__ __forceinline__ void skf_epilogue(const SkJob& job, const SkHeadBlk& hd, int ef, float* gate_y, int ldy, const SkEpiOut& eo,
                                              bool cell_tiles, const float* __restrict__ redp, int m0, int n0, int tn, const EpiPre& pre) {
     const float (*red)[32][RSF] = reinterpret_cast<const float (*)[32][RSF]>(redp);
     const int R = hd.R, M = hd.M, N = hd.N;
-    if (hd.epi == SK_EPI_STORE) {
+    if (hd.epi == SK_EPI_STORE || hd.epi == SK_EPI_GATE) {
+        const bool gate = hd.epi == SK_EPI_GATE;
+        const int c = threadIdx.x & 31;
+        // n0 = 32 tn; cell tiling: column = gate (c / 8) of hidden unit 8 tn + c % 8
+        const int unit = (n0 >> 2) + (c & 7);
+        const int col = cell_tiles ? (unit < R ? (c >> 3) * R + unit : N) : n0 + c;
+        const unsigned cb = (unsigned)col * 4u, ldc4 = (unsigned)hd.ldc * 4u, ldy4 = (unsigned)ldy * 4u;
 #pragma unroll
         for (int e = 0; e < 1024 / (NW * 64); ++e) {
-            const int idx = threadIdx.x + NW * 64 * e;
-            const int m = idx >> 5, c = idx & 31;
+            const int m = (threadIdx.x >> 5) + NW * 2 * e;
             float v = 0.f;
 #pragma unroll
             for (int w = 0; w < NW; ++w) v += red[w][m][c];
             const int row = m0 + m;
-            // n0 = 32 tn; cell tiling: column = gate (c / 8) of hidden unit 8 tn + c % 8
-            const int unit = (n0 >> 2) + (c & 7);
-            const int col = cell_tiles ? (unit < R ? (c >> 3) * R + unit : N) : n0 + c;
             if (row < M && col < N) {
-                if (ef & EF_B0) v += pre.a[4 * e];
-                if (ef & EF_B1) v += pre.a[4 * e + 1];
-                if (ef & EF_B2) v += pre.a[4 * e + 2];
-                if (ef & EF_ACC) v += pre.a[4 * e + 3];
-                if (ef & EF_RELU) v = fmaxf(v, 0.f);
-                hd.C[(size_t)row * hd.ldc + col] = v;
+                if (ef & EF_B0) v += pre.a[0];
+                if (!gate) {
+                    if (ef & EF_B1) v += pre.a[1];
+                    if (ef & EF_B2) v += pre.a[2];
+                    if (ef & EF_ACC) v += pre.a[4 + e];
+                    if (ef & EF_RELU) v = fmaxf(v, 0.f);
+                    stf(hd.C, (unsigned)row * ldc4 + cb, v);
+                } else {       // (sub_modules.py:42-47): g = dropout(relu(.)) -> C ; y = g*t + t
+                    const float g = fmaxf(v, 0.f) * xg_keep(eo.drop, (uint32_t)(row * N + col));
+                    stf(hd.C, (unsigned)row * ldc4 + cb, g);
+                    const float tv = pre.a[4 + e];
+                    stf(gate_y, (unsigned)row * ldy4 + cb, g * tv + tv);
+                }
             }
         }
     } else if (hd.epi == SK_EPI_LSTMB) {
@@ -817,25 +848,8 @@ __device__ __forceinline__ void skf_epilogue(const SkJob& job, const SkHeadBlk& 
             for (int w = 0; w < NW; ++w) v += red[w][m][c];
             const int b = m0 + m, j = n0 + c;
             if (b < M && j < N) {
-                if (ef & EF_ACC) v += hd.C[(size_t)b * hd.ldc + j];
+                if (ef & EF_ACC) v += ldf(hd.C, ((unsigned)b * (unsigned)hd.ldc + (unsigned)j) * 4u);
                 lstmb_point(job, b, j, v);
-            }
-        }
-    } else if (hd.epi == SK_EPI_GATE) {
-#pragma unroll
-        for (int e = 0; e < 1024 / (NW * 64); ++e) {
-            const int idx = threadIdx.x + NW * 64 * e;
-            const int m = idx >> 5, c = idx & 31;
-            float v = 0.f;
-#pragma unroll
-            for (int w = 0; w < NW; ++w) v += red[w][m][c];
-            const int row = m0 + m, col = n0 + c;
-            if (row < M && col < N) {
-                if (ef & EF_B0) v += pre.a[4 * e];
-                const float g = fmaxf(v, 0.f) * xg_keep(eo.drop, (uint32_t)(row * N + col));
-                hd.C[(size_t)row * hd.ldc + col] = g;
-                const float tv = pre.a[4 * e + 3];
-                gate_y[(size_t)row * ldy + col] = g * tv + tv;
             }
         }
     } else {
@@ -866,14 +880,15 @@ __device__ __forceinline__ void skf_epilogue(const SkJob& job, const SkHeadBlk& 
                 cn = cn * mk;
             }
             hn *= xg_keep(eo.drop, (uint32_t)(b * R + j));
+            const unsigned j4 = (unsigned)j * 4u, r4 = (unsigned)R * 4u;
             if (eo.gates) {
-                float* g = eo.gates + (size_t)b * eo.ldg;
-                g[j] = ig; g[R + j] = fg;
-                if (ef & EF_IFOG) { g[2 * R + j] = og; g[3 * R + j] = gg; }
-                else                           { g[2 * R + j] = gg; g[3 * R + j] = og; }
+                const unsigned go = (unsigned)b * ((unsigned)eo.ldg * 4u) + j4;
+                stf(eo.gates, go, ig); stf(eo.gates, go + r4, fg);
+                stf(eo.gates, go + 2 * r4, (ef & EF_IFOG) ? og : gg);
+                stf(eo.gates, go + 3 * r4, (ef & EF_IFOG) ? gg : og);
             }
-            eo.c_out[(size_t)b * eo.ldco + j] = cn;
-            eo.h_out[(size_t)b * eo.ldho + j] = hn;
+            stf(eo.c_out, (unsigned)b * ((unsigned)eo.ldco * 4u) + j4, cn);
+            stf(eo.h_out, (unsigned)b * ((unsigned)eo.ldho * 4u) + j4, hn);
         }
     }
 }
@@ -895,32 +910,16 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
     // per wave: the staged activation chunk (fp32 image, one bf16 image, or three bf16 plane images), later the wave's partial tile
     constexpr int WSM = PREC == 2 ? (3 * PLH) / 2 : (32 * RSF > OPF ? 32 * RSF : OPF);      // floats per wave
     static_assert(WSM >= 32 * RSF, "the reduction buffer must fit the staging area");
+    constexpr int LGNW = NW == 8 ? 3 : 2;
+    static_assert(NW == 8 || NW == 4, "waves per workgroup");
     __shared__ __attribute__((aligned(16))) float smem[NW * WSM + (SCALE ? 32 : 0)];
     const SkJob& job = args.job[blockIdx.y];
     const char* jb = reinterpret_cast<const char*>(&job);
-#ifdef SKF_WARM_NEXT
-    if (blockIdx.y + 1 < SK_MAX_JOBS) {
-        // (experiment, round 5, NOT the default: every workgroup of job j touches the cache lines of job j + 1's descriptor in the
-        //  same round as its own, so that they are in the scalar cache when the next job's workgroups land on this CU.  Measured:
-        //  the later jobs' descriptor round stays at 2.3-3.1 us and the step is 0.6 us slower -- that round is not a cache miss,
-        //  it is instruction issue: docs/EXPERIMENTS.md.)
-        const int* nb = reinterpret_cast<const int*>(jb + sizeof(SkJob));
-        int warm = 0;
-#pragma unroll
-        for (int i = 0; i < (int)sizeof(SkJob) / 64; ++i) warm |= nb[i * 16];
-        asm volatile("" ::"s"(warm));
-    }
-#endif
-    // ---- ONE round of wide scalar loads: the head and the three segments' hot parts
-    const SkHeadBlk hd = *reinterpret_cast<const SkHeadBlk*>(jb);
-    const SkSegHot sh0 = *reinterpret_cast<const SkSegHot*>(jb + offsetof(SkJob, seg));
-    const SkSegHot sh1 = *reinterpret_cast<const SkSegHot*>(jb + offsetof(SkJob, seg) + sizeof(SkSeg));
-    const SkSegHot sh2 = *reinterpret_cast<const SkSegHot*>(jb + offsetof(SkJob, seg) + 2 * sizeof(SkSeg));
-    // (round 5, measured: a scalar load issued once the launch's operand burst is under way takes 1-2.5 us to come back, so the
-    //  epilogue's two blocks ride in the same first round instead of behind the first operand request)
-    const SkEpiIn ei = *reinterpret_cast<const SkEpiIn*>(jb + offsetof(SkJob, bias));
-    const SkEpiOut eo = *reinterpret_cast<const SkEpiOut*>(jb + offsetof(SkJob, gates));
-    sk_pin(hd); sk_pin(sh0); sk_pin(sh1); sk_pin(sh2); sk_pin(ei); sk_pin(eo);
+    // ---- first round of wide scalar loads: the head, the first segment's hot part and the epilogue's input block
+    SkHeadBlk hd = *reinterpret_cast<const SkHeadBlk*>(jb);
+    SkSegHot sg = *reinterpret_cast<const SkSegHot*>(jb + offsetof(SkJob, seg));
+    SkEpiIn ei = *reinterpret_cast<const SkEpiIn*>(jb + offsetof(SkJob, bias));
+    sk_hold(hd); sk_hold(sg); sk_hold(ei);
     const int ef = (ei.bias[0] ? EF_B0 : 0) | (ei.bias[1] ? EF_B1 : 0) | (ei.bias[2] ? EF_B2 : 0) | (ei.add ? EF_ADD : 0) | (ei.mask ? EF_MASK : 0) |
                    (ei.accumulate ? EF_ACC : 0) | (ei.relu ? EF_RELU : 0) | (ei.order == XG_ORDER_IFOG ? EF_IFOG : 0) |
                    (ei.mask_mode == XG_MASK_HOLD ? EF_HOLD : 0);
@@ -947,30 +946,40 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
     if (hd.hflags & SKH_LOW_PRIO) __builtin_amdgcn_s_setprio(0);
     const int ntm = hd.ntm, ntn = hd.ntn, ks = hd.ksplit;      // (ksplit >= 1: xgk_skinny)
     const bool cell_tiles = (hd.hflags & SKH_CELL_TILES) != 0;
+    const int lg_ks = (hd.hflags >> SKH_LGKS_SHIFT) & 15;      // (the cross-workgroup split is a power of two)
     int bid = blockIdx.x;
     {   // XCD-aware: the m-tiles that share a weight slice stay on one XCD's L2 (gridDim.x is a multiple of 8)
-        const int q = hd.ntiles / 8, r = hd.ntiles % 8, xcd = bid % 8, idx = bid / 8;
+        const int q = hd.ntiles >> 3, r = hd.ntiles & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    const int tm = bid % ntm, kp = (bid / ntm) % ks, tn = bid / (ntm * ks);
+    int tm, kp, tn;
+    if (hd.hflags & SKH_POW2_NTM) {       // (every hot launch: 1, 2 or 4 m-tiles) -- no integer division in the decode
+        const int lg_ntm = (hd.hflags >> SKH_LGNTM_SHIFT) & 15;
+        tm = bid & (ntm - 1); kp = (bid >> lg_ntm) & (ks - 1); tn = bid >> (lg_ntm + lg_ks);
+    } else {
+        tm = bid % ntm; kp = (bid / ntm) & (ks - 1); tn = (bid / ntm) >> lg_ks;
+    }
     const int m0 = tm * 32, n0 = tn * 32;
     // (the wave index is the same for every lane: saying so keeps the chunk ranges, loop counters and branches of the K loop on the
     //  scalar unit instead of exec-masked vector control flow)
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), half = lane >> 5, l31 = lane & 31;
     float* As = smem + wave * WSM;
     const int lrow = lane >> 3, lcol = (lane & 7) << 2;
+    // this lane's rows of the m-tile (clamped: rows beyond M are computed from a valid row and never stored)
+    int rowi[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) rowi[i] = min(m0 + i * 8 + lrow, hd.M - 1);
 
     // ---- the gathered segment's row indices (embedding lookup inside the product): one more dependent round trip in front of
-    // that segment's operands, so they are requested first of all
+    // that segment's operands, so they are requested first of all.  (The low dword of the int64 token only: a negative token is a
+    // negative int, and the clamp keeps the row inside the table whatever the value.)
     const int gseg = ((hd.hflags >> SKH_GATHER_SHIFT) & 3) - 1;
-    // (the low dword of the int64 token only: a negative token is a negative int, and the clamp keeps the row inside the table
-    //  whatever the value -- four registers instead of eight across the earlier segments' K loops)
     int gidx[4] = {0, 0, 0, 0};
     if (gseg >= 0) {
-        const int64_t* gp = gseg == 0 ? sh0.gather : (gseg == 1 ? sh1.gather : sh2.gather);
-        const int gs = gseg == 0 ? sh0.gstride : (gseg == 1 ? sh1.gstride : sh2.gstride);
+        const int64_t* gp = job.seg[gseg].gather;
+        const unsigned gs8 = (unsigned)job.seg[gseg].gstride * 8u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) gidx[i] = *reinterpret_cast<const int*>(gp + (size_t)min(m0 + i * 8 + lrow, hd.M - 1) * gs);
+        for (int i = 0; i < 4; ++i) gidx[i] = __float_as_int(ldf(reinterpret_cast<const float*>(gp), (unsigned)rowi[i] * gs8));
     }
     SK_STAMP(6);
 
@@ -994,11 +1003,11 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
     int scaled_seg = -1;
     if (SCALE) {
 #pragma unroll
-        for (int s = 2; s >= 0; --s) if (s < hd.nseg && ((s == 0 ? sh0 : (s == 1 ? sh1 : sh2)).sflags & SKS_SCALED)) scaled_seg = s;
+        for (int s = 2; s >= 0; --s) if (s < hd.nseg && job.seg[s].row_scale) scaled_seg = s;
     }
     float exv = 0.f, exs = 1.f, rsv = 1.f;
     float* exp_ = nullptr;
-    auto scale_loads = [&]() {          // issued behind the first operand request; consumed at the scaled segment / at the very end
+    auto scale_loads = [&]() {          // consumed at the scaled segment / at the very end
         if (scaled_seg >= 0) {
             const SkSeg& sgc = job.seg[scaled_seg];
             if (threadIdx.x < 32) rsv = sgc.row_scale[min(m0 + (int)threadIdx.x, hd.M - 1)];
@@ -1016,11 +1025,14 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
     };
     if (SCALE && scaled_seg == 0) scale_loads();       // (a scaled FIRST segment: nothing to hide the loads behind)
     // ---- the epilogue's operands are requested now: they have the whole K loop to land
-    if (!LATE_PRE) epi_prefetch<NW>(pre, hd, ei, cell_tiles, m0, n0, tn);
+    if (!LATE_PRE) epi_prefetch<NW>(pre, hd, ei, ef, cell_tiles, m0, n0, tn);
+    SkEpiOut eo;
+    // this lane's 16-byte piece of a B tile, sub-piece i at + i * 1024 bytes (a bf16 tile is 2 KB: 2 pieces, an fp32 tile 4 KB: 4)
+    constexpr int TILEB = PREC == 1 ? 2048 : 4096, NPB = PREC == 1 ? 2 : 4;
+    const unsigned vB = (unsigned)(half * 32 + l31) * 16u;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         if (s >= hd.nseg) break;
-        const SkSegHot& sg = s == 0 ? sh0 : (s == 1 ? sh1 : sh2);
         const int nc = sg.nck;
         if (SCALE && s == scaled_seg) {
             if (threadIdx.x < 32) rsc_lds[threadIdx.x] = 1.0f / rsv;
@@ -1028,46 +1040,65 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
         }
         // every wave takes its share of EVERY segment, in order (a gathered or scaled operand comes last in its job, so the
         // index / scale loads have the earlier segments to land)
-        const int p0 = (kp * nc) / ks, pn = ((kp + 1) * nc) / ks - p0;      // this workgroup's part of the segment
-        const int c0 = p0 + (wave * pn) / NW, c1 = p0 + ((wave + 1) * pn) / NW;
+        const int p0 = (kp * nc) >> lg_ks, pn = (((kp + 1) * nc) >> lg_ks) - p0;      // this workgroup's part of the segment
+        const int c0 = p0 + ((wave * pn) >> LGNW), c1 = p0 + (((wave + 1) * pn) >> LGNW);
         const bool have = c0 < c1;
-        // this lane's 16-byte piece of B tile (tn, chunk c), sub-piece i: bp + c * TILE + i * 256   (float units; a bf16
-        // tile is 512 float-sized words: 2 pieces of 256, an fp32 tile 1024: 4 pieces)
-        constexpr int TILE = PREC == 1 ? 512 : 1024, NPB = PREC == 1 ? 2 : 4;
-        const float* bp = sg.Bp + ((size_t)tn * nc) * TILE + (size_t)(half * 32 + l31) * 4;
-        const float* ap[4];
+        // operands through buffer descriptors: per-lane byte offsets fixed for the segment, the chunk is the scalar offset
+        const __amdgpu_buffer_rsrc_t rB = sk_rsrc(sg.Bp), rA = sk_rsrc(sg.A);
+        const unsigned lda4 = (unsigned)sg.lda * 4u;
+        unsigned vA[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            int row = min(m0 + i * 8 + lrow, hd.M - 1);
+            int row = rowi[i];
             if (sg.gather) {
                 int t;
                 if (s == gseg) t = gidx[i];
-                else t = *reinterpret_cast<const int*>(sg.gather + (size_t)row * sg.gstride);
+                else t = __float_as_int(ldf(reinterpret_cast<const float*>(sg.gather), (unsigned)row * ((unsigned)sg.gstride * 8u)));
                 row = t < 0 ? 0 : (t > sg.gather_max ? sg.gather_max : t);
             }
-            ap[i] = sg.A + (size_t)row * sg.lda + lcol;
+            vA[i] = (unsigned)row * lda4 + (unsigned)lcol * 4u;
         }
-        const int nfull = sg.K / CK;                 // chunks >= nfull are the (single) k tail: K % 4 == 0 on this path
+        const int nfull = sg.K >> 5;                 // chunks >= nfull are the (single) k tail: K % 4 == 0 on this path
         // unnormalised attention context as an operand: rows scaled by 1 / s while they are staged; the tn == 0 tiles write
         // the normalised rows back (scaled_out has A's row pitch: checked by the host)
         const bool sc_seg = SCALE && (sg.sflags & SKS_SCALED);
         const bool wb_seg = SCALE && (sg.sflags & SKS_WRITEBACK);      // chunk c of the scaled rows is written back by n-tile c % ntn
-        const ptrdiff_t wb_delta = wb_seg ? job.seg[s].scaled_out - sg.A : 0;
+        __amdgpu_buffer_rsrc_t rW = rA;
+        if (wb_seg) rW = sk_rsrc(job.seg[s].scaled_out);
         // Operands are requested one chunk ahead of their MFMAs: ping-pong B sets, one A set (reloaded right behind its LDS store).
         // (Two chunks ahead was measured in round 3 and is not kept: it needs 10-12 registers beyond the 128 of four waves per
         // SIMD and the step got slower, docs/EXPERIMENTS.md.)
         f32x4 ra0[4], rb0[NPB], rb1[NPB];
         if (s == 0) SK_STAMP(1);
+        const unsigned sB0 = (unsigned)(tn * nc) * (unsigned)TILEB;
         auto ldB = [&](int c, f32x4 (&b)[NPB]) {
+            const unsigned so = sB0 + (unsigned)c * (unsigned)TILEB;
 #pragma unroll
-            for (int i = 0; i < NPB; ++i) b[i] = *reinterpret_cast<const f32x4*>(bp + (size_t)c * TILE + i * 256);
+            for (int i = 0; i < NPB; ++i) b[i] = bld16(rB, vB + i * 1024u, so);
         };
         auto ldAc = [&](int c, f32x4 (&a)[4]) {
-            if (c < nfull) ldA<false>(ap, c, 0, a); else ldA<true>(ap, c, sg.K - c * CK - lcol, a);
+            const unsigned so = (unsigned)c * (CK * 4u);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) a[i] = bld16(rA, vA[i], so);
+            if (c >= nfull) {                        // the k tail: pieces beyond K are zero
+                const bool ok = sg.K - c * CK - lcol > 0;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) a[i] = ok ? a[i] : z;
+            }
         };
         if (have) { ldB(c0, rb0); ldAc(c0, ra0); }
         if (s == 0 && SCALE && scaled_seg > 0) scale_loads();
-        if (!have) continue;
+        // ---- behind this segment's first operand request: the next segment's hot part, or -- behind the last one -- the
+        // epilogue's output block (scalar-cache hits: the first round touched their lines' neighbours)
+        SkSegHot sgn = sg;
+        if (s + 1 < 3 && s + 1 < hd.nseg) {
+            sgn = *reinterpret_cast<const SkSegHot*>(jb + offsetof(SkJob, seg) + (s + 1) * sizeof(SkSeg));
+            sk_hold(sgn);
+        } else {
+            eo = *reinterpret_cast<const SkEpiOut*>(jb + offsetof(SkJob, gates));
+            sk_hold(eo);
+        }
         // one chunk: stage A (scaled / written back when it is the attention context), request the next chunk's operands (A into
         // the registers just stored, B into the free set: no copies), then the 16 MFMAs of this chunk
         auto chunk = [&](int c, f32x4 (&ra)[4], const f32x4 (&cur)[NPB], f32x4 (&nxt)[NPB]) {
@@ -1075,8 +1106,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     ra[i] *= rsc_lds[i * 8 + lrow];
-                    if (wb_seg && c % ntn == tn && m0 + i * 8 + lrow < hd.M && c * CK + lcol < sg.K)
-                        *reinterpret_cast<f32x4*>(const_cast<float*>(ap[i]) + wb_delta + (size_t)c * CK) = ra[i];
+                    if (wb_seg && c % ntn == tn && m0 + i * 8 + lrow < hd.M && c * CK + lcol < sg.K) bst16(rW, vA[i], (unsigned)c * (CK * 4u), ra[i]);
                 }
             }
             if (PREC == 1) st_chunk_bf16(reinterpret_cast<unsigned short*>(As), lane, ra);
@@ -1122,14 +1152,17 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
         };
-        for (int c = c0; c < c1; c += 2) {
-            chunk(c, ra0, rb0, rb1);
-            if (c + 1 < c1) chunk(c + 1, ra0, rb1, rb0);
+        if (have) {
+            for (int c = c0; c < c1; c += 2) {
+                chunk(c, ra0, rb0, rb1);
+                if (c + 1 < c1) chunk(c + 1, ra0, rb1, rb0);
+            }
         }
+        sg = sgn;
     }
     SK_STAMP(3);
     SK_STAMP_MAX(7);
-    if (LATE_PRE) epi_prefetch<NW>(pre, hd, ei, cell_tiles, m0, n0, tn);
+    if (LATE_PRE) epi_prefetch<NW>(pre, hd, ei, ef, cell_tiles, m0, n0, tn);
     __syncthreads();
     float (*red)[32][RSF] = reinterpret_cast<float (*)[32][RSF]>(smem);
 #pragma unroll
@@ -1265,7 +1298,12 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
             any_scaled = any_scaled || sg.row_scale;
             if (sg.gather) gseg = q + 1;
         }
-        jb.hflags = (cells ? SKH_CELL_TILES : 0) | (jb.low_prio ? SKH_LOW_PRIO : 0) | (any_scaled ? SKH_HAS_SCALED : 0) | (gseg << SKH_GATHER_SHIFT);
+        int lg_ntm = 0, lg_ks = 0;
+        while ((1 << lg_ntm) < jb.ntm) ++lg_ntm;
+        while ((1 << lg_ks) < ks) ++lg_ks;
+        const bool pow2 = (1 << lg_ntm) == jb.ntm;
+        jb.hflags = (cells ? SKH_CELL_TILES : 0) | (jb.low_prio ? SKH_LOW_PRIO : 0) | (any_scaled ? SKH_HAS_SCALED : 0) | (gseg << SKH_GATHER_SHIFT) |
+                    (pow2 ? SKH_POW2_NTM : 0) | (lg_ntm << SKH_LGNTM_SHIFT) | (lg_ks << SKH_LGKS_SHIFT);
     }
     if (special && !fast) return XG_EINVAL;            // ZERO / ATTN jobs and scaled operands exist in the fast kernel only
     static const bool split_jobs = xg_diag_env("XG_SPLIT_JOBS") != nullptr;       // diagnosis: one launch per job
