@@ -187,10 +187,10 @@ enum { SKH_CELL_TILES = 1 /* weight rows in the cell tiling (LSTM epilogue or ce
        SKH_POW2_NTM = 64 /* the m-tile count is a power of two: tile decode by shifts */, SKH_LGNTM_SHIFT = 8 /* bits 8-11 */,
        SKH_LGKS_SHIFT = 12 /* bits 12-15: log2 of the cross-workgroup split */ };
 struct alignas(64) SkJob {
-    // ---- head (64 B).  ntm / ntn / ntiles / hflags / ksplit / tile0 are filled in by xgk_skinny.
+    // ---- head (64 B).  ntm / ntn / ntiles / hflags / ksplit / nck_all are filled in by xgk_skinny.
     int epi, M, N, R;
     int nseg, ksplit, ntm, ntn;
-    int ntiles, hflags, ldc, tile0;
+    int ntiles, hflags, ldc, nck_all;     // nck_all: 32-deep chunks of all segments together (the fast kernel splits THAT among its waves)
     float* C;                          // STORE epilogue output (M,N) ldc
     int* tickets;                      // cross-workgroup split-K: one zero-initialised int per tile (see ksplit_ok)
     SkSeg seg[3];

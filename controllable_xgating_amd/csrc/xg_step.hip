@@ -682,7 +682,7 @@ constexpr int RSF = 40;
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
-struct SkHeadBlk { int epi, M, N, R, nseg, ksplit, ntm, ntn, ntiles, hflags, ldc, tile0; float* C; int* tickets; };
+struct SkHeadBlk { int epi, M, N, R, nseg, ksplit, ntm, ntn, ntiles, hflags, ldc, nck_all; float* C; int* tickets; };
 struct SkSegHot { const float* A; const float* Bp; const int64_t* gather; int lda, K, nck, gstride, gather_max, sflags; };
 struct SkEpiIn { const float* bias[3]; const float* add; const float* c_prev; const float* h_prev; const float* mask;
                  int ldadd, ldcp, ldhp, ldm, accumulate, relu, order, mask_mode; const float* gate_t; int ldt, ldy; float* gate_y; };
@@ -700,7 +700,7 @@ static_assert(offsetof(SkJob, tickets) == 56 && offsetof(SkSeg, sflags) == 44 &&
 // hot part behind the current segment's first operand request, the epilogue's output block behind the last one.
 __device__ __forceinline__ void sk_hold(SkHeadBlk& h) {
     asm volatile("" : "+s"(h.epi), "+s"(h.M), "+s"(h.N), "+s"(h.R), "+s"(h.nseg), "+s"(h.ksplit), "+s"(h.ntm), "+s"(h.ntn), "+s"(h.ntiles),
-                 "+s"(h.hflags), "+s"(h.ldc), "+s"(h.C), "+s"(h.tickets));
+                 "+s"(h.hflags), "+s"(h.ldc), "+s"(h.nck_all), "+s"(h.C), "+s"(h.tickets));
 }
 __device__ __forceinline__ void sk_hold(SkSegHot& g) {
     asm volatile("" : "+s"(g.A), "+s"(g.Bp), "+s"(g.gather), "+s"(g.lda), "+s"(g.K), "+s"(g.nck), "+s"(g.gstride), "+s"(g.gather_max), "+s"(g.sflags));
@@ -912,7 +912,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
     static_assert(WSM >= 32 * RSF, "the reduction buffer must fit the staging area");
     constexpr int LGNW = NW == 8 ? 3 : 2;
     static_assert(NW == 8 || NW == 4, "waves per workgroup");
-    __shared__ __attribute__((aligned(16))) float smem[NW * WSM + (SCALE ? 32 : 0)];
+    __shared__ __attribute__((aligned(16))) float smem[NW * WSM];
     const SkJob& job = args.job[blockIdx.y];
     const char* jb = reinterpret_cast<const char*>(&job);
     // ---- first round of wide scalar loads: the head, the first segment's hot part and the epilogue's input block
@@ -920,9 +920,10 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
     SkSegHot sg = *reinterpret_cast<const SkSegHot*>(jb + offsetof(SkJob, seg));
     SkEpiIn ei = *reinterpret_cast<const SkEpiIn*>(jb + offsetof(SkJob, bias));
     sk_hold(hd); sk_hold(sg); sk_hold(ei);
-    const int ef = (ei.bias[0] ? EF_B0 : 0) | (ei.bias[1] ? EF_B1 : 0) | (ei.bias[2] ? EF_B2 : 0) | (ei.add ? EF_ADD : 0) | (ei.mask ? EF_MASK : 0) |
+    int ef = (ei.bias[0] ? EF_B0 : 0) | (ei.bias[1] ? EF_B1 : 0) | (ei.bias[2] ? EF_B2 : 0) | (ei.add ? EF_ADD : 0) | (ei.mask ? EF_MASK : 0) |
                    (ei.accumulate ? EF_ACC : 0) | (ei.relu ? EF_RELU : 0) | (ei.order == XG_ORDER_IFOG ? EF_IFOG : 0) |
                    (ei.mask_mode == XG_MASK_HOLD ? EF_HOLD : 0);
+    asm volatile("" : "+s"(ef));       // (ONE scalar tested bit by bit: left alone the compiler keeps a 64-bit lane mask per condition)
     if (hd.epi == SK_EPI_ZERO) {
         if ((size_t)blockIdx.x * 4096 < (size_t)job.M * job.N) zero_tile<NW>(job, blockIdx.x);
         return;
@@ -982,6 +983,9 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
         for (int i = 0; i < 4; ++i) gidx[i] = __float_as_int(ldf(reinterpret_cast<const float*>(gp), (unsigned)rowi[i] * gs8));
     }
     SK_STAMP(6);
+#if defined(SKF_ABLATE) && SKF_ABLATE == 1
+    if (gidx[0] != 0x7fffffff) return;            // (instruction-count ablation builds: tools/ubench/ablate_step.sh)
+#endif
 
     f32x16 acc;
 #pragma unroll
@@ -994,23 +998,23 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
 #pragma unroll
     for (int i = 0; i < 16; ++i) pre.a[i] = 0.f;
     pre.st[EP_CP] = 0.f; pre.st[EP_HP] = 0.f; pre.st[EP_MK] = 1.f;
-    // A scaled operand (the unnormalised attention context): the reciprocal row scales go to LDS behind the staging images;
-    // the workgroup meets at a barrier in front of the first scaled segment, i.e. after every wave has done its share of the
-    // segments before it -- the scale's load latency hides there (registers would be simpler, but four more live values
-    // push the K loop into scratch: measured 47.8 -> 52.9 us per step).  The unnormalised attention weights of this m-tile's
+    // A scaled operand (the unnormalised attention context): every lane holds the reciprocal scales of its four rows of the
+    // m-tile (requested up front, consumed when the wave reaches the scaled segment -- no LDS image and no workgroup barrier: a
+    // wave's chunks are one contiguous range of the concatenated segments, so some waves START in the scaled segment and a
+    // barrier there would make them wait for the others' whole share).  The unnormalised attention weights of this m-tile's
     // videos are normalised by ALL its n-tiles, a slice each: loads now, multiply + store at the very end.
-    float* rsc_lds = smem + NW * WSM;
     int scaled_seg = -1;
     if (SCALE) {
 #pragma unroll
         for (int s = 2; s >= 0; --s) if (s < hd.nseg && job.seg[s].row_scale) scaled_seg = s;
     }
-    float exv = 0.f, exs = 1.f, rsv = 1.f;
+    float exv = 0.f, exs = 1.f, rs[4] = {1.f, 1.f, 1.f, 1.f};
     float* exp_ = nullptr;
     auto scale_loads = [&]() {          // consumed at the scaled segment / at the very end
         if (scaled_seg >= 0) {
             const SkSeg& sgc = job.seg[scaled_seg];
-            if (threadIdx.x < 32) rsv = sgc.row_scale[min(m0 + (int)threadIdx.x, hd.M - 1)];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rs[i] = ldf(sgc.row_scale, (unsigned)rowi[i] * 4u);
             if (sgc.ex) {
                 const int per = (32 * sgc.ex_K + ntn - 1) / ntn;              // elements of this tile's slice
                 const int idx = tn * per + (int)threadIdx.x;
@@ -1023,25 +1027,28 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
             }
         }
     };
-    if (SCALE && scaled_seg == 0) scale_loads();       // (a scaled FIRST segment: nothing to hide the loads behind)
+    if (SCALE) scale_loads();
     // ---- the epilogue's operands are requested now: they have the whole K loop to land
     if (!LATE_PRE) epi_prefetch<NW>(pre, hd, ei, ef, cell_tiles, m0, n0, tn);
+#if defined(SKF_ABLATE) && SKF_ABLATE == 2
+    if (pre.a[0] != 1.2345e30f) return;
+#endif
     SkEpiOut eo;
     // this lane's 16-byte piece of a B tile, sub-piece i at + i * 1024 bytes (a bf16 tile is 2 KB: 2 pieces, an fp32 tile 4 KB: 4)
     constexpr int TILEB = PREC == 1 ? 2048 : 4096, NPB = PREC == 1 ? 2 : 4;
     const unsigned vB = (unsigned)(half * 32 + l31) * 16u;
+    // A wave's share of the reduction is ONE contiguous range of 32-deep chunks of the concatenated segments (round 5; before,
+    // every wave took a slice of every segment: a wave paid the segment set-up and an exposed first-operand round trip per
+    // segment -- with 2-3 segments of 2 chunks each that was most of its K loop).  Most waves now touch one segment only.
+    const int P0 = (kp * hd.nck_all) >> lg_ks, PN = (((kp + 1) * hd.nck_all) >> lg_ks) - P0;      // this workgroup's part (cross-workgroup split)
+    const int w0 = P0 + ((wave * PN) >> LGNW), w1 = P0 + (((wave + 1) * PN) >> LGNW);
+    int seg_start = 0;
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         if (s >= hd.nseg) break;
         const int nc = sg.nck;
-        if (SCALE && s == scaled_seg) {
-            if (threadIdx.x < 32) rsc_lds[threadIdx.x] = 1.0f / rsv;
-            __syncthreads();               // rsc_lds is complete (uniform: every wave passes here)
-        }
-        // every wave takes its share of EVERY segment, in order (a gathered or scaled operand comes last in its job, so the
-        // index / scale loads have the earlier segments to land)
-        const int p0 = (kp * nc) >> lg_ks, pn = (((kp + 1) * nc) >> lg_ks) - p0;      // this workgroup's part of the segment
-        const int c0 = p0 + ((wave * pn) >> LGNW), c1 = p0 + (((wave + 1) * pn) >> LGNW);
+        const int c0 = max(w0, seg_start) - seg_start, c1 = min(w1, seg_start + nc) - seg_start;
+        seg_start += nc;
         const bool have = c0 < c1;
         // operands through buffer descriptors: per-lane byte offsets fixed for the segment, the chunk is the scalar offset
         const __amdgpu_buffer_rsrc_t rB = sk_rsrc(sg.Bp), rA = sk_rsrc(sg.A);
@@ -1062,6 +1069,11 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
         // unnormalised attention context as an operand: rows scaled by 1 / s while they are staged; the tn == 0 tiles write
         // the normalised rows back (scaled_out has A's row pitch: checked by the host)
         const bool sc_seg = SCALE && (sg.sflags & SKS_SCALED);
+        float rsi[4] = {1.f, 1.f, 1.f, 1.f};
+        if (sc_seg) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) rsi[i] = 1.0f / rs[i];
+        }
         const bool wb_seg = SCALE && (sg.sflags & SKS_WRITEBACK);      // chunk c of the scaled rows is written back by n-tile c % ntn
         __amdgpu_buffer_rsrc_t rW = rA;
         if (wb_seg) rW = sk_rsrc(job.seg[s].scaled_out);
@@ -1088,7 +1100,6 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
             }
         };
         if (have) { ldB(c0, rb0); ldAc(c0, ra0); }
-        if (s == 0 && SCALE && scaled_seg > 0) scale_loads();
         // ---- behind this segment's first operand request: the next segment's hot part, or -- behind the last one -- the
         // epilogue's output block (scalar-cache hits: the first round touched their lines' neighbours)
         SkSegHot sgn = sg;
@@ -1105,8 +1116,8 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
             if (sc_seg) {
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
-                    ra[i] *= rsc_lds[i * 8 + lrow];
-                    if (wb_seg && c % ntn == tn && m0 + i * 8 + lrow < hd.M && c * CK + lcol < sg.K) bst16(rW, vA[i], (unsigned)c * (CK * 4u), ra[i]);
+                    ra[i] *= rsi[i];
+                    if (wb_seg && c == tn && m0 + i * 8 + lrow < hd.M && c * CK + lcol < sg.K) bst16(rW, vA[i], (unsigned)c * (CK * 4u), ra[i]);
                 }
             }
             if (PREC == 1) st_chunk_bf16(reinterpret_cast<unsigned short*>(As), lane, ra);
@@ -1162,6 +1173,9 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
     }
     SK_STAMP(3);
     SK_STAMP_MAX(7);
+#if defined(SKF_ABLATE) && SKF_ABLATE == 3
+    if (acc[0] != 1.2345e30f) return;
+#endif
     if (LATE_PRE) epi_prefetch<NW>(pre, hd, ei, ef, cell_tiles, m0, n0, tn);
     __syncthreads();
     float (*red)[32][RSF] = reinterpret_cast<float (*)[32][RSF]>(smem);
@@ -1169,6 +1183,9 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
     for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[r];
     __syncthreads();
     SK_STAMP(4);
+#if defined(SKF_ABLATE) && SKF_ABLATE == 4
+    if (acc[0] != 1.2345e30f) return;
+#endif
     if (ks > 1) sk_epilogue_split<RSF, NW>(job, smem, m0, n0, kp, tm + ntm * tn);
     else skf_epilogue<NW>(job, hd, ef, ei.gate_y, ei.ldy, eo, cell_tiles, smem, m0, n0, tn, pre);
     if (exp_) *exp_ = exv * (1.0f / exs);
@@ -1216,7 +1233,7 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         if (jb.M <= 0 || (!no_segs && (jb.N <= 0 || jb.nseg < 1 || jb.nseg > 3))) return XG_EINVAL;
         if (jb.epi == SK_EPI_LSTMB && (jb.N != jb.R || !jb.gates || !jb.c_prev || !jb.c_out || !jb.ds || !jb.dc_prev ||
                                        (jb.accumulate && !jb.C))) return XG_EINVAL;
-        jb.tile0 = tiles; a.tile0[j] = tiles;
+        a.tile0[j] = tiles;
         if (no_segs) {                                              // fast-kernel-only job types, no matrix segments
             int nt;
             if (jb.epi == SK_EPI_ZERO || jb.epi == SK_EPI_COPY) {
@@ -1292,8 +1309,12 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         jb.ntiles = jb.ntm * jb.ntn * ks;
         int gseg = 0;
         bool any_scaled = false;
+        jb.nck_all = 0;
         for (int q = jb.nseg - 1; q >= 0; --q) {
             SkSeg& sg = jb.seg[q];
+            jb.nck_all += sg.nck;
+            // (the n-tile that writes chunk c of the normalised rows back is tile c: there must be one)
+            if (sg.row_scale && sg.scaled_out && sg.Bp && jb.ntn < sg.nck) return XG_EINVAL;
             sg.sflags = (sg.row_scale ? SKS_SCALED : 0) | (sg.row_scale && sg.scaled_out ? SKS_WRITEBACK : 0) | (sg.row_scale && sg.ex ? SKS_EX : 0);
             any_scaled = any_scaled || sg.row_scale;
             if (sg.gather) gseg = q + 1;
