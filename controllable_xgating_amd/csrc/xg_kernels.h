@@ -179,7 +179,8 @@ struct SkSeg {
     // arrives unnormalised: af = c / s).  scaled_out (lda_out): the scaled rows are written back by the tn == 0 tiles
     // (the normalised context is a saved tensor); ex / ex_ld / ex_K: those tiles also normalise the (M, ex_K) unnormalised
     // attention weights in place.
-    const float* row_scale; float* scaled_out; float* ex; int ld_out, ex_ld, ex_K, pad_;
+    const float* row_scale; float* scaled_out; float* ex; int ld_out, ex_ld, ex_K;
+    int ex_magic, ex_per, pad_;        // ceil(2^32 / ex_K) and the weights per n-tile of the m-tile's 32 x ex_K block: filled by xgk_skinny
 };
 enum { SKS_SCALED = 1, SKS_WRITEBACK = 2, SKS_EX = 4 };
 enum { SKH_CELL_TILES = 1 /* weight rows in the cell tiling (LSTM epilogue or cell_cols) */, SKH_LOW_PRIO = 2, SKH_HAS_SCALED = 4,
@@ -224,7 +225,7 @@ struct alignas(64) SkJob {
     int low_prio;                      // 1: the job's waves drop back to default wave priority (off-critical-path side chains)
     int pad_;
 };
-static_assert(offsetof(SkJob, seg) == 64 && sizeof(SkSeg) == 104, "skf_kernel reads the head and the segments' hot parts by offset");
+static_assert(offsetof(SkJob, seg) == 64 && sizeof(SkSeg) == 112, "skf_kernel reads the head and the segments' hot parts by offset");
 static_assert(sizeof(SkJob) % 64 == 0 && sizeof(SkJob) * SK_MAX_JOBS + 64 <= 4096, "SkJob array stride / kernel-argument budget");
 struct SkArgs { int njobs; int tile0[SK_MAX_JOBS]; int pad_[10]; SkJob job[SK_MAX_JOBS]; };
 static_assert(offsetof(SkArgs, job) == 64, "descriptor lines");

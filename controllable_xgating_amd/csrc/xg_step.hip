@@ -753,7 +753,8 @@ template <int NW>
 __device__ __forceinline__ void epi_prefetch(EpiPre& p, const SkHeadBlk& hd, const SkEpiIn& ei, int ef, bool cell_tiles, int m0, int n0, int tn) {
     const int M = hd.M, N = hd.N, R = hd.R;
     if (hd.epi == SK_EPI_LSTM) {
-        // (every thread loads -- with 8 waves the upper four read what the lower four read: no exec-masked region)
+        // (the four waves that run the cell epilogue; a wave-uniform branch, no exec-masked region)
+        if (NW == 8 && __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) >= 4) return;
         const int em = (threadIdx.x >> 3) & 31, eu = threadIdx.x & 7;
         const unsigned eb = (unsigned)min(m0 + em, M - 1), cj = (unsigned)min(tn * 8 + eu, R - 1) * 4u, r4 = (unsigned)R * 4u;
         if (ef & EF_B0) {
@@ -924,6 +925,9 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
                    (ei.accumulate ? EF_ACC : 0) | (ei.relu ? EF_RELU : 0) | (ei.order == XG_ORDER_IFOG ? EF_IFOG : 0) |
                    (ei.mask_mode == XG_MASK_HOLD ? EF_HOLD : 0);
     asm volatile("" : "+s"(ef));       // (ONE scalar tested bit by bit: left alone the compiler keeps a 64-bit lane mask per condition)
+#if defined(SKF_ABLATE) && SKF_ABLATE == 6
+    if (ef != 0x7fffffff) return;                 // behind the first round of descriptor loads
+#endif
     if (hd.epi == SK_EPI_ZERO) {
         if ((size_t)blockIdx.x * 4096 < (size_t)job.M * job.N) zero_tile<NW>(job, blockIdx.x);
         return;
@@ -933,6 +937,9 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
         return;
     }
     if (hd.epi == SK_EPI_ATTN) {
+#ifdef SKF_ATTN_PRIO
+        __builtin_amdgcn_s_setprio(SKF_ATTN_PRIO);
+#endif
         if ((int)blockIdx.x < 2 * job.M) {           // (every wave of the workgroup scores its share of the rows)
 #ifdef SKF_ATTN_LDS_OFF
             float* asm_ = smem + SKF_ATTN_LDS_OFF;
@@ -1016,11 +1023,14 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
 #pragma unroll
             for (int i = 0; i < 4; ++i) rs[i] = ldf(sgc.row_scale, (unsigned)rowi[i] * 4u);
             if (sgc.ex) {
-                const int per = (32 * sgc.ex_K + ntn - 1) / ntn;              // elements of this tile's slice
+                // this tile's slice of the m-tile's 32 x ex_K weights; ex_per = elements per tile and ex_magic = ceil(2^32 / ex_K) come
+                // from the launcher: idx / ex_K as one multiply-high (exact for idx < 2^16), no integer division in the kernel
+                const int per = sgc.ex_per;
                 const int idx = tn * per + (int)threadIdx.x;
-                const int row = m0 + idx / sgc.ex_K;
+                const int r = (int)__umulhi((unsigned)idx, (unsigned)sgc.ex_magic);
+                const int row = m0 + r;
                 if ((int)threadIdx.x < per && idx < 32 * sgc.ex_K && row < hd.M) {
-                    exp_ = sgc.ex + (size_t)row * sgc.ex_ld + idx % sgc.ex_K;
+                    exp_ = sgc.ex + (size_t)row * sgc.ex_ld + (idx - r * sgc.ex_K);
                     exv = *exp_;
                     exs = sgc.row_scale[row];
                 }
@@ -1030,6 +1040,9 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
     if (SCALE) scale_loads();
     // ---- the epilogue's operands are requested now: they have the whole K loop to land
     if (!LATE_PRE) epi_prefetch<NW>(pre, hd, ei, ef, cell_tiles, m0, n0, tn);
+#ifdef SKF_KLOOP_PRIO
+    if (!(hd.hflags & SKH_LOW_PRIO)) __builtin_amdgcn_s_setprio(SKF_KLOOP_PRIO);
+#endif
 #if defined(SKF_ABLATE) && SKF_ABLATE == 2
     if (pre.a[0] != 1.2345e30f) return;
 #endif
@@ -1063,7 +1076,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
                 else t = __float_as_int(ldf(reinterpret_cast<const float*>(sg.gather), (unsigned)row * ((unsigned)sg.gstride * 8u)));
                 row = t < 0 ? 0 : (t > sg.gather_max ? sg.gather_max : t);
             }
-            vA[i] = (unsigned)row * lda4 + (unsigned)lcol * 4u;
+            vA[i] = __umul24((unsigned)row, lda4) + (unsigned)lcol * 4u;       // (rows and byte pitches are below 2^24: checked by the launcher)
         }
         const int nfull = sg.K >> 5;                 // chunks >= nfull are the (single) k tail: K % 4 == 0 on this path
         // unnormalised attention context as an operand: rows scaled by 1 / s while they are staged; the tn == 0 tiles write
@@ -1072,7 +1085,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
         float rsi[4] = {1.f, 1.f, 1.f, 1.f};
         if (sc_seg) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) rsi[i] = 1.0f / rs[i];
+            for (int i = 0; i < 4; ++i) rsi[i] = xg_rcp(rs[i]);          // (v_rcp_f32, 1 ulp: an IEEE division is ~12 instructions per row)
         }
         const bool wb_seg = SCALE && (sg.sflags & SKS_WRITEBACK);      // chunk c of the scaled rows is written back by n-tile c % ntn
         __amdgpu_buffer_rsrc_t rW = rA;
@@ -1100,6 +1113,9 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
             }
         };
         if (have) { ldB(c0, rb0); ldAc(c0, ra0); }
+#if defined(SKF_ABLATE) && SKF_ABLATE == 5
+        if (s == 0 && ra0[0][0] != 1.2345e30f) return;        // behind the first segment's set-up and first operand request
+#endif
         // ---- behind this segment's first operand request: the next segment's hot part, or -- behind the last one -- the
         // epilogue's output block (scalar-cache hits: the first round touched their lines' neighbours)
         SkSegHot sgn = sg;
@@ -1188,7 +1204,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
 #endif
     if (ks > 1) sk_epilogue_split<RSF, NW>(job, smem, m0, n0, kp, tm + ntm * tn);
     else skf_epilogue<NW>(job, hd, ef, ei.gate_y, ei.ldy, eo, cell_tiles, smem, m0, n0, tn, pre);
-    if (exp_) *exp_ = exv * (1.0f / exs);
+    if (exp_) *exp_ = exv * xg_rcp(exs);
     SK_STAMP(5);
 }
 
@@ -1225,6 +1241,20 @@ extern "C" int xg_debug_sk_trace_clear(void) {
 
 int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
     if (a.njobs <= 0 || a.njobs > SK_MAX_JOBS) return XG_EINVAL;
+    {   // Jobs are independent, so their order is free: most tiles first.  The grid is (widest job) x (jobs), dispatched job by job;
+        // a narrower job's surplus workgroups find out that they are surplus only after their first round of descriptor loads
+        // (~1 us) and hold a workgroup slot until then -- in front of a wider job they delayed its tiles by 1.5-3.4 us (in-kernel
+        // stamps, profiles/r05_sk_trace_*.txt); behind it they delay nothing.
+        static const bool no_sort = xg_diag_env("XG_SK_NOSORT") != nullptr;
+        auto job_tiles = [](const SkJob& jb) -> long {
+            if (jb.epi == SK_EPI_ZERO || jb.epi == SK_EPI_COPY) return ((long)jb.M * jb.N + 4095) / 4096;
+            if (jb.epi == SK_EPI_ATTN) return 2L * jb.M;
+            const long ntm = xg_cdiv(jb.M, 32);
+            return ntm * ((jb.epi == SK_EPI_LSTM || jb.cell_cols) ? jb.R / 8 : xg_cdiv(jb.N, 32));
+        };
+        for (int i = 1; i < a.njobs && !no_sort; ++i)
+            for (int j = i; j > 0 && job_tiles(a.job[j]) > job_tiles(a.job[j - 1]); --j) { const SkJob t = a.job[j]; a.job[j] = a.job[j - 1]; a.job[j - 1] = t; }
+    }
     bool vec = true, generic = false, packed = true, special = false;
     int tiles = 0, max_tiles = 0, max_k = 0;
     for (int j = 0; j < a.njobs; ++j) {
@@ -1267,6 +1297,9 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
             if (!sg.A || !sg.B || sg.K <= 0) return XG_EINVAL;
             max_k = sg.K > max_k ? sg.K : max_k;
             packed = packed && sg.Bp && sg.nck == xg_cdiv(sg.K, 32);
+            // (the fast kernel's 32-bit / 24-bit address arithmetic: row index and byte pitch below 2^24, operands below 2 GB)
+            packed = packed && jb.M < (1 << 24) && sg.lda < (1 << 22) && (!sg.gather || sg.gather_max < (1 << 24)) &&
+                     (double)(sg.gather ? sg.gather_max + 1 : jb.M) * sg.lda * 4.0 < 2147483647.0;
             if (sg.row_scale && (!sg.Bp || sg.gather || (sg.scaled_out && (sg.ld_out != sg.lda || ((uintptr_t)sg.scaled_out % 16))))) return XG_EINVAL;
             if (sg.gather && !sg.Bp) return XG_EINVAL;        // the row gather exists on the packed path only
             vec = vec && ((uintptr_t)sg.A % 16 == 0) && (sg.lda % 4 == 0) && (sg.K % 4 == 0);
@@ -1313,6 +1346,11 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         for (int q = jb.nseg - 1; q >= 0; --q) {
             SkSeg& sg = jb.seg[q];
             jb.nck_all += sg.nck;
+            if (sg.ex && sg.ex_K > 0) {
+                if (32 * sg.ex_K >= 65536) return XG_EINVAL;
+                sg.ex_per = (32 * sg.ex_K + jb.ntn - 1) / jb.ntn;
+                sg.ex_magic = (int)(unsigned)((0x100000000ull + (unsigned)sg.ex_K - 1) / (unsigned)sg.ex_K);
+            }
             // (the n-tile that writes chunk c of the normalised rows back is tile c: there must be one)
             if (sg.row_scale && sg.scaled_out && sg.Bp && jb.ntn < sg.nck) return XG_EINVAL;
             sg.sflags = (sg.row_scale ? SKS_SCALED : 0) | (sg.row_scale && sg.scaled_out ? SKS_WRITEBACK : 0) | (sg.row_scale && sg.ex ? SKS_EX : 0);
