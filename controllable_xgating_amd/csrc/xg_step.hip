@@ -26,6 +26,9 @@ namespace {
 #ifndef SK_WAVES
 #define SK_WAVES 8
 #endif
+#ifndef XG_SK_DEEP_DEFAULT
+#define XG_SK_DEEP_DEFAULT 0
+#endif
 constexpr int SKW = SK_WAVES;     // waves per workgroup (K split)
 constexpr int SKT = SKW * 64;     // threads
 constexpr int CK = 32;            // k-chunk depth staged per wave
@@ -345,6 +348,9 @@ __device__ __forceinline__ void sk_epilogue_split(const SkJob& job, float* __res
         }
     }
     if (job.epi != SK_EPI_LSTMB) return;
+#if defined(SKF_ABLATE) && SKF_ABLATE == 7
+    return;                                                    // (timing experiment: split tiles without the ticket / last-arriver phase)
+#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's adds have been performed
     __syncthreads();
     int* flag = reinterpret_cast<int*>(smem);                  // (the partial tiles are dead after the barrier)
@@ -904,8 +910,12 @@ __device__ __forceinline__ void skf_epilogue(const SkJob& job, const SkHeadBlk& 
 // only the launches that need it pay for it.
 // (SCALE launches are single 256-tile cell-2 launches, one workgroup per CU: they get the 256-VGPR budget of two waves per
 // SIMD instead of spilling at 128.)
-template <int NW, int PREC, bool SCALE>
-__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SCALE ? 2 : 4, SCALE ? 2 : 4))) skf_kernel(SkArgs args) {
+// DEPTH: operands requested 1 or 2 chunks ahead of their MFMAs.  2 needs three B register sets and two A sets (~150 VGPRs), i.e.
+// two waves per SIMD: four-wave workgroups two per CU, or eight-wave workgroups one per CU (round 5; the round-3 attempt spilled
+// at the 128 registers of four waves per SIMD).
+template <int NW, int PREC, bool SCALE, int DEPTH>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((SCALE || DEPTH == 2) ? 2 : 4, (SCALE || DEPTH == 2) ? 2 : 4)))
+skf_kernel(SkArgs args) {
     XG_CHAIN_PRIO();
     SK_STAMP(0);
     // per wave: the staged activation chunk (fp32 image, one bf16 image, or three bf16 plane images), later the wave's partial tile
@@ -1000,7 +1010,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
 
     // (split-bf16: the plane registers leave no room for 19 prefetched values across the K loop at 128 VGPRs -- they would go
     //  to scratch, which costs more than it hides -- so that mode requests the cell operands behind the loop, under the reduction)
-    constexpr bool LATE_PRE = PREC == 2;
+    constexpr bool LATE_PRE = PREC == 2 && DEPTH == 1 && !SCALE;
     EpiPre pre;
 #pragma unroll
     for (int i = 0; i < 16; ++i) pre.a[i] = 0.f;
@@ -1093,7 +1103,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
         // Operands are requested one chunk ahead of their MFMAs: ping-pong B sets, one A set (reloaded right behind its LDS store).
         // (Two chunks ahead was measured in round 3 and is not kept: it needs 10-12 registers beyond the 128 of four waves per
         // SIMD and the step got slower, docs/EXPERIMENTS.md.)
-        f32x4 ra0[4], rb0[NPB], rb1[NPB];
+        f32x4 ra0[4], ra1[DEPTH == 2 ? 4 : 1], rb0[NPB], rb1[NPB], rb2[DEPTH == 2 ? NPB : 1];
         if (s == 0) SK_STAMP(1);
         const unsigned sB0 = (unsigned)(tn * nc) * (unsigned)TILEB;
         auto ldB = [&](int c, f32x4 (&b)[NPB]) {
@@ -1112,7 +1122,12 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
                 for (int i = 0; i < 4; ++i) a[i] = ok ? a[i] : z;
             }
         };
-        if (have) { ldB(c0, rb0); ldAc(c0, ra0); }
+        if (have) {
+            ldB(c0, rb0); ldAc(c0, ra0);
+            if constexpr (DEPTH == 2) {
+                if (c0 + 1 < c1) { ldB(c0 + 1, rb1); ldAc(c0 + 1, *reinterpret_cast<f32x4 (*)[4]>(ra1)); }
+            }
+        }
 #if defined(SKF_ABLATE) && SKF_ABLATE == 5
         if (s == 0 && ra0[0][0] != 1.2345e30f) return;        // behind the first segment's set-up and first operand request
 #endif
@@ -1140,7 +1155,7 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
             else if (PREC == 2) st_chunk_split3(reinterpret_cast<unsigned short*>(As), lane, ra);
             else st_chunk(As, lane, ra);
             if (s == 0 && c == c0) SK_STAMP(2);
-            if (c + 1 < c1) { ldB(c + 1, nxt); ldAc(c + 1, ra); }
+            if (c + DEPTH < c1) { ldB(c + DEPTH, nxt); ldAc(c + DEPTH, ra); }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (PREC == 2) {
@@ -1180,9 +1195,21 @@ __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SC
             __builtin_amdgcn_wave_barrier();
         };
         if (have) {
-            for (int c = c0; c < c1; c += 2) {
-                chunk(c, ra0, rb0, rb1);
-                if (c + 1 < c1) chunk(c + 1, ra0, rb1, rb0);
+            if constexpr (DEPTH == 2) {       // A sets alternate (period 2), B sets rotate (period 3)
+                auto& A1 = *reinterpret_cast<f32x4 (*)[4]>(ra1);
+                for (int c = c0; c < c1; c += 6) {
+                    chunk(c, ra0, rb0, rb2);
+                    if (c + 1 < c1) chunk(c + 1, A1, rb1, rb0);
+                    if (c + 2 < c1) chunk(c + 2, ra0, rb2, rb1);
+                    if (c + 3 < c1) chunk(c + 3, A1, rb0, rb2);
+                    if (c + 4 < c1) chunk(c + 4, ra0, rb1, rb0);
+                    if (c + 5 < c1) chunk(c + 5, A1, rb2, rb1);
+                }
+            } else {
+                for (int c = c0; c < c1; c += 2) {
+                    chunk(c, ra0, rb0, rb1);
+                    if (c + 1 < c1) chunk(c + 1, ra0, rb1, rb0);
+                }
             }
         }
         sg = sgn;
@@ -1394,13 +1421,29 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
                           dbg_nw4_zero = xg_diag_env("XG_SK_NW4_ZERO") != nullptr;
         const bool nw4 = nw4_rule || (dbg_nw4_scaled && scaled) || (dbg_nw4_attn && has_attn) || (dbg_nw4_zero && has_zero);
         static const int dyn_lds = xg_diag_env("XG_SK_DYN_LDS") ? atoi(xg_diag_env("XG_SK_DYN_LDS")) : 0;      // diagnosis
-#define XG_SKF(NW_, PREC_) do { \
-            if (scaled) hipLaunchKernelGGL((skf_kernel<NW_, PREC_, true>), grid, dim3(NW_ * 64), dyn_lds, st, a); \
-            else hipLaunchKernelGGL((skf_kernel<NW_, PREC_, false>), grid, dim3(NW_ * 64), dyn_lds, st, a); } while (0)
-        if (bf16)        { if (nw4) XG_SKF(4, 1); else XG_SKF(8, 1); }
-        else if (bf16x3) { if (nw4) XG_SKF(4, 2); else XG_SKF(8, 2); }
-        else             { if (nw4) XG_SKF(4, 0); else XG_SKF(8, 0); }
+        // operands two chunks ahead (DEPTH 2, two waves per SIMD): XG_SK_DEEP bit 0 = launches of at most one tile per CU as
+        // eight-wave workgroups, bit 1 = launches of up to two tiles per CU as four-wave workgroups, bit 2 = the split launches
+        // (measured, round 5: stand-alone step unchanged at 39.6-41.0 us for every setting, iteration 5.62-5.75 against 5.56 ms --
+        //  half the occupancy co-schedules worse beside the background products; the variants exist in the diag build only)
+#ifdef XG_DIAG
+        static const int deep_env = xg_diag_env("XG_SK_DEEP") ? atoi(xg_diag_env("XG_SK_DEEP")) : XG_SK_DEEP_DEFAULT;
+        const bool deep8 = (deep_env & 1) && !nw4_rule && !has_attn && tiles <= 256;
+        const bool deep4 = ((deep_env & 2) && !nw4_rule && !has_attn && tiles > 256 && tiles <= 512) || ((deep_env & 4) && ks > 1 && tiles <= 512);
+#else
+        constexpr bool deep8 = false, deep4 = false;
+#endif
+#define XG_SKF2(NW_, PREC_, D_) do { \
+            if (scaled) hipLaunchKernelGGL((skf_kernel<NW_, PREC_, true, D_>), grid, dim3(NW_ * 64), dyn_lds, st, a); \
+            else hipLaunchKernelGGL((skf_kernel<NW_, PREC_, false, D_>), grid, dim3(NW_ * 64), dyn_lds, st, a); } while (0)
+#ifdef XG_DIAG
+#define XG_SKF(PREC_) do { \
+            if (deep4) XG_SKF2(4, PREC_, 2); else if (deep8) XG_SKF2(8, PREC_, 2); else if (nw4) XG_SKF2(4, PREC_, 1); else XG_SKF2(8, PREC_, 1); } while (0)
+#else
+#define XG_SKF(PREC_) do { if (nw4) XG_SKF2(4, PREC_, 1); else XG_SKF2(8, PREC_, 1); } while (0)
+#endif
+        if (bf16) XG_SKF(1); else if (bf16x3) XG_SKF(2); else XG_SKF(0);
 #undef XG_SKF
+#undef XG_SKF2
         XG_CHECK_LAUNCH();
 #ifdef XG_DIAG
         static const bool dbg_sync = xg_diag_env("XG_SYNC_LAUNCH") != nullptr;
