@@ -10,6 +10,7 @@
 //   decoder tensors are time-major (T, B, .) so each step's rows are contiguous and the stacked
 //   (T*B, .) matrices feed the batched head / weight-gradient GEMMs directly.
 #include "xg_common.h"
+#include <cstring>
 #include "xg_kernels.h"
 
 #include <new>
@@ -1505,9 +1506,29 @@ extern "C" int xg_aux_create(void** aux) {
     if (!a) return XG_EHIP;
     a->magic = XG_AUX_MAGIC;
     for (int i = 0; i < XG_NEV; ++i) a->ev[i] = nullptr;
-    bool ok = hipGetDevice(&a->device) == hipSuccess &&
-              hipStreamCreateWithFlags(&a->s, hipStreamNonBlocking) == hipSuccess &&
-              hipStreamCreateWithFlags(&a->s2, hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipGetDevice(&a->device) == hipSuccess;
+    // (experiment, diag build: XG_AUX_CUMASK=n[,m] keeps the first side stream -- the background products -- on the first n CUs
+    //  of every XCD and the second -- the cell-1 chain and its products -- on the first m (default n): the main stream's launch
+    //  chains then find (32 - n) CUs per XCD that no background workgroup occupies.  Mask bit i = XCD i % 8, CU i / 8 of it:
+    //  tools/ubench/cumask_probe.hip)
+    int cu_n = 0, cu_m = 0;
+    if (const char* e = xg_diag_env("XG_AUX_CUMASK")) { cu_n = atoi(e); const char* c = strchr(e, ','); cu_m = c ? atoi(c + 1) : cu_n; }
+    // (experiment, diag build: XG_AUX_PRIO=1 creates the side streams at the LOWEST queue priority, so that the dispatcher serves
+    //  the caller's stream -- the launch chains -- first when both have workgroups pending)
+    static const bool low_prio = xg_diag_env("XG_AUX_PRIO") != nullptr;
+    auto masked = [](hipStream_t* st, int n) {
+        if (low_prio && (n <= 0 || n >= 32)) {
+            int least = 0, greatest = 0;
+            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return false;
+            return hipStreamCreateWithPriority(st, hipStreamNonBlocking, least) == hipSuccess;
+        }
+        if (n <= 0 || n >= 32) return hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
+        uint32_t mask[8];
+        for (int w = 0; w < 8; ++w) mask[w] = 0;
+        for (int i = 0; i < 8 * n; ++i) mask[i >> 5] |= 1u << (i & 31);
+        return hipExtStreamCreateWithCUMask(st, 8, mask) == hipSuccess;
+    };
+    ok = ok && masked(&a->s, cu_n) && masked(&a->s2, cu_m);
     for (int i = 0; ok && i < XG_NEV; ++i) ok = hipEventCreateWithFlags(&a->ev[i], hipEventDisableTiming) == hipSuccess;
     if (!ok) { xg_aux_destroy(a); return XG_EHIP; }
     *aux = a;
