@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("XG_LIBRARY") or os.path.join(_HERE, "lib", "libxgate_hip.so")
 LIB_DIAG_PATH = os.path.join(_HERE, "lib", "libxgate_hip_diag.so")
 
-XG_VERSION = 205                      # include/xgate.h
+XG_VERSION = 206                      # include/xgate.h
 XG_ROLLOUT_GREEDY, XG_ROLLOUT_SAMPLE, XG_ROLLOUT_REPLAY = 0, 1, 2
 
 
@@ -118,6 +118,7 @@ def lib():
         "xg_adam_tick": [vp, vp, f32, f32],
         "xg_clip_adam_dev": [vp, i64, vp, vp, vp, vp, vp, f32, f32, f32, f32, f32, i32],
         "xg_pack_weights": [vp, PD, PP, vp, C.c_size_t, i32, i32],
+        "xg_pack_weights_part": [vp, PD, PP, vp, C.c_size_t, i32, i32, i32],
         "xg_reward_fwd": [vp, vp, i32, vp, i32, vp, i32, i32, vp, i32, i32, vp],
         "xg_reward_bwd": [vp, vp, i32, vp, i32, i32, vp, i32, i32, vp, vp, vp, i32],
     }

@@ -187,28 +187,45 @@ extern "C" size_t xg_packed_bytes(const XgDims* d, int dtype) {
     return xgk_packed_total_bytes(*d, dtype);
 }
 
+static int pack_part(void* stream, const XgDims* d, const XgParams* p, void* packed, size_t packed_bytes, int dtype, int with_backward, int part);
 extern "C" int xg_pack_weights(void* stream, const XgDims* d, const XgParams* p, void* packed, size_t packed_bytes,
                                int dtype, int with_backward) {
+    return pack_part(stream, d, p, packed, packed_bytes, dtype, with_backward, 0);
+}
+// part 1: everything but the CG encoder's recurrent matrices; part 2: those only (fp32 tiles only).  The decoder's matrices are
+// final -- updated -- long before the encoder's (train.ClipAdam(overlap=True)): a caller can refresh their tiles under the
+// encoder's backward and only the encoder's four tiles at the head of the next iteration.
+extern "C" int xg_pack_weights_part(void* stream, const XgDims* d, const XgParams* p, void* packed, size_t packed_bytes,
+                                    int dtype, int with_backward, int part) {
+    if (part < 0 || part > 2 || (part != 0 && dtype != 0)) return XG_EINVAL;
+    return pack_part(stream, d, p, packed, packed_bytes, dtype, with_backward, part);
+}
+static int pack_part(void* stream, const XgDims* d, const XgParams* p, void* packed, size_t packed_bytes, int dtype, int with_backward, int part) {
     if (!d || !p || !packed || d->R <= 0 || d->A <= 0 || d->E <= 0) return XG_EINVAL;
     if (d->R % 8 != 0 || ((uintptr_t)packed % 16) != 0 || (dtype != 0 && dtype != 1)) return XG_EINVAL;
     if (dtype == 1 && (d->V <= 1 || d->F1 <= 0 || d->F2 <= 0)) return XG_EINVAL;
     if (packed_bytes < xgk_packed_total_bytes(*d, dtype)) return XG_EWORKSPACE;
-    PackArgs a{};
-    describe(*d, *p, a.e);
+    PackDesc all[PK_COUNT];
+    describe(*d, *p, all);
     PackedView v;
     if (!xgk_packed_view(*d, packed, dtype, &v)) return XG_EINVAL;
-    a.first = 0;
-    a.last = with_backward ? PK_COUNT : PKB_L2_A2H;
+    PackArgs a{};
+    const int last = with_backward ? PK_COUNT : PKB_L2_A2H;
     a.bf16 = dtype == 1;
-    int tiles = 0;
-    for (int i = 0; i < a.last; ++i) {
-        if (!a.e[i].src) return XG_EINVAL;
-        a.dst[i] = const_cast<float*>(v.m[i]);
-        a.tile0[i] = tiles;
-        tiles += (int)(entry_floats(a.e[i]) / 1024);
+    int tiles = 0, n = 0;
+    for (int i = 0; i < last; ++i) {
+        const bool enc = i == PK_ENC_RGB || i == PK_ENC_OPFL || i == PKB_ENC_RGB || i == PKB_ENC_OPFL;
+        if ((part == 1 && enc) || (part == 2 && !enc)) continue;
+        if (!all[i].src) return XG_EINVAL;
+        a.e[n] = all[i];                         // (entries compacted: the kernel walks [first, last) of ITS arrays)
+        a.dst[n] = const_cast<float*>(v.m[i]);
+        a.tile0[n] = tiles;
+        tiles += (int)(entry_floats(all[i]) / 1024);
+        ++n;
     }
-    a.tile0[a.last] = tiles;
-    hipLaunchKernelGGL(pack_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
+    a.first = 0; a.last = n;
+    a.tile0[n] = tiles;
+    if (tiles > 0) hipLaunchKernelGGL(pack_kernel, dim3(tiles), dim3(256), 0, (hipStream_t)stream, a);
     XG_CHECK_LAUNCH();
     if (dtype == 1) {                            // the plain bf16 copies of the large products' weights
         W16Desc we[W16_COUNT];

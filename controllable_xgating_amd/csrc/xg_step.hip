@@ -77,8 +77,8 @@ __device__ __forceinline__ void st_chunk(float* __restrict__ lds, int lane, cons
 // In-kernel phase stamps (tools/sk_trace_run.py): 8 slots per workgroup of the launches whose grid matches the filter set through
 // xg_debug_sk_trace_filter (jobs, grid x).  Slot 7 = the LAST wave's end of the K loop (atomic max), the others are wave 0's view.
 __device__ long long sk_trace_buf[4096 * 8];
-__device__ int sk_trace_sel[2] = {1, 256};
-#define SK_TRACE_ON() ((int)gridDim.y == sk_trace_sel[0] && (int)gridDim.x == sk_trace_sel[1])
+__device__ int sk_trace_sel[3] = {1, 256, 0};
+#define SK_TRACE_ON() ((int)gridDim.y == sk_trace_sel[0] && (int)gridDim.x == sk_trace_sel[1] && (sk_trace_sel[2] == 0 || (int)blockDim.x == sk_trace_sel[2]))
 #define SK_STAMP(i) do { if (threadIdx.x == 0 && SK_TRACE_ON()) sk_trace_buf[(blockIdx.x + blockIdx.y * gridDim.x) * 8 + (i)] = wall_clock64(); } while (0)
 #define SK_STAMP_MAX(i) do { if ((threadIdx.x & 63) == 0 && SK_TRACE_ON()) atomicMax((unsigned long long*)&sk_trace_buf[(blockIdx.x + blockIdx.y * gridDim.x) * 8 + (i)], (unsigned long long)wall_clock64()); } while (0)
 #else
@@ -1255,8 +1255,12 @@ static int skinny_fallback(hipStream_t st, const SkJob& jb, int gemm_mode) {
 extern "C" int xg_debug_sk_trace(long long* out, int n) {
     return hipMemcpyFromSymbol(out, HIP_SYMBOL(sk_trace_buf), sizeof(long long) * (size_t)n) == hipSuccess ? 0 : -1;
 }
+extern "C" int xg_debug_sk_trace_filter3(int njobs, int gx, int threads) {
+    const int sel[3] = {njobs, gx, threads};
+    return hipMemcpyToSymbol(HIP_SYMBOL(sk_trace_sel), sel, sizeof(sel)) == hipSuccess ? 0 : -1;
+}
 extern "C" int xg_debug_sk_trace_filter(int njobs, int gx) {
-    const int sel[2] = {njobs, gx};
+    const int sel[3] = {njobs, gx, 0};
     return hipMemcpyToSymbol(HIP_SYMBOL(sk_trace_sel), sel, sizeof(sel)) == hipSuccess ? 0 : -1;
 }
 extern "C" int xg_debug_sk_trace_clear(void) {

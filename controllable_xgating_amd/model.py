@@ -305,6 +305,29 @@ class SAModel(nn.Module):
         has its own version counter.  Call this method after such writes."""
         self._packed_epoch += 1
 
+    def pack_early(self):
+        """For an optimizer that has JUST updated every parameter group except the CG encoder's on the current stream (and will
+        call mark_params_changed() when the rest is done): refresh the packed tiles of the decoder's matrices here and now, under
+        the encoder's backward, instead of at the head of the next iteration (xg_pack_weights_part, part 1).  The next
+        _packed_ptr() then only packs the encoder's tiles.  No-op when there is nothing to gain (bf16 tiles, no shadow yet, a
+        HIP-graph capture)."""
+        if self.precision == "bf16" or self._packed is None or torch.cuda.is_current_stream_capturing():
+            return
+        self._ensure_flat()
+        key = (self._flat.data_ptr(), self._flat._version, self._packed_epoch, 0, tuple(p._version for p in self._plist()))
+        d = self._dims(1, 1, 1)
+        nbytes = nv.lib().xg_packed_bytes(C.byref(d), 0)
+        if nbytes == 0 or self._packed.numel() < nbytes + 16:
+            return
+        ptr = (self._packed.data_ptr() + 15) & ~15
+        ps = self._params_struct()
+        nv.check(nv.lib().xg_pack_weights_part(_stream(), C.byref(d), C.byref(ps), C.c_void_p(ptr), C.c_size_t(nbytes), 0, 1, 1),
+                 "xg_pack_weights_part")
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream())
+        # valid for exactly the NEXT epoch (the optimizer's mark_params_changed) with nothing else changed in between
+        self._early_event, self._early_epoch, self._early_key = ev, self._packed_epoch + 1, key[:2] + key[3:]
+
     def _aux_handle(self):
         """Side-stream handle (include/xgate.h: xg_aux_create) for the current device and stream, created on first use."""
         if torch.cuda.is_current_stream_capturing():
@@ -331,12 +354,24 @@ class SAModel(nn.Module):
             if nbytes == 0:
                 self._packed = None
             else:
-                if self._packed is None or self._packed.device != self._flat.device or self._packed.numel() < nbytes + 16:
+                fresh = self._packed is None or self._packed.device != self._flat.device or self._packed.numel() < nbytes + 16
+                if fresh:
                     self._packed = torch.empty(nbytes + 16, dtype=torch.uint8, device=self._flat.device)
                 ptr = (self._packed.data_ptr() + 15) & ~15
                 ps = self._params_struct()
-                nv.check(nv.lib().xg_pack_weights(_stream(), C.byref(d), C.byref(ps), C.c_void_p(ptr), C.c_size_t(nbytes), dtype, 1),
-                         "xg_pack_weights")
+                # the decoder's matrices may already have been refreshed behind the optimizer's update of their parameter group
+                # (pack_early, under the CG encoder's backward): then only the encoder's four tiles are left for the head of the
+                # iteration, behind an event that completed long ago
+                early = (not fresh and dtype == 0 and getattr(self, "_early_key", None) == key[:2] + key[3:] and
+                         self._early_epoch == self._packed_epoch and not torch.cuda.is_current_stream_capturing())
+                if early:
+                    torch.cuda.current_stream().wait_event(self._early_event)
+                    nv.check(nv.lib().xg_pack_weights_part(_stream(), C.byref(d), C.byref(ps), C.c_void_p(ptr), C.c_size_t(nbytes), 0, 1, 2),
+                             "xg_pack_weights_part")
+                else:
+                    nv.check(nv.lib().xg_pack_weights(_stream(), C.byref(d), C.byref(ps), C.c_void_p(ptr), C.c_size_t(nbytes), dtype, 1),
+                             "xg_pack_weights")
+                self._early_key = None
                 # the shadow is (re)written on THIS stream: calls on any other stream must wait for it (a rollout on a side
                 # stream right after an optimizer step, driver.scst_rollouts(mode="streams"))
                 if torch.cuda.is_current_stream_capturing():       # (a HIP graph: ordering is the graph's own business)
@@ -631,13 +666,15 @@ class _XELossFunction(torch.autograd.Function):
         cm = None if class_mask is None else class_mask.detach().contiguous().float()
         losses = torch.empty(3, dtype=torch.float32, device=dev)
         ps, bn, run = model._params_struct(), model._bn_struct(), model._run(save)
+        # (the counters' increment is independent of the forward: enqueued in FRONT of it, it is not one more small launch on the
+        #  main stream between the loss and the start of the backward)
+        model._bump_bn()
         nv.check(nv.lib().xg_xe_loss_fwd(_stream(), C.byref(d), C.byref(ps), C.byref(bn), C.byref(b), nv.ptr(cc),
                                          nv.ptr(cm), weight_class, C.byref(run), wp, wn, nv.ptr(losses)), "xg_xe_loss_fwd")
-        model._bump_bn()
         ctx.model, ctx.d, ctx.ws, ctx.keep, ctx.run, ctx.saved_ws = model, d, ws, keep, run, save
         ctx.cc, ctx.cm, ctx.wc = cc, cm, weight_class
         model.last_losses = losses
-        return losses[0].clone()
+        return losses[0]                           # (a view of the three-element result: no copy kernel)
 
     @staticmethod
     def backward(ctx, dloss):

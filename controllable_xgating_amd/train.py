@@ -152,6 +152,10 @@ class ClipAdam:
             with torch.cuda.stream(self._side):
                 self.update_segment(self._split, a0)
                 self.update_segment(a1, n)
+                # every matrix the per-step products stream except the encoder's is final now: their packed tiles are
+                # refreshed here, under the encoder's backward, instead of at the head of the next iteration
+                if hasattr(self.model, "pack_early") and not _NO_EARLY_PACK:
+                    self.model.pack_early()
             self.update_segment(0, self._split)          # the encoder's gradients: after the whole backward (stream order)
             main.wait_stream(self._side)
         else:
@@ -254,6 +258,8 @@ import os as _os
 _FORCE = _os.environ.get("XG_FORCE_DIST") == "1"      # run the collective even at world size 1 (single-GPU smoke of the path)
 
 
+import os as _os0
+_NO_EARLY_PACK = _os0.environ.get("XG_NO_EARLY_PACK") == "1"      # measurement switch (Python side; the library reads no environment)
 _SKIP_COLLECTIVE = False    # measurement switch (bench.py: exposed communication = iteration with - without the collective)
 
 

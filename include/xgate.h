@@ -40,10 +40,10 @@
 extern "C" {
 #endif
 
-#define XG_VERSION 205   /* 200: XgRun gained packed/aux/event fields, xg_set_grad_event removed, xg_vproj takes XgRun;
+#define XG_VERSION 206   /* 200: XgRun gained packed/aux/event fields, xg_set_grad_event removed, xg_vproj takes XgRun;
                             201: + xg_clip_adam_zero; 202: XgRun.prof_event0/1, xg_adam_tick, xg_clip_adam_dev;
                             203: + xg_rollout_pair_compact; 204: + xg_abi_check;
-                            205: + xg_rollout_pair_videos, xg_workspace_bytes_mode */
+                            205: + xg_rollout_pair_videos, xg_workspace_bytes_mode; 206: + xg_pack_weights_part */
 
 enum {
     XG_OK = 0,
@@ -329,6 +329,12 @@ int xg_reward_bwd(void *stream, const int64_t *seq, int ld_seq, const float *rew
 size_t xg_packed_bytes(const XgDims *d, int dtype);
 int xg_pack_weights(void *stream, const XgDims *d, const XgParams *p, void *packed, size_t packed_bytes,
                     int dtype, int with_backward);
+/* The same refresh in two parts (dtype 0 only): part 1 = every matrix but the CG encoder's recurrent ones, part 2 = those
+ * (part 0 = xg_pack_weights).  An optimizer that updates the parameter groups as their gradients become final -- the decoder's
+ * before the CG encoder's backward, train.ClipAdam(overlap=True) -- refreshes part 1 right behind that update, under the
+ * encoder's backward, and part 2 at the head of the next iteration (6 us instead of 42 in front of the first product). */
+int xg_pack_weights_part(void *stream, const XgDims *d, const XgParams *p, void *packed, size_t packed_bytes,
+                         int dtype, int with_backward, int part);
 
 /* ---- update: clip_gradient + Adam (caption_src/myutils.py:79-85, caption_src/starttrain.py:76,137) ----
  * Elementwise clamp of g to +-clip (clip <= 0 disables), then torch.optim.Adam semantics

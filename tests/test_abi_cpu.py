@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol(built):
 def test_version_strerror_and_param_table(built):
     from controllable_xgating_amd import _native as nv
     L = nv.lib()
-    assert L.xg_version() == 205 == nv.XG_VERSION
+    assert L.xg_version() == 206 == nv.XG_VERSION
     assert L.xg_strerror(0) == b"ok"
     assert b"workspace" in L.xg_strerror(-4)
     d = pg.make_dims(**CFG["c1"])

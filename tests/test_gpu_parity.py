@@ -606,6 +606,35 @@ def test_overlapped_update_equals_plain_update():
         assert float((p0[n] - p1[n]).abs().max()) < 5e-6, n
 
 
+def test_early_repack_of_the_decoder_tiles_equals_a_full_repack():
+    """ClipAdam(overlap=True) refreshes the packed tiles of every matrix but the CG encoder's right behind the update of their
+    parameter group (SAModel.pack_early: xg_pack_weights_part, part 1, on the optimizer's side stream, under the encoder's
+    backward) and the next call only packs the encoder's tiles (part 2): the shadow must be bit-identical to a full
+    xg_pack_weights of the updated parameters -- and stale when the early part is skipped on purpose (the test tests something)."""
+    from controllable_xgating_amd.train import ClipAdam
+    d = pg.make_dims(**CFG["mid"])
+    x = to_dev(pg.make_inputs(d, seed=0, ragged=True))
+    model = make_model(d)
+    opt = ClipAdam(model, lr=4e-4, grad_clip=0.1, overlap=True, fused_zero=True)
+    for it in range(3):
+        opt.zero_grad()
+        loss = model.xe_loss(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+        opt.arm()
+        loss.backward()
+        before = model._packed.clone()
+        opt.step()
+        assert model._early_key is not None and model._early_epoch == model._packed_epoch       # the early part ran
+        model._packed_ptr()                                   # what the next forward would do: encoder tiles only
+        assert model._early_key is None
+        torch.cuda.synchronize()
+        two_part = model._packed.clone()
+        model.mark_params_changed()
+        model._packed_ptr()                                   # a full re-pack of the same parameters
+        torch.cuda.synchronize()
+        assert torch.equal(two_part, model._packed)
+        assert not torch.equal(before, model._packed)         # (the update really changed the tiles)
+
+
 def test_fused_zero_grad_update_equals_plain_update():
     """ClipAdam(fused_zero=True): the update leaves .grad at zero (xg_clip_adam_zero) and the next zero_grad() is skipped --
     same parameters as the plain update over three iterations (with and without the overlapped segments); and zero_grad()
