@@ -1345,6 +1345,13 @@ int xgk_gemm_cs(hipStream_t st, int mode, bool transA, bool transB, int M, int N
                 float* cs3) {
     if (M <= 0 || N <= 0) return XG_OK;
     if (K < 0 || !A || !B || !C) return XG_EINVAL;
+#ifdef XG_DIAG
+    {   // sensitivity experiment (results wrong on purpose): every tiled product with its reduction depth scaled -- "what would the
+        // iteration be with GEMMs that much faster" (XG_GEMM_KSCALE=0.8: 20 % less matrix work per product, same launches / tiles)
+        static const float kscale = xg_diag_env("XG_GEMM_KSCALE") ? (float)atof(xg_diag_env("XG_GEMM_KSCALE")) : 1.0f;
+        if (kscale != 1.0f && K >= 256) K = ((int)(K * kscale) / 32) * 32;
+    }
+#endif
     const bool want_cs = cs1 != nullptr;
     if (want_cs && !transA) return XG_EINVAL;
     const int bg = (mode & XGK_GEMM_BG) ? 1 : 0;
