@@ -1349,7 +1349,12 @@ int xgk_gemm_cs(hipStream_t st, int mode, bool transA, bool transB, int M, int N
     {   // sensitivity experiment (results wrong on purpose): every tiled product with its reduction depth scaled -- "what would the
         // iteration be with GEMMs that much faster" (XG_GEMM_KSCALE=0.8: 20 % less matrix work per product, same launches / tiles)
         static const float kscale = xg_diag_env("XG_GEMM_KSCALE") ? (float)atof(xg_diag_env("XG_GEMM_KSCALE")) : 1.0f;
-        if (kscale != 1.0f && K >= 256) K = ((int)(K * kscale) / 32) * 32;
+        // XG_GEMM_KSEL: which products are scaled -- bit 0 weight-gradient layout (TN), 1 NT, 2 NN, 3 vocabulary-sized only (a
+        // dimension >= 10000), 4 everything but vocabulary-sized
+        static const int ksel = xg_diag_env("XG_GEMM_KSEL") ? atoi(xg_diag_env("XG_GEMM_KSEL")) : 7;
+        const bool vocab = M >= 10000 || N >= 10000 || K >= 10000;
+        const int cls = transA ? 1 : (transB ? 2 : 4);
+        if (kscale != 1.0f && K >= 256 && (ksel & cls) && (!(ksel & 8) || vocab) && (!(ksel & 16) || !vocab)) K = ((int)(K * kscale) / 32) * 32;
     }
 #endif
     const bool want_cs = cs1 != nullptr;
