@@ -660,7 +660,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         // (at hidden 1024 / 40 frames E wins instead: 8.51 vs 8.63 ms -- the stand-alone attention is then 24 us per step)
         static const char xe_env = xg_diag_env("XG_XE_FORM") ? xg_diag_env("XG_XE_FORM")[0] : 0;          // experiment switch (B / D / E)
         const char xe_form = xe_env ? xe_env : (R >= 1024 ? 'E' : 'D');
-        const bool fused_attn = (!s.pre1 || xe_form == 'E') && !no_fused && A <= 2048 && d.K <= 128 && ((uintptr_t)V % 8 == 0) &&
+        const bool fused_attn = (!s.pre1 || xe_form == 'E' || xe_form == 'G') && !no_fused && A <= 2048 && d.K <= 128 && ((uintptr_t)V % 8 == 0) &&
                                 ((uintptr_t)vproj % 16 == 0) && ((uintptr_t)p.a2w_w % 16 == 0);
         // S2' = h2 W_h2h2 + b rides in launch 1 (teacher forcing form B; the rollout form beyond 64 rows, where the three
         // launches are then 512 / 512 / 256 workgroups, one round each, instead of 256 / 768 / 256: 49.4 -> 46.5 us per step
@@ -670,7 +670,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         // launch 1 as well, so that launch 2 -- the attention beside cell 1 -- keeps only cell 1's pos' product (K = R)
         static const int s1_env = xg_diag_env("XG_S1_FIRST") ? atoi(xg_diag_env("XG_S1_FIRST")) : -1;
         const bool s1_first = !s.pre1 && (s1_env >= 0 ? s1_env != 0 : false);
-        const bool s2_in_cell2 = s.pre1 != nullptr && xe_form == 'D';       // ... or stays a segment of cell 2 (measured for the
+        const bool s2_in_cell2 = s.pre1 != nullptr && (xe_form == 'D' || xe_form == 'G');     // (G, round 5: D with the attention as two workgroups per video inside launch 2)       // ... or stays a segment of cell 2 (measured for the
                                                                             // rollout form at 128 rows too: 48.3 us)
         SkArgs k1{}, k2{}, k3{};
         int n1 = 0, n2 = 0, n3 = 0;
