@@ -35,7 +35,11 @@ def main():
     rows.sort(key=lambda r: r["s"])
     # an iteration starts with the weight re-pack (one pack_kernel per optimizer step, first thing of the next forward); the
     # update itself is several clip_adam launches on two streams (train.ClipAdam(overlap=True)), so it cannot delimit
-    marks = [i for i, r in enumerate(rows) if r["name"].startswith("pack_kernel")]
+    # -- the one on the MAIN queue only: since round 5 the decoder's tiles are re-packed early on the optimizer's side stream
+    # (model.pack_early), a second pack_kernel per iteration that must not delimit
+    from collections import Counter
+    main_queue = Counter(r["q"] for r in rows).most_common(1)[0][0]
+    marks = [i for i, r in enumerate(rows) if r["name"].startswith("pack_kernel") and r["q"] == main_queue]
     if len(marks) > back + 1:
         lo, hi = marks[-back - 1], marks[-back]
     else:
