@@ -11,6 +11,7 @@
 //   (T*B, .) matrices feed the batched head / weight-gradient GEMMs directly.
 #include "xg_common.h"
 #include <cstring>
+#include <ctime>
 #include "xg_kernels.h"
 
 #include <new>
@@ -48,6 +49,9 @@ struct Streams {
     // parameter-gradient work of the decoder backward that nothing downstream waits for, handed to the encoder backward, which
     // enqueues it when its own latency-bound recurrence starts (decoder_bwd_core -> encoder_bwd)
     std::function<int()> deferred;
+    // the vocabulary head's weight gradient (heads_bwd), enqueued by decoder_bwd_core at reverse-time step head_wgrad_step
+    std::function<int()> head_wgrad;
+    int head_wgrad_step = -1;
     Streams(hipStream_t m, const XgRun* run) : main(m), aux(m), aux2(m), a(aux_of(run)) {
         if (a) { aux = a->s; aux2 = a->s2; }
         if (run) { grad_event = static_cast<hipEvent_t>(run->grad_event); grad_event_head = static_cast<hipEvent_t>(run->grad_event_head); }
@@ -1172,9 +1176,33 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     const int wg_chunks = (ss.overlap() && T >= 8 && w.gm == 0) ? (wg_chunks_env < 1 ? 1 : (wg_chunks_env > 4 ? 4 : wg_chunks_env)) : 1;
     int wg_hi = T, wg_mark = -1;                 // steps [wg_hi, T) already have their weight gradients enqueued
     int c1_next = T - 1;                         // the next step chain 1 has to do
+    // (diagnosis, XG_LEAD_PROBE=1: how far ahead of the GPU is the enqueueing thread inside this loop?  One event per step on the
+    //  main stream; at the top of step t the host asks which steps' events have completed and prints the table at the end)
+    static const bool lead_probe = xg_diag_env("XG_LEAD_PROBE") != nullptr;
+    static hipEvent_t lead_ev[64];
+    static bool lead_init = false;
+    double lead_host_us[64]; int lead_done[64]; double lead_step_us[64];
+    if (lead_probe && !lead_init) { for (int i = 0; i < 64; ++i) (void)hipEventCreate(&lead_ev[i]); lead_init = true; }
+    auto now_us = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
+    const double lead_t0 = lead_probe ? now_us() : 0.0;
+    if (lead_probe && T <= 64) {                 // the PREVIOUS call's events: GPU time of each step (complete by now, or skipped)
+        static int lead_seen = 0;
+        if (++lead_seen % 8 == 1 && lead_seen > 1 && hipEventQuery(lead_ev[0]) == hipSuccess) {
+            fprintf(stderr, "[lead probe] GPU time between the step events of the previous call (us):");
+            for (int t = T - 2; t >= 0; --t) { float ms = 0.f; (void)hipEventElapsedTime(&ms, lead_ev[t + 1], lead_ev[t]); fprintf(stderr, " t=%d:%.1f", t, ms * 1e3f); }
+            fprintf(stderr, "\n");
+        }
+    }
     for (int t = T - 1; t >= 0; --t) {
+        if (lead_probe && T <= 64) {
+            lead_host_us[t] = now_us() - lead_t0;
+            int done = T;                          // the lowest step whose event has completed (T = none yet)
+            for (int u = T - 1; u > t; --u) { if (hipEventQuery(lead_ev[u]) == hipSuccess) done = u; else break; }
+            lead_done[t] = done;
+        }
         // dH of the early steps comes from the auxiliary stream; fused, step t-1's cell backward runs inside step t
         if (t == ss.dh_split_step - (fuse ? 0 : 1)) XG_TRY(ss.wait_mark(ss.dh_mark));
+        if (ss.head_wgrad && t <= ss.head_wgrad_step) { std::function<int()> f = std::move(ss.head_wgrad); ss.head_wgrad = nullptr; XG_TRY(f()); }
         float* dh2p = w.dst[cur ^ 1][2];
         float* ds2 = w.DS2 + (size_t)t * B * 4 * R;
         float* dp = w.DP + (size_t)t * B * A;
@@ -1205,6 +1233,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
             XG_TRY(xgk_skinny(st, sk, w.gm));
         }
         cur ^= 1;
+        if (lead_probe && T <= 64) { (void)hipEventRecord(lead_ev[t], st); lead_step_us[t] = now_us() - lead_t0; }
         // chain 2 has finished step t: chain 1 may do it.  One event per c1_lag steps (an event record between two dependent
         // launches of the main chain costs it ~6 us; chain 1 has slack: its launch is shorter than chain 2's three)
         static const int c1_lag = xg_diag_env("XG_C1_LAG") ? atoi(xg_diag_env("XG_C1_LAG")) : 7;
@@ -1225,6 +1254,15 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
             wg_mark = ss.mark();              // the last one covers the earlier ones (same stream)
             if (wg_mark == -2) return XG_EHIP;
             wg_hi = t;
+        }
+    }
+    if (lead_probe && T <= 64) {
+        static int lead_calls = 0;
+        if (++lead_calls % 8 == 0) {
+            fprintf(stderr, "[lead probe] reverse-time loop, call %d: host time at the top of step t (us since the loop's start) | host time after the step's three launches | steps the GPU had completed\n", lead_calls);
+            for (int t = T - 1; t >= 0; --t)
+                fprintf(stderr, "[lead probe]   t=%2d  host %8.1f  %8.1f   GPU has finished step %s%d (host is %d steps ahead)\n", t, lead_host_us[t], lead_step_us[t],
+                        lead_done[t] == T ? ">" : "", lead_done[t] == T ? T - 1 : lead_done[t], (lead_done[t] == T ? T : lead_done[t]) - t - 1);
         }
     }
     const int cur2 = cur;
@@ -1330,14 +1368,20 @@ int heads_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams& g
         if (ss.dh_mark == -2) return XG_EHIP;
     }
     // dW_logit / db: parameter gradients, under the loop as well
-    XG_TRY(tn16(ss.aux, bgm, rows, d.V, R, w.LOGITS, m16(w, w.LOGITS), d.V, Hout, hout16, R, g.logit_w, R, g.logit_b));
-    // XgRun.grad_event_head: the vocabulary head's gradients are final, long before anything else, AND logit.* is not read
-    // any more in this backward (the product above was its last reader) -- a caller may all-reduce those gradients and
-    // even update logit.* from here on
-    if (ss.grad_event_head) {
-        XG_TRY(ss.fork());
-        if (hipEventRecord(ss.grad_event_head, ss.aux) != hipSuccess) return XG_EHIP;
-    }
+    auto dwl = [=, &ss, &w, &g]() -> int {
+        XG_TRY(tn16(ss.aux, bgm, rows, d.V, R, w.LOGITS, m16(w, w.LOGITS), d.V, Hout, hout16, R, g.logit_w, R, g.logit_b));
+        // XgRun.grad_event_head: the vocabulary head's gradients are final, long before anything else, AND logit.* is not read
+        // any more in this backward (the product above was its last reader) -- a caller may all-reduce those gradients and
+        // even update logit.* from here on
+        if (ss.grad_event_head) {
+            XG_TRY(ss.fork());
+            if (hipEventRecord(ss.grad_event_head, ss.aux) != hipSuccess) return XG_EHIP;
+        }
+        return XG_OK;
+    };
+    static const int dwl_at = xg_diag_env("XG_DWL_AT") ? atoi(xg_diag_env("XG_DWL_AT")) : -1;   // experiment: enqueue it from inside the loop
+    if (dwl_at >= 0 && th > 0) { ss.head_wgrad = dwl; ss.head_wgrad_step = dwl_at < d.T ? dwl_at : d.T - 1; }
+    else XG_TRY(dwl());
     if (have_cls) {
         XG_TRY(gemm_tn_cs(st, w.gm, rows, d.C, d.H, w.DCL, d.C, w.HC, d.H, g.cls3_w, d.H, g.cls3_b));
         XG_TRY(gemm_nn(st, w.gm, rows, d.H, d.C, w.DCL, d.C, p.cls3_w, d.H, w.DHC, d.H, false));
