@@ -1365,6 +1365,21 @@ int xgk_gemm_cs(hipStream_t st, int mode, bool transA, bool transB, int M, int N
     if ((mode == 1 || mode == 3) && M >= 256 && N >= 64 && K >= 64) {
         return xgk_gemm_bf16(st, mode, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, cs1, cs2, cs3);
     }
+#ifdef XG_DIAG
+    {   // experiment: plain products through the vendor library.  XG_BLASLT = mask: 1 weight-gradient layout (TN), 2 NT, 4 NN,
+        // 8 vocabulary-sized only, 16 everything but vocabulary-sized, 32 also products with bias-gradient side outputs (their
+        // column sums as a separate pass), 64 not the background products
+        static const int lt = xg_diag_env("XG_BLASLT") ? atoi(xg_diag_env("XG_BLASLT")) : 0;
+        const bool vocab = M >= 10000 || N >= 10000 || K >= 10000;
+        const int cls = transA ? 1 : (transB ? 2 : 4);
+        if (mode == 0 && (lt & cls) && (!(lt & 8) || vocab) && (!(lt & 16) || !vocab) && (!want_cs || (lt & 32)) && (!bg || !(lt & 64)) &&
+            M >= 64 && N >= 64 && K >= 64) {
+            const int rc = xgk_blaslt_gemm(st, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate);
+            if (rc == XG_OK && want_cs) return xgk_colsum3(st, A, lda, K, M, cs1, cs2, cs3);
+            if (rc != 1) return rc;
+        }
+    }
+#endif
     GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1, 0, 1, bg, {nullptr, nullptr, nullptr}};
     const bool akc = !transA;   // A (M,K) row-major -> k contiguous
     const bool bkc = transB;    // B (N,K) row-major -> k contiguous

@@ -103,6 +103,9 @@ int xgk_relu_drop_bwd(hipStream_t st, float* dy, const float* y, int64_t n, XgDr
 // column reductions over rows of X (N,Cn) ld: out[c] += sum_r X[r][c]  (atomic accumulate; caller zeroes)
 int xgk_colsum(hipStream_t st, const float* X, int ld, int N, int Cn, float* out);
 // the same sums added into up to three accumulators (out2 / out3 may be null)
+// a plain fp32 product through hipBLASLt (xg_blaslt.hip): XG_OK, or 1 when the library has no kernel for it
+int xgk_blaslt_gemm(hipStream_t st, bool transA, bool transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
+                    float* C, int ldc, const float* bias, bool relu, bool accumulate);
 int xgk_colsum3(hipStream_t st, const float* X, int ld, int N, int Cn, float* out, float* out2, float* out3);
 // out1[c] += sum_r X*Y ; (used for BN dgamma and a2w weight grad)
 int xgk_colsum_prod(hipStream_t st, const float* X, int ldx, const float* Y, int ldy, int N, int Cn, float* out);
