@@ -1015,6 +1015,20 @@ int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatc
             if (early_loss)
                 XG_TRY(xgk_xent_fwd(ss.aux, w.LOGITS, d.V, x.seq, x.seq_mask, nullptr, B, T, d.V, 1, w.LSE, w.sums, 0, th * B, false));
         }
+        // (experiment, diag build: XG_FWD_TH2=<step> -- a SECOND background product for the steps [th, th2), so that fewer rows are left
+        //  for the product behind the loop)
+        static const int th2_env = xg_diag_env("XG_FWD_TH2") ? atoi(xg_diag_env("XG_FWD_TH2")) : 0;
+        if (th > 0 && th2_env > th && th2_env < T && t == th2_env - 1) {
+            const int n2 = (th2_env - th) * B;
+            const float* h2 = w.H2 + BR + (size_t)th * BR;
+            XG_TRY(ss.fork());
+            XG_TRY(cvt16(ss.aux, w, h2, (size_t)n2 * R));
+            XG_TRY(lin16(ss.aux, w.gm | (fwd_bg ? XGK_GEMM_BG : 0), n2, d.V, R, h2, m16(w, h2), R, p.logit_w, w16(w, W16_LOGIT), p.logit_b,
+                         w.LOGITS + (size_t)th * B * d.V, d.V));
+            *logit_rows_done = th2_env * B;
+            if (early_loss)
+                XG_TRY(xgk_xent_fwd(ss.aux, w.LOGITS, d.V, x.seq, x.seq_mask, nullptr, B, T, d.V, 1, w.LSE, w.sums, th * B, n2, false));
+        }
     }
     if (run.prof_event1 && hipEventRecord(static_cast<hipEvent_t>(run.prof_event1), st) != hipSuccess) return XG_EHIP;
     return XG_OK;
