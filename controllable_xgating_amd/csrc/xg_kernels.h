@@ -280,6 +280,11 @@ int xgk_attn_fwd(hipStream_t st, const float* p, const float* vproj, const float
 int xgk_attn_bwd(hipStream_t st, const float* daf, int lddaf, const float* p, const float* vproj, const float* V,
                  const float* w, const float* alpha, float* de, float* dp, int B, int K, int R, int A);
 // after the time loop: dvproj[b][k][a] = w_a sum_t de_t (1-th^2) ; dw[a] += sum de_t th ; dV[b][k][r] (+)= sum_t alpha_t daf_t
+// the same from x = ds2 (B, J = 4R) and M = V W_a2h^T (B, K, J): dalpha_k = x . M_k (xg_attn.hip: attn_bwd_split_m); 1 = shapes do not fit
+bool xgk_attn_bwd_m_ok(const float* x, int ldx, const float* p, const float* vproj, const float* M, int J, const float* w,
+                       const float* dp, int K, int A);
+int xgk_attn_bwd_m(hipStream_t st, const float* x, int ldx, const float* p, const float* vproj, const float* M, int J, const float* w,
+                   const float* alpha, float* de, float* dp, int B, int K, int A);
 int xgk_attn_bwd_post(hipStream_t st, const float* P /*(T,B,A)*/, const float* vproj, const float* w,
                       const float* DE /*(T,B,K)*/, float* dvproj, float* dw, int T, int B, int K, int A);
 // dV = sum_t alpha_t dAF_t (plain store) and dq / dw of the hoisted projection as ONE launch (T <= 32; otherwise the two passes)

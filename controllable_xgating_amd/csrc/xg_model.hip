@@ -44,6 +44,7 @@ struct Streams {
     int next = 0, next_mark = 0;
     bool forked = false, forked2 = false;
     int dh_split_step = 0, dh_mark = -1;      // heads_bwd -> decoder_bwd_core hand-off (see heads_bwd)
+    bool m_ready = false;                     // heads_bwd has enqueued M = V W_a2h^T into Ws::PRE[0] on the second side chain (ma_form)
     hipEvent_t grad_event = nullptr;          // XgRun.grad_event: recorded when every gradient but the encoder's is final
     hipEvent_t grad_event_head = nullptr;     // XgRun.grad_event_head: recorded when the logit.* gradients are final
     // parameter-gradient work of the decoder backward that nothing downstream waits for, handed to the encoder backward, which
@@ -1068,8 +1069,10 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     // The pointwise LSTM backward of step t-1 runs in the epilogue of the product that completes its dh.
     const bool fuse = R % 4 == 0;
     int cur = 0;
+    const bool ma = ss.m_ready && fuse;
+    if (ma && !w.zeroed) XG_TRY(ss.join2());     // M (heads_bwd, second auxiliary stream)
     if (w.zeroed) {
-        XG_TRY(ss.join2());                      // the zero block (zero_backward_block, second auxiliary stream)
+        XG_TRY(ss.join2());                      // the zero block (zero_backward_block, second auxiliary stream) -- and M behind it
     } else {
         for (int j = 0; j < 4; ++j) ZERO(w.dst[0][j], BR);
         ZERO(w.DAF, (size_t)T * BR);             // the dAF products accumulate (split-K across workgroups)
@@ -1222,6 +1225,21 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         float* dp = w.DP + (size_t)t * B * A;
         float* daf = w.DAF + t * BR;
         if (!fuse || t == T - 1) XG_TRY(xgk_lstm_bwd(st, cell2_bwd(t, cur)));
+        if (ma) {
+            // two launches: the attention backward straight from ds2 (dalpha_k = ds2 . M_k), then dh2 = dp Wh2a[:, R:] + ds2 Wh (+ the
+            // held part + dH2OUT) with cell 2's backward at t-1 in the epilogue.  d(context) for dV: one product behind the loop.
+            XG_TRY(xgk_attn_bwd_m(st, ds2, 4 * R, w.P + (size_t)t * B * A, w.vproj, w.PRE[0], 4 * R, p.a2w_w, w.ALPHA + (size_t)t * B * K,
+                                  w.DE + (size_t)t * B * K, dp, B, K, A));
+            SkArgs sk{};
+            sk.njobs = 1;
+            if (t > 0) sk.job[0] = job_lstm_bwd(cell2_bwd(t - 1, cur ^ 1), dh2p, R);
+            else sk.job[0] = job_store(B, R, dh2p, R, true);
+            sk.job[0].nseg = 2;
+            sk.job[0].seg[0] = seg_nn(w, PKB_L2_H2H, ds2, 4 * R, p.l2_h2h_w, R, 4 * R);      // (available first: the other operand comes out of the launch in front)
+            sk.job[0].seg[1] = seg_nn(w, PKB_H2A2, dp, A, p.h2a_w + R, 2 * R, A);
+            allow_split(sk, 0, w);
+            XG_TRY(xgk_skinny(st, sk, w.gm));
+        } else {
         {   // s2 = h1' Wi + af Wa + h2 Wh : the two data gradients chain 2 needs now
             SkArgs sk{};
             sk.njobs = 2;
@@ -1245,6 +1263,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
             static const int b_ks = xg_diag_env("XG_B_KS") ? atoi(xg_diag_env("XG_B_KS")) : 0;      // experiment: split cap of launch B
             sk.job[0].ksplit_cap = b_ks;
             XG_TRY(xgk_skinny(st, sk, w.gm));
+        }
         }
         cur ^= 1;
         if (lead_probe && T <= 64) { (void)hipEventRecord(lead_ev[t], st); lead_step_us[t] = now_us() - lead_t0; }
@@ -1285,6 +1304,10 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     // ---- after the loop.  Main chain (the encoder backward waits for it): dVproj -> dV.  Everything else is a
     // parameter gradient and goes to the auxiliary stream, under the encoder's recurrent backward.
     // (dV first, as a plain store: accumulating on top of the product below it would read every element back)
+    if (ma) {                                 // d(context) of every step at once: DAF = DS2 W_a2h
+        XG_TRY(cvt16(st, w, w.DS2, (size_t)T * B * 4 * R));
+        XG_TRY(nn16(st, w.gm, T * B, R, 4 * R, w.DS2, m16(w, w.DS2), 4 * R, p.l2_a2h_w, nullptr, R, w.DAF, R, false));
+    }
     XG_TRY(xgk_attn_post_dV(st, w.P, w.vproj, p.a2w_w, w.DE, w.DVPROJ, g.a2w_w, w.ALPHA, w.DAF, R, (int64_t)BR, w.DV, T, B, K, A, R));
     XG_TRY(cvt16(st, w, w.DVPROJ, (size_t)N * A));
     XG_TRY(nn16(st, w.gm, N, R, A, w.DVPROJ, m16(w, w.DVPROJ), A, p.v2a_w, w16(w, W16_V2A), R, w.DV, R, true));
@@ -1334,6 +1357,22 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
 // heads backward from dlogits (rows,V) in w.LOGITS and dcl (rows,C) in w.DCL -> DH2OUT, head param grads
 // Start of a full backward pass: clear the zero block beside whatever the main stream does first (the loss backward and
 // the first data-gradient product); decoder_bwd_core joins it.
+// The reverse-time loop in a TWO-launch form (round 5, XG_MA=1 of the diag build): the attention backward takes
+// dalpha_k = ds2 . M_k with M = V W_a2h^T (N x 4R, one product per backward, into the encoder's PRE[0] block, which nothing
+// reads after the encoder's forward recurrence) instead of d(context) . V_k, so the per-step product d(context) = ds2 W_a2h
+// leaves the chain -- it is formed for all steps at once behind the loop (dV needs it) -- and dh2 += ds2 W_h2h rides in the
+// step's remaining launch as a second segment.  Per step: attention backward -> one skinny launch, instead of skinny ->
+// attention backward -> skinny.  Parity suite green with it.  MEASURED AND NOT THE DEFAULT: 5.64-5.65 against 5.54-5.55 ms per
+// iteration.  The loop itself is only 60 us shorter (1285 vs 1344 us): the launch that disappears was 13 us of mostly real
+// work, and it comes back as +6 us in the attention backward (each of a video's two workgroups reads its 213 KB of M: 54 MB
+// per step) and +7 us in the remaining launch (K = 1536 -> 3584); the batched d(context) product (76 us) then sits on the main
+// chain in front of dV, and M (80 us) runs beside the head's products.
+bool ma_form(const XgDims& d, const XgParams& p, const Ws& w) {
+    static const bool on = xg_diag_env("XG_MA") != nullptr;
+    return on && d.R % 4 == 0 &&
+           xgk_attn_bwd_m_ok(w.DS2, 4 * d.R, w.P, w.vproj, w.PRE[0], 4 * d.R, p.a2w_w, w.DP, d.K, d.A);
+}
+
 int zero_backward_block(Streams& ss, Ws& w) {
     w.zeroed = false;
     if (!ss.overlap()) return XG_OK;
@@ -1354,6 +1393,13 @@ int heads_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams& g
     const int B = d.B, R = d.R, TB = d.T * B;
     const float* Hout = w.H2 + (size_t)B * R;
     XG_TRY(zero_backward_block(ss, w));       // (every caller continues with decoder_bwd_core, which joins it)
+    ss.m_ready = false;
+    if (ma_form(d, p, w)) {                   // M = V W_a2h^T for the attention backward of every step (see ma_form), beside the head's products
+        const int N = B * d.K;
+        if (!w.zeroed) XG_TRY(ss.fork2());    // (zero_backward_block forked the second side chain otherwise)
+        XG_TRY(lin16(ss.aux2, w.gm, N, 4 * R, R, w.Venc, m16(w, w.Venc), R, p.l2_a2h_w, nullptr, nullptr, w.PRE[0], 4 * R));
+        ss.m_ready = true;
+    }
     if (rows < TB) ZERO(w.DH2OUT + (size_t)rows * R, (size_t)(TB - rows) * R);
     // dH = dlogits * W: the reverse-time loop starts from the LAST step, so the rows of the late steps go first on the
     // main stream and the early steps' rows are produced on the auxiliary stream while the loop is already running.
