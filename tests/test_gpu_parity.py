@@ -1754,16 +1754,20 @@ def test_paired_rollout_over_videos_equals_the_repeated_batch_entry_point():
     np.testing.assert_allclose(lp[:B, :w[0]].cpu().numpy(), slp[:, :w[0]].cpu().numpy(), atol=2e-6)
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
-def test_in_place_steps_are_bitwise_reproducible(precision):
-    """Three consecutive xg_step_fwd calls on an in-place state (128 rows: the 8-wave launches that carry the fused attention
-    beside cell tiles), twelve times over: every repetition must give the same bits.  Round 4 found single elements of the
-    attention context differing from run to run in the split-bf16 mode (a compiler-formed v_pk_fma_f32 with operand-select
-    modifiers, see __graft_entry__.FLAGS); the accumulation order of the step is fixed, so anything but identical bits is a bug."""
+@pytest.mark.parametrize("precision,cfg,rows", [("fp32", "c1", 128), ("bf16x3", "c1", 128), ("bf16", "c1", 128), ("fp32", "c1", 64),
+                                                ("bf16x3", "c1", 64), ("fp32", "c1", 40), ("bf16", "c5", 128), ("bf16x3", "c5", 128),
+                                                ("fp32", "c5", 64)])
+def test_in_place_steps_are_bitwise_reproducible(precision, cfg, rows):
+    """Three consecutive xg_step_fwd calls on an in-place state, twelve times over: every repetition must give the same bits.
+    Round 4 found single elements of the attention context differing from run to run in the split-bf16 mode (a compiler-formed
+    v_pk_fma_f32 with operand-select modifiers, see __graft_entry__.FLAGS); the accumulation order of the step is fixed, so
+    anything but identical bits is a bug.  Shapes: 128 rows (the 8-wave launches that carry the fused attention beside cell
+    tiles), 64 and 40 rows (two row tiles, one of them ragged), hidden 1024 / 40 frames (4-wave workgroups), all three
+    arithmetic modes."""
     import ctypes as C
     from controllable_xgating_amd import _native as nv
     from controllable_xgating_amd.model import _stream, _ws_ptr
-    d = pg.make_dims(**dict(CFG["c1"], B=128))
+    d = pg.make_dims(**dict(CFG[cfg], B=rows))
     x = to_dev(pg.make_inputs(d, seed=0))
     model = make_model(d, train=False, precision=precision)
     with torch.no_grad():
@@ -1787,4 +1791,29 @@ def test_in_place_steps_are_bitwise_reproducible(precision):
             if first is None:
                 first = s.clone()
             else:
-                assert torch.equal(s, first), (precision, rep, float((s - first).abs().max()))
+                assert torch.equal(s, first), (precision, cfg, rows, rep, float((s - first).abs().max()))
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16x3"])
+def test_greedy_rollout_is_reproducible(precision):
+    """A whole greedy rollout (encoder, 20 core steps with the vocabulary product and the token choice per step) three times on
+    the same inputs.  fp32 arithmetic: identical tokens and identical log-probabilities, bit for bit.  Split-bf16: the tiled
+    products of that path split deep reductions across workgroups and add the partial tiles with fp32 atomics in arrival order
+    (xg_gemm_bf16.hip: splitk), so the encoder's output moves in its last bit from run to run (1.5e-7 measured): identical
+    tokens, log-probabilities within 2e-5.  (Plain bf16 rounds those differences up to 1e-4 and a near-tie may flip a token:
+    not asserted)"""
+    d = pg.make_dims(**dict(CFG["c1"], B=64))
+    x = to_dev(pg.make_inputs(d, seed=0))
+    model = make_model(d, train=False, precision=precision)
+    first = None
+    for rep in range(3):
+        with torch.no_grad():
+            seq, lp = model.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"sample_max": 1})
+        torch.cuda.synchronize()
+        if first is None:
+            first = (seq.clone(), lp.clone())
+        elif precision == "fp32":
+            assert torch.equal(seq, first[0]) and torch.equal(lp, first[1]), (precision, rep)
+        else:
+            assert torch.equal(seq, first[0]), (precision, rep)
+            np.testing.assert_allclose(lp.cpu().numpy(), first[1].cpu().numpy(), atol=2e-5, rtol=0)
