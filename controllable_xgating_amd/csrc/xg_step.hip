@@ -598,11 +598,10 @@ __device__ __forceinline__ void attn_part(const SkJob& job, int tile, float* sme
         if (lane == 0 && nrow > 0) atomicAdd(job.attn_s + b, ssum);
     }
     __syncthreads();
-#ifndef SKF_ATTN_NODRAIN
-    // Every vector-memory operation this wave has in flight lands before the context loop starts to recycle registers (round 4:
-    // without this the accumulated context showed run-to-run differences of single elements -- one frame's term, the low lane of
-    // the packed multiply-add -- whenever split-bf16 cell tiles shared the launch; the generated loop waits with vmcnt(N > 0)
-    // counts that assume a fixed number of older operations in flight, tools/step_mode_check.py).
+#ifdef SKF_ATTN_DRAIN
+    // (round 4 waited here for every vector-memory operation of the wave, `s_waitcnt vmcnt(0)`, as one of several changes made at
+    //  once against the run-to-run differences described below; round 5 took the changes apart -- tools/ubench notes in
+    //  docs/EXPERIMENTS.md -- and this one is not needed: 4 x 12 reproducibility cases without it)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
     // unnormalised context of this half: thread -> two adjacent columns
@@ -622,9 +621,14 @@ __device__ __forceinline__ void attn_part(const SkJob& job, int tile, float* sme
         }
 #else
         // four rows per trip, written out: the four loads are requested first, then the four weights come out of LDS one by one
-        // (scalar reads, no b128), then the multiply-adds.  (Round 4: the compiler's own 4-way unrolling of the simple loop --
-        // address registers of the loads recycled as the destination of a ds_read_b128 two instructions later -- gave run-to-run
-        // differences of single context elements beside split-bf16 cell tiles in the same launch; tools/step_mode_check.py.)
+        // (scalar reads, no b128), then the multiply-adds as plain v_fmac_f32, pinned.  Why: when the SLP vectorizer pairs the two
+        // accumulators (one ds_read_b128 for the four weights, four v_pk_fma_f32 with operand-select modifiers, one v_mov that
+        // moves the fourth weight into the first pair) the accumulated context shows run-to-run differences of single elements
+        // (~1e-4) -- but ONLY beside split-bf16 cell tiles in the same launch: the very same instruction sequence inside the
+        // fp32 and bf16 instantiations never does (round 5: loop ISA identical to the register numbers, -DSKF_ATTN_PKFMA with
+        // -fslp-vectorize fails 1-2 of 9 shapes per run, always bf16x3 at 128 rows; the pinned form passes with the vectorizer
+        // on, the plain form passes with it off).  No cause inside the instruction stream was found; the narrow remedy is this
+        // pinned form, the global -fno-slp-vectorize (__graft_entry__.FLAGS) is kept as the guard for every other float2 loop.
         const float* vp = Vb + (size_t)k0 * R + c;
         int r = 0;
         for (; r + 4 <= nrow; r += 4) {
