@@ -29,9 +29,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/xe5 -- python bench
 python tools/prof_summary.py $OUT/xe5 $OUT/${R}_xe5_bf16_kernel_stats.txt 15 > /dev/null
 # 4. large products alone
 python tools/ubench/gemm_bench.py > $OUT/${R}_gemm_bench_raw.txt 2>&1
-# 5. in-kernel stamps of the step's launches and instruction counts by region (variant libraries built beforehand)
+# 5. in-kernel stamps of the step's launches and instruction counts by region (variant libraries built beforehand: tools/ubench/build_ablate.py,
+#    __graft_entry__.build_variant('sktrace', ['-DSK_TRACE']); skipped when they are not there)
+if [ -f controllable_xgating_amd/lib/libxgate_hip_sktrace.so ] && [ -f controllable_xgating_amd/lib/libxgate_hip_abl1.so ]; then
 { echo "# tools/sk_trace_all.sh on the final round-5 kernel: in-kernel stamps of the decoder step's launches, B = 128 (same columns as r05_sk_trace_before.txt)"; SK_PRECS="fp32 bf16" bash tools/sk_trace_all.sh 2>&1 | grep -v amdgpu.ids; echo; echo "# launches inside the training iteration (tools/sk_trace_iter.py): 2 jobs x 256 x 256 threads = the encoder's backward recurrence (last launch), 1 x 128 x 256 = chain 1"; XG_LIBRARY=$GRAFT_REPO_ROOT/controllable_xgating_amd/lib/libxgate_hip_sktrace.so python tools/sk_trace_iter.py 2>&1 | grep -v amdgpu.ids; } > $OUT/${R}_sk_trace_after.txt
 { echo "# tools/ubench/ablate_step.sh: rocprofv3 --pmc instruction counts of the step's launches for builds that return behind (6) the descriptor round,"; echo "# (1) tile decode, (2) epilogue-operand requests, (5) first segment set-up + first operand request, (3) the K loops, (4) the reduction; per-dispatch totals"; echo "# (skf_kernel<8,0,true,1> = cell 2's launch: 4096 waves of which 2048 belong to product tiles)"; bash tools/ubench/ablate_step.sh 2>&1; } > $OUT/${R}_step_ablation.txt
+fi
 # 6. the bench lines themselves (un-profiled)
 python bench.py > $OUT/${R}_bench_line.json 2> $OUT/bench_line.err
 python bench.py --no-cpu-baseline --workload scst > $OUT/${R}_bench_line_scst.json 2>/dev/null
