@@ -512,7 +512,11 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
             for (int m = 0; m < 2; ++m) {
                 // dh of frame i-1 = dS[i] Whh (+ dHs[i-1]); fused: frame i-1's cell backward in the epilogue
                 // (the product accumulates into dHs[i-1], which nothing reads afterwards: split-K across workgroups allowed)
-                if (fuse) { sk.job[m] = job_lstm_bwd(enc_cell_bwd(m, i - 1, curc, true), w.dHs[m] + (size_t)(i - 1) * R, K * R); allow_split(sk, m, w); }
+                if (fuse) {
+                    sk.job[m] = job_lstm_bwd(enc_cell_bwd(m, i - 1, curc, true), w.dHs[m] + (size_t)(i - 1) * R, K * R); allow_split(sk, m, w);
+                    static const int enc_ks = xg_diag_env("XG_ENC_KS") ? atoi(xg_diag_env("XG_ENC_KS")) : 0;     // experiment: split cap of the encoder's backward launches
+                    sk.job[m].ksplit_cap = enc_ks;
+                }
                 else sk.job[m] = job_store(B, R, w.dHrec[m], R, false);
                 sk.job[m].nseg = 1;
                 sk.job[m].seg[0] = seg_nn(w, m == 0 ? PKB_ENC_RGB : PKB_ENC_OPFL, w.dS[m] + (size_t)i * 4 * R, K * 4 * R, whh[m], R, 4 * R);
@@ -1139,10 +1143,12 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         allow_split(sk, 0, w); j.tickets = w.tickets + 2 * 1024;       // chain 1 runs beside chain 2 / the encoder: own counters
         // Chain 1 has slack (one launch per step against chain 2's three) and only feeds parameter gradients: it must not crowd
         // chain 2.  Launched one step behind with the full 8-way split (512 workgroups) it took the wave slots the attention
-        // backward needed beside a background product (attention 40 us in situ against 12.7 alone).  So: at most a 2-way split
-        // (128 workgroups), default wave priority, and its launches in batches of c1_lag steps (measured on MI355X,
+        // backward needed beside a background product (attention 40 us in situ against 12.7 alone).  So: a capped split
+        // (round 4: 2-way, 128 workgroups), default wave priority, and its launches in batches of c1_lag steps (measured on MI355X,
         // tools/ubench/c1_sweep.sh: 6.08 -> 5.93 ms per iteration).
-        static const int c1_ks = xg_diag_env("XG_C1_KS") ? atoi(xg_diag_env("XG_C1_KS")) : 2;
+        // (round 5, lean kernel + the launcher's one-workgroup-per-CU split rule: a 4-way split -- 256 workgroups -- is the better
+        //  cap again, 5.47-5.48 -> 5.44-5.45 ms; tools/ubench/caps_iter.sh)
+        static const int c1_ks = xg_diag_env("XG_C1_KS") ? atoi(xg_diag_env("XG_C1_KS")) : 4;
         static const int c1_lowprio = xg_diag_env("XG_C1_LOWPRIO") ? atoi(xg_diag_env("XG_C1_LOWPRIO")) : 1;
         j.ksplit_cap = c1_ks; j.low_prio = c1_lowprio;
         XG_TRY(xgk_skinny(s1, sk, w.gm));

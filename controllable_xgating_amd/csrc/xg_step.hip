@@ -1364,7 +1364,15 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         }
         int cap = 8;
         for (int j = 0; j < a.njobs; ++j) if (a.job[j].ksplit_cap > 0 && a.job[j].ksplit_cap < cap) cap = a.job[j].ksplit_cap;
-        if (ok) while (ks < cap && tiles * ks * 2 <= 512 && min_chunks / (ks * 2) >= 4) ks *= 2;
+        // Split until the launch has one workgroup per CU; beyond that (up to two per CU) only while every part keeps a deep
+        // reduction.  (Round 4 filled 512 slots whenever it could; with the lean kernel of round 5 a part's fixed cost is
+        // instruction issue and the ticket phase, not latency, and FEWER, longer parts win at hidden 512 -- encoder backward
+        // and the reverse-time launches 4 / 4 / 8 -> 2 / 2 / 4 parts: 5.54-5.56 -> 5.50-5.51 ms, SCST 6.04 -> 6.00 -- while the
+        // 128-chunk reductions of hidden 1024 still want their two parts: tools/ubench/sktarget_iter.sh.)
+        static const int target = xg_diag_env("XG_SK_TARGET") ? atoi(xg_diag_env("XG_SK_TARGET")) : 256;     // diagnosis
+        static const int deep = xg_diag_env("XG_SK_DEEP_CHUNKS") ? atoi(xg_diag_env("XG_SK_DEEP_CHUNKS")) : 64;
+        if (ok) while (ks < cap && min_chunks / (ks * 2) >= 4 &&
+                       (tiles * ks * 2 <= target || (tiles * ks * 2 <= 512 && min_chunks / ks >= deep))) ks *= 2;
         for (int j = 0; j < a.njobs; ++j) a.job[j].ksplit = ks;
         tiles *= ks; max_tiles *= ks;
     }
