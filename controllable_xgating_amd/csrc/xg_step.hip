@@ -1426,7 +1426,8 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         // (bf16 tiles, hidden 1024: 4-wave workgroups throughout -- half the register footprint per workgroup is easier to place
         //  beside the bf16 GEMMs of the other streams: 8.20 -> 8.14 ms; at hidden 512 the rule above stands: fp32 6.08 vs 6.09,
         //  bf16 4.59 vs 4.66 ms)
-        const bool nw4_rule = ks > 1 || (force_nw ? force_nw == 4 : ((bf16 && max_k >= 1024) || tiles > 2 * 256));
+        static const int split_nw = xg_diag_env("XG_SK_SPLIT_NW") ? atoi(xg_diag_env("XG_SK_SPLIT_NW")) : 4;     // experiment: waves of a split launch's workgroups
+        const bool nw4_rule = (ks > 1 && (split_nw != 8 || tiles > 256)) || (force_nw ? force_nw == 4 : ((bf16 && max_k >= 1024) || tiles > 2 * 256));
         const dim3 grid((max_tiles + 7) & ~7, a.njobs);
         bool scaled = false;
         for (int j = 0; j < a.njobs; ++j)
