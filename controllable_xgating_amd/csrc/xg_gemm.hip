@@ -1294,7 +1294,8 @@ int dispatch(hipStream_t st, GemmArgs g, bool vec) {
         g.splitk = (int)sk;
     }
     else if (!g.relu && t64 >= 4) {
-        const long target = (AKC && BKC) ? 768 : 1536;
+        static const long tgt_pct = xg_diag_env("XG_GEMM_SPLIT_PCT") ? atol(xg_diag_env("XG_GEMM_SPLIT_PCT")) : 100;     // experiment: scale the split target
+        const long target = ((AKC && BKC) ? 768 : 1536) * tgt_pct / 100;
         long sk = target / t64;
         if (sk > nslab / 16) sk = nslab / 16;      // keep K >= 512 per split
         if (sk >= 2) g.splitk = (int)sk;
