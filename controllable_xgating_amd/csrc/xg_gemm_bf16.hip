@@ -687,6 +687,10 @@ int xgk_gemm_bf16x(hipStream_t st, int planes, bool transA, bool transB, int M, 
         g.gm = xgk_group_rows(2 * K / g.splitk);
         return bkc ? launch_bx<256, 128, 4, 2, true, true>(st, g) : launch_bx<256, 128, 4, 2, true, false>(st, g);
     }
+    // both operands bf16 in memory: tiles by LDS-DMA, 64-deep slabs, one barrier per slab (xg_gemm_g16.hip)
+    static const bool no_g16 = xg_diag_env("XG_NO_G16") != nullptr;
+    if (g.A16 && g.B16 && !no_g16 && xgk_gemm_g16_ok(transA, transB, M, N, K, g.A16, lda, g.B16, ldb))
+        return xgk_gemm_g16(st, transA, transB, M, N, K, g.A16, lda, g.B16, ldb, C, ldc, bias, relu, accumulate, 0, cs1, cs2, cs3);
     g.gm = xgk_group_rows(K / g.splitk);
     if (g.A16 || g.B16) {
         if (akc && bkc) return dispatch16<true, true>(st, g);

@@ -37,6 +37,11 @@ int xgk_gemm_bf16(hipStream_t st, int planes, bool transA, bool transB, int M, i
 int xgk_gemm_bf16x(hipStream_t st, int planes, bool transA, bool transB, int M, int N, int K, const float* A, const unsigned short* A16,
                    int lda, const float* B, const unsigned short* B16, int ldb, float* C, int ldc, const float* bias, bool relu,
                    bool accumulate, float* cs1 = nullptr, float* cs2 = nullptr, float* cs3 = nullptr);
+// xg_gemm_g16.hip: both operands bf16 in memory, tiles by LDS-DMA (round 5); xgk_gemm_g16_ok says whether a product qualifies
+bool xgk_gemm_g16_ok(bool transA, bool transB, int M, int N, int K, const unsigned short* A16, int lda, const unsigned short* B16, int ldb);
+int xgk_gemm_g16(hipStream_t st, bool transA, bool transB, int M, int N, int K, const unsigned short* A16, int lda,
+                 const unsigned short* B16, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate, int splitk,
+                 float* cs1, float* cs2, float* cs3);
 int xgk_cvt_bf16(hipStream_t st, const float* src, unsigned short* dst, size_t n);      // fp32 -> bf16 (RNE), both 16-byte aligned
 // Y[M,N] (+)= X[M,K] W[N,K]^T + bias   (nn.Linear forward)
 static inline int xgk_linear(hipStream_t st, int mode, int M, int N, int K, const float* X, int ldx, const float* W,

@@ -876,6 +876,34 @@ def test_scheduled_sampling_vs_oracle():
 
 # ---------------------------------------------------------------- bf16 matrix-core modes (BASELINE.json configs[4])
 @pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
+@pytest.mark.parametrize("M,N,K", [(256, 256, 128), (2688, 1000, 1024), (328, 2048, 2688), (1408, 512, 20000), (136, 264, 200),
+                                   (5120, 1024, 1536)])
+def test_gemm_bf16_operands_in_memory(M, N, K, ta, tb):
+    """Both operands bf16 in memory (xg_gemm_bf16_operands; round 5: tiles by LDS-DMA, xg_gemm_g16.hip, where the shape
+    qualifies -- ragged M / N edges, a K tail next to an m-contiguous operand, deep reductions split across workgroups; the
+    register-staged kernel elsewhere).  The operands ARE the bf16 values, so the product is checked element by element against
+    fp64 of the same values at fp32-accumulation tolerance -- a misplaced fragment or a wrong swizzle cannot hide in bf16
+    round-off."""
+    from controllable_xgating_amd import _native as nv
+    L = nv.lib()
+    g = torch.Generator().manual_seed(11 * M + 5 * N + K + ta * 2 + tb)
+    A = torch.randn((K, M) if ta else (M, K), generator=g).bfloat16(); Bm = torch.randn((N, K) if tb else (K, N), generator=g).bfloat16()
+    bias = torch.randn(N, generator=g); C0 = torch.randn(M, N, generator=g)
+    ref = (A.t() if ta else A).double() @ (Bm.t() if tb else Bm).double() + bias.double()
+    A16, B16, bd = A.cuda(), Bm.cuda(), bias.cuda()
+    Af, Bf = A16.float(), B16.float()
+    for relu, acc in ((0, 0), (1, 0), (0, 1)):
+        Cd = C0.clone().cuda()
+        assert L.xg_gemm_bf16_operands(None, ta, tb, M, N, K, nv.ptr(Af), nv.ptr(A16), A.shape[1], nv.ptr(Bf), nv.ptr(B16), Bm.shape[1],
+                                       nv.ptr(Cd), N, nv.ptr(bd), relu, acc) == 0
+        want = ref + (C0.double() if acc else 0)
+        if relu:
+            want = want.clamp(min=0)
+        err = float((Cd.cpu().double() - want).abs().max())
+        assert err <= (2e-6 * np.sqrt(K) * 4 + 1e-6) * max(1.0, float(want.abs().max())), (relu, acc, err)
+
+
+@pytest.mark.parametrize("ta,tb", [(0, 1), (0, 0), (1, 0), (1, 1)])
 @pytest.mark.parametrize("M,N,K", [(512, 384, 300), (300, 200, 129), (2688, 512, 468)])
 def test_gemm_bf16_modes(M, N, K, ta, tb):
     """mode 3 (split-bf16, 6 MFMAs) must be fp32-class; mode 1 (bf16 operands) within bf16 round-off."""

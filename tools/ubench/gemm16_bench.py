@@ -32,7 +32,10 @@ for name, ta, tb, M, N, K in SHAPES:
     sl = slice(0, min(256, M))
     ref = ((A.t() if ta else A)[sl].double() @ (B.t() if tb else B).double())
     res = {}
-    for tag, a16, b16 in (("fp32 operands", None, None), ("A bf16", A16, None), ("B bf16", None, B16), ("both bf16", A16, B16)):
+    cases = (("fp32 operands", None, None), ("A bf16", A16, None), ("B bf16", None, B16), ("both bf16", A16, B16))
+    if len(sys.argv) > 1 and sys.argv[1] == "both":
+        cases = cases[3:]
+    for tag, a16, b16 in cases:
         def call():
             assert L.xg_gemm_bf16_operands(None, ta, tb, M, N, K, nv.ptr(A), nv.ptr(a16), A.shape[1], nv.ptr(B), nv.ptr(b16), B.shape[1],
                                            nv.ptr(Cc), N, None, 0, 0) == 0
