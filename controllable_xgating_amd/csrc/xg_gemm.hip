@@ -1363,7 +1363,14 @@ int xgk_gemm_cs(hipStream_t st, int mode, bool transA, bool transB, int M, int N
     const int bg = (mode & XGK_GEMM_BG) ? 1 : 0;
     mode &= ~XGK_GEMM_BG;
     // large products may run on the bf16 matrix cores (split-bf16 or plain bf16); skinny / tiny ones stay fp32
-    if ((mode == 1 || mode == 3) && M >= 256 && N >= 64 && K >= 64) {
+    // Split-bf16 (mode 3) keeps the weight-gradient layout (transA) in exact fp32 (round 5): alone the fp32 kernels are level or
+    // ahead there (2048 x 512 x 2688: 60 against 65 us, dW_logit 504 against 530), and inside the iteration the 21 split-bf16
+    // weight gradients ran at 131 us each beside the chains (63 alone) and held the encoder's backward and the update back by
+    // 0.4 ms.  The other layouts stay split (logits 453 against 539 us, dH 381 against 514, PRE 58 against 80).
+    // (diag: XG_X3_FP32 = mask of the classes routed to exact fp32 in mode 3 -- 1 TN, 2 NT, 4 NN; default 1)
+    static const int x3_fp32 = xg_diag_env("XG_X3_FP32") ? atoi(xg_diag_env("XG_X3_FP32")) : 1;
+    const bool x3_exact = mode == 3 && (x3_fp32 & (transA ? 1 : (transB ? 2 : 4)));
+    if ((mode == 1 || mode == 3) && !x3_exact && M >= 256 && N >= 64 && K >= 64) {
         return xgk_gemm_bf16(st, mode, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, cs1, cs2, cs3);
     }
 #ifdef XG_DIAG

@@ -668,8 +668,13 @@ int xgk_gemm_bf16x(hipStream_t st, int planes, bool transA, bool transB, int M, 
     const int nslab = xg_cdiv(K, BK);
     if (!relu && tiles < 512) {                     // fill the chip by splitting deep reductions (3 workgroups per CU would fit,
                                                     // but 768 shares were measured slower: dX 52 -> 83 us, dW_logit 157 -> 169 us)
-        long sk = (512 + tiles - 1) / tiles;
+        // ... and never PAST the 512 slots (round 5): the rule used to round up, so 104 tiles became 5 x 104 = 520 workgroups -- a
+        // second round for 8 of them -- and 416 tiles two rounds of 832.  Rounded down (split-bf16, alone): encoder embedding
+        // 98 -> 63 us, dX 110 -> 74, PRE 104 -> 59, v2a(V) 94 -> 58 (tools/ubench/bs_skmax.sh)
+        long sk = 512 / tiles;
         if (sk > nslab / 8) sk = nslab / 8;
+        static const char* skmax = xg_diag_env("XG_BS_SKMAX");      // diag: cap of the split (sweeps)
+        if (skmax && sk > atoi(skmax)) sk = atoi(skmax);
         if (sk >= 2) g.splitk = (int)sk;
     }
     // plain bf16 with a k-contiguous A (forward and data-gradient layouts): 256 x 128 tiles, 43 flop per operand byte instead
