@@ -192,12 +192,13 @@ extern "C" int xg_pack_weights(void* stream, const XgDims* d, const XgParams* p,
                                int dtype, int with_backward) {
     return pack_part(stream, d, p, packed, packed_bytes, dtype, with_backward, 0);
 }
-// part 1: everything but the CG encoder's recurrent matrices; part 2: those only (fp32 tiles only).  The decoder's matrices are
+// part 1: everything but the CG encoder's matrices; part 2: those only (bf16 tiles, dtype 1: the plain bf16 weight copies are
+// split the same way -- the encoder's embeddings, input-side LSTM matrices, cross gates and fusion belong to part 2).  The decoder's matrices are
 // final -- updated -- long before the encoder's (train.ClipAdam(overlap=True)): a caller can refresh their tiles under the
 // encoder's backward and only the encoder's four tiles at the head of the next iteration.
 extern "C" int xg_pack_weights_part(void* stream, const XgDims* d, const XgParams* p, void* packed, size_t packed_bytes,
                                     int dtype, int with_backward, int part) {
-    if (part < 0 || part > 2 || (part != 0 && dtype != 0)) return XG_EINVAL;
+    if (part < 0 || part > 2) return XG_EINVAL;
     return pack_part(stream, d, p, packed, packed_bytes, dtype, with_backward, part);
 }
 static int pack_part(void* stream, const XgDims* d, const XgParams* p, void* packed, size_t packed_bytes, int dtype, int with_backward, int part) {
@@ -234,12 +235,15 @@ static int pack_part(void* stream, const XgDims* d, const XgParams* p, void* pac
         unsigned wgs = 0;
         for (int i = 0; i < W16_COUNT; ++i) {
             if (!we[i].src || ((uintptr_t)we[i].src % 16) || we[i].n % 8) return XG_EINVAL;
-            c.src[i] = we[i].src; c.dst[i] = const_cast<unsigned short*>(v.w16[i]); c.n8[i] = (unsigned)(we[i].n / 8);
+            const bool enc = i == W16_EMB_RGB || i == W16_EMB_OPFL || i == W16_WIH_RGB || i == W16_WIH_OPFL || i == W16_GATE_RGB ||
+                             i == W16_GATE_OPFL || i == W16_FUSION;            // two_spatial_encoder.*
+            const bool skip = (part == 1 && enc) || (part == 2 && !enc);
+            c.src[i] = we[i].src; c.dst[i] = const_cast<unsigned short*>(v.w16[i]); c.n8[i] = skip ? 0u : (unsigned)(we[i].n / 8);
             c.wg0[i] = wgs;
             wgs += (c.n8[i] + 255) / 256;
         }
         c.wg0[W16_COUNT] = wgs;
-        hipLaunchKernelGGL(cvt_multi_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, c);
+        if (wgs > 0) hipLaunchKernelGGL(cvt_multi_kernel, dim3(wgs), dim3(256), 0, (hipStream_t)stream, c);
         XG_CHECK_LAUNCH();
     }
     return XG_OK;

@@ -309,19 +309,20 @@ class SAModel(nn.Module):
         """For an optimizer that has JUST updated every parameter group except the CG encoder's on the current stream (and will
         call mark_params_changed() when the rest is done): refresh the packed tiles of the decoder's matrices here and now, under
         the encoder's backward, instead of at the head of the next iteration (xg_pack_weights_part, part 1).  The next
-        _packed_ptr() then only packs the encoder's tiles.  No-op when there is nothing to gain (bf16 tiles, no shadow yet, a
-        HIP-graph capture)."""
-        if self.precision == "bf16" or self._packed is None or torch.cuda.is_current_stream_capturing():
+        _packed_ptr() then only packs the encoder's tiles (and, with bf16 tiles, the bf16 copies of the encoder's weights).  No-op
+        when there is nothing to gain (no shadow yet, a HIP-graph capture)."""
+        if self._packed is None or torch.cuda.is_current_stream_capturing():
             return
         self._ensure_flat()
-        key = (self._flat.data_ptr(), self._flat._version, self._packed_epoch, 0, tuple(p._version for p in self._plist()))
+        dtype = 1 if self.precision == "bf16" else 0
+        key = (self._flat.data_ptr(), self._flat._version, self._packed_epoch, dtype, tuple(p._version for p in self._plist()))
         d = self._dims(1, 1, 1)
-        nbytes = nv.lib().xg_packed_bytes(C.byref(d), 0)
+        nbytes = nv.lib().xg_packed_bytes(C.byref(d), dtype)
         if nbytes == 0 or self._packed.numel() < nbytes + 16:
             return
         ptr = (self._packed.data_ptr() + 15) & ~15
         ps = self._params_struct()
-        nv.check(nv.lib().xg_pack_weights_part(_stream(), C.byref(d), C.byref(ps), C.c_void_p(ptr), C.c_size_t(nbytes), 0, 1, 1),
+        nv.check(nv.lib().xg_pack_weights_part(_stream(), C.byref(d), C.byref(ps), C.c_void_p(ptr), C.c_size_t(nbytes), dtype, 1, 1),
                  "xg_pack_weights_part")
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
@@ -362,11 +363,11 @@ class SAModel(nn.Module):
                 # the decoder's matrices may already have been refreshed behind the optimizer's update of their parameter group
                 # (pack_early, under the CG encoder's backward): then only the encoder's four tiles are left for the head of the
                 # iteration, behind an event that completed long ago
-                early = (not fresh and dtype == 0 and getattr(self, "_early_key", None) == key[:2] + key[3:] and
+                early = (not fresh and getattr(self, "_early_key", None) == key[:2] + key[3:] and
                          self._early_epoch == self._packed_epoch and not torch.cuda.is_current_stream_capturing())
                 if early:
                     torch.cuda.current_stream().wait_event(self._early_event)
-                    nv.check(nv.lib().xg_pack_weights_part(_stream(), C.byref(d), C.byref(ps), C.c_void_p(ptr), C.c_size_t(nbytes), 0, 1, 2),
+                    nv.check(nv.lib().xg_pack_weights_part(_stream(), C.byref(d), C.byref(ps), C.c_void_p(ptr), C.c_size_t(nbytes), dtype, 1, 2),
                              "xg_pack_weights_part")
                 else:
                     nv.check(nv.lib().xg_pack_weights(_stream(), C.byref(d), C.byref(ps), C.c_void_p(ptr), C.c_size_t(nbytes), dtype, 1),

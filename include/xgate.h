@@ -329,7 +329,7 @@ int xg_reward_bwd(void *stream, const int64_t *seq, int ld_seq, const float *rew
 size_t xg_packed_bytes(const XgDims *d, int dtype);
 int xg_pack_weights(void *stream, const XgDims *d, const XgParams *p, void *packed, size_t packed_bytes,
                     int dtype, int with_backward);
-/* The same refresh in two parts (dtype 0 only): part 1 = every matrix but the CG encoder's recurrent ones, part 2 = those
+/* The same refresh in two parts: part 1 = every matrix but the CG encoder's (two_spatial_encoder.*), part 2 = those
  * (part 0 = xg_pack_weights).  An optimizer that updates the parameter groups as their gradients become final -- the decoder's
  * before the CG encoder's backward, train.ClipAdam(overlap=True) -- refreshes part 1 right behind that update, under the
  * encoder's backward, and part 2 at the head of the next iteration (6 us instead of 42 in front of the first product). */

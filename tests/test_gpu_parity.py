@@ -627,15 +627,17 @@ def test_overlapped_update_equals_plain_update():
         assert float((p0[n] - p1[n]).abs().max()) < 5e-6, n
 
 
-def test_early_repack_of_the_decoder_tiles_equals_a_full_repack():
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_early_repack_of_the_decoder_tiles_equals_a_full_repack(precision):
     """ClipAdam(overlap=True) refreshes the packed tiles of every matrix but the CG encoder's right behind the update of their
     parameter group (SAModel.pack_early: xg_pack_weights_part, part 1, on the optimizer's side stream, under the encoder's
     backward) and the next call only packs the encoder's tiles (part 2): the shadow must be bit-identical to a full
-    xg_pack_weights of the updated parameters -- and stale when the early part is skipped on purpose (the test tests something)."""
+    xg_pack_weights of the updated parameters -- and stale when the early part is skipped on purpose (the test tests something).
+    bf16: the same for the bf16 tiles and the bf16 copies of the large products' weights (round 5)."""
     from controllable_xgating_amd.train import ClipAdam
     d = pg.make_dims(**CFG["mid"])
     x = to_dev(pg.make_inputs(d, seed=0, ragged=True))
-    model = make_model(d)
+    model = make_model(d, precision=precision)
     opt = ClipAdam(model, lr=4e-4, grad_clip=0.1, overlap=True, fused_zero=True)
     for it in range(3):
         opt.zero_grad()

@@ -15,7 +15,11 @@ SHAPES = [  # name, ta, tb, M, N, K
     ("enc dX NN 5120x1024 K=4096", 0, 0, 5120, 1024, 4096),
     ("dec wgrad TN 4096x1024 K=2688", 1, 0, 4096, 1024, 2688),
     ("emb NT 5120x1024 K=1536", 0, 1, 5120, 1024, 1536),
+    ("emb dW TN 1024x1536 K=5120", 1, 0, 1024, 1536, 5120),
+    ("emb dW TN 1024x1024 K=5120", 1, 0, 1024, 1024, 5120),
 ]
+if os.environ.get("XG_GEMM_SHAPES"):
+    SHAPES = [s for s in SHAPES if any(k in s[0] for k in os.environ["XG_GEMM_SHAPES"].split(","))]
 def bench(fn, n=20):
     for _ in range(3): fn()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
