@@ -344,6 +344,8 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
     opt = make_opt(None, vocab_size=cfg["V"], seq_length=cfg["L"], drop_prob_lm=args.drop, precision=precision,
                    rnn_size=cfg["R"], att_size=cfg["A"], input_encoding_size=cfg["E"], feat_size=cfg["F1"], feat_size2=cfg["F2"])
     model = SAModel(opt).to(dev)
+    if os.environ.get("XG_X3_TILES") is not None:       # diagnosis: split-bf16 over fp32 tiles (0: split in registers) instead of pre-split planes
+        model._packed_dtype_override = int(os.environ["XG_X3_TILES"])
     model.train()
     broadcast_parameters(model)
     x = synth_inputs(cfg["B"], cfg["K"], cfg["L"], cfg["V"], cfg["R"], cfg["F1"], cfg["F2"], cfg["C"], seed=rank, device=dev)
@@ -643,6 +645,8 @@ def step_group_by_arithmetic(args, ctx):
         opt = make_opt(None, vocab_size=cfg["V"], seq_length=cfg["L"], precision=precision, rnn_size=cfg["R"], att_size=cfg["A"],
                        input_encoding_size=cfg["E"], feat_size=cfg["F1"], feat_size2=cfg["F2"])
         model = SAModel(opt).to(ctx["dev"])
+        if os.environ.get("XG_X3_TILES") is not None:
+            model._packed_dtype_override = int(os.environ["XG_X3_TILES"])
         model.eval()
         out[precision] = round(measure_step_group(model, x) * 1e6, 2)
         del model

@@ -238,6 +238,8 @@ static_assert(sizeof(SkJob) % 64 == 0 && sizeof(SkJob) * SK_MAX_JOBS + 64 <= 409
 struct SkArgs { int njobs; int tile0[SK_MAX_JOBS]; int pad_[10]; SkJob job[SK_MAX_JOBS]; };
 static_assert(offsetof(SkArgs, job) == 64, "descriptor lines");
 // gemm_mode 1 (plain bf16) rounds the staged chunks to bf16 (LDS-staged kernel); 0 / 3: exact fp32
+// `gemm_mode | XGK_SK_PLANES` (mode 3 only): the packed tiles (SkSeg::Bp) hold three pre-split bf16 planes (xg_pack.hip, dtype 2)
+enum { XGK_SK_PLANES = 0x200 };
 int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode);
 
 // ---- xg_dstep.hip : one decoder step (attention + POS gate + the two cells, sub_modules.py:671-687) as ONE dataflow launch
@@ -271,7 +273,7 @@ enum { PK_H2A1 = 0, PK_H2A2, PK_DGATE, PK_L1_I2H, PK_L1_A2H, PK_L1_H2H, PK_L2_I2
 // the bf16 GEMMs read them instead of converting the fp32 weights on every pass (BASELINE.json configs[4])
 enum { W16_LOGIT = 0, W16_EMB_RGB, W16_EMB_OPFL, W16_WIH_RGB, W16_WIH_OPFL, W16_GATE_RGB, W16_GATE_OPFL, W16_FUSION, W16_V2A,
        W16_DGATE, W16_L1_I2H, W16_L1_A2H, W16_COUNT };
-struct PackedView { const float* m[PK_COUNT]; int nck[PK_COUNT]; int dtype;       // dtype 0: fp32 tiles (4 KB), 1: bf16 tiles (2 KB)
+struct PackedView { const float* m[PK_COUNT]; int nck[PK_COUNT]; int dtype;       // dtype 0: fp32 tiles (4 KB), 1: bf16 tiles (2 KB), 2: three bf16 planes (6 KB)
                     const unsigned short* w16[W16_COUNT]; };                      // (null for dtype 0)
 size_t xgk_packed_floats(const XgDims& d);
 size_t xgk_packed_total_bytes(const XgDims& d, int dtype);

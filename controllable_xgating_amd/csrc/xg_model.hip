@@ -305,12 +305,16 @@ inline int zero_dsync(hipStream_t st, const Ws& w) {
     return XG_OK;
 #endif
 }
-// (the tile element type must fit the arithmetic: bf16 tiles for gemm_mode 1, fp32 tiles otherwise)
+// (the tile element type must fit the arithmetic: bf16 tiles for gemm_mode 1; fp32 tiles otherwise; pre-split planes -- dtype 2 --
+// for gemm_mode 3 only)
 inline void attach_packed(Ws& w, const XgDims& d, const XgRun* run) {
     static const bool disabled = xg_diag_env("XG_NO_PACKED") != nullptr;
     w.packed = !disabled && run && run->packed && (run->gemm_mode == 1) == (run->packed_dtype == 1) &&
+               (run->packed_dtype != 2 || run->gemm_mode == 3) &&
                xgk_packed_view(d, run->packed, run->packed_dtype, &w.pk);
 }
+// what the per-step launcher is told: the arithmetic mode, and whether the attached tiles are pre-split planes
+inline int sk_mode(const Ws& w) { return w.gm | ((w.gm == 3 && w.packed && w.pk.dtype == 2) ? XGK_SK_PLANES : 0); }
 inline SkJob job_store(int M, int N, float* C, int ldc, bool acc, bool relu = false) {
     SkJob j{};
     j.M = M; j.N = N; j.C = C; j.ldc = ldc; j.accumulate = acc ? 1 : 0; j.relu = relu ? 1 : 0; j.epi = SK_EPI_STORE;
@@ -419,7 +423,7 @@ int encoder_fwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgBnSt
                 XG_TRY(xgk_lstm_fwd(st, a));
             }
         }
-        if (R % 8 == 0) XG_TRY(xgk_skinny(st, sk, w.gm));
+        if (R % 8 == 0) XG_TRY(xgk_skinny(st, sk, sk_mode(w)));
     }
     // cross gates, all frames at once (gated values are not fed back): sub_modules.py:151-152
     XG_TRY(cvt16(st, w, w.Hs[0], (size_t)N * R));
@@ -521,7 +525,7 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
                 sk.job[m].nseg = 1;
                 sk.job[m].seg[0] = seg_nn(w, m == 0 ? PKB_ENC_RGB : PKB_ENC_OPFL, w.dS[m] + (size_t)i * 4 * R, K * 4 * R, whh[m], R, 4 * R);
             }
-            XG_TRY(xgk_skinny(st, sk, w.gm));
+            XG_TRY(xgk_skinny(st, sk, sk_mode(w)));
         }
     }
     for (int m = 0; m < 2; ++m) XG_TRY(cvt16(st, w, w.dS[m], (size_t)N * 4 * R));      // read by three products each
@@ -566,7 +570,7 @@ int init_hidden(hipStream_t st, const XgDims& d, const XgParams& p, const float*
             sk.job[j] = job_store(B, R, out[j], R, false);
             sk.job[j].nseg = 1; sk.job[j].seg[0] = seg_nt(w.vbar, R, wt[j], R, R); sk.job[j].bias[0] = bs[j];
         }
-        return xgk_skinny(st, sk, w.gm);
+        return xgk_skinny(st, sk, sk_mode(w));
     }
     for (int j = 0; j < 4; ++j) XG_TRY(xgk_linear(st, w.gm, B, R, R, w.vbar, R, wt[j], bs[j], out[j], R));
     return XG_OK;
@@ -629,7 +633,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
     // below ~16 rows (30 vs 34 us at 8 rows).
 #ifdef XG_DIAG
     static const bool use_dstep = xg_diag_env("XG_DSTEP") != nullptr;
-    if (use_dstep && step_packed(w, d) && xgk_dstep_ok(d) && ((uintptr_t)V % 16 == 0) && ((uintptr_t)vproj % 16 == 0) &&
+    if (use_dstep && w.pk.dtype != 2 && step_packed(w, d) && xgk_dstep_ok(d) && ((uintptr_t)V % 16 == 0) && ((uintptr_t)vproj % 16 == 0) &&
         ((uintptr_t)p.a2w_w % 16 == 0)) {
         DStepArgs a2{};
         a2.B = B; a2.R = R; a2.A = A; a2.E = E; a2.K = d.K; a2.V1 = d.V - 1;
@@ -742,7 +746,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
             j.epi = SK_EPI_ZERO; j.M = 1; j.N = B * R + ((B + 3) & ~3); j.C = w.AFU;
         }
         k1.njobs = n1;
-        XG_TRY(xgk_skinny(st, k1, w.gm));
+        XG_TRY(xgk_skinny(st, k1, sk_mode(w)));
         // ---- launch 2: attention || rollout: cell 1 = h1 W_h2h + pos' W_a2h + xt W_i2h || S2'
         // (XG_L2_ORDER=1 of the diag build: cell 1's tiles dispatched in front of the attention's workgroups)
         static const int l2_order = xg_diag_env("XG_L2_ORDER") ? atoi(xg_diag_env("XG_L2_ORDER")) : 0;
@@ -771,7 +775,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         if (!s2_first && !s2_in_cell2) s2_job(k2.job[n2++]);
         if (fused_attn && l2_order != 0) attn_job(k2.job[n2++]);
         k2.njobs = n2;
-        if (n2 > 0) XG_TRY(xgk_skinny(st, k2, w.gm));
+        if (n2 > 0) XG_TRY(xgk_skinny(st, k2, sk_mode(w)));
         if (!fused_attn) XG_TRY(xgk_attn_fwd(st, s.P, vproj, V, p.a2w_w, s.alpha, s.af, B, d.K, R, A, s.half_attn));
         // ---- launch 3: cell 2 = h1' W_i2h + af W_a2h + S2'                                                :684
         if (!s2_in_cell2) { c.add = w.S2; c.ldadd = 4 * R; }
@@ -793,7 +797,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
             j.epi = SK_EPI_COPY; j.M = 1; j.N = B * R; j.C = s.h1o; j.seg[0].A = h1_new;
         }
         k3.njobs = n3;
-        XG_TRY(xgk_skinny(st, k3, w.gm));
+        XG_TRY(xgk_skinny(st, k3, sk_mode(w)));
         return XG_OK;
     }
     if (!s.xt) return XG_EINVAL;                 // the token gather exists on the packed path only
@@ -809,7 +813,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         if (s.pre1) {
             k1.job[1].nseg = 1;
             k1.job[1].seg[0] = seg_nt(s.h1, R, p.l1_h2h_w, R, R); k1.job[1].bias[0] = p.l1_h2h_b;
-            XG_TRY(xgk_skinny(st, k1, w.gm));
+            XG_TRY(xgk_skinny(st, k1, sk_mode(w)));
         } else {
             // rollout form: [p || POS gate] first (the gate feeds cell 1), then cell 1 with all three products
             SkJob cell1 = k1.job[1];
@@ -818,7 +822,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
             k1.job[1].seg[0] = seg_nt(s.xt, E, p.dgate_w, E, E); k1.job[1].bias[0] = p.dgate_b;
             k1.job[1].gate_t = s.pos; k1.job[1].ldt = R; k1.job[1].gate_y = s.posg; k1.job[1].ldy = R;
             k1.job[1].drop = xg_make_drop(&run, XG_SITE_DGATE, s.t);
-            XG_TRY(xgk_skinny(st, k1, w.gm));
+            XG_TRY(xgk_skinny(st, k1, sk_mode(w)));
             SkArgs k1b{};
             k1b.njobs = 1;
             k1b.job[0] = cell1;
@@ -826,7 +830,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
             k1b.job[0].seg[0] = seg_nt(s.xt, E, p.l1_i2h_w, E, E); k1b.job[0].bias[0] = p.l1_i2h_b;
             k1b.job[0].seg[1] = seg_nt(s.posg, R, p.l1_a2h_w, R, R); k1b.job[0].bias[1] = p.l1_a2h_b;
             k1b.job[0].seg[2] = seg_nt(s.h1, R, p.l1_h2h_w, R, R); k1b.job[0].bias[2] = p.l1_h2h_b;
-            XG_TRY(xgk_skinny(st, k1b, w.gm));
+            XG_TRY(xgk_skinny(st, k1b, sk_mode(w)));
         }
         XG_TRY(xgk_attn_fwd(st, s.P, vproj, V, p.a2w_w, s.alpha, s.af, B, d.K, R, A));
         SkArgs k2{};
@@ -836,7 +840,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         k2.job[0].seg[0] = seg_nt(s.h1o, R, p.l2_i2h_w, R, R); k2.job[0].bias[0] = p.l2_i2h_b;
         k2.job[0].seg[1] = seg_nt(s.af, R, p.l2_a2h_w, R, R); k2.job[0].bias[1] = p.l2_a2h_b;
         k2.job[0].seg[2] = seg_nt(s.h2, R, p.l2_h2h_w, R, R); k2.job[0].bias[2] = p.l2_h2h_b;
-        XG_TRY(xgk_skinny(st, k2, w.gm));
+        XG_TRY(xgk_skinny(st, k2, sk_mode(w)));
         return XG_OK;
     }
     // generic path (R not a multiple of 8): plain GEMMs + pointwise cell kernels
@@ -940,7 +944,7 @@ int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatc
         {   // ahead of the loop: cell 1(0) || the h1 half of p(0)
             SkArgs k0{};
             k0.njobs = 2; k0.job[0] = cell1(0); k0.job[1] = p_h1(0);
-            XG_TRY(xgk_skinny(st, k0, w.gm));
+            XG_TRY(xgk_skinny(st, k0, sk_mode(w)));
         }
         for (int t = 0; t < T; ++t) {
             {   // L1
@@ -951,7 +955,7 @@ int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatc
                 k1.job[0].seg[0] = seg_nt(w, PK_H2A2, w.H2 + t * BR, R, p.h2a_w + R, 2 * R, R);
                 k1.job[1] = SkJob{};
                 k1.job[1].epi = SK_EPI_ZERO; k1.job[1].M = 1; k1.job[1].N = B * R + ((B + 3) & ~3); k1.job[1].C = w.AFU;
-                XG_TRY(xgk_skinny(st, k1, w.gm));
+                XG_TRY(xgk_skinny(st, k1, sk_mode(w)));
             }
             {   // L2
                 SkArgs k2{};
@@ -968,7 +972,7 @@ int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatc
                 js.seg[0] = seg_nt(w, PK_L2_I2H, w.H1 + (t + 1) * BR, R, p.l2_i2h_w, R, R); js.bias[0] = p.l2_i2h_b;
                 js.seg[1] = seg_nt(w, PK_L2_H2H, w.H2 + t * BR, R, p.l2_h2h_w, R, R); js.bias[1] = p.l2_h2h_b;
                 k2.njobs = n2;
-                XG_TRY(xgk_skinny(st, k2, w.gm));
+                XG_TRY(xgk_skinny(st, k2, sk_mode(w)));
             }
             {   // L3
                 LstmFwdArgs c{};
@@ -986,7 +990,7 @@ int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatc
                 j.seg[0] = seg_nt(w, PK_L2_A2H, w.AFU, R, p.l2_a2h_w, R, R); j.bias[0] = p.l2_a2h_b;
                 SkSeg& g = j.seg[0];
                 g.row_scale = w.ATS; g.scaled_out = w.AF + t * BR; g.ld_out = R; g.ex = w.ALPHA + (size_t)t * B * K; g.ex_ld = K; g.ex_K = K;
-                XG_TRY(xgk_skinny(st, k3, w.gm));
+                XG_TRY(xgk_skinny(st, k3, sk_mode(w)));
             }
             if (th > 0 && t == th - 1) {
                 XG_TRY(ss.fork());
@@ -1125,7 +1129,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
             sk.njobs = 1;
             sk.job[0] = job_store(B, R, w.DH1X + t * BR, R, false);
             from_chain2(sk.job[0], 0, t);
-            XG_TRY(xgk_skinny(s1, sk, w.gm));
+            XG_TRY(xgk_skinny(s1, sk, sk_mode(w)));
             XG_TRY(xgk_lstm_bwd(s1, cell1_bwd(t, cur1, w.DH1X + t * BR)));
         }
         SkArgs sk{};
@@ -1151,7 +1155,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         static const int c1_ks = xg_diag_env("XG_C1_KS") ? atoi(xg_diag_env("XG_C1_KS")) : 4;
         static const int c1_lowprio = xg_diag_env("XG_C1_LOWPRIO") ? atoi(xg_diag_env("XG_C1_LOWPRIO")) : 1;
         j.ksplit_cap = c1_ks; j.low_prio = c1_lowprio;
-        XG_TRY(xgk_skinny(s1, sk, w.gm));
+        XG_TRY(xgk_skinny(s1, sk, sk_mode(w)));
         cur1 ^= 1;
         return XG_OK;
     };
@@ -1244,7 +1248,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
             sk.job[0].seg[0] = seg_nn(w, PKB_L2_H2H, ds2, 4 * R, p.l2_h2h_w, R, 4 * R);      // (available first: the other operand comes out of the launch in front)
             sk.job[0].seg[1] = seg_nn(w, PKB_H2A2, dp, A, p.h2a_w + R, 2 * R, A);
             allow_split(sk, 0, w);
-            XG_TRY(xgk_skinny(st, sk, w.gm));
+            XG_TRY(xgk_skinny(st, sk, sk_mode(w)));
         } else {
         {   // s2 = h1' Wi + af Wa + h2 Wh : the two data gradients chain 2 needs now
             SkArgs sk{};
@@ -1254,7 +1258,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
             allow_split(sk, 0, w); allow_split(sk, 1, w);
             static const int a_ks = xg_diag_env("XG_A_KS") ? atoi(xg_diag_env("XG_A_KS")) : 0;      // experiment: split cap of launch A
             sk.job[0].ksplit_cap = a_ks;
-            XG_TRY(xgk_skinny(st, sk, w.gm));
+            XG_TRY(xgk_skinny(st, sk, sk_mode(w)));
         }
         XG_TRY(xgk_attn_bwd(st, daf, R, w.P + (size_t)t * B * A, w.vproj, w.Venc, p.a2w_w, w.ALPHA + (size_t)t * B * K,
                             w.DE + (size_t)t * B * K, dp, B, K, R, A));
@@ -1268,7 +1272,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
             allow_split(sk, 0, w);
             static const int b_ks = xg_diag_env("XG_B_KS") ? atoi(xg_diag_env("XG_B_KS")) : 0;      // experiment: split cap of launch B
             sk.job[0].ksplit_cap = b_ks;
-            XG_TRY(xgk_skinny(st, sk, w.gm));
+            XG_TRY(xgk_skinny(st, sk, sk_mode(w)));
         }
         }
         cur ^= 1;

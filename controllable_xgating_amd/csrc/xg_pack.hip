@@ -12,6 +12,11 @@
 // (round-to-nearest-even) instead of on every pass of every step, as [i(2)][h(2)][n(32)][8]: element (n, k = 16 i + 8 h + q),
 // the B operand of v_mfma_f32_32x32x16_bf16, two 1 KB wave loads per tile; half the weight bytes per step.
 //
+// dtype 2 = three bf16 planes per weight (XgRun.gemm_mode 3, split-bf16; round 5): x = p0 + p1 + p2 exactly (p0 = x truncated to
+// bf16, p1 = (x - p0) truncated, p2 = the rest rounded: the split xg_step.hip used to do in registers on every pass of every
+// step -- ~160 vector instructions per lane per 32-deep chunk, the largest single cost of those launches), as six 1 KB pieces
+// per tile [j(2)][q(3)][h(2)][n(32)][8]: plane q of element (n, k = 16 h + 8 j + e).  6 bytes per weight instead of 4.
+//
 // The shadow is caller-owned (xg_packed_bytes / xg_pack_weights), refreshed after every optimizer step
 // (reference update: caption_src/starttrain.py:136-137) and handed to the entry points through XgRun.packed.
 //   NT entries (forward, y = x W^T, W (N,K) row-major):  h2a[:, :R], h2a[:, R:], decoder gate, lstm_1.{i2h,a2h,h2h},
@@ -82,6 +87,27 @@ __global__ void __launch_bounds__(256) pack_kernel(PackArgs a) {
         t[nn][kk] = v;
     }
     __syncthreads();
+    if (a.bf16 == 2) {
+        unsigned short* dst = reinterpret_cast<unsigned short*>(a.dst[ei]) + (size_t)tile * 3072;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int o = threadIdx.x + 256 * r;                      // [j(2)][h(2)][n(32)][e(8)] of the tile's 1024 elements
+            const int e = o & 7, nn = (o >> 3) & 31, h = (o >> 8) & 1, j = o >> 9;
+            // the same split as xg_step.hip: split3_pair (two truncations, then round to nearest even)
+            const float x = t[nn][16 * h + 8 * j + e];
+            const unsigned u0 = __float_as_uint(x) & 0xFFFF0000u;
+            const float r1 = x - __uint_as_float(u0);                 // exact
+            const unsigned u1 = __float_as_uint(r1) & 0xFFFF0000u;
+            const float r2 = r1 - __uint_as_float(u1);                // exact
+            unsigned u2 = __float_as_uint(r2);
+            u2 += 0x7FFFu + ((u2 >> 16) & 1u);
+            const int at = h * 256 + nn * 8 + e;
+            dst[(j * 3 + 0) * 512 + at] = (unsigned short)(u0 >> 16);
+            dst[(j * 3 + 1) * 512 + at] = (unsigned short)(u1 >> 16);
+            dst[(j * 3 + 2) * 512 + at] = (unsigned short)(u2 >> 16);
+        }
+        return;
+    }
     if (a.bf16) {
         unsigned short* dst = reinterpret_cast<unsigned short*>(a.dst[ei]) + (size_t)tile * 1024;
 #pragma unroll
@@ -134,7 +160,7 @@ __global__ void __launch_bounds__(256) cvt_multi_kernel(CvtArgs a) {
 }  // namespace
 
 size_t xgk_packed_total_bytes(const XgDims& d, int dtype) {
-    size_t n = ((xgk_packed_floats(d) * (dtype == 1 ? 2 : 4)) + 255) & ~(size_t)255;
+    size_t n = ((xgk_packed_floats(d) * (dtype == 1 ? 2 : (dtype == 2 ? 6 : 4))) + 255) & ~(size_t)255;
     if (dtype == 1) {
         XgParams p{};
         W16Desc e[W16_COUNT];
@@ -154,12 +180,12 @@ size_t xgk_packed_floats(const XgDims& d) {
 }
 
 bool xgk_packed_view(const XgDims& d, const void* packed, int dtype, PackedView* v) {
-    if (!packed || d.R % 8 != 0 || ((uintptr_t)packed % 16) != 0 || (dtype != 0 && dtype != 1)) return false;
+    if (!packed || d.R % 8 != 0 || ((uintptr_t)packed % 16) != 0 || dtype < 0 || dtype > 2) return false;
     XgParams p{};
     PackDesc e[PK_COUNT];
     describe(d, p, e);
     const char* base = static_cast<const char*>(packed);
-    const size_t esz = dtype == 1 ? 2 : 4;
+    const size_t esz = dtype == 1 ? 2 : (dtype == 2 ? 6 : 4);
     size_t off = 0;
     for (int i = 0; i < PK_COUNT; ++i) {
         v->m[i] = reinterpret_cast<const float*>(base + off);
@@ -182,7 +208,7 @@ bool xgk_packed_view(const XgDims& d, const void* packed, int dtype, PackedView*
 }
 
 extern "C" size_t xg_packed_bytes(const XgDims* d, int dtype) {
-    if (!d || d->R <= 0 || d->A <= 0 || d->E <= 0 || d->R % 8 != 0 || (dtype != 0 && dtype != 1)) return 0;
+    if (!d || d->R <= 0 || d->A <= 0 || d->E <= 0 || d->R % 8 != 0 || dtype < 0 || dtype > 2) return 0;
     if (dtype == 1 && (d->V <= 1 || d->F1 <= 0 || d->F2 <= 0)) return 0;
     return xgk_packed_total_bytes(*d, dtype);
 }
@@ -203,7 +229,7 @@ extern "C" int xg_pack_weights_part(void* stream, const XgDims* d, const XgParam
 }
 static int pack_part(void* stream, const XgDims* d, const XgParams* p, void* packed, size_t packed_bytes, int dtype, int with_backward, int part) {
     if (!d || !p || !packed || d->R <= 0 || d->A <= 0 || d->E <= 0) return XG_EINVAL;
-    if (d->R % 8 != 0 || ((uintptr_t)packed % 16) != 0 || (dtype != 0 && dtype != 1)) return XG_EINVAL;
+    if (d->R % 8 != 0 || ((uintptr_t)packed % 16) != 0 || dtype < 0 || dtype > 2) return XG_EINVAL;
     if (dtype == 1 && (d->V <= 1 || d->F1 <= 0 || d->F2 <= 0)) return XG_EINVAL;
     if (packed_bytes < xgk_packed_total_bytes(*d, dtype)) return XG_EWORKSPACE;
     PackDesc all[PK_COUNT];
@@ -212,7 +238,7 @@ static int pack_part(void* stream, const XgDims* d, const XgParams* p, void* pac
     if (!xgk_packed_view(*d, packed, dtype, &v)) return XG_EINVAL;
     PackArgs a{};
     const int last = with_backward ? PK_COUNT : PKB_L2_A2H;
-    a.bf16 = dtype == 1;
+    a.bf16 = dtype;                                // 0 fp32 tiles, 1 bf16 tiles, 2 three bf16 planes
     int tiles = 0, n = 0;
     for (int i = 0; i < last; ++i) {
         const bool enc = i == PK_ENC_RGB || i == PK_ENC_OPFL || i == PKB_ENC_RGB || i == PKB_ENC_OPFL;

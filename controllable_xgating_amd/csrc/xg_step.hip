@@ -142,6 +142,13 @@ __device__ __forceinline__ void st_chunk_split3(unsigned short* __restrict__ lds
 }
 // the 8 fp32 weights a lane holds for one 16-deep MFMA block (two f32x4 pieces) -> three bf16x8 operands
 __device__ __forceinline__ void split3_b(const f32x4& x, const f32x4& y, bf16x8 (&pl)[3]) {
+#ifdef SKF_SPLIT_FREE
+    // timing experiment only (results wrong): what would the split-bf16 step cost if the weight planes came pre-split from memory
+    // (the bytes of the extra half plane not counted)?  tools/ubench/split_free.sh
+    { const uint4 u = {__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(y[0]), __float_as_uint(y[1])};
+      const uint4 v = {__float_as_uint(x[2]), __float_as_uint(x[3]), __float_as_uint(y[2]), __float_as_uint(y[3])};
+      pl[0] = __builtin_bit_cast(bf16x8, u); pl[1] = __builtin_bit_cast(bf16x8, v); pl[2] = pl[0]; return; }
+#endif
     unsigned w[3][4];
     split3_pair(x[0], x[1], w[0][0], w[1][0], w[2][0]);
     split3_pair(x[2], x[3], w[0][1], w[1][1], w[2][1]);
@@ -923,7 +930,8 @@ skf_kernel(SkArgs args) {
     XG_CHAIN_PRIO();
     SK_STAMP(0);
     // per wave: the staged activation chunk (fp32 image, one bf16 image, or three bf16 plane images), later the wave's partial tile
-    constexpr int WSM = PREC == 2 ? (3 * PLH) / 2 : (32 * RSF > OPF ? 32 * RSF : OPF);      // floats per wave
+    constexpr bool SPLIT3 = PREC == 2 || PREC == 3;      // split-bf16: weight planes split in registers (2) or pre-split in memory (3)
+    constexpr int WSM = SPLIT3 ? (3 * PLH) / 2 : (32 * RSF > OPF ? 32 * RSF : OPF);      // floats per wave
     static_assert(WSM >= 32 * RSF, "the reduction buffer must fit the staging area");
     constexpr int LGNW = NW == 8 ? 3 : 2;
     static_assert(NW == 8 || NW == 4, "waves per workgroup");
@@ -1014,7 +1022,7 @@ skf_kernel(SkArgs args) {
 
     // (split-bf16: the plane registers leave no room for 19 prefetched values across the K loop at 128 VGPRs -- they would go
     //  to scratch, which costs more than it hides -- so that mode requests the cell operands behind the loop, under the reduction)
-    constexpr bool LATE_PRE = PREC == 2 && DEPTH == 1 && !SCALE;
+    constexpr bool LATE_PRE = SPLIT3 && DEPTH == 1 && !SCALE;
     EpiPre pre;
 #pragma unroll
     for (int i = 0; i < 16; ++i) pre.a[i] = 0.f;
@@ -1062,7 +1070,8 @@ skf_kernel(SkArgs args) {
 #endif
     SkEpiOut eo;
     // this lane's 16-byte piece of a B tile, sub-piece i at + i * 1024 bytes (a bf16 tile is 2 KB: 2 pieces, an fp32 tile 4 KB: 4)
-    constexpr int TILEB = PREC == 1 ? 2048 : 4096, NPB = PREC == 1 ? 2 : 4;
+    // (PREC 3: a tile is six 1 KB pieces -- block j, plane q at piece 3 j + q -- of three pre-split bf16 planes: xg_pack.hip, dtype 2)
+    constexpr int TILEB = PREC == 1 ? 2048 : (PREC == 3 ? 6144 : 4096), NPB = PREC == 1 ? 2 : (PREC == 3 ? 6 : 4);
     const unsigned vB = (unsigned)(half * 32 + l31) * 16u;
     // A wave's share of the reduction is ONE contiguous range of 32-deep chunks of the concatenated segments (round 5; before,
     // every wave took a slice of every segment: a wave paid the segment set-up and an exposed first-operand round trip per
@@ -1156,20 +1165,25 @@ skf_kernel(SkArgs args) {
                 }
             }
             if (PREC == 1) st_chunk_bf16(reinterpret_cast<unsigned short*>(As), lane, ra);
-            else if (PREC == 2) st_chunk_split3(reinterpret_cast<unsigned short*>(As), lane, ra);
+            else if (SPLIT3) st_chunk_split3(reinterpret_cast<unsigned short*>(As), lane, ra);
             else st_chunk(As, lane, ra);
             if (s == 0 && c == c0) SK_STAMP(2);
             if (c + DEPTH < c1) { ldB(c + DEPTH, nxt); ldAc(c + DEPTH, ra); }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
-            if (PREC == 2) {
+            if (SPLIT3) {
                 // lane (column l31, half h) holds the weights of k = 16 h + 4 i + kk in piece i: block j = pieces 2j, 2j + 1 =
                 // k in [16 h + 8 j, + 8), and the activation fragment is read at the same k (any k order does, if both sides agree)
                 const unsigned short* Ah = reinterpret_cast<const unsigned short*>(As);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     bf16x8 bp3[3], ap3[3];
-                    split3_b(cur[2 * j], cur[2 * j + 1], bp3);
+                    if constexpr (PREC == 3) {
+#pragma unroll
+                        for (int q = 0; q < 3; ++q) bp3[q] = __builtin_bit_cast(bf16x8, cur[3 * j + q]);     // the planes as packed: no VALU on the weight side
+                    } else {
+                        split3_b(cur[2 * j], cur[2 * j + 1], bp3);
+                    }
 #pragma unroll
                     for (int q = 0; q < 3; ++q) ap3[q] = *reinterpret_cast<const bf16x8*>(Ah + q * PLH + l31 * LDH + half * 16 + j * 8);
                     // smallest terms first
@@ -1275,6 +1289,8 @@ extern "C" int xg_debug_sk_trace_clear(void) {
 #endif
 
 int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
+    const bool planes = (gemm_mode & XGK_SK_PLANES) != 0;        // split-bf16 with pre-split weight planes in the packed tiles (dtype 2)
+    gemm_mode &= ~XGK_SK_PLANES;
     if (a.njobs <= 0 || a.njobs > SK_MAX_JOBS) return XG_EINVAL;
     {   // Jobs are independent, so their order is free: most tiles first.  The grid is (widest job) x (jobs), dispatched job by job;
         // a narrower job's surplus workgroups find out that they are surplus only after their first round of descriptor loads
@@ -1414,7 +1430,7 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         for (int j = 0; j < a.njobs; ++j) {
             SkArgs one{};
             one.njobs = 1; one.job[0] = a.job[j];
-            XG_TRY(xgk_skinny(st, one, gemm_mode));
+            XG_TRY(xgk_skinny(st, one, gemm_mode | (planes ? XGK_SK_PLANES : 0)));
         }
         return XG_OK;
     }
@@ -1458,7 +1474,7 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
 #else
 #define XG_SKF(PREC_) do { if (nw4) XG_SKF2(4, PREC_, 1); else XG_SKF2(8, PREC_, 1); } while (0)
 #endif
-        if (bf16) XG_SKF(1); else if (bf16x3) XG_SKF(2); else XG_SKF(0);
+        if (bf16) XG_SKF(1); else if (bf16x3 && planes) XG_SKF(3); else if (bf16x3) XG_SKF(2); else XG_SKF(0);
 #undef XG_SKF
 #undef XG_SKF2
         XG_CHECK_LAUNCH();

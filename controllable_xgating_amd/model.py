@@ -305,6 +305,12 @@ class SAModel(nn.Module):
         has its own version counter.  Call this method after such writes."""
         self._packed_epoch += 1
 
+    def _packed_dtype(self):
+        """Element type of the packed recurrent weights (include/xgate.h: XgRun.packed_dtype): bf16 tiles for the bf16 arithmetic,
+        three pre-split bf16 planes for split-bf16, fp32 tiles otherwise."""
+        over = getattr(self, "_packed_dtype_override", None)      # tests: split-bf16 over plain fp32 tiles (split in registers)
+        return {"bf16": 1, "bf16x3": 2}.get(self.precision, 0) if over is None else over
+
     def pack_early(self):
         """For an optimizer that has JUST updated every parameter group except the CG encoder's on the current stream (and will
         call mark_params_changed() when the rest is done): refresh the packed tiles of the decoder's matrices here and now, under
@@ -314,7 +320,7 @@ class SAModel(nn.Module):
         if self._packed is None or torch.cuda.is_current_stream_capturing():
             return
         self._ensure_flat()
-        dtype = 1 if self.precision == "bf16" else 0
+        dtype = self._packed_dtype()
         key = (self._flat.data_ptr(), self._flat._version, self._packed_epoch, dtype, tuple(p._version for p in self._plist()))
         d = self._dims(1, 1, 1)
         nbytes = nv.lib().xg_packed_bytes(C.byref(d), dtype)
@@ -346,7 +352,7 @@ class SAModel(nn.Module):
         """Device pointer of the packed recurrent weights (include/xgate.h: xg_pack_weights), valid for the current
         parameter values; None when the shapes do not allow it (rnn_size % 8 != 0)."""
         self._ensure_flat()
-        dtype = 1 if self.precision == "bf16" else 0
+        dtype = self._packed_dtype()
         key = (self._flat.data_ptr(), self._flat._version, self._packed_epoch, dtype,
                tuple(p._version for p in self._plist()))
         if key != self._packed_key:
@@ -404,7 +410,7 @@ class SAModel(nn.Module):
         r.bn_momentum, r.bn_eps = 0.1, 1e-5
         r.gemm_mode = {"fp32": 0, "bf16": 1, "bf16x3": 3}[self.precision]
         r.packed = self._packed_ptr()
-        r.packed_dtype = 1 if self.precision == "bf16" else 0
+        r.packed_dtype = self._packed_dtype()
         r.aux = self._aux_handle()
         pe = getattr(self, "_prof_events", None)       # measurement hook (bench.py): a pair of timing events around the T decoder steps
         if pe is not None:

@@ -109,7 +109,8 @@ typedef struct XgRun {
                              1 = bf16 operands, fp32 accumulate, for the large AND the per-step products
                              (BASELINE.json configs[4], tolerance 1e-2).  Accumulation, the cell arithmetic, the
                              attention and every reduction are fp32 in all modes. */
-    int32_t packed_dtype; /* element type of `packed`: 0 = fp32 tiles (gemm_mode 0 / 3), 1 = bf16 tiles (gemm_mode 1) */
+    int32_t packed_dtype; /* element type of `packed`: 0 = fp32 tiles (gemm_mode 0 / 3), 1 = bf16 tiles (gemm_mode 1),
+                             2 = three pre-split bf16 planes (gemm_mode 3 only: same results as 0 there, fewer instructions) */
     const void *packed;   /* optional: the recurrent weights in MFMA-fragment order (xg_pack_weights), valid for the
                              CURRENT parameter values; NULL (or a dtype that does not fit gemm_mode) = stream the plain
                              weights through LDS.  Same results (bf16: the same rounding, done once instead of per pass). */
@@ -325,7 +326,9 @@ int xg_reward_bwd(void *stream, const int64_t *seq, int ld_seq, const float *rew
  * matrix cores consume them (32 x 32 tiles, xg_pack.hip) lets the step kernels load the B operand straight into
  * registers.  The caller owns the buffer (xg_packed_bytes, 16-byte aligned), refreshes it with xg_pack_weights after
  * every parameter update (with_backward = 0 skips the data-gradient tiles: inference) and passes it in XgRun.packed
- * with XgRun.packed_dtype.  dtype 0: fp32 tiles; dtype 1: bf16 tiles for gemm_mode 1 (weights rounded once, half the bytes). */
+ * with XgRun.packed_dtype.  dtype 0: fp32 tiles; dtype 1: bf16 tiles for gemm_mode 1 (weights rounded once, half the bytes);
+ * dtype 2: three bf16 planes per weight for gemm_mode 3 (the exact split x = p0 + p1 + p2 done once per update instead of in
+ * registers on every pass of every step; 6 bytes per weight; bit-identical results to dtype 0 under gemm_mode 3). */
 size_t xg_packed_bytes(const XgDims *d, int dtype);
 int xg_pack_weights(void *stream, const XgDims *d, const XgParams *p, void *packed, size_t packed_bytes,
                     int dtype, int with_backward);

@@ -1720,6 +1720,27 @@ def test_split_bf16_greedy_token_for_token_vs_reference(name, tag, ragged):
     np.testing.assert_allclose(slp, want_lp, atol=3e-4)
 
 
+def test_split_bf16_presplit_weight_planes_equal_the_in_register_split():
+    """Round 5: the packed recurrent weights of the split-bf16 mode are three bf16 planes split ONCE per update (xg_pack_weights
+    dtype 2) instead of fp32 tiles split in registers by every launch.  Same split, same MFMA order: the teacher-forced forward
+    (log-probabilities, category log-probabilities) and a greedy rollout must be bit-identical between the two tile formats."""
+    d = pg.make_dims(**CFG["mid"])
+    x = to_dev(pg.make_inputs(d, seed=3, ragged=True))
+    args = (x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+    outs = []
+    for over in (None, 0):
+        model = make_model(d, precision="bf16x3", train=False)
+        model._packed_dtype_override = over
+        with torch.no_grad():
+            logp, cat = model(*args)
+            seq, slp = model.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], {"sample_max": 1})
+        torch.cuda.synchronize()
+        assert model._packed_dtype() == (2 if over is None else 0)
+        outs.append((logp.clone(), cat.clone(), seq.clone(), slp.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+
+
 def test_split_bf16_raw_step_equals_exact_fp32_step():
     """xg_step_fwd at 128 rows (the benchmarked launch group) in gemm_mode 3 against gemm_mode 0: new state within 2e-6."""
     from controllable_xgating_amd import _native as nv
