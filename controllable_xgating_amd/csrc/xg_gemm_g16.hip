@@ -52,9 +52,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t g16_rsrc(const unsigned short*
 
 // per-lane byte offsets of a wave's four DMA instructions into the operand, slab 0 (the range check of a raw buffer looks at
 // the VECTOR offset only, so the whole offset lives there; a slab advance is one add per instruction)
-template <bool KC, int TK>
-__device__ __forceinline__ void g16_offsets(unsigned (&off)[TK / 16], int ld, int r0, int wave, int lane) {
-    constexpr int NI = TK / 16;
+template <bool KC, int TK, int NI>
+__device__ __forceinline__ void g16_offsets(unsigned (&off)[NI], int ld, int r0, int wave, int lane) {
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
         const int q = wave * NI + i;
@@ -73,9 +72,13 @@ __device__ __forceinline__ void g16_offsets(unsigned (&off)[TK / 16], int ld, in
     }
 }
 
-template <bool AKC, bool BKC, int TK, int NS>
-__global__ void __launch_bounds__(256, 2) gemm_g16_kernel(GArgs g) {
-    constexpr int NI = TK / 16, OPB = opb<TK>(), STB = stb<TK>(), P = NS - 1;
+// KG = 2: eight waves -- two groups of four that share the tile and split every slab's depth between them (same tile, same operand
+// traffic, twice the waves per workgroup: ONE workgroup per CU with a four-stage ring = three slabs in flight instead of one);
+// the groups exchange the half of the accumulators they do not store through LDS at the end.
+template <bool AKC, bool BKC, int TK, int NS, int KG>
+__global__ void __launch_bounds__(256 * KG, 2) gemm_g16_kernel(GArgs g) {
+    constexpr int NI = TK / 16 / KG, OPB = opb<TK>(), STB = stb<TK>(), P = NS - 1;      // NI: DMA instructions per wave, operand and slab
+    static_assert(KG == 1 || (KG == 2 && TK == 64), "two wave groups: 64-deep slabs, two 16-deep blocks each");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem_g16[];
 
     const int ntm = (g.M + TM - 1) / TM, ntn = (g.N + TN - 1) / TN;
@@ -96,7 +99,8 @@ __global__ void __launch_bounds__(256, 2) gemm_g16_kernel(GArgs g) {
     }
     const int m0 = tm * TM, n0 = tn * TN;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int wm = wave >> 1, wn = wave & 1, half = lane >> 5, l31 = lane & 31;
+    const int w4 = wave & 3, kg = wave >> 2;
+    const int wm = w4 >> 1, wn = w4 & 1, half = lane >> 5, l31 = lane & 31;
 
     const int nslab_all = (g.K + TK - 1) / TK;
     const int s_begin = (int)(((long)ks * nslab_all) / g.splitk), s_end = (int)(((long)(ks + 1) * nslab_all) / g.splitk);
@@ -105,12 +109,15 @@ __global__ void __launch_bounds__(256, 2) gemm_g16_kernel(GArgs g) {
     const __amdgpu_buffer_rsrc_t rsA = g16_rsrc(g.A, AKC ? ((unsigned)(g.M - 1) * g.lda + g.K) * 2u : ((unsigned)(g.K - 1) * g.lda + g.M) * 2u);
     const __amdgpu_buffer_rsrc_t rsB = g16_rsrc(g.B, BKC ? ((unsigned)(g.N - 1) * g.ldb + g.K) * 2u : ((unsigned)(g.K - 1) * g.ldb + g.N) * 2u);
     unsigned offA[NI], offB[NI];
-    g16_offsets<AKC, TK>(offA, g.lda, m0, wave, lane);
-    g16_offsets<BKC, TK>(offB, g.ldb, n0, wave, lane);
+    g16_offsets<AKC, TK, NI>(offA, g.lda, m0, wave, lane);
+    g16_offsets<BKC, TK, NI>(offB, g.ldb, n0, wave, lane);
     const unsigned slabA = AKC ? TK * 2u : (unsigned)TK * (unsigned)g.lda * 2u;
     const unsigned slabB = BKC ? TK * 2u : (unsigned)TK * (unsigned)g.ldb * 2u;
 #pragma unroll
     for (int i = 0; i < NI; ++i) { offA[i] += (unsigned)s_begin * slabA; offB[i] += (unsigned)s_begin * slabB; }
+    // (Every workgroup walks its slabs from the first one.  Workgroups of one round run in step and the tiles that share an operand
+    // panel then ask L2 for the same slab at the same moment; a tile-dependent start -- tried against the suspicion that 2 KB row
+    // pitches pile every request of a moment onto two L2 channels -- made every shape 5-45 % SLOWER: tools/ubench/g16_rot.sh.)
     auto issue = [&](int buf) {
         unsigned char* base = smem_g16 + buf * STB + wave * (NI * 1024);
 #pragma unroll
@@ -119,6 +126,18 @@ __global__ void __launch_bounds__(256, 2) gemm_g16_kernel(GArgs g) {
 #pragma unroll
         for (int i = 0; i < NI; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(base + OPB + i * 1024), 16, (int)offB[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) { offA[i] += slabA; offB[i] += slabB; }
+    };
+    // the same slab one DMA instruction at a time (piece 0 .. 2 NI - 1: A's, then B's): placed BETWEEN the MFMA groups of the slab that
+    // is being multiplied -- issued in one burst in front of them, a wave's eight instructions hold its instruction stream for their
+    // whole issue time (the address unit takes them at 100-200 cycles apiece under load) before its first fragment read
+    auto issue_piece = [&](int buf, int pc) {
+        unsigned char* base = smem_g16 + buf * STB + wave * (NI * 1024);
+        if (pc < NI) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(base + pc * 1024), 16, (int)offA[pc], 0, 0, 0);
+        else __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void*)(base + OPB + (pc - NI) * 1024), 16, (int)offB[pc - NI], 0, 0, 0);
+    };
+    auto issue_advance = [&]() {
 #pragma unroll
         for (int i = 0; i < NI; ++i) { offA[i] += slabA; offB[i] += slabB; }
     };
@@ -179,16 +198,20 @@ __global__ void __launch_bounds__(256, 2) gemm_g16_kernel(GArgs g) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                           // slab s is in LDS for everybody; everybody is done with slab s - 1
         __builtin_amdgcn_sched_barrier(0);
-        if (s + P < s_end) { if (!(g.dbg & 1)) issue(ibuf); ++nis; }              // ... whose stage takes slab s + P
+        const bool more = s + P < s_end;                        // ... whose stage takes slab s + P
+        const bool burst = (g.dbg & 8) != 0;                    // (diag: the DMA instructions in one burst in front of the fragment reads)
+        if (more && burst) { if (!(g.dbg & 1)) issue(ibuf); }
+        const int jbuf = ibuf;
+        if (more) ++nis;
         ibuf = ibuf + 1 == NS ? 0 : ibuf + 1;
         const unsigned char* Ai = smem_g16 + buf * STB;
         const unsigned char* Bi = Ai + OPB;
         if (cs_on) {
-            // thread -> m pair (t & 63), k rows wave * TK / 4 .. of the [TK k][128 m] image
+            // thread -> m pair (t & 63), k rows wave * TK / (4 KG) .. of the [TK k][128 m] image
             const unsigned mb = (unsigned)(threadIdx.x & 63) * 4u;
 #pragma unroll
-            for (int e = 0; e < TK / 4; ++e) {
-                const unsigned k = (unsigned)(wave * (TK / 4) + e);
+            for (int e = 0; e < TK / (4 * KG); ++e) {
+                const unsigned k = (unsigned)(wave * (TK / (4 * KG)) + e);
                 const unsigned w = *reinterpret_cast<const unsigned*>(Ai + k * 256u + (mb ^ ((k & 3u) << 6)));
                 csv0 += __uint_as_float(w << 16);
                 csv1 += __uint_as_float(w & 0xFFFF0000u);
@@ -197,25 +220,37 @@ __global__ void __launch_bounds__(256, 2) gemm_g16_kernel(GArgs g) {
         if (!(g.dbg & 2)) {
             // every fragment of the slab is requested before its first MFMA (a wave's LDS reads then run under its own MFMAs,
             // not only under the other waves'); the scheduler is told to keep that order
-            constexpr int KK = TK / 16;
+            constexpr int KK = TK / 16 / KG;                    // 16-deep blocks of the slab this wave multiplies
+            const int kk0 = kg * KK;
             bf16x8 fa[KK][2], fb[KK][2];
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) fa[kk][i] = frag(Ai, AKC, fa0, i, kk);
+                for (int i = 0; i < 2; ++i) fa[kk][i] = frag(Ai, AKC, fa0, i, kk0 + kk);
 #pragma unroll
-                for (int j = 0; j < 2; ++j) fb[kk][j] = frag(Bi, BKC, fb0, j, kk);
+                for (int j = 0; j < 2; ++j) fb[kk][j] = frag(Bi, BKC, fb0, j, kk0 + kk);
             }
 #ifndef G16_NO_FRAG_AHEAD
             __builtin_amdgcn_sched_barrier(0);
 #endif
+            constexpr int PPK = 2 * NI / KK;                    // DMA pieces per 16-deep block
 #pragma unroll
-            for (int kk = 0; kk < KK; ++kk)
+            for (int kk = 0; kk < KK; ++kk) {
+                if (more && !burst && !(g.dbg & 1)) {
+#pragma unroll
+                    for (int q = 0; q < PPK; ++q) issue_piece(jbuf, kk * PPK + q);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (more && !burst) issue_advance();
+        } else if (more && !burst && !(g.dbg & 1)) {            // (ablation without the products: the slab still has to be requested)
+            issue(jbuf);
         }
         buf = buf + 1 == NS ? 0 : buf + 1;
     }
@@ -231,15 +266,14 @@ __global__ void __launch_bounds__(256, 2) gemm_g16_kernel(GArgs g) {
             if (r < TM && m0 + r < g.M) {
                 float v = 0.f;
 #pragma unroll
-                for (int w = 0; w < 4; ++w) v += red[((r >> 1) + 64 * w) * 2 + (r & 1)];
+                for (int w = 0; w < 4 * KG; ++w) v += red[((r >> 1) + 64 * w) * 2 + (r & 1)];
 #pragma unroll
                 for (int o = 0; o < 3; ++o) if (g.csum[o]) unsafeAtomicAdd(g.csum[o] + m0 + r, v);
             }
         }
     }
     if (g.dbg & 4) { if (acc[0][0][0] == 123.456f) g.C[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1]; return; }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
+    auto store_rows = [&](int i, const f32x16 (&ai)[2]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
             const int col = n0 + wn * 64 + j * 32 + l31;
@@ -250,7 +284,7 @@ __global__ void __launch_bounds__(256, 2) gemm_g16_kernel(GArgs g) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (row < g.M) {
                     float* dst = g.C + (size_t)row * g.ldc + col;
-                    float v = acc[i][j][r] + bv;
+                    float v = ai[j][r] + bv;
                     if (g.splitk > 1) { unsafeAtomicAdd(dst, v); continue; }
                     if (g.accumulate) v += *dst;
                     if (g.relu) v = fmaxf(v, 0.f);
@@ -258,9 +292,47 @@ __global__ void __launch_bounds__(256, 2) gemm_g16_kernel(GArgs g) {
                 }
             }
         }
+    };
+    if constexpr (KG == 1) {
+        store_rows(0, acc[0]);
+        store_rows(1, acc[1]);
+    } else {
+        // group kg stores the wave's 32-row block i = kg: it hands the other block's partial sums to the other group through LDS
+        // ([group][wave][j][r][lane] floats, 32 KB per group) and adds what the other group left for its own block
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __syncthreads();                                        // every wave is done with the stage images
+        float* X = reinterpret_cast<float*>(smem_g16);
+        float* mine = X + kg * 8192 + w4 * 2048 + lane;
+        const float* theirs = X + (1 - kg) * 8192 + w4 * 2048 + lane;
+        if (kg == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[(j * 16 + r) * 64] = acc[1][j][r];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mine[(j * 16 + r) * 64] = acc[0][j][r];
+        }
+        __syncthreads();
+        if (kg == 0) {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[0][j][r] += theirs[(j * 16 + r) * 64];
+            store_rows(0, acc[0]);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[1][j][r] += theirs[(j * 16 + r) * 64];
+            store_rows(1, acc[1]);
+        }
+    }
 }
 
-template <bool AKC, bool BKC, int TK, int NS>
+template <bool AKC, bool BKC, int TK, int NS, int KG>
 int launch_g16(hipStream_t st, const GArgs& g) {
     const int ntm = xg_cdiv(g.M, TM), ntn = xg_cdiv(g.N, TN);
     if (g.splitk > 1 && !g.accumulate) {
@@ -270,18 +342,18 @@ int launch_g16(hipStream_t st, const GArgs& g) {
     constexpr int lds = NS * stb<TK>();
     if (lds > 65536) {
         static std::atomic<unsigned> optin{0};
-        XG_TRY(xg_lds_optin(optin, reinterpret_cast<const void*>(&gemm_g16_kernel<AKC, BKC, TK, NS>), lds));
+        XG_TRY(xg_lds_optin(optin, reinterpret_cast<const void*>(&gemm_g16_kernel<AKC, BKC, TK, NS, KG>), lds));
     }
-    hipLaunchKernelGGL((gemm_g16_kernel<AKC, BKC, TK, NS>), dim3(ntm * ntn * g.splitk), dim3(256), lds, st, g);
+    hipLaunchKernelGGL((gemm_g16_kernel<AKC, BKC, TK, NS, KG>), dim3(ntm * ntn * g.splitk), dim3(256 * KG), lds, st, g);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
-template <int TK, int NS>
+template <int TK, int NS, int KG = 1>
 int launch_g16_layout(hipStream_t st, const GArgs& g, bool akc, bool bkc) {
-    if (akc && bkc) return launch_g16<true, true, TK, NS>(st, g);
-    if (akc && !bkc) return launch_g16<true, false, TK, NS>(st, g);
-    if (!akc && !bkc) return launch_g16<false, false, TK, NS>(st, g);
-    return launch_g16<false, true, TK, NS>(st, g);
+    if (akc && bkc) return launch_g16<true, true, TK, NS, KG>(st, g);
+    if (akc && !bkc) return launch_g16<true, false, TK, NS, KG>(st, g);
+    if (!akc && !bkc) return launch_g16<false, false, TK, NS, KG>(st, g);
+    return launch_g16<false, true, TK, NS, KG>(st, g);
 }
 
 }  // namespace
@@ -310,36 +382,44 @@ int xgk_gemm_g16(hipStream_t st, bool transA, bool transB, int M, int N, int K, 
     if (cs1 && !transA) return XG_EINVAL;
     const bool akc = !transA, bkc = transB;
     GArgs g{A16, B16, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1, 1, {cs1, cs2, cs3}, 0};
+    // Configuration <wave groups, slab depth, ring stages> (tools/ubench/g16_cfg.sh / g16_burst.sh, products alone):
+    //   64-deep slabs in two stages, four waves, two workgroups per CU ("642") everywhere but the weight-gradient layout, where
+    //   - with at most one tile per CU, EIGHT waves per tile win (two groups of four that split every slab's depth; one workgroup
+    //     per CU, four-stage ring: "844"): 4096 x 1024 x 5120 58-65 against 71-73 us, 4096 x 1024 x 2688 36-40 against 48-53,
+    //     1024 x 1536 x 5120 40-43 against 48-54 -- and lose everywhere else (logits 241 against 200, dH 193 against 143);
+    //   - with >= 1024 tiles, 32-deep slabs in three stages (three workgroups per CU, "323") are 10-20 % ahead (dW_logit 143
+    //     against 173 us); wherever an operand is k-contiguous they lose (64-byte row pieces = half cache lines).
+    //   One workgroup of four waves per CU with three 64-deep stages loses everywhere (277 against 188 us on the logits): what this
+    //   kernel needs is waves to switch to, not bytes in flight.
+    const long tiles = (long)xg_cdiv(M, TM) * xg_cdiv(N, TN);
+    static const char* cfg = xg_diag_env("XG_G16_CFG");     // diag build: 642 / 643 / 322 / 323 / 324 / 325 / 843 / 844
+    const bool tn_layout = !akc && !bkc;
+    static const bool no8 = xg_diag_env("XG_G16_NO8") != nullptr;      // diag: without the eight-wave form
+    const int c = cfg ? atoi(cfg) : (tn_layout && tiles >= 1024 ? 323 : (tn_layout && tiles <= 256 && !no8 ? 844 : 642));
     // Split of the reduction across workgroups (`splitk` <= 0: this kernel's own rule; the register-staged kernel's rule
     // filled 512 slots whenever the tiles did not).  A part's result is added with fp32 atomics behind a memset of C, and that
     // epilogue is expensive here: 5120 x 1024 x 1536 takes 34 us unsplit and 58-70 us in two parts, 5120 x 1024 x 4096 76 against
-    // 85-114 us.  Measured rule (tools/ubench/g16_sk.sh): split only while tiles x parts stay ONE round of the 512 slots (two
-    // workgroups per CU) and every part keeps a reduction of >= 2560 -- 4096 x 1024 x 5120: 2 parts (77 against 91 us),
-    // 2688 x 1024 x 20000: 3 parts (158 us; 1 / 2 / 4 parts: 322 / 198 / 228).
-    const long tiles = (long)xg_cdiv(M, TM) * xg_cdiv(N, TN);
+    // 85-114 us.  Measured rule (tools/ubench/g16_sk.sh): split only while tiles x parts stay ONE round of the slots (512 with two
+    // workgroups per CU, 256 with one) and every part keeps a reduction of >= 2560 -- 2688 x 1024 x 20000: 3 parts (158 us; 1 / 2 / 4
+    // parts: 322 / 198 / 228) -- or, while the tiles alone leave CUs empty, of >= 1024 (1024 x 1536 x 5120, 96 tiles, four waves:
+    // 87 / 65 / 55 / 51 / 52 us in 1 / 2 / 3 / 4 / 5 parts).
     if (splitk > 0) g.splitk = splitk;
     else if (!relu) {
-        // (... and while the tiles alone leave CUs empty -- fewer than 256 -- parts of >= 1024 are worth it: 1024 x 1536 x 5120,
-        // 96 tiles, 87 / 65 / 55 / 51 / 52 us in 1 / 2 / 3 / 4 / 5 parts)
+        const long slots = c >= 800 ? 256 : 512;
         const int deep = tiles < 256 ? 1024 : 2560;
-        long sk = 512 / tiles;
+        long sk = slots / tiles;
         if (sk > K / deep) sk = K / deep;
         g.splitk = sk < 1 ? 1 : (int)sk;
     }
     { static const char* d = xg_diag_env("XG_G16_DBG"); if (d) g.dbg = atoi(d); }
     { static const char* d = xg_diag_env("XG_G16_SK"); if (d && !relu) g.splitk = atoi(d); }
     g.gm = xgk_group_rows(K / g.splitk / 2);          // (an operand panel is 128 x k_depth bf16 = half the bytes the rule was made for)
-    // Configuration <slab depth, ring stages>: 64-deep slabs in two stages (two workgroups per CU) everywhere but the
-    // weight-gradient layout with many tiles (dW_logit: 20000 x 1024 x 2688, 1256 tiles), where 32-deep slabs in three stages
-    // (three workgroups per CU) are 10 % ahead (156-168 against 168-193 us); every other shape is equal or 5-25 % slower with
-    // them (tools/ubench/g16_cfg.sh).  One workgroup per CU with three 64-deep stages loses everywhere (277 against 188 us on
-    // the logits): what this kernel needs is waves to switch to, not bytes in flight.
-    static const char* cfg = xg_diag_env("XG_G16_CFG");     // diag build: "<TK><NS>" = 642 / 643 / 322 / 323 / 324 / 325
-    const int c = cfg ? atoi(cfg) : ((!akc && !bkc && tiles >= 1024) ? 323 : 642);
     switch (c) {
     case 323: return launch_g16_layout<32, 3>(st, g, akc, bkc);
+    case 844: return launch_g16_layout<64, 4, 2>(st, g, akc, bkc);       // eight waves (two k groups), one workgroup per CU
 #ifdef XG_DIAG
     case 322: return launch_g16_layout<32, 2>(st, g, akc, bkc);
+    case 843: return launch_g16_layout<64, 3, 2>(st, g, akc, bkc);
     case 643: return launch_g16_layout<64, 3>(st, g, akc, bkc);
     case 324: return launch_g16_layout<32, 4>(st, g, akc, bkc);
     case 325: return launch_g16_layout<32, 5>(st, g, akc, bkc);

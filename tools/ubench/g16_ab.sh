@@ -10,6 +10,7 @@ XG_NO_G16=1 python tools/ubench/gemm16_bench.py 2>/dev/null | cut -d'|' -f1 | se
 cat $OUT/gemm16.txt
 X5="python bench.py --workload xe5 --precision bf16 --steps 20 --warmup 5 --no-cpu-baseline --no-pmc --no-secondary"
 for rep in 1 2; do
+  XG_G16_NO8=1 $X5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('xe5 bf16, LDS-DMA, no 8-wave form', d['ms_per_step'], d.get('parity_loss_delta'))" | tee -a $OUT/xe5.txt
   $X5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('xe5 bf16, LDS-DMA kernel      ', d['ms_per_step'], d.get('parity_loss_delta'))" | tee -a $OUT/xe5.txt
   XG_NO_G16=1 $X5 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('xe5 bf16, register-staged     ', d['ms_per_step'], d.get('parity_loss_delta'))" | tee -a $OUT/xe5.txt
 done
