@@ -2,9 +2,13 @@
 // global -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 1 KiB per wave-instruction), never through registers.
 //
 //   C[M,N] (+)= op(A) op(B) (+ bias, relu), fp32 accumulate, v_mfma_f32_32x32x16_bf16.
-//   128 x 128 x 64 tiles, 256 threads = 4 waves (2 x 2), each wave 64 x 64 = 2 x 2 MFMA tiles; TWO LDS stages of 32 KiB
-//   (A 16 KiB + B 16 KiB) -> 64 KiB per workgroup, two workgroups per CU.  Slab s + 1 is in flight (8 DMA instructions per
-//   wave) while slab s is multiplied; ONE barrier per slab.
+//   128 x 128 tiles, a wave's share 64 x 64 = 2 x 2 MFMA tiles; a ring of NS LDS stages of TK-deep slabs, filled by DMA and drained
+//   by COUNT (s_waitcnt vmcnt(N) + the raw s_barrier: __syncthreads() would drain the whole DMA queue), ONE barrier per slab; the
+//   DMA instructions of the next slab sit between the MFMA groups of the slab being multiplied.  Three forms (xgk_gemm_g16 picks):
+//     TK 64, NS 2, four waves  -- 64 KiB, two workgroups per CU: the default;
+//     TK 32, NS 3, four waves  -- 48 KiB, three workgroups per CU: the weight-gradient layout with >= 1024 tiles;
+//     TK 64, NS 4, EIGHT waves -- two groups of four share the tile and split every slab's depth, 128 KiB, one workgroup per CU:
+//                                 weight gradients of at most one tile per CU.
 //
 // The predecessor (xg_gemm_bf16.hip: gemm_bs_kernel<1,..,A16,B16>) staged 32-deep slabs through registers into ONE LDS image with
 // two barriers per slab: 516-576 TF alone on the hidden-1024 vocabulary shapes.  What an LDS-DMA costs is that the LDS image of
