@@ -1370,7 +1370,10 @@ int xgk_gemm_cs(hipStream_t st, int mode, bool transA, bool transB, int M, int N
     // (diag: XG_X3_FP32 = mask of the classes routed to exact fp32 in mode 3 -- 1 TN, 2 NT, 4 NN; default 1)
     static const int x3_fp32 = xg_diag_env("XG_X3_FP32") ? atoi(xg_diag_env("XG_X3_FP32")) : 1;
     const bool x3_exact = mode == 3 && (x3_fp32 & (transA ? 1 : (transB ? 2 : 4)));
-    if ((mode == 1 || mode == 3) && !x3_exact && M >= 256 && N >= 64 && K >= 64) {
+    // (... and shallow reductions: the gradients of the initial-state projections are R x R x B products -- 1024 x 1024 x 128 at hidden
+    // 1024 -- that took 62 us each on the bf16 tile kernel, four slabs per tile; diag: XG_BF16_MINK = the old threshold 64)
+    static const int bf16_mink = xg_diag_env("XG_BF16_MINK") ? atoi(xg_diag_env("XG_BF16_MINK")) : 256;
+    if ((mode == 1 || mode == 3) && !x3_exact && M >= 256 && N >= 64 && K >= bf16_mink) {
         return xgk_gemm_bf16(st, mode, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, cs1, cs2, cs3);
     }
 #ifdef XG_DIAG
@@ -1412,7 +1415,7 @@ int xgk_gemm_cs(hipStream_t st, int mode, bool transA, bool transB, int M, int N
 int xgk_gemm_x(hipStream_t st, int mode, bool transA, bool transB, int M, int N, int K, const float* A, const unsigned short* A16,
                int lda, const float* B, const unsigned short* B16, int ldb, float* C, int ldc, const float* bias, bool relu,
                bool accumulate, float* cs1, float* cs2, float* cs3) {
-    if ((mode & ~XGK_GEMM_BG) == 1 && (A16 || B16) && M >= 256 && N >= 64 && K >= 64) {
+    if ((mode & ~XGK_GEMM_BG) == 1 && (A16 || B16) && M >= 256 && N >= 64 && K >= 256) {
         if (cs1 && !transA) return XG_EINVAL;
         return xgk_gemm_bf16x(st, 1, transA, transB, M, N, K, A, A16, lda, B, B16, ldb, C, ldc, bias, relu, accumulate, cs1, cs2, cs3);
     }
