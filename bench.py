@@ -651,8 +651,9 @@ def step_group_by_arithmetic(args, ctx):
         out[precision] = round(measure_step_group(model, x) * 1e6, 2)
         del model
     out["what"] = ("xg_step_fwd stand-alone, 128 rows, hidden 512, 200 back-to-back calls; fp32 = v_mfma_f32_32x32x2_f32 on packed fp32 "
-                   "tiles; bf16x3 = the same tiles split into three bf16 planes in registers, 6 x v_mfma_f32_32x32x16_bf16 per 16-deep "
-                   "block (0.375 of the fp32 matrix time); bf16 = packed bf16 tiles, 1 MFMA per block")
+                   "tiles; bf16x3 = the same weights as three pre-split bf16 planes in the packed tiles (packed_dtype 2), activations split "
+                   "while staged, 6 x v_mfma_f32_32x32x16_bf16 per 16-deep block (0.375 of the fp32 matrix time); bf16 = packed bf16 "
+                   "tiles, 1 MFMA per block")
     return out
 
 
