@@ -1417,7 +1417,7 @@ int xgk_gemm_x(hipStream_t st, int mode, bool transA, bool transB, int M, int N,
                bool accumulate, float* cs1, float* cs2, float* cs3) {
     if ((mode & ~XGK_GEMM_BG) == 1 && (A16 || B16) && M >= 256 && N >= 64 && K >= 256) {
         if (cs1 && !transA) return XG_EINVAL;
-        return xgk_gemm_bf16x(st, 1, transA, transB, M, N, K, A, A16, lda, B, B16, ldb, C, ldc, bias, relu, accumulate, cs1, cs2, cs3);
+        return xgk_gemm_bf16x(st, 1 | (mode & XGK_GEMM_BG), transA, transB, M, N, K, A, A16, lda, B, B16, ldb, C, ldc, bias, relu, accumulate, cs1, cs2, cs3);
     }
     return xgk_gemm_cs(st, mode, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, cs1, cs2, cs3);
 }

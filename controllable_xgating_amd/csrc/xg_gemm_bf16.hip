@@ -656,6 +656,8 @@ int xgk_gemm_bf16x(hipStream_t st, int planes, bool transA, bool transB, int M, 
                    bool accumulate, float* cs1, float* cs2, float* cs3) {
     // (column sums are a side output of the weight-gradient layout only: transA)
     if (cs1 && !transA) return XG_EINVAL;
+    const bool bg = (planes & XGK_GEMM_BG) != 0;      // launched beside a latency-bound chain (xg_kernels.h)
+    planes &= ~XGK_GEMM_BG;
     BArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1, 1, nullptr, nullptr, {cs1, cs2, cs3}};
     const bool akc = !transA, bkc = transB;
     bool vec = ((uintptr_t)A % 16 == 0) && ((uintptr_t)B % 16 == 0) && (lda % 4 == 0) && (ldb % 4 == 0);
@@ -695,7 +697,7 @@ int xgk_gemm_bf16x(hipStream_t st, int planes, bool transA, bool transB, int M, 
     // both operands bf16 in memory: tiles by LDS-DMA, 64-deep slabs, one barrier per slab (xg_gemm_g16.hip)
     static const bool no_g16 = xg_diag_env("XG_NO_G16") != nullptr;
     if (g.A16 && g.B16 && !no_g16 && xgk_gemm_g16_ok(transA, transB, M, N, K, g.A16, lda, g.B16, ldb))
-        return xgk_gemm_g16(st, transA, transB, M, N, K, g.A16, lda, g.B16, ldb, C, ldc, bias, relu, accumulate, 0, cs1, cs2, cs3);
+        return xgk_gemm_g16(st, transA, transB, M, N, K, g.A16, lda, g.B16, ldb, C, ldc, bias, relu, accumulate, bg ? -1 : 0, cs1, cs2, cs3);
     g.gm = xgk_group_rows(K / g.splitk);
     if (g.A16 || g.B16) {
         if (akc && bkc) return dispatch16<true, true>(st, g);

@@ -337,13 +337,13 @@ __global__ void __launch_bounds__(256 * KG, 2) gemm_g16_kernel(GArgs g) {
 }
 
 template <bool AKC, bool BKC, int TK, int NS, int KG>
-int launch_g16(hipStream_t st, const GArgs& g) {
+int launch_g16(hipStream_t st, const GArgs& g, int extra_lds = 0) {
     const int ntm = xg_cdiv(g.M, TM), ntn = xg_cdiv(g.N, TN);
     if (g.splitk > 1 && !g.accumulate) {
         if (g.ldc == g.N) { if (hipMemsetAsync(g.C, 0, sizeof(float) * (size_t)g.M * g.N, st) != hipSuccess) return XG_EHIP; }
         else if (hipMemset2DAsync(g.C, sizeof(float) * g.ldc, 0, sizeof(float) * g.N, g.M, st) != hipSuccess) return XG_EHIP;
     }
-    constexpr int lds = NS * stb<TK>();
+    const int lds = NS * stb<TK>() + extra_lds;     // (extra_lds: diag -- a product beside a chain kept to one workgroup per CU)
     if (lds > 65536) {
         static std::atomic<unsigned> optin{0};
         XG_TRY(xg_lds_optin(optin, reinterpret_cast<const void*>(&gemm_g16_kernel<AKC, BKC, TK, NS, KG>), lds));
@@ -353,11 +353,11 @@ int launch_g16(hipStream_t st, const GArgs& g) {
     return XG_OK;
 }
 template <int TK, int NS, int KG = 1>
-int launch_g16_layout(hipStream_t st, const GArgs& g, bool akc, bool bkc) {
-    if (akc && bkc) return launch_g16<true, true, TK, NS, KG>(st, g);
-    if (akc && !bkc) return launch_g16<true, false, TK, NS, KG>(st, g);
-    if (!akc && !bkc) return launch_g16<false, false, TK, NS, KG>(st, g);
-    return launch_g16<false, true, TK, NS, KG>(st, g);
+int launch_g16_layout(hipStream_t st, const GArgs& g, bool akc, bool bkc, int extra_lds = 0) {
+    if (akc && bkc) return launch_g16<true, true, TK, NS, KG>(st, g, extra_lds);
+    if (akc && !bkc) return launch_g16<true, false, TK, NS, KG>(st, g, extra_lds);
+    if (!akc && !bkc) return launch_g16<false, false, TK, NS, KG>(st, g, extra_lds);
+    return launch_g16<false, true, TK, NS, KG>(st, g, extra_lds);
 }
 
 }  // namespace
@@ -407,9 +407,13 @@ int xgk_gemm_g16(hipStream_t st, bool transA, bool transB, int M, int N, int K, 
     // workgroups per CU, 256 with one) and every part keeps a reduction of >= 2560 -- 2688 x 1024 x 20000: 3 parts (158 us; 1 / 2 / 4
     // parts: 322 / 198 / 228) -- or, while the tiles alone leave CUs empty, of >= 1024 (1024 x 1536 x 5120, 96 tiles, four waves:
     // 87 / 65 / 55 / 51 / 52 us in 1 / 2 / 3 / 4 / 5 parts).
+    // splitk == -1: the product was launched beside a latency-bound chain (XGK_GEMM_BG).  diag XG_G16_BG=1: it then keeps to ONE
+    // workgroup per CU (32 KiB of LDS it does not use) and leaves the other half of every CU to the chain's launches
+    static const bool bg_on = xg_diag_env("XG_G16_BG") != nullptr;
+    const int extra_lds = (splitk == -1 && bg_on && c == 642) ? 32768 : 0;
     if (splitk > 0) g.splitk = splitk;
     else if (!relu) {
-        const long slots = c >= 800 ? 256 : 512;
+        const long slots = (c >= 800 || extra_lds) ? 256 : 512;
         const int deep = tiles < 256 ? 1024 : 2560;
         long sk = slots / tiles;
         if (sk > K / deep) sk = K / deep;
@@ -428,6 +432,6 @@ int xgk_gemm_g16(hipStream_t st, bool transA, bool transB, int M, int N, int K, 
     case 324: return launch_g16_layout<32, 4>(st, g, akc, bkc);
     case 325: return launch_g16_layout<32, 5>(st, g, akc, bkc);
 #endif
-    default: return launch_g16_layout<64, 2>(st, g, akc, bkc);
+    default: return launch_g16_layout<64, 2>(st, g, akc, bkc, extra_lds);
     }
 }
