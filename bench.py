@@ -153,13 +153,16 @@ def load_traffic():
         return None, None
 
 
-def cpu_baseline(cfg, budget_s=20.0, hip_model=None, hip_x=None):
+def cpu_baseline(cfg, budget_s=20.0, hip_model=None, hip_x=None, p=0.0, seed=0):
     """Oracle (port of the reference's CPU path; reference-faithful: v2a(V) recomputed every step).
     Timed at two thread counts (all host cores, and 8 like SURVEY.md's anchors); the faster one is `value`.
     With `hip_model` the leg is also the run's parity check: the HIP model takes the oracle's procedural weights and its
     XE loss on the very same batch is compared with the oracle's (`parity` in the result).
     budget_s <= 0 (the secondary lines): ONE forward + backward at 8 threads, no warm-up -- the parity check plus a
-    one-iteration rate."""
+    one-iteration rate.
+    p > 0 (train-mode dropout, the reference's default 0.5: myopts.py:37): the oracle draws its masks from the integer hash of
+    (seed, site, step, element) and the HIP model is pinned to the same seed (SAModel.dropout_seed), so both see the very same
+    masks (the machinery of tests/test_gpu_parity.py:test_dropout_masks_match_oracle_hash)."""
     from oracle import paramgen as pg
     d = pg.make_dims(B=cfg["B"], K=cfg["K"], R=cfg["R"], A=cfg["A"], E=cfg["E"], V=cfg["V"], C=cfg["C"], L=cfg["L"],
                      F1=cfg["F1"], F2=cfg["F2"])
@@ -168,7 +171,7 @@ def cpu_baseline(cfg, budget_s=20.0, hip_model=None, hip_x=None):
     res = []
     for nt in (sorted({min(8, ncores), ncores}) if budget_s > 0 else [min(8, ncores)]):
         torch.set_num_threads(nt)
-        res.append(_cpu_baseline_once(cfg, d, Pn, budget_s / 2))
+        res.append(_cpu_baseline_once(cfg, d, Pn, budget_s / 2, p, seed))
     torch.set_num_threads(ncores)
     best = max(res, key=lambda r: r["value"])
     best["sample"] += "; all thread counts tried: " + ", ".join("%d threads -> %.1f/s" % (r["cores"], r["value"]) for r in res)
@@ -178,14 +181,16 @@ def cpu_baseline(cfg, budget_s=20.0, hip_model=None, hip_x=None):
     if hip_model is not None:
         hip_model.load_state_dict({k: torch.from_numpy(v) for k, v in Pn.items()}, strict=False)
         hip_model.train()
+        hip_model.dropout_seed = seed if p > 0.0 else None
         with torch.no_grad():
             hl = hip_model.xe_loss(hip_x["feats_rgb"], hip_x["feats_opfl"], hip_x["feat_mask"], hip_x["pos_feats"], hip_x["seq"],
                                    hip_x["seq_mask"])
+        hip_model.dropout_seed = None
         best["parity"] = {"oracle_loss": oracle_loss, "hip_loss": float(hl.item()), "delta": abs(float(hl.item()) - oracle_loss)}
     return best
 
 
-def _cpu_baseline_once(cfg, d, Pn, budget_s):
+def _cpu_baseline_once(cfg, d, Pn, budget_s, p=0.0, seed=0):
     from oracle import xgate_oracle as xo
     P = xo.to_torch_params(Pn, requires_grad=True)
     x = {k: v.cpu() for k, v in synth_inputs(cfg["B"], cfg["K"], cfg["L"], cfg["V"], cfg["R"], cfg["F1"], cfg["F2"], cfg["C"],
@@ -196,7 +201,7 @@ def _cpu_baseline_once(cfg, d, Pn, budget_s):
         for p_ in P.values():
             p_.grad = None
         logp, cat, _ = xo.forward_xe(P, x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"],
-                                     x["seq_mask"], train=True, running=running, hoist=False)
+                                     x["seq_mask"], train=True, running=running, hoist=False, p=p, seed=seed)
         loss = xo.lm_criterion(logp, x["seq"], x["seq_mask"])
         loss.backward()
         return float(loss.item())
@@ -325,9 +330,10 @@ def scst_parity(model, cfg, x, reward_b):
     return {"oracle_loss": loss_o, "hip_loss": loss_h, "delta": abs(loss_h - loss_o), "rollout_width": n_s}
 
 
-def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pmc=True, comm_diag=True):
+def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pmc=True, comm_diag=True, drop=None):
     """One timed workload on this rank; returns (json-able dict | None on ranks != 0, parity failure text | None)."""
     world, rank, dev, use_dist = ctx["world"], ctx["rank"], ctx["dev"], ctx["use_dist"]
+    drop = args.drop if drop is None else drop
     if use_dist:
         import torch.distributed as dist
     from controllable_xgating_amd import LanguageModelCriterion, RewardCriterion, SAModel, make_opt
@@ -341,7 +347,7 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
     if workload == "xe5":          # BASELINE.json configs[4]: hidden 1024, 40 frames, vocab 20k
         cfg.update(K=40, R=1024)
     T = cfg["L"] + 1
-    opt = make_opt(None, vocab_size=cfg["V"], seq_length=cfg["L"], drop_prob_lm=args.drop, precision=precision,
+    opt = make_opt(None, vocab_size=cfg["V"], seq_length=cfg["L"], drop_prob_lm=drop, precision=precision,
                    rnn_size=cfg["R"], att_size=cfg["A"], input_encoding_size=cfg["E"], feat_size=cfg["F1"], feat_size2=cfg["F2"])
     model = SAModel(opt).to(dev)
     if os.environ.get("XG_X3_TILES") is not None:       # diagnosis: split-bf16 over fp32 tiles (0: split in registers) instead of pre-split planes
@@ -352,7 +358,7 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
     # clamp + Adam start per parameter group as soon as its gradient is final (XG_NO_UPDATE_OVERLAP=1: after the backward)
     # --graph: the fixed-shape XE iteration replayed as ONE HIP graph (train.GraphedXEStep).  Not the default: the capture has to
     # be single-stream on this ROCm, which costs more GPU time (7.05 vs 6.10 ms) than the 2.4 ms of host work it removes
-    use_graph = (args.graph and not use_dist and workload in ("xe", "xe5") and args.path == "fused" and args.drop == 0.0
+    use_graph = (args.graph and not use_dist and workload in ("xe", "xe5") and args.path == "fused" and drop == 0.0
                  and not os.environ.get("XG_BENCH_SLEEP_MS"))
     optim = ClipAdam(model, lr=4e-4, grad_clip=0.1, overlap=os.environ.get("XG_NO_UPDATE_OVERLAP") is None,
                      fused_zero=os.environ.get("XG_NO_FUSED_ZERO") is None, device_state=use_graph)
@@ -575,7 +581,7 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
         "data": "synthetic",
         "config": {"workload": wl,
                    "global_batch": world * cfg["B"], "per_gpu_batch": cfg["B"], "parallelism": "dp%d" % world,
-                   "path": args.path, "drop_prob_lm": args.drop, "gemm_precision": precision,
+                   "path": args.path, "drop_prob_lm": drop, "gemm_precision": precision,
                    "timed_region": ("zero_grad + sampled + greedy rollouts (30 core steps, one 2m-row batch) + reward criterion + backward"
                                     if workload == "scst" else
                                     "zero_grad + encoder fwd + 21 decoder steps + heads/loss + full backward")
@@ -620,10 +626,11 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
             par = scst_parity(model, cfg, x, reward_b)
             what = "RewardCriterion loss of the HIP paired rollout vs the CPU oracle replaying the tokens it drew (same weights, same batch)"
         else:
-            cb = cpu_baseline(cfg, args.cpu_budget if workload == "xe" else 0.0, model, x)
+            cb = cpu_baseline(cfg, args.cpu_budget if (workload == "xe" and drop == args.drop) else 0.0, model, x, p=drop, seed=20240605)
             par = cb.pop("parity", None)
             out["cpu_baseline"] = cb
-            what = "XE loss of this run's HIP model vs the CPU oracle, same procedural weights, same batch"
+            what = "XE loss of this run's HIP model vs the CPU oracle, same procedural weights, same batch" + \
+                   (" and the same dropout masks (p = %g, shared integer-hash seed)" % drop if drop > 0.0 else "")
         if par is not None:
             out["parity_loss_delta"] = round(par["delta"], 7)
             out["parity"] = {"hip_loss": round(par["hip_loss"], 6), "oracle_loss": round(par["oracle_loss"], 6), "tol": tol, "what": what}
@@ -729,9 +736,14 @@ def main():
     if (not args.no_secondary and world == 1 and not use_dist and args.workload == "xe" and args.precision == "fp32"
             and args.batch == 128 and args.path == "fused"):
         sec = {}
-        for key, (wl_, prec_) in {"scst": ("scst", "fp32"), "xe5_bf16": ("xe5", "bf16"), "xe_bf16x3": ("xe", "bf16x3")}.items():
+        # ... and the headline configuration at the reference's default drop_prob_lm = 0.5 (myopts.py:37; SURVEY.md 8d: "throughput
+        # reported at 0.0 and 0.5"): secondary.xe_drop05
+        for key, (wl_, prec_, drop_) in {"scst": ("scst", "fp32", None), "xe5_bf16": ("xe5", "bf16", None), "xe_bf16x3": ("xe", "bf16x3", None),
+                                         "xe_drop05": ("xe", "fp32", 0.5)}.items():
+            if drop_ is not None and drop_ == args.drop:
+                continue
             try:
-                o, f = run_workload(args, wl_, prec_, 10, 5, ctx, pmc=False, comm_diag=False)
+                o, f = run_workload(args, wl_, prec_, 10, 5, ctx, pmc=False, comm_diag=False, drop=drop_)
                 sec[key] = {k: o[k] for k in ("metric", "value", "unit", "ms_per_step", "host_enqueue_ms_per_step", "dtype", "config",
                                               "final_loss", "roofline", "parity_loss_delta", "parity", "steps", "warmup") if k in o}
                 if "cpu_baseline" in o:

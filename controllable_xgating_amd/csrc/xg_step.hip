@@ -23,13 +23,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
 
-#ifndef SK_WAVES
-#define SK_WAVES 8
-#endif
-#ifndef XG_SK_DEEP_DEFAULT
-#define XG_SK_DEEP_DEFAULT 0
-#endif
-constexpr int SKW = SK_WAVES;     // waves per workgroup (K split)
+constexpr int SKW = 8;            // waves per workgroup (K split)
 constexpr int SKT = SKW * 64;     // threads
 constexpr int CK = 32;            // k-chunk depth staged per wave
 constexpr int LDR = CK + 4;       // LDS row stride (floats): 9 16-B slots -> conflict-free b128 fragment reads
@@ -142,13 +136,6 @@ __device__ __forceinline__ void st_chunk_split3(unsigned short* __restrict__ lds
 }
 // the 8 fp32 weights a lane holds for one 16-deep MFMA block (two f32x4 pieces) -> three bf16x8 operands
 __device__ __forceinline__ void split3_b(const f32x4& x, const f32x4& y, bf16x8 (&pl)[3]) {
-#ifdef SKF_SPLIT_FREE
-    // timing experiment only (results wrong): what would the split-bf16 step cost if the weight planes came pre-split from memory
-    // (the bytes of the extra half plane not counted)?  tools/ubench/split_free.sh
-    { const uint4 u = {__float_as_uint(x[0]), __float_as_uint(x[1]), __float_as_uint(y[0]), __float_as_uint(y[1])};
-      const uint4 v = {__float_as_uint(x[2]), __float_as_uint(x[3]), __float_as_uint(y[2]), __float_as_uint(y[3])};
-      pl[0] = __builtin_bit_cast(bf16x8, u); pl[1] = __builtin_bit_cast(bf16x8, v); pl[2] = pl[0]; return; }
-#endif
     unsigned w[3][4];
     split3_pair(x[0], x[1], w[0][0], w[1][0], w[2][0]);
     split3_pair(x[2], x[3], w[0][1], w[1][1], w[2][1]);
@@ -355,9 +342,6 @@ __device__ __forceinline__ void sk_epilogue_split(const SkJob& job, float* __res
         }
     }
     if (job.epi != SK_EPI_LSTMB) return;
-#if defined(SKF_ABLATE) && SKF_ABLATE == 7
-    return;                                                    // (timing experiment: split tiles without the ticket / last-arriver phase)
-#endif
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's adds have been performed
     __syncthreads();
     int* flag = reinterpret_cast<int*>(smem);                  // (the partial tiles are dead after the barrier)
@@ -465,12 +449,10 @@ __global__ void __launch_bounds__(SKT) __attribute__((amdgpu_waves_per_eu(4, 4))
                 st_chunk(Bs, lane, rb);
             }
             if (s == 0 && c == c0) SK_STAMP(2);
-#ifndef SK_NO_LOAD
             if (c + 1 < c1) {   // next chunk's global loads fly while this chunk's MFMAs run
                 ld_chunk<VEC>(pa, c + 1, c + 1 >= nfull, va, 0, ra);
                 ld_chunk<VEC>(pb, c + 1, c + 1 >= nfull, vb, bn ? 8 : 0, rb);
             }
-#endif
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (PREC == 1) {
@@ -500,12 +482,8 @@ __global__ void __launch_bounds__(SKT) __attribute__((amdgpu_waves_per_eu(4, 4))
                 } else {
                     b = *reinterpret_cast<const f32x4*>(Bs + l31 * LDR + kb * 8 + half * 4);
                 }
-#ifdef SK_NO_MFMA
-                acc[0] += a[0] * b[0] + a[1] * b[1] + a[2] * b[2] + a[3] * b[3];
-#else
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[kk], b[kk], acc, 0, 0, 0);
-#endif
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -605,28 +583,9 @@ __device__ __forceinline__ void attn_part(const SkJob& job, int tile, float* sme
         if (lane == 0 && nrow > 0) atomicAdd(job.attn_s + b, ssum);
     }
     __syncthreads();
-#ifdef SKF_ATTN_DRAIN
-    // (round 4 waited here for every vector-memory operation of the wave, `s_waitcnt vmcnt(0)`, as one of several changes made at
-    //  once against the run-to-run differences described below; round 5 took the changes apart -- tools/ubench notes in
-    //  docs/EXPERIMENTS.md -- and this one is not needed: 4 x 12 reproducibility cases without it)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
     // unnormalised context of this half: thread -> two adjacent columns
     for (int c = threadIdx.x * 2; c < R; c += NWV * 128) {
         float ax = 0.f, ay = 0.f;
-#if defined(SKF_ATTN_UNROLL1)
-#pragma unroll 1
-        for (int r = 0; r < nrow; ++r) {
-            const float2 v = *reinterpret_cast<const float2*>(Vb + (size_t)(k0 + r) * R + c);
-            ax += sx[r] * v.x; ay += sx[r] * v.y;
-        }
-#elif defined(SKF_ATTN_OLD)
-#pragma unroll 4
-        for (int r = 0; r < nrow; ++r) {
-            const float2 v = *reinterpret_cast<const float2*>(Vb + (size_t)(k0 + r) * R + c);
-            ax += sx[r] * v.x; ay += sx[r] * v.y;
-        }
-#else
         // four rows per trip, written out: the four loads are requested first, then the four weights come out of LDS one by one
         // (scalar reads, no b128), then the multiply-adds as plain v_fmac_f32, pinned.  Why: when the SLP vectorizer pairs the two
         // accumulators (one ds_read_b128 for the four weights, four v_pk_fma_f32 with operand-select modifiers, one v_mov that
@@ -643,9 +602,6 @@ __device__ __forceinline__ void attn_part(const SkJob& job, int tile, float* sme
             const float2 v1 = *reinterpret_cast<const float2*>(vp + (size_t)(r + 1) * R);
             const float2 v2 = *reinterpret_cast<const float2*>(vp + (size_t)(r + 2) * R);
             const float2 v3 = *reinterpret_cast<const float2*>(vp + (size_t)(r + 3) * R);
-#ifdef SKF_ATTN_NOP
-            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-#endif
             const float s0 = sx[r], s1 = sx[r + 1], s2 = sx[r + 2], s3 = sx[r + 3];
 #ifdef SKF_ATTN_PKFMA
             ax += s0 * v0.x; ay += s0 * v0.y;
@@ -664,16 +620,6 @@ __device__ __forceinline__ void attn_part(const SkJob& job, int tile, float* sme
             const float2 v = *reinterpret_cast<const float2*>(vp + (size_t)r * R);
             ax += sx[r] * v.x; ay += sx[r] * v.y;
         }
-#ifdef SKF_ATTN_CHECK
-        {   // diagnosis: is the LDS copy of the weights still what wave 0 stored (== the attn_ex rows in memory)?
-            asm volatile("s_nop 7\n\ts_nop 7" ::: "memory");
-            for (int q = 0; q < nrow; ++q) {
-                const float a = sx[q], bq = __hip_atomic_load(job.attn_ex + (size_t)b * K + k0 + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                if (a != bq) printf("attn check: wg %d tid %d q %d lds %.9g mem %.9g\n", (int)blockIdx.x, (int)threadIdx.x, q, a, bq);
-            }
-        }
-#endif
-#endif
         atomicAdd(job.attn_c + (size_t)b * R + c, ax);
         atomicAdd(job.attn_c + (size_t)b * R + c + 1, ay);
     }
@@ -947,9 +893,6 @@ skf_kernel(SkArgs args) {
                    (ei.accumulate ? EF_ACC : 0) | (ei.relu ? EF_RELU : 0) | (ei.order == XG_ORDER_IFOG ? EF_IFOG : 0) |
                    (ei.mask_mode == XG_MASK_HOLD ? EF_HOLD : 0);
     asm volatile("" : "+s"(ef));       // (ONE scalar tested bit by bit: left alone the compiler keeps a 64-bit lane mask per condition)
-#if defined(SKF_ABLATE) && SKF_ABLATE == 6
-    if (ef != 0x7fffffff) return;                 // behind the first round of descriptor loads
-#endif
     if (hd.epi == SK_EPI_ZERO) {
         if ((size_t)blockIdx.x * 4096 < (size_t)job.M * job.N) zero_tile<NW>(job, blockIdx.x);
         return;
@@ -959,16 +902,8 @@ skf_kernel(SkArgs args) {
         return;
     }
     if (hd.epi == SK_EPI_ATTN) {
-#ifdef SKF_ATTN_PRIO
-        __builtin_amdgcn_s_setprio(SKF_ATTN_PRIO);
-#endif
         if ((int)blockIdx.x < 2 * job.M) {           // (every wave of the workgroup scores its share of the rows)
-#ifdef SKF_ATTN_LDS_OFF
-            float* asm_ = smem + SKF_ATTN_LDS_OFF;
-#else
-            float* asm_ = smem;
-#endif
-            if (job.attn_A <= 1536) attn_part<6, NW>(job, blockIdx.x, asm_); else attn_part<8, NW>(job, blockIdx.x, asm_);
+            if (job.attn_A <= 1536) attn_part<6, NW>(job, blockIdx.x, smem); else attn_part<8, NW>(job, blockIdx.x, smem);
         }
         return;
     }
@@ -1012,9 +947,6 @@ skf_kernel(SkArgs args) {
         for (int i = 0; i < 4; ++i) gidx[i] = __float_as_int(ldf(reinterpret_cast<const float*>(gp), (unsigned)rowi[i] * gs8));
     }
     SK_STAMP(6);
-#if defined(SKF_ABLATE) && SKF_ABLATE == 1
-    if (gidx[0] != 0x7fffffff) return;            // (instruction-count ablation builds: tools/ubench/ablate_step.sh)
-#endif
 
     f32x16 acc;
 #pragma unroll
@@ -1062,12 +994,6 @@ skf_kernel(SkArgs args) {
     if (SCALE) scale_loads();
     // ---- the epilogue's operands are requested now: they have the whole K loop to land
     if (!LATE_PRE) epi_prefetch<NW>(pre, hd, ei, ef, cell_tiles, m0, n0, tn);
-#ifdef SKF_KLOOP_PRIO
-    if (!(hd.hflags & SKH_LOW_PRIO)) __builtin_amdgcn_s_setprio(SKF_KLOOP_PRIO);
-#endif
-#if defined(SKF_ABLATE) && SKF_ABLATE == 2
-    if (pre.a[0] != 1.2345e30f) return;
-#endif
     SkEpiOut eo;
     // this lane's 16-byte piece of a B tile, sub-piece i at + i * 1024 bytes (a bf16 tile is 2 KB: 2 pieces, an fp32 tile 4 KB: 4)
     // (PREC 3: a tile is six 1 KB pieces -- block j, plane q at piece 3 j + q -- of three pre-split bf16 planes: xg_pack.hip, dtype 2)
@@ -1141,9 +1067,6 @@ skf_kernel(SkArgs args) {
                 if (c0 + 1 < c1) { ldB(c0 + 1, rb1); ldAc(c0 + 1, *reinterpret_cast<f32x4 (*)[4]>(ra1)); }
             }
         }
-#if defined(SKF_ABLATE) && SKF_ABLATE == 5
-        if (s == 0 && ra0[0][0] != 1.2345e30f) return;        // behind the first segment's set-up and first operand request
-#endif
         // ---- behind this segment's first operand request: the next segment's hot part, or -- behind the last one -- the
         // epilogue's output block (scalar-cache hits: the first round touched their lines' neighbours)
         SkSegHot sgn = sg;
@@ -1234,9 +1157,6 @@ skf_kernel(SkArgs args) {
     }
     SK_STAMP(3);
     SK_STAMP_MAX(7);
-#if defined(SKF_ABLATE) && SKF_ABLATE == 3
-    if (acc[0] != 1.2345e30f) return;
-#endif
     if (LATE_PRE) epi_prefetch<NW>(pre, hd, ei, ef, cell_tiles, m0, n0, tn);
     __syncthreads();
     float (*red)[32][RSF] = reinterpret_cast<float (*)[32][RSF]>(smem);
@@ -1244,9 +1164,6 @@ skf_kernel(SkArgs args) {
     for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * half][l31] = acc[r];
     __syncthreads();
     SK_STAMP(4);
-#if defined(SKF_ABLATE) && SKF_ABLATE == 4
-    if (acc[0] != 1.2345e30f) return;
-#endif
     if (ks > 1) sk_epilogue_split<RSF, NW>(job, smem, m0, n0, kp, tm + ntm * tn);
     else skf_epilogue<NW>(job, hd, ef, ei.gate_y, ei.ldy, eo, cell_tiles, smem, m0, n0, tn, pre);
     if (exp_) *exp_ = exv * xg_rcp(exs);
@@ -1459,7 +1376,7 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         // (measured, round 5: stand-alone step unchanged at 39.6-41.0 us for every setting, iteration 5.62-5.75 against 5.56 ms --
         //  half the occupancy co-schedules worse beside the background products; the variants exist in the diag build only)
 #ifdef XG_DIAG
-        static const int deep_env = xg_diag_env("XG_SK_DEEP") ? atoi(xg_diag_env("XG_SK_DEEP")) : XG_SK_DEEP_DEFAULT;
+        static const int deep_env = xg_diag_env("XG_SK_DEEP") ? atoi(xg_diag_env("XG_SK_DEEP")) : 0;
         const bool deep8 = (deep_env & 1) && !nw4_rule && !has_attn && tiles <= 256;
         const bool deep4 = ((deep_env & 2) && !nw4_rule && !has_attn && tiles > 256 && tiles <= 512) || ((deep_env & 4) && ks > 1 && tiles <= 512);
 #else

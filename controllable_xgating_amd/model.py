@@ -180,6 +180,7 @@ class SAModel(nn.Module):
         self._gs_cache = None
         self._offsets = []
         self._call = 0
+        self.dropout_seed = None        # fixed seed of the dropout hash (tests / bench parity leg: a checker can regenerate the same masks); None = a fresh seed per call
         self._packed = None          # recurrent weights in MFMA-fragment order (xg_pack_weights), refreshed lazily
         self._packed_key = None
         self._packed_epoch = 0
@@ -296,14 +297,20 @@ class SAModel(nn.Module):
         d.C, d.H, d.F1, d.F2, d.T = self.category_size, 128, self.feat_size, self.feat_size2, T
         return d
 
-    def mark_params_changed(self):
+    def mark_params_changed(self, only_encoder_since_pack_early=False):
         """Tell the model its parameters were rewritten behind torch's back (a HIP kernel on the flat buffer, e.g.
         train.ClipAdam.step): the packed shadow of the recurrent weights is rebuilt before the next call.  Updates made
         through torch on the parameters themselves (optimizers, load_state_dict, ``p.copy_()``, ``p.mul_()`` under
         no_grad) are noticed by themselves (tensor version counters).  NOT noticed: in-place writes through ``p.data``
         (``p.data.copy_()``, ``p.data.uniform_()`` -- common in code written against the reference's torch 0.3): ``.data``
-        has its own version counter.  Call this method after such writes."""
+        has its own version counter.  Call this method after such writes.
+        ``only_encoder_since_pack_early=True`` is the statement of an optimizer that called ``pack_early()`` right behind its
+        update of every parameter group except the CG encoder's and has written NOTHING but the encoder's segment of the flat
+        buffer since (train.ClipAdam): only then may the next call keep the early-packed decoder tiles.  Any other caller gets
+        the full re-pack."""
         self._packed_epoch += 1
+        if not only_encoder_since_pack_early:
+            self._early_key = None           # whatever pack_early() covered may be stale again: the next call re-packs everything
 
     def _packed_dtype(self):
         """Element type of the packed recurrent weights (include/xgate.h: XgRun.packed_dtype): bf16 tiles for the bf16 arithmetic,
@@ -402,6 +409,8 @@ class SAModel(nn.Module):
         r = nv.XgRun()
         r.train = 1 if self.training else 0
         r.drop_p = float(self.drop_prob_lm)
+        if seed is None and self.dropout_seed is not None:
+            seed = int(self.dropout_seed) & 0xFFFFFFFF
         if seed is None:
             self._call += 1
             seed = (int(torch.initial_seed()) * 2654435761 + self._call * 40503) & 0xFFFFFFFF
@@ -676,11 +685,15 @@ class _XELossFunction(torch.autograd.Function):
         # (the counters' increment is independent of the forward: enqueued in FRONT of it, it is not one more small launch on the
         #  main stream between the loss and the start of the backward)
         model._bump_bn()
-        nv.check(nv.lib().xg_xe_loss_fwd(_stream(), C.byref(d), C.byref(ps), C.byref(bn), C.byref(b), nv.ptr(cc),
-                                         nv.ptr(cm), weight_class, C.byref(run), wp, wn, nv.ptr(losses)), "xg_xe_loss_fwd")
+        try:
+            nv.check(nv.lib().xg_xe_loss_fwd(_stream(), C.byref(d), C.byref(ps), C.byref(bn), C.byref(b), nv.ptr(cc),
+                                             nv.ptr(cm), weight_class, C.byref(run), wp, wn, nv.ptr(losses)), "xg_xe_loss_fwd")
+        except Exception:
+            model._bump_bn(-1)                     # the call was refused: num_batches_tracked stays where it was
+            raise
         ctx.model, ctx.d, ctx.ws, ctx.keep, ctx.run, ctx.saved_ws = model, d, ws, keep, run, save
         ctx.cc, ctx.cm, ctx.wc = cc, cm, weight_class
-        model.last_losses = losses
+        model.last_losses = losses.detach()        # READ-ONLY for callers: it shares storage with the returned loss (no copy kernel)
         return losses[0]                           # (a view of the three-element result: no copy kernel)
 
     @staticmethod

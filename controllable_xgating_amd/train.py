@@ -138,6 +138,7 @@ class ClipAdam:
 
     def step(self):
         n = self.model.flat_parameters().numel()
+        early = False
         if self._segments_done:                # a data-parallel GradSync.finish updated every segment behind its all-reduce
             self._segments_done = False
         elif self.overlap and self._armed:
@@ -156,6 +157,7 @@ class ClipAdam:
                 # refreshed here, under the encoder's backward, instead of at the head of the next iteration
                 if hasattr(self.model, "pack_early") and not _NO_EARLY_PACK:
                     self.model.pack_early()
+                    early = True               # from here on this step writes the encoder's segment [0, split) only
             self.update_segment(0, self._split)          # the encoder's gradients: after the whole backward (stream order)
             main.wait_stream(self._side)
         else:
@@ -166,7 +168,8 @@ class ClipAdam:
                 self.model._grad_event = None
                 self.model._grad_event_head = None
             self._armed = False
-        self.model.mark_params_changed()       # the kernel wrote the flat buffer directly: re-pack the recurrent weights
+        # the kernel wrote the flat buffer directly: re-pack the recurrent weights (all of them, unless pack_early covered the decoder's)
+        self.model.mark_params_changed(only_encoder_since_pack_early=early)
         self._zero_stamp = self._grad_stamp() if self.fused_zero else None   # every segment has been updated (and zeroed)
 
     def state_dict(self):

@@ -72,6 +72,51 @@ def test_config2_b128_xe_loss_logprobs_and_every_gradient_vs_oracle(path, ragged
         np.testing.assert_allclose(bn.running_var.cpu().numpy(), running[pre + "running_var"].numpy(), atol=1e-5)
 
 
+# ------------------------------------------------------------------ configs[1] at the reference's default drop_prob_lm = 0.5
+def test_config2_b128_xe_with_dropout_half_loss_and_every_gradient_vs_oracle():
+    """B = 128 teacher-forced XE in train mode at p = 0.5 (myopts.py:37; mask sites sub_modules.py:123,128,45,69-71,767 and
+    SAModel.py:49): the HIP kernels regenerate the oracle's integer-hash masks from the shared seed, so loss (1e-4), running
+    statistics and EVERY gradient compare as in the p = 0 case -- at the benchmarked size, through the fused loss path that
+    bench.py's secondary.xe_drop05 line times."""
+    d = pg.make_dims(**dict(CFG["c1"], B=128))
+    Pn = _params(d.V, 8.0, 0.0)
+    xn = pg.make_inputs(d, seed=0, ragged=True)
+    seed, p = 987654321, 0.5
+    P = xo.to_torch_params(Pn, requires_grad=True)
+    xi = xo.to_torch_inputs(xn)
+    running = xo.new_running(d)
+    logp_o, _, _ = xo.forward_xe(P, xi["feats_rgb"], xi["feats_opfl"], xi["feat_mask"], xi["pos_feats"], xi["seq"],
+                                 xi["seq_mask"], train=True, p=p, seed=seed, running=running)
+    loss_o = xo.lm_criterion(logp_o, xi["seq"], xi["seq_mask"])
+    loss_o.backward()
+    # the masks matter: the same weights and batch without dropout give another loss
+    with torch.no_grad():
+        logp_0, _, _ = xo.forward_xe(xo.to_torch_params(Pn), xi["feats_rgb"], xi["feats_opfl"], xi["feat_mask"], xi["pos_feats"],
+                                     xi["seq"], xi["seq_mask"], train=True, running=xo.new_running(d))
+        assert abs(xo.lm_criterion(logp_0, xi["seq"], xi["seq_mask"]).item() - loss_o.item()) > 1e-3
+    model = make_model(d, P=Pn, p_drop=p)
+    model.dropout_seed = seed
+    x = to_dev(xn)
+    loss = model.xe_loss(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+    loss.backward()
+    torch.cuda.synchronize()
+    assert abs(loss.item() - loss_o.item()) < 1e-4, (loss.item(), loss_o.item())
+    # (relu_flips: the surviving activations are doubled and half as many, so one ReLU derivative that flips between the two fp32
+    #  evaluations shows at up to ~2 % of a gradient's largest entry -- tests/util.py:relu_flip_exposed; everything downstream of
+    #  the ReLUs keeps the strict bounds)
+    assert_grads_close(model, oracle_grads(P), skip=ZERO_GRAD_PARAMS, relu_flips=True)
+    for mod in ("rgb", "opfl"):
+        bn = getattr(model.two_spatial_encoder, f"visual_emb_{mod}")[1]
+        pre = xo.ENC + f"visual_emb_{mod}.1."
+        np.testing.assert_allclose(bn.running_mean.cpu().numpy(), running[pre + "running_mean"].numpy(), atol=1e-5)
+        np.testing.assert_allclose(bn.running_var.cpu().numpy(), running[pre + "running_var"].numpy(), atol=1e-5)
+    # a second call with another seed draws other masks
+    model.dropout_seed = seed + 1
+    with torch.no_grad():
+        loss2 = model.xe_loss(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+    assert abs(loss2.item() - loss.item()) > 1e-5
+
+
 # ------------------------------------------------------------------ configs[4]: bf16, hidden 1024, 40 frames, vocab 20k, B = 128
 def test_config5_b128_hidden1024_bf16_and_split_bf16_vs_oracle():
     """BASELINE.json configs[4] at its FULL size (B = 128, K = 40, R = 1024, V = 20000): the kernel paths only this size

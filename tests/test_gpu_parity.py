@@ -297,9 +297,7 @@ def run_hip_xe(d, ragged, p=0.0, seed=None, weight_class=WEIGHT_CLASS, precision
     model = make_model(d, p_drop=p, precision=precision)
     x = to_dev(pg.make_inputs(d, seed=0, ragged=ragged))
     if seed is not None:
-        model._run_seed_override = seed
-        orig = model._run
-        model._run = lambda save, s=None, **kw: orig(save, seed, **kw)
+        model.dropout_seed = seed
     logp, cat = model(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
     l_xe = LanguageModelCriterion()(logp, x["seq"], x["seq_mask"])
     l_cls = ClassiferCriterion()(cat, x["cap_classes"], x["seq_mask"], x["class_mask"])
@@ -627,13 +625,19 @@ def test_overlapped_update_equals_plain_update():
         assert float((p0[n] - p1[n]).abs().max()) < 5e-6, n
 
 
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16x3"])
 def test_early_repack_of_the_decoder_tiles_equals_a_full_repack(precision):
     """ClipAdam(overlap=True) refreshes the packed tiles of every matrix but the CG encoder's right behind the update of their
     parameter group (SAModel.pack_early: xg_pack_weights_part, part 1, on the optimizer's side stream, under the encoder's
     backward) and the next call only packs the encoder's tiles (part 2): the shadow must be bit-identical to a full
     xg_pack_weights of the updated parameters -- and stale when the early part is skipped on purpose (the test tests something).
-    bf16: the same for the bf16 tiles and the bf16 copies of the large products' weights (round 5)."""
+    bf16: the same for the bf16 tiles and the bf16 copies of the large products' weights (round 5); bf16x3: the three pre-split
+    bf16 planes (packed_dtype 2, the default of split-bf16).  Also: any other writer between pack_early() and the next call
+    (a plain mark_params_changed()) voids the early part -- the full re-pack runs."""
+    import ctypes as C
+    from controllable_xgating_amd import _native as nv
+    from controllable_xgating_amd import train as tr
+    from controllable_xgating_amd.model import _stream
     from controllable_xgating_amd.train import ClipAdam
     d = pg.make_dims(**CFG["mid"])
     x = to_dev(pg.make_inputs(d, seed=0, ragged=True))
@@ -656,6 +660,50 @@ def test_early_repack_of_the_decoder_tiles_equals_a_full_repack(precision):
         torch.cuda.synchronize()
         assert torch.equal(two_part, model._packed)
         assert not torch.equal(before, model._packed)         # (the update really changed the tiles)
+    full = model._packed.clone()
+    # negative control: one more update WITHOUT the early part, then only part 2 (the encoder's tiles) -> the decoder's tiles are
+    # the previous step's, the shadow differs from a full pack of the updated parameters
+    opt.zero_grad()
+    loss = model.xe_loss(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+    opt.arm()
+    loss.backward()
+    tr._NO_EARLY_PACK, keep = True, tr._NO_EARLY_PACK
+    try:
+        opt.step()
+    finally:
+        tr._NO_EARLY_PACK = keep
+    assert model._early_key is None
+    dt = model._packed_dtype()
+    dd = model._dims(1, 1, 1)
+    nbytes = nv.lib().xg_packed_bytes(C.byref(dd), dt)
+    ptr = (model._packed.data_ptr() + 15) & ~15
+    ps = model._params_struct()
+    nv.check(nv.lib().xg_pack_weights_part(_stream(), C.byref(dd), C.byref(ps), C.c_void_p(ptr), C.c_size_t(nbytes), dt, 1, 2),
+             "xg_pack_weights_part")
+    torch.cuda.synchronize()
+    stale = model._packed.clone()
+    assert not torch.equal(stale, full)                       # (the encoder's tiles did move)
+    model._packed_ptr()                                       # the model itself saw no early part: a full re-pack
+    torch.cuda.synchronize()
+    assert not torch.equal(stale, model._packed)              # part 2 alone left the decoder's tiles stale
+    # ... and a foreign writer between pack_early() and the next call voids the early part
+    opt.zero_grad()
+    loss = model.xe_loss(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
+    opt.arm()
+    loss.backward()
+    opt.step()
+    assert model._early_key is not None
+    with torch.no_grad():
+        model.flat_parameters().data.mul_(1.0001)             # through .data: no version counter moves
+    model.mark_params_changed()
+    assert model._early_key is None
+    model._packed_ptr()
+    torch.cuda.synchronize()
+    a = model._packed.clone()
+    model.mark_params_changed()
+    model._packed_ptr()
+    torch.cuda.synchronize()
+    assert torch.equal(a, model._packed)
 
 
 def test_fused_zero_grad_update_equals_plain_update():

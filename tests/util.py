@@ -72,11 +72,24 @@ def oracle_grads(P):
 ZERO_GRAD_PARAMS = ("two_spatial_encoder.visual_emb_rgb.0.bias", "two_spatial_encoder.visual_emb_opfl.0.bias", "lstmcore.a2w.bias")
 
 
-def assert_grads_close(model, ref, rtol=2e-3, atol=2e-6, skip=(), cos_min=0.99999, rtol_elem=None, report=None):
+def relu_flip_exposed(name):
+    """Parameters UPSTREAM of a ReLU (the encoder's BatchNorm-ReLU embeddings, cross gates and fusion: sub_modules.py:98-103,44,71;
+    the decoder's POS gate: sub_modules.py:44 via :682).  A pre-activation within round-off of zero takes its derivative 0 on
+    one side and 1 on the other; two fp32 evaluations with different summation orders (MFMA chain vs CPU BLAS, or the fp32 oracle
+    vs the same oracle in float64: tools/r6/drop_diag.py) disagree on a handful of the 1.7 M elements of such a layer at B = 128,
+    and each disagreement moves ONE row / column of the upstream weight gradients by up to a few per cent of their largest entry
+    (measured round 6: which parameter is hit changes with the input seed; 1.6e-2 of the maximum at worst).  Forward values and
+    every parameter downstream of the ReLUs are unaffected."""
+    return name.startswith("two_spatial_encoder.") or name in ("embed.weight", "lstmcore.gate.gate.0.weight", "lstmcore.gate.gate.0.bias")
+
+
+def assert_grads_close(model, ref, rtol=2e-3, atol=2e-6, skip=(), cos_min=0.99999, rtol_elem=None, report=None, relu_flips=False):
     """Three bounds per parameter (round 5: the max-norm bound alone lets a defect confined to a gradient's small entries through):
     (1) max |g - r| <= atol + rtol * max |r|; (2) direction: cosine(g, r) >= cos_min; (3) element-wise: |g_i - r_i| <=
     atol + rtol |r_i| + (rtol / 10) max |r| -- the share of the bound that does not scale with the element itself is a tenth
-    of (1)'s.  Parameters whose true gradient is exactly zero (ZERO_GRAD_PARAMS) only make sense under (1) with their own scale
+    of (1)'s.  relu_flips=True (full-size cases with dropout): a parameter upstream of a ReLU (relu_flip_exposed) that misses (1) or
+    (3) is re-judged as a LOCALISED defect -- at most 1 % of its elements outside (3), none further than 5 % of the largest entry,
+    cosine >= 0.9999 -- which a flipped ReLU derivative is and a wrong kernel is not.  Parameters whose true gradient is exactly zero (ZERO_GRAD_PARAMS) only make sense under (1) with their own scale
     and are passed in `skip` by the callers.  `report`: optional dict filled with the worst figures (for tolerances to be set from)."""
     bad = []
     rt_e = rtol if rtol_elem is None else rtol_elem
@@ -88,6 +101,15 @@ def assert_grads_close(model, ref, rtol=2e-3, atol=2e-6, skip=(), cos_min=0.9999
         r = ref[name]
         scale = np.abs(r).max()
         err = np.abs(g - r).max()
+        if relu_flips and relu_flip_exposed(name):
+            excess = np.abs(g - r) - (atol + (rtol if rtol_elem is None else rtol_elem) * np.abs(r) + 0.1 * rtol * scale)
+            if not (err <= atol + rtol * scale and excess.max() <= 0):
+                gd, rd = g.astype(np.float64).ravel(), r.astype(np.float64).ravel()
+                cos = float(gd @ rd / max(np.linalg.norm(gd) * np.linalg.norm(rd), 1e-300))
+                frac = float((excess > 0).mean())
+                if not (frac <= 0.01 and err <= atol + 5e-2 * scale and cos >= 0.9999):
+                    bad.append((name, "not a localised (ReLU-flip) difference", frac, float(err), float(scale), cos))
+                continue
         if not err <= atol + rtol * scale:
             bad.append((name, "max", float(err), float(scale)))
         gd, rd = g.astype(np.float64).ravel(), r.astype(np.float64).ravel()
