@@ -5,6 +5,7 @@
 // coalesced loads, max / sum-exp are reduced with wave64 shuffles + LDS across the 16 waves.
 #include "xg_common.h"
 #include "xg_kernels.h"
+#include "xg_select.h"
 #include <type_traits>
 #include <cstdlib>
 
@@ -410,40 +411,7 @@ __global__ void __launch_bounds__(RT) choose_kernel(const float* __restrict__ lo
 // One launch per rollout step (SAModel.py:182-215): token choice straight from the RAW logits of the previous step
 // (log-probs are never materialised: logp[v] = logit[v] - lse), the unfinished / emit bookkeeping, the reference's
 // n (first step at which every row is finished) and the embedding gather of the chosen token.  One workgroup per video.
-struct RollStepArgs {
-    const float* logits;      // (B,V) raw logits of step t-1, null at t = 0
-    const float* uniforms;    // (B) for SAMPLE
-    const int64_t* forced;    // element b at forced[b * fstride], for REPLAY
-    int64_t fstride;
-    const float* unf_prev;    // (B) unfinished after step t-1 (t >= 2)
-    const float* table;       // embedding (V,E)
-    int64_t* tok; float* tok_logp; float* unf; float* lse;      // (B) each, step-t slices
-    int64_t* seq; float* seq_logp;                               // (B,Tm1)
-    int32_t* maxf;            // running max over rows of the step at which the row finished (T if it never does)
-    float* xt;                // (B,E) out
-    float temperature;
-    int V, E, t, T, mode;
-    int split;                // rows >= split of a SAMPLE rollout decode greedily and report into maxf[1] (paired SCST rollout)
-};
-
-// the per-row bookkeeping of a rollout step once its token is chosen (one thread): unfinished &= it > 0 ; it *= unfinished ;
-// append (SAModel.py:200-210), the running "first step at which every row is finished" (:211-215)
-__device__ __forceinline__ void roll_bookkeep(const RollStepArgs& a, int b, int mode, int64_t tk, float lp, float lse, int32_t* maxf) {
-    const float u = (a.t == 1 ? 1.0f : a.unf_prev[b]) * (tk > 0 ? 1.0f : 0.0f);
-    if (mode != XG_ROLLOUT_REPLAY) {
-        const bool was = a.t == 1 ? true : a.unf_prev[b] > 0.f;
-        if (was && u == 0.f) atomicMax(maxf, a.t);                 // this row finishes at step t
-        else if (u > 0.f && a.t == a.T - 1) atomicMax(maxf, a.T);  // never finished
-    } else if (a.t == a.T - 1) {
-        atomicMax(maxf, a.T);
-    }
-    a.unf[b] = u;
-    a.lse[b] = lse;
-    a.tok[b] = tk;                                                   // xt = embed(it) uses the raw draw (:198)
-    a.tok_logp[b] = lp;
-    a.seq[(size_t)b * (a.T - 1) + (a.t - 1)] = mode == XG_ROLLOUT_REPLAY ? tk : (u > 0.f ? tk : 0);
-    a.seq_logp[(size_t)b * (a.T - 1) + (a.t - 1)] = lp;
-}
+// (RollStepArgs / roll_bookkeep: xg_select.h, shared with the SELECT prologue of the step kernel)
 
 // STAGE: the row's V logits are parked in LDS by the first pass (V * 4 bytes <= 150 KB), so the log-sum-exp / chunk-sum /
 // owner passes read LDS instead of going back to L2 three more times.
@@ -579,7 +547,7 @@ struct VocabPartArgs {
     const float* W; const float* bias;    // (V, R) row-major, (V)
     int B, R, V;
     float* logits; int wr_rows;           // rows [0, wr_rows) of the (B, V) logits are stored
-    float* part;                          // (B, ntiles, 4): max, sum exp(x - max), sum exp((x - max) / T), argmax column (int bits)
+    float* part;                          // (B, rs_pitch(ntiles), 4): max, sum exp(x - max), sum exp((x - max) / T), argmax column (int bits); slot order: xg_select.h
     float inv_t;
 };
 __global__ void __launch_bounds__(256) vocab_part_kernel(VocabPartArgs a) {
@@ -675,7 +643,7 @@ __global__ void __launch_bounds__(256) vocab_part_kernel(VocabPartArgs a) {
     if (row < a.B) {
         if (h == 0) {
             v_f32x4 pv = {m, e1, et, __int_as_float(mc)};
-            *reinterpret_cast<v_f32x4*>(a.part + ((size_t)row * ntiles + blockIdx.x) * 4) = pv;
+            *reinterpret_cast<v_f32x4*>(a.part + ((size_t)row * rs_pitch(ntiles) + rs_slot(blockIdx.x, rs_per(ntiles))) * 4) = pv;
         }
         if (row < a.wr_rows) {
             float* dst = a.logits + (size_t)row * a.V + c0;
@@ -854,7 +822,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     if (row < a.B) {
         if (h == 0) {
             v_f32x4 pv = {m, e1, et, __int_as_float(mc)};
-            *reinterpret_cast<v_f32x4*>(a.part + ((size_t)row * ntiles + blockIdx.x) * 4) = pv;
+            *reinterpret_cast<v_f32x4*>(a.part + ((size_t)row * rs_pitch(ntiles) + rs_slot(blockIdx.x, rs_per(ntiles))) * 4) = pv;
         }
         if (row < a.wr_rows) {
             float* dst = a.logits + (size_t)row * a.V + c0;
@@ -873,11 +841,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 }
 
 constexpr int ST = 256;                   // threads of a selection workgroup
-struct RollSelectArgs {
-    RollStepArgs r;                       // (r.logits = the rows stored by vocab_part_kernel; r.t >= 1)
-    const float* part; int ntiles;
-    int tw;                               // columns per tile statistic (32: vocab_part_kernel, 80: vocab_part16_kernel)
-};
 __global__ void __launch_bounds__(ST) roll_select_kernel(RollSelectArgs q) {
     XG_CHAIN_PRIO();
     const RollStepArgs& a = q.r;
@@ -889,7 +852,8 @@ __global__ void __launch_bounds__(ST) roll_select_kernel(RollSelectArgs q) {
     const int mode = (second && a.mode == XG_ROLLOUT_SAMPLE) ? XG_ROLLOUT_GREEDY : a.mode;
     int32_t* maxf = a.maxf + (second ? 1 : 0);
     const int nt = q.ntiles, per = (nt + ST - 1) / ST;           // tiles per thread, contiguous: thread tid owns [tid per, ..)
-    const v_f32x4* pr = reinterpret_cast<const v_f32x4*>(q.part) + (size_t)b * nt;
+    const int sper = rs_per(nt);
+    const v_f32x4* pr = reinterpret_cast<const v_f32x4*>(q.part) + (size_t)b * (sper << 4);
     constexpr int PMAX = 4;                                     // V <= 32 * 4 * 256 (launcher)
     v_f32x4 pv[PMAX];
     float best = -INFINITY; int bi = 0x7fffffff;
@@ -897,7 +861,7 @@ __global__ void __launch_bounds__(ST) roll_select_kernel(RollSelectArgs q) {
     for (int i = 0; i < PMAX; ++i) {
         const int j = tid * per + i;
         const v_f32x4 z = {-INFINITY, 0.f, 0.f, 0.f};
-        pv[i] = (i < per && j < nt) ? pr[j] : z;
+        pv[i] = (i < per && j < nt) ? pr[rs_slot(j, sper)] : z;
         const int c = __float_as_int(pv[i][3]);
         if (i < per && j < nt && (pv[i][0] > best || (pv[i][0] == best && c < bi))) { best = pv[i][0]; bi = c; }
     }
@@ -1198,14 +1162,21 @@ int xgk_vocab_part(hipStream_t st, int B, int R, int V, const float* H, int ldh,
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
+RollSelectArgs xgk_roll_select_args(const float* logits, const float* part, const float* uniforms, const int64_t* forced, int64_t fstride,
+                                    const float* unf_prev, const float* table, int64_t* tok, float* tok_logp, float* unf, float* lse,
+                                    int64_t* seq, float* seq_logp, int32_t* maxf, float* xt, float temperature, int V, int E, int t, int T,
+                                    int mode, int split) {
+    const int tw = xgk_vocab_tile_width(V);
+    return RollSelectArgs{{logits, uniforms, forced, fstride, unf_prev, table, tok, tok_logp, unf, lse, seq, seq_logp, maxf, xt,
+                           temperature, V, E, t, T, mode, split}, part, xg_cdiv(V, tw), tw};
+}
 int xgk_roll_select(hipStream_t st, int B, const float* logits, const float* part, const float* uniforms, const int64_t* forced,
                     int64_t fstride, const float* unf_prev, const float* table, int64_t* tok, float* tok_logp, float* unf,
                     float* lse, int64_t* seq, float* seq_logp, int32_t* maxf, float* xt, float temperature, int V, int E,
                     int t, int T, int mode, int split) {
     if (t < 1) return XG_EINVAL;
-    const int tw = xgk_vocab_tile_width(V);
-    RollSelectArgs q{{logits, uniforms, forced, fstride, unf_prev, table, tok, tok_logp, unf, lse, seq, seq_logp, maxf, xt,
-                      temperature, V, E, t, T, mode, split}, part, xg_cdiv(V, tw), tw};
+    const RollSelectArgs q = xgk_roll_select_args(logits, part, uniforms, forced, fstride, unf_prev, table, tok, tok_logp, unf, lse, seq,
+                                                  seq_logp, maxf, xt, temperature, V, E, t, T, mode, split);
     hipLaunchKernelGGL(roll_select_kernel, dim3(B), dim3(ST), 0, st, q);
     XG_CHECK_LAUNCH();
     return XG_OK;

@@ -1,6 +1,7 @@
 // Internal launcher prototypes (host side).  Every launcher enqueues on `st` and returns XG_OK / XG_EHIP.
 #pragma once
 #include "xg_common.h"
+#include "xg_select.h"
 #include <cstddef>
 
 // ---- xg_gemm.hip
@@ -160,6 +161,7 @@ enum { SK_EPI_STORE = 0, SK_EPI_LSTM = 1, SK_EPI_GATE = 2,
        SK_EPI_ZERO = 4,
        // (fast kernel only) copy job: C[0 .. M*N) = seg[0].A[0 .. M*N), one tile per 4096 floats, 16-byte aligned
        SK_EPI_COPY = 6,
+
        // (fast kernel only) temporal attention of one step, TWO workgroups per video (sub_modules.py:678-680):
        //   workgroup (b, part) scores its half of the K frames, e_k = w . tanh(p_b + q_bk), and adds its share of the
        //   UNNORMALISED softmax -- ex_k = exp(e_k - e_0), s = sum ex_k, c = sum ex_k V_bk -- into attn_s[b] / attn_c[b][:]
@@ -192,6 +194,7 @@ struct SkSeg {
 };
 enum { SKS_SCALED = 1, SKS_WRITEBACK = 2, SKS_EX = 4 };
 enum { SKH_CELL_TILES = 1 /* weight rows in the cell tiling (LSTM epilogue or cell_cols) */, SKH_LOW_PRIO = 2, SKH_HAS_SCALED = 4,
+       SKH_SELECT = 8 /* the token choice runs in front of the gathered segment (SkJob.select) */,
        SKH_GATHER_SHIFT = 4 /* bits 4-5: 1 + index of the first gathered segment (0 = none) */,
        SKH_POW2_NTM = 64 /* the m-tile count is a power of two: tile decode by shifts */, SKH_LGNTM_SHIFT = 8 /* bits 8-11 */,
        SKH_LGKS_SHIFT = 12 /* bits 12-15: log2 of the cross-workgroup split */ };
@@ -231,12 +234,15 @@ struct alignas(64) SkJob {
     int ksplit_ok;
     int ksplit_cap;                    // > 0: upper bound of the cross-workgroup split of THIS launch (a side chain that must not crowd the main one)
     int low_prio;                      // 1: the job's waves drop back to default wave priority (off-critical-path side chains)
-    int pad_;
+    int select;                        // 1: the job's workgroups first CHOOSE the tokens of their 32 rows (SkArgs.sel) and gather by them
 };
 static_assert(offsetof(SkJob, seg) == 64 && sizeof(SkSeg) == 112, "skf_kernel reads the head and the segments' hot parts by offset");
 static_assert(sizeof(SkJob) % 64 == 0 && sizeof(SkJob) * SK_MAX_JOBS + 64 <= 4096, "SkJob array stride / kernel-argument budget");
-struct SkArgs { int njobs; int tile0[SK_MAX_JOBS]; int pad_[10]; SkJob job[SK_MAX_JOBS]; };
+// `sel` (round 6): the token choice of a rollout step as the prologue of the launch's SELECT job (SkJob.select: the POS-gate tiles,
+// whose row gather then takes the tokens their own workgroup has just chosen): xg_select.h.  Read only by that job's workgroups.
+struct SkArgs { int njobs; int tile0[SK_MAX_JOBS]; int pad_[10]; SkJob job[SK_MAX_JOBS]; RollSelectArgs sel; };
 static_assert(offsetof(SkArgs, job) == 64, "descriptor lines");
+static_assert(sizeof(SkArgs) <= 4096, "kernel-argument budget");
 // gemm_mode 1 (plain bf16) rounds the staged chunks to bf16 (LDS-staged kernel); 0 / 3: exact fp32
 // `gemm_mode | XGK_SK_PLANES` (mode 3 only): the packed tiles (SkSeg::Bp) hold three pre-split bf16 planes (xg_pack.hip, dtype 2)
 enum { XGK_SK_PLANES = 0x200 };
@@ -331,8 +337,13 @@ int xgk_rollout_step(hipStream_t st, int B, const float* logits, const float* un
 int xgk_rollout_finalize(hipStream_t st, const int32_t* maxf, int32_t* n_steps, int Tm1, int nparts);
 // rollout steps of <= 128 rows: vocabulary product with per-tile row statistics + token choice over them (xg_heads.hip)
 bool xgk_vocab_select_ok(int B, int R, int V, const float* H, int ldh, const float* W);
+int xgk_vocab_tile_width(int V);                 // columns per tile statistic of xgk_vocab_part for this vocabulary
 int xgk_vocab_part(hipStream_t st, int B, int R, int V, const float* H, int ldh, const float* W, const float* bias, float* logits,
                    int wr_rows, float* part, float temperature);
+RollSelectArgs xgk_roll_select_args(const float* logits, const float* part, const float* uniforms, const int64_t* forced, int64_t fstride,
+                                    const float* unf_prev, const float* table, int64_t* tok, float* tok_logp, float* unf, float* lse,
+                                    int64_t* seq, float* seq_logp, int32_t* maxf, float* xt, float temperature, int V, int E, int t, int T,
+                                    int mode, int split);
 int xgk_roll_select(hipStream_t st, int B, const float* logits, const float* part, const float* uniforms, const int64_t* forced,
                     int64_t fstride, const float* unf_prev, const float* table, int64_t* tok, float* tok_logp, float* unf,
                     float* lse, int64_t* seq, float* seq_logp, int32_t* maxf, float* xt, float temperature, int V, int E,

@@ -190,7 +190,7 @@ Ws carve(const XgDims& d, void* base) {
     w.TOK = c.take<int64_t>(TB); w.TOKLP = c.take<float>(TB); w.UNF = c.take<float>(TB);
     w.alive = c.take<int32_t>(4);
     c.off = (c.off + 15) & ~(size_t)15;
-    w.VPART = c.take<float>(B * ((V + 31) / 32) * 4);         // per-tile row statistics of a rollout step's vocabulary product
+    w.VPART = c.take<float>(B * ((V + 31) / 32 + 16) * 4);    // per-tile row statistics of a rollout step's vocabulary product (row pitch: xg_select.h rs_pitch)
     w.dsync = c.take<int32_t>(XGK_DSTEP_SYNC_BYTES / sizeof(int32_t));
     {   // the zero block
         c.off = (c.off + 255) & ~(size_t)255;
@@ -598,6 +598,7 @@ struct StepIO {
     float *P, *alpha, *af, *g1, *g2;  // saved per-step tensors (alpha / gates may be scratch)
     int t;
     bool half_attn;       // stand-alone attention in its half-CU form (a background product runs beside the steps)
+    const RollSelectArgs* sel;   // rollout steps t >= 1 (packed form, xt == null): the step's first launch CHOOSES the tokens (xg_select.h) and writes tok / mask / xt rows itself
 };
 
 // the packed-weight form of the step needs 16-byte rows everywhere (R % 8 covers R; E and A are checked here)
@@ -633,7 +634,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
     // below ~16 rows (30 vs 34 us at 8 rows).
 #ifdef XG_DIAG
     static const bool use_dstep = xg_diag_env("XG_DSTEP") != nullptr;
-    if (use_dstep && w.pk.dtype != 2 && step_packed(w, d) && xgk_dstep_ok(d) && ((uintptr_t)V % 16 == 0) && ((uintptr_t)vproj % 16 == 0) &&
+    if (use_dstep && !s.sel && w.pk.dtype != 2 && step_packed(w, d) && xgk_dstep_ok(d) && ((uintptr_t)V % 16 == 0) && ((uintptr_t)vproj % 16 == 0) &&
         ((uintptr_t)p.a2w_w % 16 == 0)) {
         DStepArgs a2{};
         a2.B = B; a2.R = R; a2.A = A; a2.E = E; a2.K = d.K; a2.V1 = d.V - 1;
@@ -682,7 +683,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         // rollout form: S1' = h1 W_h2h1 + xt W_i2h1 + b (everything of cell 1 that does not wait for the POS gate) rides in
         // launch 1 as well, so that launch 2 -- the attention beside cell 1 -- keeps only cell 1's pos' product (K = R)
         static const int s1_env = xg_diag_env("XG_S1_FIRST") ? atoi(xg_diag_env("XG_S1_FIRST")) : -1;
-        const bool s1_first = !s.pre1 && (s1_env >= 0 ? s1_env != 0 : false);
+        const bool s1_first = !s.pre1 && !s.sel && (s1_env >= 0 ? s1_env != 0 : false);
         const bool s2_in_cell2 = s.pre1 != nullptr && (xe_form == 'D' || xe_form == 'G');     // (G, round 5: D with the attention as two workgroups per video inside launch 2)       // ... or stays a segment of cell 2 (measured for the
                                                                             // rollout form at 128 rows too: 48.3 us)
         SkArgs k1{}, k2{}, k3{};
@@ -710,6 +711,10 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
             j.seg[0] = xt_seg(PK_DGATE, p.dgate_w); j.bias[0] = p.dgate_b;
             j.gate_t = s.pos; j.ldt = R; j.gate_y = s.posg; j.ldy = R;
             j.drop = xg_make_drop(&run, XG_SITE_DGATE, s.t);
+            if (s.sel) {
+                if (s.xt) return XG_EINVAL;
+                j.select = 1; k1.sel = *s.sel;
+            }
         }
         {   // p = h2a([h1 ; h2])                                                                         :677
             SkJob& j = k1.job[n1++];
@@ -1643,7 +1648,9 @@ extern "C" int xg_aux_create(void** aux) {
         return hipExtStreamCreateWithCUMask(st, 8, mask) == hipSuccess;
     };
     ok = ok && masked(&a->s, cu_n) && masked(&a->s2, cu_m);
-    for (int i = 0; ok && i < XG_NEV; ++i) ok = hipEventCreateWithFlags(&a->ev[i], hipEventDisableTiming) == hipSuccess;
+    unsigned evflags = hipEventDisableTiming;
+    if (const char* e = xg_diag_env("XG_AUX_EVFLAGS")) evflags = (unsigned)strtoul(e, nullptr, 0);
+    for (int i = 0; ok && i < XG_NEV; ++i) ok = hipEventCreateWithFlags(&a->ev[i], evflags) == hipSuccess;
     if (!ok) { xg_aux_destroy(a); return XG_EHIP; }
     *aux = a;
     return XG_OK;
@@ -1997,13 +2004,35 @@ static int rollout_impl(hipStream_t st, const XgDims* d, const XgParams* p, cons
     const bool alt = logits_alt != nullptr && fused_select && mode == XG_ROLLOUT_SAMPLE && split < B;
     if (used_alt) *used_alt = alt;
     auto logits_of = [&](int t) { return alt ? logits_alt + (size_t)t * split * d->V : w.LOGITS + (size_t)t * B * d->V; };
+    auto step_io = [&](int t) {
+        StepIO s{};
+        s.xt = w.Xe + (size_t)t * B * E; s.pos = pos_rows; s.gp = w.GP + t * BR; s.posg = w.POSG + t * BR; s.pre1 = nullptr;
+        s.mask = w.UNF + (size_t)t * B; s.ldm = 1;
+        s.h1 = w.H1 + t * BR; s.c1 = w.C1 + t * BR; s.h2 = w.H2 + t * BR; s.c2 = w.C2 + t * BR;
+        s.h1o = w.H1 + (t + 1) * BR; s.c1o = w.C1 + (t + 1) * BR; s.h2o = w.H2 + (t + 1) * BR; s.c2o = w.C2 + (t + 1) * BR;
+        s.P = w.P + (size_t)t * B * A; s.alpha = w.ALPHA + (size_t)t * B * d->K; s.af = w.AF + t * BR;
+        s.g1 = w.G1 + (size_t)t * B * 4 * R; s.g2 = w.G2 + (size_t)t * B * 4 * R; s.t = t;
+        return s;
+    };
+    // Steps t >= 1 on the packed fp32 path CHOOSE their tokens themselves: the choice is the prologue of the step's first launch
+    // (its POS-gate tiles: xg_step.hip SEL, xg_select.h) instead of a launch of its own between the vocabulary product and the step
+    // -- four dependent launches per step instead of five.  The last choice of a rollout (no step follows) keeps its launch.
+    static const bool no_step_select = xg_diag_env("XG_NO_STEP_SELECT") != nullptr;
+    const bool step_select = fused_select && !no_step_select && step_packed(w, *d) && xg_cdiv(d->V, xgk_vocab_tile_width(d->V)) <= 256;
     for (int t = 0; t < T; ++t) {
         int64_t* tok = w.TOK + (size_t)t * B;
         float* unf = w.UNF + (size_t)t * B;
         float* xt = w.Xe + (size_t)t * B * E;
         const float* prev_logits = t >= 1 ? logits_of(t - 1) : nullptr;
         // token choice from the previous step's raw logits + bookkeeping + embedding gather: one launch (:183-215)
-        if (t >= 1 && fused_select)
+        const bool in_step = step_select && t >= 1 && t + 1 < T;
+        RollSelectArgs sel{};
+        if (in_step)
+            sel = xgk_roll_select_args(prev_logits, w.VPART, uniforms ? uniforms + (size_t)t * split : nullptr,
+                                       forced ? forced + (t - 1) : nullptr, T - 1, t >= 2 ? unf - B : nullptr, p->embed_w, tok,
+                                       w.TOKLP + (size_t)t * B, unf, w.LSE + (size_t)(t - 1) * B, seq, seq_logp, w.alive, xt, temperature,
+                                       d->V, E, t, T, mode, split);
+        else if (t >= 1 && fused_select)
             XG_TRY(xgk_roll_select(st, B, prev_logits, w.VPART, uniforms ? uniforms + (size_t)t * split : nullptr,
                                    forced ? forced + (t - 1) : nullptr, T - 1, t >= 2 ? unf - B : nullptr, p->embed_w, tok,
                                    w.TOKLP + (size_t)t * B, unf, w.LSE + (size_t)(t - 1) * B, seq, seq_logp, w.alive, xt, temperature,
@@ -2014,14 +2043,8 @@ static int rollout_impl(hipStream_t st, const XgDims* d, const XgParams* p, cons
                                     T - 1, t >= 2 ? unf - B : nullptr, p->embed_w, tok, w.TOKLP + (size_t)t * B, unf,
                                     t >= 1 ? w.LSE + (size_t)(t - 1) * B : nullptr, seq, seq_logp, w.alive, xt, temperature, d->V, E,
                                     t, T, mode, split));
-        float* gp = w.GP + t * BR;
-        float* posg = w.POSG + t * BR;
-        StepIO s{};
-        s.xt = xt; s.pos = pos_rows; s.gp = gp; s.posg = posg; s.pre1 = nullptr; s.mask = unf; s.ldm = 1;
-        s.h1 = w.H1 + t * BR; s.c1 = w.C1 + t * BR; s.h2 = w.H2 + t * BR; s.c2 = w.C2 + t * BR;
-        s.h1o = w.H1 + (t + 1) * BR; s.c1o = w.C1 + (t + 1) * BR; s.h2o = w.H2 + (t + 1) * BR; s.c2o = w.C2 + (t + 1) * BR;
-        s.P = w.P + (size_t)t * B * A; s.alpha = w.ALPHA + (size_t)t * B * d->K; s.af = w.AF + t * BR;
-        s.g1 = w.G1 + (size_t)t * B * 4 * R; s.g2 = w.G2 + (size_t)t * B * 4 * R; s.t = t;
+        StepIO s = step_io(t);
+        if (in_step) { s.sel = &sel; s.xt = nullptr; s.tok = tok; }
         // The reference runs the core once more at t = L and discards what it computes (SAModel.py:182,217: the loop ends before
         // those logits are ever read, and no state is returned): that step feeds neither an output nor a gradient and is not run.
         if (t + 1 == T) break;
@@ -2034,6 +2057,10 @@ static int rollout_impl(hipStream_t st, const XgDims* d, const XgParams* p, cons
                 XG_TRY(xgk_linear(st, w.gm, B, d->V, R, s.h2o, R, p->logit_w, p->logit_b, w.LOGITS + (size_t)t * B * d->V, d->V));
         }
     }
+    // the steps that chose their own tokens gathered their embedding rows inside the products: the (T, B, E) copy the backward (and a
+    // compaction) reads is made here for all of them at once, off the token's path
+    if (step_select && T >= 3)
+        XG_TRY(xgk_embed_gather(st, p->embed_w, E, w.TOK + B, (T - 2) * B, 1, 0, (T - 2) * B, d->V, w.Xe + (size_t)B * E, E));
     if (run->prof_event1 && hipEventRecord(static_cast<hipEvent_t>(run->prof_event1), st) != hipSuccess) return XG_EHIP;
     XG_TRY(xgk_rollout_finalize(st, w.alive, n_steps, T - 1, split < B ? 2 : 1));
     return XG_OK;

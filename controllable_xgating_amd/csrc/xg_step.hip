@@ -673,6 +673,14 @@ __device__ __forceinline__ void sk_hold(SkEpiIn& e) {
     asm volatile("" : "+s"(e.ldadd), "+s"(e.ldcp), "+s"(e.ldhp), "+s"(e.ldm), "+s"(e.accumulate), "+s"(e.relu), "+s"(e.order), "+s"(e.mask_mode),
                  "+s"(e.gate_t), "+s"(e.ldt), "+s"(e.ldy), "+s"(e.gate_y));
 }
+// the token choice's arguments (xg_select.h): one round of wide scalar loads from the tail of the kernel arguments, held -- read
+// field by field where first used they were a dozen dependent scalar-cache round trips inside the gate tiles' prologue
+__device__ __forceinline__ void sk_hold(RollSelectArgs& q) {
+    RollStepArgs& a = q.r;
+    asm volatile("" : "+s"(a.logits), "+s"(a.uniforms), "+s"(a.forced), "+s"(a.fstride), "+s"(a.unf_prev), "+s"(a.table), "+s"(a.tok), "+s"(a.tok_logp));
+    asm volatile("" : "+s"(a.unf), "+s"(a.lse), "+s"(a.seq), "+s"(a.seq_logp), "+s"(a.maxf), "+s"(a.xt), "+s"(q.part));
+    asm volatile("" : "+s"(a.temperature), "+s"(a.V), "+s"(a.E), "+s"(a.t), "+s"(a.T), "+s"(a.mode), "+s"(a.split), "+s"(q.ntiles), "+s"(q.tw));
+}
 __device__ __forceinline__ void sk_hold(SkEpiOut& e) {
     asm volatile("" : "+s"(e.gates), "+s"(e.c_out), "+s"(e.h_out), "+s"(e.ldg), "+s"(e.ldco), "+s"(e.ldho), "+s"(e.cell_cols), "+s"(e.drop.seed),
                  "+s"(e.drop.site), "+s"(e.drop.step), "+s"(e.drop.thresh), "+s"(e.drop.scale));
@@ -870,7 +878,11 @@ __device__ __forceinline__ void skf_epilogue(const SkJob& job, const SkHeadBlk& 
 // DEPTH: operands requested 1 or 2 chunks ahead of their MFMAs.  2 needs three B register sets and two A sets (~150 VGPRs), i.e.
 // two waves per SIMD: four-wave workgroups two per CU, or eight-wave workgroups one per CU (round 5; the round-3 attempt spilled
 // at the 128 registers of four waves per SIMD).
-template <int NW, int PREC, bool SCALE, int DEPTH>
+// SEL (round 6, rollout steps): the launch's SELECT job -- the POS gate -- first chooses the tokens of its tile's 32 rows from the
+// previous step's vocabulary statistics (one wave per row: xg_select.h), then gathers its embedding rows by them; the n-tile 0
+// workgroups also do the rows' bookkeeping.  Every n-tile of an m-tile repeats the choice (same data, same code: same tokens) --
+// 128 KB of L2 reads per workgroup instead of a launch of its own in front of the step.
+template <int NW, int PREC, bool SCALE, int DEPTH, bool SEL = false>
 __global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((SCALE || DEPTH == 2) ? 2 : 4, (SCALE || DEPTH == 2) ? 2 : 4)))
 skf_kernel(SkArgs args) {
     XG_CHAIN_PRIO();
@@ -888,6 +900,8 @@ skf_kernel(SkArgs args) {
     SkHeadBlk hd = *reinterpret_cast<const SkHeadBlk*>(jb);
     SkSegHot sg = *reinterpret_cast<const SkSegHot*>(jb + offsetof(SkJob, seg));
     SkEpiIn ei = *reinterpret_cast<const SkEpiIn*>(jb + offsetof(SkJob, bias));
+    RollSelectArgs sel;
+    if constexpr (SEL) { sel = args.sel; sk_hold(sel); }       // (same round of scalar loads as the job's own blocks)
     sk_hold(hd); sk_hold(sg); sk_hold(ei);
     int ef = (ei.bias[0] ? EF_B0 : 0) | (ei.bias[1] ? EF_B1 : 0) | (ei.bias[2] ? EF_B2 : 0) | (ei.add ? EF_ADD : 0) | (ei.mask ? EF_MASK : 0) |
                    (ei.accumulate ? EF_ACC : 0) | (ei.relu ? EF_RELU : 0) | (ei.order == XG_ORDER_IFOG ? EF_IFOG : 0) |
@@ -940,7 +954,24 @@ skf_kernel(SkArgs args) {
     // negative int, and the clamp keeps the row inside the table whatever the value.)
     const int gseg = ((hd.hflags >> SKH_GATHER_SHIFT) & 3) - 1;
     int gidx[4] = {0, 0, 0, 0};
-    if (gseg >= 0) {
+    bool chosen = false;
+    if constexpr (SEL) {
+        if (hd.hflags & SKH_SELECT) {                         // (job-uniform: every wave of the workgroup meets the barrier)
+            __shared__ int tok_s[32];
+            // four rows per wave and pass, 16 lanes each (xg_select.h): NW = 8 -> one pass over the tile's 32 rows, NW = 4 -> two
+#pragma unroll
+            for (int r0 = 0; r0 < 32; r0 += 4 * NW) {
+                const int r = r0 + wave * 4 + (lane >> 4), b = m0 + r;
+                const int tk = roll_select_rows16(sel, b < hd.M ? b : -1, tn == 0 && kp == 0);
+                if ((lane & 15) == 0) tok_s[r] = tk;
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gidx[i] = tok_s[rowi[i] - m0];
+            chosen = true;
+        }
+    }
+    if (gseg >= 0 && !chosen) {
         const int64_t* gp = job.seg[gseg].gather;
         const unsigned gs8 = (unsigned)job.seg[gseg].gstride * 8u;
 #pragma unroll
@@ -1220,8 +1251,10 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
             const long ntm = xg_cdiv(jb.M, 32);
             return ntm * ((jb.epi == SK_EPI_LSTM || jb.cell_cols) ? jb.R / 8 : xg_cdiv(jb.N, 32));
         };
+        // (a SELECT job goes first whatever its width: its tiles carry the launch's longest prologue)
+        auto before = [&](const SkJob& x, const SkJob& y) { return x.select != y.select ? x.select > y.select : job_tiles(x) > job_tiles(y); };
         for (int i = 1; i < a.njobs && !no_sort; ++i)
-            for (int j = i; j > 0 && job_tiles(a.job[j]) > job_tiles(a.job[j - 1]); --j) { const SkJob t = a.job[j]; a.job[j] = a.job[j - 1]; a.job[j - 1] = t; }
+            for (int j = i; j > 0 && before(a.job[j], a.job[j - 1]); --j) { const SkJob t = a.job[j]; a.job[j] = a.job[j - 1]; a.job[j - 1] = t; }
     }
     bool vec = true, generic = false, packed = true, special = false;
     int tiles = 0, max_tiles = 0, max_k = 0;
@@ -1337,7 +1370,9 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         while ((1 << lg_ntm) < jb.ntm) ++lg_ntm;
         while ((1 << lg_ks) < ks) ++lg_ks;
         const bool pow2 = (1 << lg_ntm) == jb.ntm;
+        if (jb.select && (gseg != 1 || jb.nseg != 1)) return XG_EINVAL;       // the chosen tokens feed the job's one (gathered) segment
         jb.hflags = (cells ? SKH_CELL_TILES : 0) | (jb.low_prio ? SKH_LOW_PRIO : 0) | (any_scaled ? SKH_HAS_SCALED : 0) | (gseg << SKH_GATHER_SHIFT) |
+                    (jb.select ? SKH_SELECT : 0) |
                     (pow2 ? SKH_POW2_NTM : 0) | (lg_ntm << SKH_LGNTM_SHIFT) | (lg_ks << SKH_LGKS_SHIFT);
     }
     if (special && !fast) return XG_EINVAL;            // ZERO / ATTN jobs and scaled operands exist in the fast kernel only
@@ -1365,8 +1400,18 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         bool scaled = false;
         for (int j = 0; j < a.njobs; ++j)
             for (int q = 0; q < a.job[j].nseg; ++q) scaled = scaled || a.job[j].seg[q].row_scale != nullptr;
-        bool has_attn = false, has_zero = false;
-        for (int j = 0; j < a.njobs; ++j) { has_attn = has_attn || a.job[j].epi == SK_EPI_ATTN; has_zero = has_zero || a.job[j].epi == SK_EPI_ZERO; }
+        bool has_attn = false, has_zero = false, has_select = false;
+        for (int j = 0; j < a.njobs; ++j) {
+            has_attn = has_attn || a.job[j].epi == SK_EPI_ATTN; has_zero = has_zero || a.job[j].epi == SK_EPI_ZERO;
+            has_select = has_select || a.job[j].select != 0;
+        }
+        if (has_select) {            // the token choice in front of the gate tiles: exact-fp32 launches without a scaled operand
+            if (bf16 || bf16x3 || scaled || ks > 1 || a.sel.ntiles < 1 || a.sel.ntiles > 16 * RSW_PER || a.sel.tw > 128 || !a.sel.part || a.sel.r.E % 4) return XG_EINVAL;
+            if (nw4_rule) hipLaunchKernelGGL((skf_kernel<4, 0, false, 1, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((skf_kernel<8, 0, false, 1, true>), grid, dim3(512), 0, st, a);
+            XG_CHECK_LAUNCH();
+            return XG_OK;
+        }
         static const bool dbg_nw4_scaled = xg_diag_env("XG_SK_NW4_SCALED") != nullptr, dbg_nw4_attn = xg_diag_env("XG_SK_NW4_ATTN") != nullptr,
                           dbg_nw4_zero = xg_diag_env("XG_SK_NW4_ZERO") != nullptr;
         const bool nw4 = nw4_rule || (dbg_nw4_scaled && scaled) || (dbg_nw4_attn && has_attn) || (dbg_nw4_zero && has_zero);
