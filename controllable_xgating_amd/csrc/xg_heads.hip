@@ -691,8 +691,16 @@ __device__ __forceinline__ void vt_interleave() {
 // MFMAs (vt_interleave).  k order inside a 16-deep block: lane group g = lane / 16 owns k = 4 g .. 4 g + 3 (one ds_read_b128 per
 // fragment, the same permutation for both operands).
 constexpr int V16_TW = 80, V16_NG = 5;
+#ifdef VP_TRACE
+// in-kernel phase stamps of the vocabulary product (tools/r6/vp_trace.py): entry, first slab staged, K loop done, tile in LDS, end
+__device__ long long vp_trace_buf[512 * 8];
+#define VP_STAMP(i) do { if (threadIdx.x == 0) vp_trace_buf[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#else
+#define VP_STAMP(i) do {} while (0)
+#endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) vocab_part16_kernel(VocabPartArgs a) {
     XG_CHAIN_PRIO();
+    VP_STAMP(0);
     constexpr int STAGE = (128 + V16_TW) * VT_LD;                   // floats per LDS stage
     __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = (lane >> 4) << 2;
@@ -740,6 +748,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     if (ns > 1) load_slab(1, ra[1], rw[1]);
     store_slab(smem, ra[0], rw[0]);
     __syncthreads();
+    VP_STAMP(1);
     auto slab = [&](int s, auto set_tag, auto load_tag, auto store_tag) {
         constexpr int SET = decltype(set_tag)::value;                // == s & 1
         constexpr bool LOAD = decltype(load_tag)::value, STORE = decltype(store_tag)::value;      // slab s + 2 / s + 1 exist
@@ -784,6 +793,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         else if (s + 1 < ns) { slab(s, T0{}, N{}, Y{}); slab(s + 1, T1{}, N{}, N{}); }
         else if (s < ns) slab(s, T0{}, N{}, N{});
     }
+    VP_STAMP(2);
     // epilogue through LDS as vocab_part_kernel: the tile as [128][81]; MFMA result layout: column 16 gi + l15, rows 4 (lane / 16) + r
     constexpr int TL = V16_TW + 1;
     float* tl = smem;
@@ -797,6 +807,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             for (int r = 0; r < 4; ++r) tl[(wave * 32 + rb * 16 + g4 + r) * TL + gi * 16 + l15] = acc[rb][gi][r] + bv;
     }
     __syncthreads();
+    VP_STAMP(3);
     constexpr int HW = V16_TW / 2;                                  // columns per (row, half-row) thread
     const int row = tid >> 1, h = tid & 1, c0 = n0 + h * HW;
     float x[HW];
@@ -838,6 +849,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             }
         }
     }
+    VP_STAMP(4);
 }
 
 constexpr int ST = 256;                   // threads of a selection workgroup
@@ -1181,6 +1193,11 @@ int xgk_roll_select(hipStream_t st, int B, const float* logits, const float* par
     XG_CHECK_LAUNCH();
     return XG_OK;
 }
+#ifdef VP_TRACE
+extern "C" int xg_debug_vp_trace(long long* out, int n) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(vp_trace_buf), sizeof(long long) * (size_t)n) == hipSuccess ? 0 : -1;
+}
+#endif
 int xgk_rollout_finalize(hipStream_t st, const int32_t* maxf, int32_t* n_steps, int Tm1, int nparts) {
     hipLaunchKernelGGL(rollout_finalize_kernel, dim3(1), dim3(1), 0, st, maxf, n_steps, Tm1, nparts);
     XG_CHECK_LAUNCH();

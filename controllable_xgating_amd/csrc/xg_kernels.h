@@ -169,6 +169,8 @@ enum { SK_EPI_STORE = 0, SK_EPI_LSTM = 1, SK_EPI_GATE = 2,
        //   The cell-2 job of the NEXT launch normalises while it stages af (SkSeg.row_scale) -- no merge launch.
        SK_EPI_ATTN = 5 };
 constexpr int SK_MAX_JOBS = 5;
+constexpr int XGK_SKPART_TILES = 256;            // (tile, publishing part) slabs of 1024 8-byte granules in one job's split scratch
+constexpr size_t SKPART_INTS = (size_t)XGK_SKPART_TILES * 1024 * 2;        // int32 words of one job's split scratch
 // Field ORDER matters to the fast kernel (xg_step.hip: skf_kernel): it reads a job's 64-byte head and the first 48 bytes of each
 // segment with ONE round of wide scalar loads at kernel entry (s_load_dwordx16 / x8 / x4) instead of field by field behind
 // branches -- a chain of ~15 dependent scalar-cache round trips in front of the first operand request before round 5.
@@ -204,7 +206,7 @@ struct alignas(64) SkJob {
     int nseg, ksplit, ntm, ntn;
     int ntiles, hflags, ldc, nck_all;     // nck_all: 32-deep chunks of all segments together (the fast kernel splits THAT among its waves)
     float* C;                          // STORE epilogue output (M,N) ldc
-    int* tickets;                      // cross-workgroup split-K: one zero-initialised int per tile (see ksplit_ok)
+    int* tickets;                      // cross-workgroup split-K of an LSTMB job: XGK_SKPART_TILES x 8 KB of scratch, ZERO between launches (see ksplit_ok)
     SkSeg seg[3];
     // ---- epilogue INPUTS, contiguous (requested before the K loop so that their latency hides under it)
     const float* bias[3];
@@ -228,9 +230,10 @@ struct alignas(64) SkJob {
     const float *attn_p, *attn_q, *attn_v, *attn_w; float *attn_ex, *attn_s, *attn_c; int attn_K, attn_A;
     // Cross-workgroup split-K (fast kernel; STORE and LSTMB jobs whose result ACCUMULATES into C): ksplit_ok = 1 lets
     // xgk_skinny spread a tile's reduction over several workgroups when the launch would leave CUs idle (the backward
-    // chains' dh = ds W products are 64-128 tiles, K = 1536-2048 deep).  Each part adds its partial tile into C with fp32
-    // atomics; for LSTMB the last part to arrive (tickets: one zero-initialised int per tile, left at zero again) reads the
-    // completed dh back and runs the pointwise backward.  ksplit is filled in by xgk_skinny.
+    // chains' dh = ds W products are 64-128 tiles, K = 1536-2048 deep).  STORE: each part adds its partial tile into C with fp32
+    // atomics.  LSTMB: parts 0 .. ksplit - 2 publish their tiles as tagged 8-byte granules in the scratch at `tickets` (1024
+    // granules per tile and part, left at zero again) and the last part -- dispatched last -- sums them in part order and runs the
+    // pointwise backward (xg_step.hip: sk_epilogue_split).  ksplit is filled in by xgk_skinny.
     int ksplit_ok;
     int ksplit_cap;                    // > 0: upper bound of the cross-workgroup split of THIS launch (a side chain that must not crowd the main one)
     int low_prio;                      // 1: the job's waves drop back to default wave priority (off-critical-path side chains)

@@ -128,7 +128,7 @@ struct Ws {
     float *AFU, *ATS;                  // unnormalised attention context (B,R) and softmax denominators (B), contiguous
     // ---- rollout
     int64_t* TOK; float *TOKLP, *UNF; int32_t* alive; float* VPART;
-    int32_t* tickets;                  // split-K arrival counters (xg_step.hip), SK_MAX_JOBS x 1024, zero between launches
+    int32_t* tickets;                  // split-K hand-off scratch of the LSTMB jobs (xg_step.hip): SK_MAX_JOBS blocks of XGK_SKPART_TILES x 8 KB, zero between launches
     int32_t* dsync;                    // sync words of the dataflow step kernel (xg_dstep.hip): zero between launches
     // everything a backward pass needs ZERO on entry is one contiguous block (dst[0][*], DAF, the encoder's carried
     // gradients, the BatchNorm sums, the tickets): one memset on a side stream instead of a dozen on the critical path
@@ -202,7 +202,7 @@ Ws carve(const XgDims& d, void* base) {
             w.dHrec[m] = c.take<float>(B * R); w.dCrec[m][0] = c.take<float>(B * R);
             w.bn_s1[m] = c.take<float>(R); w.bn_s2[m] = c.take<float>(R);
         }
-        w.tickets = c.take<int32_t>(SK_MAX_JOBS * 1024);
+        w.tickets = c.take<int32_t>((size_t)SK_MAX_JOBS * SKPART_INTS);
         w.zbytes = c.off - z0;
     }
     w.bytes = (c.off + 255) & ~(size_t)255;
@@ -286,12 +286,12 @@ inline SkSeg seg_nn(const Ws& w, int which, const float* dY, int lddy, const flo
     return s;
 }
 // let xgk_skinny split the reduction of job j across workgroups (its result accumulates into C: see SkJob.ksplit_ok)
-inline void allow_split(SkArgs& sk, int j, const Ws& w) { sk.job[j].ksplit_ok = 1; sk.job[j].tickets = w.tickets + j * 1024; }
+inline void allow_split(SkArgs& sk, int j, const Ws& w) { sk.job[j].ksplit_ok = 1; sk.job[j].tickets = w.tickets + j * SKPART_INTS; }
 // (the last arriver of every tile leaves its counter at zero; the memsets only make a launch independent of whatever an
 // aborted run left behind.  njobs: how many 1024-counter blocks the caller's launches on THIS stream use -- the decoder
 // backward's cell-1 chain runs on a side stream with block 2 while the encoder backward uses blocks 0-1.)
 inline int zero_tickets(hipStream_t st, const Ws& w, int njobs) {
-    return hipMemsetAsync(w.tickets, 0, sizeof(int32_t) * njobs * 1024, st) == hipSuccess ? XG_OK : XG_EHIP;
+    return hipMemsetAsync(w.tickets, 0, sizeof(int32_t) * njobs * SKPART_INTS, st) == hipSuccess ? XG_OK : XG_EHIP;
 }
 // The dataflow step kernel's sync words are zero between launches (its last workgroup leaves them so); whole-sequence entry
 // points clear them once more per sequence, so that a sequence never inherits what an aborted launch left behind.  The
@@ -1149,7 +1149,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
             j.seg[1] = seg_nn(w, PKB_H2A1, w.DP, A, p.h2a_w, 2 * R, A);
             j.nseg = 2;
         }
-        allow_split(sk, 0, w); j.tickets = w.tickets + 2 * 1024;       // chain 1 runs beside chain 2 / the encoder: own counters
+        allow_split(sk, 0, w); j.tickets = w.tickets + 2 * SKPART_INTS;       // chain 1 runs beside chain 2 / the encoder: own scratch
         // Chain 1 has slack (one launch per step against chain 2's three) and only feeds parameter gradients: it must not crowd
         // chain 2.  Launched one step behind with the full 8-way split (512 workgroups) it took the wave slots the attention
         // backward needed beside a background product (attention 40 us in situ against 12.7 alone).  So: a capped split
@@ -1648,7 +1648,11 @@ extern "C" int xg_aux_create(void** aux) {
         return hipExtStreamCreateWithCUMask(st, 8, mask) == hipSuccess;
     };
     ok = ok && masked(&a->s, cu_n) && masked(&a->s2, cu_m);
-    unsigned evflags = hipEventDisableTiming;
+    // The ring / mark events only order launches of THIS device's streams against each other: kernels publish their results at
+    // agent scope when they end, so the event's own system-scope fence (an L2 write-back + invalidate in front of whatever the
+    // waiting stream runs next) buys nothing here and is switched off (round 6: 5.45 -> 5.40 ms per iteration, tools/r6/xe_ab.sh;
+    // XG_AUX_EVFLAGS=<flags> of the diag build overrides).  Nothing the host reads is published through these events.
+    unsigned evflags = hipEventDisableTiming | hipEventDisableSystemFence;
     if (const char* e = xg_diag_env("XG_AUX_EVFLAGS")) evflags = (unsigned)strtoul(e, nullptr, 0);
     for (int i = 0; ok && i < XG_NEV; ++i) ok = hipEventCreateWithFlags(&a->ev[i], evflags) == hipSuccess;
     if (!ok) { xg_aux_destroy(a); return XG_EHIP; }

@@ -185,18 +185,28 @@ __device__ __forceinline__ LstmPre lstm_prefetch(const SkJob& job, int m0, int t
 
 // pointwise LSTM backward of one (row b, unit j) given dh = d(loss)/d(h') before the optional add term (same arithmetic as
 // xg_pointwise.hip:lstm_bwd_body)
-__device__ __forceinline__ void lstmb_point(const SkJob& job, int b, int j, float v) {
+// (the cell's own operands, requested ahead of the value they are combined with: lstmb_load, then lstmb_finish)
+struct LstmbOps { float add, ig, fg, og, gg, cp, cn, mk, dc; };
+__device__ __forceinline__ LstmbOps lstmb_load(const SkJob& job, int b, int j) {
     const int R = job.R;
-    if (job.add) v += job.add[(size_t)b * job.ldadd + j];
+    LstmbOps o;
+    o.add = job.add ? job.add[(size_t)b * job.ldadd + j] : 0.0f;
     const float* g = job.gates + (size_t)b * job.ldg;
-    const float ig = g[j], fg = g[R + j];
-    const float og = job.order == XG_ORDER_IFOG ? g[2 * R + j] : g[3 * R + j];
-    const float gg = job.order == XG_ORDER_IFOG ? g[3 * R + j] : g[2 * R + j];
-    const float cp = job.c_prev[(size_t)b * job.ldcp + j];
-    const float cn = job.c_out[(size_t)b * job.ldco + j];
-    const float mk = job.mask ? job.mask[(size_t)b * job.ldm] : 1.0f;
+    o.ig = g[j]; o.fg = g[R + j];
+    o.og = job.order == XG_ORDER_IFOG ? g[2 * R + j] : g[3 * R + j];
+    o.gg = job.order == XG_ORDER_IFOG ? g[3 * R + j] : g[2 * R + j];
+    o.cp = job.c_prev[(size_t)b * job.ldcp + j];
+    o.cn = job.c_out[(size_t)b * job.ldco + j];
+    o.mk = job.mask ? job.mask[(size_t)b * job.ldm] : 1.0f;
+    o.dc = job.dc_in ? job.dc_in[(size_t)b * job.lddci + j] : 0.0f;
+    return o;
+}
+__device__ __forceinline__ void lstmb_finish(const SkJob& job, int b, int j, float v, const LstmbOps& o) {
+    const int R = job.R;
+    if (job.add) v += o.add;
+    const float ig = o.ig, fg = o.fg, og = o.og, gg = o.gg, cp = o.cp, cn = o.cn, mk = o.mk;
     float dh = v * xg_keep(job.drop, (uint32_t)(b * R + j));
-    float dc = job.dc_in ? job.dc_in[(size_t)b * job.lddci + j] : 0.0f;
+    float dc = o.dc;
     float dht, dct, dcp;
     const float tc = xg_tanh(cn);
     if (job.mask_mode == XG_MASK_HOLD) {
@@ -221,6 +231,7 @@ __device__ __forceinline__ void lstmb_point(const SkJob& job, int b, int j, floa
     else                            { ds[2 * R + j] = dsg; ds[3 * R + j] = dso; }
     job.dc_prev[(size_t)b * job.lddcp + j] = dcp;
 }
+__device__ __forceinline__ void lstmb_point(const SkJob& job, int b, int j, float v) { lstmb_finish(job, b, j, v, lstmb_load(job, b, j)); }
 
 template <int RS, int NW>
 __device__ __forceinline__ void sk_epilogue(const SkJob& job, const float* __restrict__ redp, int m0, int n0, const LstmPre& pre) {
@@ -320,10 +331,88 @@ __device__ __forceinline__ void sk_epilogue(const SkJob& job, const float* __res
     }
 }
 
-// Split-K epilogue (see SkJob.ksplit_ok): this part's tile goes into C with atomics; LSTMB: last arriver finishes.
+// Split-K epilogue (see SkJob.ksplit_ok).  STORE: this part's tile goes into C with atomics.  LSTMB (round 6): no atomics and no
+// ticket.  Parts 0 .. ksplit - 2 PUBLISH their partial tile as 8-byte {tag = 1, value} granules (one agent-scope store each:
+// cdna_hip_programming.md guideline 16, form R2 -- the data is the flag) and are done; the workgroups of the LAST part are the
+// highest block indices of the launch (tile decode of skf_kernel), i.e. dispatched behind every publisher, and each of their
+// threads collects its elements' ksplit - 1 granules (requested together with the cell's own operands, re-read until every tag is
+// there), adds them in part order -- the sum no longer depends on the arrival order: the chains' dh is bit-reproducible -- puts
+// the granules back to zero and runs the cell's pointwise backward.  Before: every part added its tile into C with atomics, waited
+// for them, took a ticket (a returning atomic), and the last arriver re-read C: three dependent memory round trips behind the K
+// loop of every part (6.6 us of the reverse-time step, in-kernel stamps of round 5) against one for the last part only.
+typedef __attribute__((address_space(1))) unsigned long long sk_gu64;
 template <int RS, int NW>
 __device__ __forceinline__ void sk_epilogue_split(const SkJob& job, float* __restrict__ smem, int m0, int n0, int kp, int tile_id) {
     const float (*red)[32][RS] = reinterpret_cast<const float (*)[32][RS]>(smem);
+    if (job.epi == SK_EPI_LSTMB) {
+        constexpr int EPT = 1024 / (NW * 64);
+        const int ks = job.ksplit;
+        sk_gu64* slab = (sk_gu64*)(unsigned long long*)job.tickets + (size_t)tile_id * (ks - 1) * 1024;
+        float v[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int idx = threadIdx.x + NW * 64 * e;
+            const int m = idx >> 5, c = idx & 31;
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) s += red[w][m][c];
+            v[e] = s;
+        }
+        if (kp != ks - 1) {                                       // a publishing part: one 8-byte store per element, nothing to wait for
+#pragma unroll
+            for (int e = 0; e < EPT; ++e)
+                __hip_atomic_store(slab + (size_t)kp * 1024 + threadIdx.x + NW * 64 * e,
+                                   (1ull << 32) | (unsigned long long)__float_as_uint(v[e]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            return;
+        }
+        // the finishing part: the cell's operands and what C already holds (earlier launches) are requested first, then the other
+        // parts' tiles (all of them per pass: one round trip when the publishers are through, which they usually are)
+        LstmbOps ops[EPT];
+        float cacc[EPT];
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int idx = threadIdx.x + NW * 64 * e;
+            const int b = min(m0 + (idx >> 5), job.M - 1), j = min(n0 + (idx & 31), job.N - 1);      // (clamped: never stored)
+            ops[e] = lstmb_load(job, b, j);
+            cacc[e] = job.accumulate ? job.C[(size_t)b * job.ldc + j] : 0.f;
+        }
+        constexpr int PMAX = 3;                                   // ksplit <= 4 for LSTMB jobs (xgk_skinny): 24 registers of granules at four elements per thread
+        unsigned long long g[PMAX][EPT];
+        for (unsigned spins = 0;; ++spins) {
+            bool ok = true;
+#pragma unroll
+            for (int p = 0; p < PMAX; ++p) {
+                if (p < ks - 1) {
+#pragma unroll
+                    for (int e = 0; e < EPT; ++e) {
+                        g[p][e] = __hip_atomic_load(slab + (size_t)p * 1024 + threadIdx.x + NW * 64 * e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        ok = ok && (g[p][e] >> 32) == 1ull;
+                    }
+                }
+            }
+            if (ok) break;
+            if (spins > 16) __builtin_amdgcn_s_sleep(1);
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) v[e] += cacc[e];
+#pragma unroll
+        for (int p = 0; p < PMAX; ++p) {
+            if (p < ks - 1) {
+#pragma unroll
+                for (int e = 0; e < EPT; ++e) {
+                    v[e] += __uint_as_float((unsigned)g[p][e]);
+                    __hip_atomic_store(slab + (size_t)p * 1024 + threadIdx.x + NW * 64 * e, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < EPT; ++e) {
+            const int idx = threadIdx.x + NW * 64 * e;
+            const int b = m0 + (idx >> 5), j = n0 + (idx & 31);
+            if (b < job.M && j < job.N) lstmb_finish(job, b, j, v[e], ops[e]);
+        }
+        return;
+    }
 #pragma unroll
     for (int e = 0; e < 1024 / (NW * 64); ++e) {
         const int idx = threadIdx.x + NW * 64 * e;
@@ -340,24 +429,6 @@ __device__ __forceinline__ void sk_epilogue_split(const SkJob& job, float* __res
             }
             atomicAdd(job.C + (size_t)row * job.ldc + col, v);
         }
-    }
-    if (job.epi != SK_EPI_LSTMB) return;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's adds have been performed
-    __syncthreads();
-    int* flag = reinterpret_cast<int*>(smem);                  // (the partial tiles are dead after the barrier)
-    if (threadIdx.x == 0) {
-        const int t = atomicAdd(job.tickets + tile_id, 1);
-        if (t == job.ksplit - 1) job.tickets[tile_id] = 0;     // every part has passed: ready for the next launch
-        *flag = t;
-    }
-    __syncthreads();
-    if (*flag != job.ksplit - 1) return;
-#pragma unroll
-    for (int e = 0; e < 1024 / (NW * 64); ++e) {
-        const int idx = threadIdx.x + NW * 64 * e;
-        const int b = m0 + (idx >> 5), j = n0 + (idx & 31);
-        if (b < job.M && j < job.N)     // device-scope load: the other parts' atomics were performed at that scope
-            lstmb_point(job, b, j, __hip_atomic_load(job.C + (size_t)b * job.ldc + j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
     }
 }
 
@@ -926,17 +997,21 @@ skf_kernel(SkArgs args) {
     const int ntm = hd.ntm, ntn = hd.ntn, ks = hd.ksplit;      // (ksplit >= 1: xgk_skinny)
     const bool cell_tiles = (hd.hflags & SKH_CELL_TILES) != 0;
     const int lg_ks = (hd.hflags >> SKH_LGKS_SHIFT) & 15;      // (the cross-workgroup split is a power of two)
-    int bid = blockIdx.x;
-    {   // XCD-aware: the m-tiles that share a weight slice stay on one XCD's L2 (gridDim.x is a multiple of 8)
-        const int q = hd.ntiles >> 3, r = hd.ntiles & 7, xcd = bid & 7, idx = bid >> 3;
+    // A split launch's parts are whole ranges of block indices, part 0 first: the workgroups of the LAST part -- the ones that wait
+    // for the others' tiles (sk_epilogue_split) -- are dispatched behind every workgroup they wait for.
+    const int nt1 = hd.ntiles >> lg_ks;                        // tiles of one part
+    int bid = blockIdx.x, kp = 0;
+    if (ks > 1) { kp = bid / nt1; bid -= kp * nt1; }
+    {   // XCD-aware: the m-tiles that share a weight slice stay on one XCD's L2 (block b runs on XCD b % 8)
+        const int q = nt1 >> 3, r = nt1 & 7, xcd = bid & 7, idx = bid >> 3;
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
-    int tm, kp, tn;
+    int tm, tn;
     if (hd.hflags & SKH_POW2_NTM) {       // (every hot launch: 1, 2 or 4 m-tiles) -- no integer division in the decode
         const int lg_ntm = (hd.hflags >> SKH_LGNTM_SHIFT) & 15;
-        tm = bid & (ntm - 1); kp = (bid >> lg_ntm) & (ks - 1); tn = bid >> (lg_ntm + lg_ks);
+        tm = bid & (ntm - 1); tn = bid >> lg_ntm;
     } else {
-        tm = bid % ntm; kp = (bid / ntm) & (ks - 1); tn = (bid / ntm) >> lg_ks;
+        tm = bid % ntm; tn = bid / ntm;
     }
     const int m0 = tm * 32, n0 = tn * 32;
     // (the wave index is the same for every lane: saying so keeps the chunk ranges, loop counters and branches of the K loop on the
@@ -1337,6 +1412,13 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         // 128-chunk reductions of hidden 1024 still want their two parts: tools/ubench/sktarget_iter.sh.)
         static const int target = xg_diag_env("XG_SK_TARGET") ? atoi(xg_diag_env("XG_SK_TARGET")) : 256;     // diagnosis
         static const int deep = xg_diag_env("XG_SK_DEEP_CHUNKS") ? atoi(xg_diag_env("XG_SK_DEEP_CHUNKS")) : 64;
+        // (an LSTMB job's parts hand their tiles over through XGK_SKPART_TILES 8 KB slabs of scratch per job: SkJob.tickets)
+        for (int j = 0; j < a.njobs && ok; ++j)
+            if (a.job[j].epi == SK_EPI_LSTMB) {
+                const int jt = xg_cdiv(a.job[j].M, 32) * xg_cdiv(a.job[j].N, 32);
+                if (cap > 4) cap = 4;                            // (the finishing part holds every other part's granules at once)
+                while (cap > 1 && jt * (cap - 1) > XGK_SKPART_TILES) cap >>= 1;
+            }
         if (ok) while (ks < cap && min_chunks / (ks * 2) >= 4 &&
                        (tiles * ks * 2 <= target || (tiles * ks * 2 <= 512 && min_chunks / ks >= deep))) ks *= 2;
         for (int j = 0; j < a.njobs; ++j) a.job[j].ksplit = ks;
