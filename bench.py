@@ -721,7 +721,18 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         ctx["rccl_log"] = rccl_debug_setup(rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        from controllable_xgating_amd.train import dist_diagnosis
+        try:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            probe = torch.ones(1, device=dev)
+            dist.all_reduce(probe)                  # the first collective brings the communicator up: fail HERE, with the one line that explains it
+            torch.cuda.synchronize()
+            assert int(probe.item()) == world, probe
+        except Exception:
+            print(dist_diagnosis(), file=sys.stderr, flush=True)
+            raise
+        if rank == 0:
+            print(dist_diagnosis(), file=sys.stderr, flush=True)
 
     import __graft_entry__ as ge
     if rank == 0:

@@ -575,103 +575,6 @@ __global__ void __launch_bounds__(512, 4) attn_bwd_split_lr(const float* __restr
 }
 
 
-// The two-workgroup backward WITHOUT the context gradient as an input (round 5).  In the reverse-time loop d(context) =
-// ds2 W_a2h is a product of its own launch and the attention backward waited for it -- three dependent launches per step.  But
-// the context gradient is only ever used here for  dalpha_k = d(context) . V_k = ds2 . (W_a2h V_k) = ds2 . M_k,  M = V W_a2h^T
-// (N x 4R, one batched product per iteration: the caller's `M`), so the dots can be taken from ds2 directly and the product
-// leaves the chain (its result is still needed for dV -- as ONE batched product behind the loop).  Same kernel as
-// attn_bwd_split_lr with the dots over J = 4R columns in passes of 1024 (x: the step's ds2 row, ldx = 4R).
-template <int NQ, int DB>
-__global__ void __launch_bounds__(512, 4) attn_bwd_split_m(const float* __restrict__ x, int ldx, const float* __restrict__ p,
-                                                           const float* __restrict__ vproj, const float* __restrict__ M, int J,
-                                                           const float* __restrict__ w, const float* __restrict__ alpha,
-                                                           float* __restrict__ de, float* __restrict__ dp, int K, int A) {
-    extern __shared__ float sm[];                     // dalpha[K]
-    XG_CHAIN_PRIO();
-    constexpr int NWV = 8, DC = 4, DR = (NQ + NWV - 1) / NWV, NT = (NQ + 2) / 3;
-    static_assert(DR % DB == 0, "rows per wave must divide into stages");
-    const int b = blockIdx.x >> 1, part = blockIdx.x & 1, tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // (uniform: the rows' base addresses stay on the scalar unit)
-    const float* qb = vproj + (size_t)b * K * A;
-    const float* Mb = M + (size_t)b * K * J;
-    const float* xb = x + (size_t)b * ldx;
-    const int ah = A >> 1;
-    const int a0 = part * ah + tid * 2;
-    const bool a_ok = tid * 2 < ah;
-    float2 qa[NT], qc[NT];                            // two thirds in flight at most
-    constexpr bool EARLY_Q = NQ <= 32;                // (48 frames: the first third's 32 registers are needed by the dots)
-    if constexpr (EARLY_Q) {
-#pragma unroll
-        for (int k = 0; k < NT; ++k) qa[k] = (a_ok && k < K) ? *reinterpret_cast<const float2*>(qb + (size_t)k * A + a0) : make_float2(0, 0);
-    }
-    const float al_lane = lane < K ? alpha[(size_t)b * K + lane] : 0.f;
-    const float2 pa = a_ok ? *reinterpret_cast<const float2*>(p + (size_t)b * A + a0) : make_float2(0, 0);
-    const float2 wa = a_ok ? *reinterpret_cast<const float2*>(w + a0) : make_float2(0, 0);
-    float acc[DR];
-#pragma unroll
-    for (int j = 0; j < DR; ++j) acc[j] = 0.f;
-#pragma unroll 1
-    for (int c0 = 0; c0 < J; c0 += 256 * DC) {       // dalpha_k = x . M_k, this wave's rows k = wave + 8 j
-        float4 dv[DC];
-        const int rl = c0 + lane * 4;                 // this lane's first column of the pass
-#pragma unroll
-        for (int c = 0; c < DC; ++c) dv[c] = rl + 256 * c < J ? *reinterpret_cast<const float4*>(xb + rl + 256 * c) : make_float4(0, 0, 0, 0);
-#pragma unroll
-        for (int j0 = 0; j0 < DR; j0 += DB) {
-            float4 vv[DB][DC];
-#pragma unroll
-            for (int jj = 0; jj < DB; ++jj)
-#pragma unroll
-                for (int c = 0; c < DC; ++c) {
-                    const int k = wave + (j0 + jj) * NWV;
-                    const float* row = Mb + (size_t)k * J;          // (scalar)
-                    vv[jj][c] = (rl + 256 * c < J && k < K) ? *reinterpret_cast<const float4*>(row + rl + 256 * c) : make_float4(0, 0, 0, 0);
-                }
-#pragma unroll
-            for (int jj = 0; jj < DB; ++jj)
-#pragma unroll
-                for (int c = 0; c < DC; ++c)
-                    acc[j0 + jj] += dv[c].x * vv[jj][c].x + dv[c].y * vv[jj][c].y + dv[c].z * vv[jj][c].z + dv[c].w * vv[jj][c].w;
-            __builtin_amdgcn_sched_barrier(0);       // (one stage of rows in registers at a time: left alone the scheduler requests them all)
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < DR; ++j) {
-        const int k = wave + j * NWV;
-        const float a = wave_sum(acc[j]);
-        if (lane == 0 && k < K) sm[k] = a;
-    }
-    if constexpr (!EARLY_Q) {
-#pragma unroll
-        for (int k = 0; k < NT; ++k) qa[k] = (a_ok && k < K) ? *reinterpret_cast<const float2*>(qb + (size_t)k * A + a0) : make_float2(0, 0);
-    }
-#pragma unroll
-    for (int k = 0; k < NT; ++k) qc[k] = (a_ok && NT + k < K) ? *reinterpret_cast<const float2*>(qb + (size_t)(NT + k) * A + a0) : make_float2(0, 0);
-    __syncthreads();
-    const float da = lane < K ? sm[lane] : 0.f;
-    const float dot = wave_sum(al_lane * da);
-    const float d_lane = al_lane * (da - dot);
-    if (part == 0 && wave == 0 && lane < K) de[(size_t)b * K + lane] = d_lane;
-    float sx = 0.f, sy = 0.f;
-    auto third = [&](const float2 (&q)[NT], int k0) {
-#pragma unroll
-        for (int k = 0; k < NT; ++k) {
-            if (k0 + k < K) {
-                const float dk = xg_readlane(d_lane, k0 + k);
-                const float tx = xg_tanh(pa.x + q[k].x), ty = xg_tanh(pa.y + q[k].y);
-                sx += dk * (1.0f - tx * tx);
-                sy += dk * (1.0f - ty * ty);
-            }
-        }
-    };
-    third(qa, 0);
-#pragma unroll
-    for (int k = 0; k < NT; ++k) qa[k] = (a_ok && 2 * NT + k < K) ? *reinterpret_cast<const float2*>(qb + (size_t)(2 * NT + k) * A + a0) : make_float2(0, 0);
-    third(qc, NT);
-    third(qa, 2 * NT);
-    if (a_ok) *reinterpret_cast<float2*>(dp + (size_t)b * A + a0) = make_float2(sx * wa.x, sy * wa.y);
-}
-
 }  // namespace
 
 int xgk_attn_fwd(hipStream_t st, const float* p, const float* vproj, const float* V, const float* w, float* alpha,
@@ -719,9 +622,7 @@ int xgk_attn_bwd(hipStream_t st, const float* daf, int lddaf, const float* p, co
     // them fits into the half of a CU a background GEMM workgroup leaves free (xg_gemm.hip: XGK_GEMM_BG) -- the
     // one-workgroup form (1024 threads x 125 VGPRs) needs an EMPTY CU and waited for one for up to 240 us per step beside
     // dW_logit.  For 33-48 frames: the staged form attn_bwd_split_lr (the one-workgroup form would spill there).
-    // XG_ATTN_BWD_ONE=1 selects the one-workgroup form for comparison.
-    static const int one_wg = xg_diag_env("XG_ATTN_BWD_ONE") ? 1 : 0;
-    if (!one_wg && al16 && A % 4 == 0 && A <= 2048 && R % 4 == 0 && R <= 1024 && lddaf % 4 == 0 && K <= 48) {
+    if (al16 && A % 4 == 0 && A <= 2048 && R % 4 == 0 && R <= 1024 && lddaf % 4 == 0 && K <= 48) {
         const size_t lds = (size_t)K * sizeof(float);
         if (K <= 16) hipLaunchKernelGGL((attn_bwd_split<16>), dim3(2 * B), dim3(512), lds, st, daf, lddaf, p, vproj, V, w, alpha, de, dp, K, R, A);
         else if (K <= 32) hipLaunchKernelGGL((attn_bwd_split<32>), dim3(2 * B), dim3(512), lds, st, daf, lddaf, p, vproj, V, w, alpha, de, dp, K, R, A);
@@ -739,24 +640,6 @@ int xgk_attn_bwd(hipStream_t st, const float* daf, int lddaf, const float* p, co
     }
     hipLaunchKernelGGL(attn_bwd_kernel, dim3(B), dim3(ATPB), K * sizeof(float), st, daf, lddaf, p, vproj, V, w, alpha,
                        de, dp, K, R, A);
-    XG_CHECK_LAUNCH();
-    return XG_OK;
-}
-// the attention backward from x = ds2 (B, J = 4R; ldx) and M = V W_a2h^T (B, K, J) instead of the context gradient (see
-// attn_bwd_split_m); returns 1 when the shapes do not fit this form (the caller then forms the context gradient first)
-bool xgk_attn_bwd_m_ok(const float* x, int ldx, const float* p, const float* vproj, const float* M, int J, const float* w,
-                       const float* dp, int K, int A) {
-    const bool al16 = ((uintptr_t)p % 16 == 0) && ((uintptr_t)vproj % 16 == 0) && ((uintptr_t)M % 16 == 0) &&
-                      ((uintptr_t)w % 16 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)dp % 16 == 0);
-    return al16 && A % 4 == 0 && A <= 2048 && J % 4 == 0 && ldx % 4 == 0 && K <= 48 && K >= 1;
-}
-int xgk_attn_bwd_m(hipStream_t st, const float* x, int ldx, const float* p, const float* vproj, const float* M, int J, const float* w,
-                   const float* alpha, float* de, float* dp, int B, int K, int A) {
-    if (!xgk_attn_bwd_m_ok(x, ldx, p, vproj, M, J, w, dp, K, A)) return 1;
-    const size_t lds = (size_t)K * sizeof(float);
-    if (K <= 16) hipLaunchKernelGGL((attn_bwd_split_m<16, 2>), dim3(2 * B), dim3(512), lds, st, x, ldx, p, vproj, M, J, w, alpha, de, dp, K, A);
-    else if (K <= 32) hipLaunchKernelGGL((attn_bwd_split_m<32, 2>), dim3(2 * B), dim3(512), lds, st, x, ldx, p, vproj, M, J, w, alpha, de, dp, K, A);
-    else hipLaunchKernelGGL((attn_bwd_split_m<48, 3>), dim3(2 * B), dim3(512), lds, st, x, ldx, p, vproj, M, J, w, alpha, de, dp, K, A);
     XG_CHECK_LAUNCH();
     return XG_OK;
 }

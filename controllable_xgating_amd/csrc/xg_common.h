@@ -126,5 +126,14 @@ static inline const char* xg_diag_env(const char* name) { return getenv(name); }
 static inline constexpr const char* xg_diag_env(const char*) { return nullptr; }
 #endif
 
+// -DXG_NULL_LAUNCH (measurement build, tools/host8_enqueue.py): every kernel launch of the library becomes the launch of an empty
+// kernel on the same stream -- same host-side call sequence, events and stream waits, no GPU time behind it.  What the host loop
+// costs can then be told apart from what it WAITS for when several launcher processes share one GPU.  Results are garbage.
+#ifdef XG_NULL_LAUNCH
+static __global__ void xg_null_kernel(int) {}
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernel_, grid_, block_, lds_, stream_, ...) do { xg_null_kernel<<<dim3(1), dim3(64), 0, (stream_)>>>(0); } while (0)
+#endif
+
 static inline int xg_cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int64_t xg_cdiv64(int64_t a, int64_t b) { return (a + b - 1) / b; }

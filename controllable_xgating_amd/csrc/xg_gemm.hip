@@ -29,10 +29,7 @@ namespace {
 
 constexpr int BKS = 32;          // slab depth
 constexpr int LDK = BKS + 4;     // row stride of a k-contiguous LDS image
-#ifndef GEMM_MC_PAD
-#define GEMM_MC_PAD 4
-#endif
-constexpr int MCP = GEMM_MC_PAD;  // padding of a k-row of an m-contiguous LDS image
+constexpr int MCP = 4;           // padding of a k-row of an m-contiguous LDS image
 
 template <int ROWS, bool KC>
 struct TileGeom {
@@ -163,23 +160,13 @@ __device__ __forceinline__ void w1_interleave() {
     }
 }
 
-// One 32-deep slab of MFMAs out of the LDS images.  Default: per 8-deep block [fragment reads][4 MT NT MFMAs], scheduled by the
-// compiler ([reads][s_waitcnt][MFMAs]: a wave's matrix pipe idles for one LDS round trip per block, which the other waves of the
-// SIMD cover).  -DGEMM_FRAG_PIPE: the fragments of block kb + 1 are requested BEFORE the MFMAs of block kb (two fragment sets,
-// order pinned with sched_barrier) -- measured (tools/ubench/gemm_ablate.py, round 3): no gain on k-contiguous operands
-// (enc embed 55.8 -> 54.8 us with everything but LDS reads + MFMAs compiled out) and a loss on m-contiguous ones (wgrad TN
-// 58.8 -> 69.2 us): with two or more waves per SIMD the round trip was already hidden, and the pinned order costs more than it hides.
+// One 32-deep slab of MFMAs out of the LDS images: per 8-deep block [fragment reads][4 MT NT MFMAs], scheduled by the compiler
+// ([reads][s_waitcnt][MFMAs]: a wave's matrix pipe idles for one LDS round trip per block, which the other waves of the SIMD
+// cover).  (Fragments requested one block ahead with a pinned order were measured in round 3 and are gone: no gain on
+// k-contiguous operands, a loss on m-contiguous ones -- docs/EXPERIMENTS.md.)
 template <int BM, int BN, bool AKC, bool BKC, int MT, int NT>
 __device__ __forceinline__ void slab_mfma_pipelined(const float* __restrict__ as, const float* __restrict__ bs, int arow, int brow,
                                                     int half, f32x16 (&acc)[MT][NT]) {
-#if defined(GEMM_FRAG_PIPE)
-    constexpr bool PIPE = true;
-#elif defined(GEMM_FRAG_PIPE_KC)
-    constexpr bool PIPE = AKC && BKC;            // both operands k-contiguous (one b128 read per fragment): the forward products
-#else
-    constexpr bool PIPE = false;
-#endif
-    if constexpr (!PIPE) {
 #pragma unroll
     for (int kb = 0; kb < BKS / 8; ++kb) {
         f32x4 fa[MT], fb[NT];
@@ -194,32 +181,6 @@ __device__ __forceinline__ void slab_mfma_pipelined(const float* __restrict__ as
 #pragma unroll
                 for (int j = 0; j < NT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][kk], fb[j][kk], acc[i][j], 0, 0, 0);
-    }
-    } else {
-    f32x4 fa[2][MT], fb[2][NT];
-#pragma unroll
-    for (int i = 0; i < MT; ++i) fa[0][i] = read_frag<BM, AKC>(as, arow + i * 32, 0, half);
-#pragma unroll
-    for (int j = 0; j < NT; ++j) fb[0][j] = read_frag<BN, BKC>(bs, brow + j * 32, 0, half);
-#pragma unroll
-    for (int kb = 0; kb < BKS / 8; ++kb) {
-        const int c = kb & 1, n = c ^ 1;
-        if (kb + 1 < BKS / 8) {
-#pragma unroll
-            for (int i = 0; i < MT; ++i) fa[n][i] = read_frag<BM, AKC>(as, arow + i * 32, kb + 1, half);
-#pragma unroll
-            for (int j = 0; j < NT; ++j) fb[n][j] = read_frag<BN, BKC>(bs, brow + j * 32, kb + 1, half);
-        }
-#pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-            for (int i = 0; i < MT; ++i)
-#pragma unroll
-                for (int j = 0; j < NT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[c][i][kk], fb[c][j][kk], acc[i][j], 0, 0, 0);
-        if (kb + 1 < BKS / 8) w1_interleave<4 * MT * NT, MT * (AKC ? 1 : 2) + NT * (BKC ? 1 : 2), 0>();
-        __builtin_amdgcn_sched_barrier(0);
-    }
     }
 }
 
@@ -257,14 +218,8 @@ __device__ __forceinline__ void csum_flush(const f32x4& cs, f32x4* red4, int m0,
     }
 }
 
-#ifdef GEMM_CLK
-__device__ long long gemm_clk_buf[4];
-#endif
 template <int BM, int BN, bool AKC, bool BKC, bool VEC>
 __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
-#ifdef GEMM_CLK
-    const long long clk0 = clock64(), wall0 = wall_clock64();
-#endif
     constexpr int WM = BM / 2, WN = BN / 2;      // per-wave tile
     constexpr int MT = WM / 32, NT = WN / 32;    // MFMA tiles per wave
     constexpr int A_FL = TileGeom<BM, AKC>::lds_floats;
@@ -331,7 +286,6 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
 
     for (int s = s_begin; s < nslab; ++s) {
         const int cur = (s - s_begin) & 1;
-#ifndef GEMM_NO_GLOBAL
         if (s + 1 < nslab) {
             if (fast && s + 1 < nfull) {
                 load_fast<NVA>(reinterpret_cast<const char*>(g.A) + (size_t)(s + 1) * stepA, offA, ra);
@@ -341,11 +295,9 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
                 load_tile<BN, BKC, VEC>(g.B, g.ldb, n0, (s + 1) * BKS, g.N, g.K, rb);
             }
         }
-#endif
         const float* as = smem + cur * STAGE;
         const float* bs = as + A_FL;
         slab_mfma_pipelined<BM, BN, AKC, BKC, MT, NT>(as, bs, wm * WM + l31, wn * WN + l31, half, acc);
-#ifndef GEMM_NO_LDS_STORE
         if (s + 1 < nslab) {
             if (do_cs) {
 #pragma unroll
@@ -354,10 +306,7 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
             store_tile<BM, AKC>(smem + (cur ^ 1) * STAGE, ra);
             store_tile<BN, BKC>(smem + (cur ^ 1) * STAGE + A_FL, rb);
         }
-#endif
-#ifndef GEMM_NO_SYNC
         __syncthreads();
-#endif
     }
     if (do_cs) {                                 // (the staging buffers are free: every wave is past its last slab)
         f32x4* red4 = reinterpret_cast<f32x4*>(smem);
@@ -366,9 +315,6 @@ __global__ void __launch_bounds__(256) gemm_kernel(GemmArgs g) {
         csum_flush<BM>(cs, red4, m0, g.M, g.csum);
     }
 
-#ifdef GEMM_CLK
-    if (blockIdx.x == 100 && threadIdx.x == 0) { gemm_clk_buf[0] = clock64() - clk0; gemm_clk_buf[1] = wall_clock64() - wall0; }
-#endif
     // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -682,13 +628,7 @@ __device__ long long pk_trace_buf[512 * 40];
 #else
 #define PK_STAMP(i) do { } while (0)
 #endif
-#ifdef PK_ASM_BARRIER
-// workgroup barrier that orders LDS only: __syncthreads() also waits for every outstanding global store (vmcnt(0)), i.e.
-// for the result tile just written
-#define PK_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#else
 #define PK_BARRIER() __syncthreads()
-#endif
 
 __device__ __forceinline__ void pk_tile_coords(int t, int ntm, int ntn, int GM, int& tm, int& tn) {
     const int per = GM * ntn, grp = t / per, in = t - grp * per;
@@ -825,7 +765,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
         for (int s = cur.s0; s + 1 < cur.s1; ++s) {
-#ifndef GEMM_NO_GLOBAL
             if (s + 1 < nfull) {
                 load_fast<NVA>(reinterpret_cast<const char*>(g.A) + (size_t)(s + 1) * stepA, offA, ra);
                 load_fast<NVB>(reinterpret_cast<const char*>(g.B) + (size_t)(s + 1) * stepB, offB, rb);
@@ -833,22 +772,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 load_tile<BM, AKC, true>(g.A, g.lda, m0, (s + 1) * BKS, g.M, g.K, ra);
                 load_tile<BN, BKC, true>(g.B, g.ldb, n0, (s + 1) * BKS, g.N, g.K, rb);
             }
-#endif
             slab_mfma(buf);
-#ifdef GEMM_SCHED_BARRIER
-            __builtin_amdgcn_sched_barrier(0);
-#endif
-#ifndef GEMM_NO_LDS_STORE
             if (cs_on) {
 #pragma unroll
                 for (int i = 0; i < NVA; ++i) cs += ra[i];
             }
             store_tile<BM, AKC>(smem + (buf ^ 1) * STAGE, ra);
             store_tile<BN, BKC>(smem + (buf ^ 1) * STAGE + A_FL, rb);
-#endif
-#ifndef GEMM_NO_SYNC
             __syncthreads();
-#endif
             buf ^= 1;
         }
         // last slab of the item: the first slab of the NEXT item is fetched under it
@@ -864,7 +795,6 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             tile_offsets<BM, AKC>(g.lda, nm0, g.M, offA);
             tile_offsets<BN, BKC>(g.ldb, nn0, g.N, offB);
             load_bias(nx, nn0, bvn);
-#ifndef GEMM_NO_GLOBAL
             if (nx.s0 < nfull) {
                 load_fast<NVA>(reinterpret_cast<const char*>(g.A) + (size_t)nx.s0 * stepA, offA, ra);
                 load_fast<NVB>(reinterpret_cast<const char*>(g.B) + (size_t)nx.s0 * stepB, offB, rb);
@@ -872,10 +802,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 load_tile<BM, AKC, true>(g.A, g.lda, nm0, nx.s0 * BKS, g.M, g.K, ra);
                 load_tile<BN, BKC, true>(g.B, g.ldb, nn0, nx.s0 * BKS, g.N, g.K, rb);
             }
-#endif
         }
         slab_mfma(buf);
-#ifndef GEMM_NO_LDS_STORE
         if (has) {
             csn = f32x4{0.f, 0.f, 0.f, 0.f};
             if (csn_on) {
@@ -885,12 +813,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
             store_tile<BM, AKC>(smem + (buf ^ 1) * STAGE, ra);
             store_tile<BN, BKC>(smem + (buf ^ 1) * STAGE + A_FL, rb);
         }
-#endif
         if (cs_on) red4[threadIdx.x] = cs;       // (read behind the barrier below)
         PK_STAMP(3 + 4 * item_no);
-#ifdef GEMM_NO_EPI
-        if (g.M < 0)
-#endif
         {
             // result of item `cur`: whole tile -> stores (bias / ReLU; += C via atomics), part of a reduction -> atomics
             const bool part = cur.s0 != 0 || cur.s1 != g.nslab;
@@ -913,9 +837,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))
                 }
         }
         PK_STAMP(4 + 4 * item_no);
-#ifndef GEMM_NO_SYNC
         PK_BARRIER();
-#endif
         if (cs_on) csum_flush<BM>(cs, red4, m0, g.M, g.csum);
         PK_STAMP(5 + 4 * item_no);
         ++item_no;
@@ -940,14 +862,8 @@ int launch_pk(hipStream_t st, const GemmArgs& a, long min_units_default) {
     // measured (tools/ubench/gemm_bench.py): the persistent form wins 3-6 % when every workgroup has >= ~40 slabs of work
     // (vocabulary head: logits, dW_logit, dH) and loses 10-15 % to 64x64 tiles + split-K on the mid-size products
     static const long min_units_env = xg_diag_env("XG_PK_MIN") ? atol(xg_diag_env("XG_PK_MIN")) : -1;
-    // (experiment, XG_BG_MIN: a BACKGROUND product takes the persistent form from that many slabs per workgroup on -- beside a
-    //  launch chain the one-workgroup-per-CU form is about not crowding the chain, not about the product's own time)
-    static const long bg_min_env = xg_diag_env("XG_BG_MIN") ? atol(xg_diag_env("XG_BG_MIN")) : -1;
-    const bool bg_req = a.bg && !xg_diag_env("XG_GEMM_NO_BG");
-    const long min_units = (bg_req && bg_min_env >= 0) ? bg_min_env : (min_units_env >= 0 ? min_units_env : min_units_default);
+    const long min_units = min_units_env >= 0 ? min_units_env : min_units_default;      // (XG_PK_MIN: tests force the kernel onto small shapes)
     if (units < 512L * min_units) return 1;
-    static const int env_g = xg_diag_env("XG_PK_G") ? atoi(xg_diag_env("XG_PK_G")) : 0;
-    static const int env_split = xg_diag_env("XG_PK_SPLIT") ? atoi(xg_diag_env("XG_PK_SPLIT")) : 1;
     // 2 workgroups per CU (73.7 KB of LDS each) -- or, for a background product, ONE per CU (LDS padded past half a CU so
     // that the dispatcher cannot pair them): 512 persistent workgroups own every register file and LDS for the whole
     // product (0.7 ms for dW_logit), and a recurrent chain on another stream then waits for leftovers -- its step took
@@ -956,9 +872,9 @@ int launch_pk(hipStream_t st, const GemmArgs& a, long min_units_default) {
     static const int bg_off = xg_diag_env("XG_GEMM_NO_BG") ? 1 : 0;
     static const int bg_all = xg_diag_env("XG_GEMM_FORCE_BG") ? 1 : 0;     // tests: every product takes the background form
     const bool bg = (a.bg + bg_all > 0) && !bg_off;
-    const int GMAX = env_g > 0 ? env_g : (bg ? 256 : 512);
+    const int GMAX = bg ? 256 : 512;
     int G;
-    const bool split = !a.relu && g.nslab >= 2 && env_split;
+    const bool split = !a.relu && g.nslab >= 2;
     if (!split) {
         if (T < GMAX) return 1;
         // whole tiles only (a ReLU epilogue cannot be split): the fewest rounds, evened out over the workgroups; the ragged
@@ -1172,17 +1088,13 @@ int launch_td(hipStream_t st, const GemmArgs& a) {
     g.ntm = xg_cdiv(a.M, 64); g.ntn = xg_cdiv(a.N, 64);
     const long tiles = (long)g.ntm * g.ntn;
     if (tiles < 32) return 1;
-    static const long tmin = xg_diag_env("XG_TD_TILES_MIN") ? atol(xg_diag_env("XG_TD_TILES_MIN")) : 0;
-    static const long tmax = xg_diag_env("XG_TD_TILES_MAX") ? atol(xg_diag_env("XG_TD_TILES_MAX")) : (1L << 40);
-    static const int only_bg = xg_diag_env("XG_TD_ONLY_BG") ? atoi(xg_diag_env("XG_TD_ONLY_BG")) : 0;     // 1: background products only, 2: the others only
-    if (tiles < tmin || tiles > tmax || (only_bg == 1 && !a.bg) || (only_bg == 2 && a.bg)) return 1;
     // Production rule: the vocabulary head's weight gradient (a background product, or >= 1024 tiles).  The mid-size weight
     // gradients are 18 % faster here when they run ALONE (51.6 vs 61.0 us at 2048 x 512 x 2688) but the iteration is 1 % slower
     // with them (5.95-5.99 vs 5.88-5.91 ms, three runs each way, tools/ubench/td_iter*.sh): they run beside the recurrent launch
     // chains, which are the critical path, and a product that keeps 16 wide loads per wave in flight lengthens every round trip of
     // the chain next to it.  XG_TD_ALL=1 (diag library) sends every eligible product here.
     static const int td_all = xg_diag_env("XG_TD_ALL") ? atoi(xg_diag_env("XG_TD_ALL")) : 0;
-    if (!td_all && !only_bg && tmin == 0 && !a.bg && tiles < 1024) return 1;
+    if (!td_all && !a.bg && tiles < 1024) return 1;
     static const int ks_env = xg_diag_env("XG_TD_KS") ? atoi(xg_diag_env("XG_TD_KS")) : 0;
     int ks = 1;
     if (tiles < 192) { ks = (int)(256 / tiles); if (ks > g.nrounds / 16) ks = g.nrounds / 16; if (ks < 1) ks = 1; }
@@ -1194,8 +1106,7 @@ int launch_td(hipStream_t st, const GemmArgs& a) {
         else if (hipMemset2DAsync(a.C, sizeof(float) * a.ldc, 0, sizeof(float) * a.N, a.M, st) != hipSuccess) return XG_EHIP;
     }
     static const int bg_off = xg_diag_env("XG_GEMM_NO_BG") ? 1 : 0;
-    static const int pad_all = xg_diag_env("XG_TD_PAD") ? atoi(xg_diag_env("XG_TD_PAD")) : 0;      // experiment: every td launch one workgroup per CU
-    const bool bg = (a.bg && !bg_off) || (pad_all && tiles <= 512);
+    const bool bg = a.bg && !bg_off;
     const long items = tiles * ks;
     const int GMAX = bg ? 256 : 512;
     const long rounds = xg_cdiv64(items, GMAX);
@@ -1203,8 +1114,7 @@ int launch_td(hipStream_t st, const GemmArgs& a) {
     size_t lds = (4 * 64 * TD_LDW + 256) * sizeof(float);
     if (bg && lds < 82 * 1024) lds = 82 * 1024;      // one workgroup per CU beside a launch chain (see launch_pk)
     static const int depth_all = xg_diag_env("XG_TD_DEPTH") ? atoi(xg_diag_env("XG_TD_DEPTH")) : 8;
-    static const int depth_bg = xg_diag_env("XG_TD_BG_DEPTH") ? atoi(xg_diag_env("XG_TD_BG_DEPTH")) : depth_all;
-    const int depth_env = bg ? depth_bg : depth_all;
+    const int depth_env = depth_all;          // (XG_TD_DEPTH: tests run the 4- and 12-step rings too)
     if (depth_env == 4) {
         static std::atomic<unsigned> optin4{0};
         XG_TRY(xg_lds_optin(optin4, reinterpret_cast<const void*>(&gemm_td_kernel<4>), 84 * 1024));
@@ -1294,8 +1204,7 @@ int dispatch(hipStream_t st, GemmArgs g, bool vec) {
         g.splitk = (int)sk;
     }
     else if (!g.relu && t64 >= 4) {
-        static const long tgt_pct = xg_diag_env("XG_GEMM_SPLIT_PCT") ? atol(xg_diag_env("XG_GEMM_SPLIT_PCT")) : 100;     // experiment: scale the split target
-        const long target = ((AKC && BKC) ? 768 : 1536) * tgt_pct / 100;
+        const long target = (AKC && BKC) ? 768 : 1536;
         long sk = target / t64;
         if (sk > nslab / 16) sk = nslab / 16;      // keep K >= 512 per split
         if (sk >= 2) g.splitk = (int)sk;
@@ -1318,12 +1227,7 @@ int dispatch(hipStream_t st, GemmArgs g, bool vec) {
         if (rc1 != 1) return rc1;
     }
     if (vec && !force) {
-        // diagnosis: XG_PK_TILE = 1 (128 x 64 tiles) / 2 (64 x 64) sends the product to the persistent stream-K kernel over smaller tiles
-        static const int pk_tile = xg_diag_env("XG_PK_TILE") ? atoi(xg_diag_env("XG_PK_TILE")) : 0;
-        int rc = 1;
-        if (pk_tile == 1) rc = launch_pk<128, 64, AKC, BKC>(st, g, 8);
-        else if (pk_tile == 2) rc = launch_pk<64, 64, AKC, BKC>(st, g, 8);
-        if (rc == 1) rc = launch_pk<128, 128, AKC, BKC>(st, g, 40);
+        const int rc = launch_pk<128, 128, AKC, BKC>(st, g, 40);
         if (rc != 1) return rc;
     }
     g.gm = xgk_group_rows(g.K / g.splitk);
@@ -1346,18 +1250,6 @@ int xgk_gemm_cs(hipStream_t st, int mode, bool transA, bool transB, int M, int N
                 float* cs3) {
     if (M <= 0 || N <= 0) return XG_OK;
     if (K < 0 || !A || !B || !C) return XG_EINVAL;
-#ifdef XG_DIAG
-    {   // sensitivity experiment (results wrong on purpose): every tiled product with its reduction depth scaled -- "what would the
-        // iteration be with GEMMs that much faster" (XG_GEMM_KSCALE=0.8: 20 % less matrix work per product, same launches / tiles)
-        static const float kscale = xg_diag_env("XG_GEMM_KSCALE") ? (float)atof(xg_diag_env("XG_GEMM_KSCALE")) : 1.0f;
-        // XG_GEMM_KSEL: which products are scaled -- bit 0 weight-gradient layout (TN), 1 NT, 2 NN, 3 vocabulary-sized only (a
-        // dimension >= 10000), 4 everything but vocabulary-sized
-        static const int ksel = xg_diag_env("XG_GEMM_KSEL") ? atoi(xg_diag_env("XG_GEMM_KSEL")) : 7;
-        const bool vocab = M >= 10000 || N >= 10000 || K >= 10000;
-        const int cls = transA ? 1 : (transB ? 2 : 4);
-        if (kscale != 1.0f && K >= 256 && (ksel & cls) && (!(ksel & 8) || vocab) && (!(ksel & 16) || !vocab)) K = ((int)(K * kscale) / 32) * 32;
-    }
-#endif
     const bool want_cs = cs1 != nullptr;
     if (want_cs && !transA) return XG_EINVAL;
     const int bg = (mode & XGK_GEMM_BG) ? 1 : 0;
@@ -1371,26 +1263,11 @@ int xgk_gemm_cs(hipStream_t st, int mode, bool transA, bool transB, int M, int N
     static const int x3_fp32 = xg_diag_env("XG_X3_FP32") ? atoi(xg_diag_env("XG_X3_FP32")) : 1;
     const bool x3_exact = mode == 3 && (x3_fp32 & (transA ? 1 : (transB ? 2 : 4)));
     // (... and shallow reductions: the gradients of the initial-state projections are R x R x B products -- 1024 x 1024 x 128 at hidden
-    // 1024 -- that took 62 us each on the bf16 tile kernel, four slabs per tile; diag: XG_BF16_MINK = the old threshold 64)
-    static const int bf16_mink = xg_diag_env("XG_BF16_MINK") ? atoi(xg_diag_env("XG_BF16_MINK")) : 256;
+    // 1024 -- that took 62 us each on the bf16 tile kernel, four slabs per tile)
+    constexpr int bf16_mink = 256;
     if ((mode == 1 || mode == 3) && !x3_exact && M >= 256 && N >= 64 && K >= bf16_mink) {
         return xgk_gemm_bf16(st, mode, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, cs1, cs2, cs3);
     }
-#ifdef XG_DIAG
-    {   // experiment: plain products through the vendor library.  XG_BLASLT = mask: 1 weight-gradient layout (TN), 2 NT, 4 NN,
-        // 8 vocabulary-sized only, 16 everything but vocabulary-sized, 32 also products with bias-gradient side outputs (their
-        // column sums as a separate pass), 64 not the background products
-        static const int lt = xg_diag_env("XG_BLASLT") ? atoi(xg_diag_env("XG_BLASLT")) : 0;
-        const bool vocab = M >= 10000 || N >= 10000 || K >= 10000;
-        const int cls = transA ? 1 : (transB ? 2 : 4);
-        if (mode == 0 && (lt & cls) && (!(lt & 8) || vocab) && (!(lt & 16) || !vocab) && (!want_cs || (lt & 32)) && (!bg || !(lt & 64)) &&
-            M >= 64 && N >= 64 && K >= 64) {
-            const int rc = xgk_blaslt_gemm(st, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate);
-            if (rc == XG_OK && want_cs) return xgk_colsum3(st, A, lda, K, M, cs1, cs2, cs3);
-            if (rc != 1) return rc;
-        }
-    }
-#endif
     GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1, 0, 1, bg, {nullptr, nullptr, nullptr}};
     const bool akc = !transA;   // A (M,K) row-major -> k contiguous
     const bool bkc = transB;    // B (N,K) row-major -> k contiguous

@@ -60,11 +60,6 @@ __device__ __forceinline__ void split(float x, unsigned short (&h)[NP]) {
         u += 0x7FFFu + ((u >> 16) & 1u);                 // round to nearest even
         h[0] = (unsigned short)(u >> 16);
     } else {
-#ifdef XG_SPLIT_CHEAP
-        // timing experiment only (results wrong): what would the split-bf16 products cost if the planes came pre-split from memory?
-        h[0] = (unsigned short)(__float_as_uint(x) >> 16); h[1] = h[0]; h[NP - 1] = h[0];
-        return;
-#endif
         unsigned u0 = __float_as_uint(x) & 0xFFFF0000u;
         const float r1 = x - __uint_as_float(u0);        // exact
         unsigned u1 = __float_as_uint(r1) & 0xFFFF0000u;

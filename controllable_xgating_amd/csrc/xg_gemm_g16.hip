@@ -43,7 +43,7 @@ struct GArgs {
     const unsigned short* A; const unsigned short* B; float* C; const float* bias;
     int M, N, K, lda, ldb, ldc, relu, accumulate, splitk, gm;
     float* csum[3];
-    int dbg;          // diag build, timing only (results wrong): 1 = no DMA inside the loop, 2 = no fragment reads / MFMAs, 4 = no epilogue
+    int pad_;
 };
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -203,8 +203,6 @@ __global__ void __launch_bounds__(256 * KG, 2) gemm_g16_kernel(GArgs g) {
         __builtin_amdgcn_s_barrier();                           // slab s is in LDS for everybody; everybody is done with slab s - 1
         __builtin_amdgcn_sched_barrier(0);
         const bool more = s + P < s_end;                        // ... whose stage takes slab s + P
-        const bool burst = (g.dbg & 8) != 0;                    // (diag: the DMA instructions in one burst in front of the fragment reads)
-        if (more && burst) { if (!(g.dbg & 1)) issue(ibuf); }
         const int jbuf = ibuf;
         if (more) ++nis;
         ibuf = ibuf + 1 == NS ? 0 : ibuf + 1;
@@ -221,7 +219,7 @@ __global__ void __launch_bounds__(256 * KG, 2) gemm_g16_kernel(GArgs g) {
                 csv1 += __uint_as_float(w & 0xFFFF0000u);
             }
         }
-        if (!(g.dbg & 2)) {
+        {
             // every fragment of the slab is requested before its first MFMA (a wave's LDS reads then run under its own MFMAs,
             // not only under the other waves'); the scheduler is told to keep that order
             constexpr int KK = TK / 16 / KG;                    // 16-deep blocks of the slab this wave multiplies
@@ -234,13 +232,11 @@ __global__ void __launch_bounds__(256 * KG, 2) gemm_g16_kernel(GArgs g) {
 #pragma unroll
                 for (int j = 0; j < 2; ++j) fb[kk][j] = frag(Bi, BKC, fb0, j, kk0 + kk);
             }
-#ifndef G16_NO_FRAG_AHEAD
             __builtin_amdgcn_sched_barrier(0);
-#endif
             constexpr int PPK = 2 * NI / KK;                    // DMA pieces per 16-deep block
 #pragma unroll
             for (int kk = 0; kk < KK; ++kk) {
-                if (more && !burst && !(g.dbg & 1)) {
+                if (more) {
 #pragma unroll
                     for (int q = 0; q < PPK; ++q) issue_piece(jbuf, kk * PPK + q);
                 }
@@ -252,9 +248,7 @@ __global__ void __launch_bounds__(256 * KG, 2) gemm_g16_kernel(GArgs g) {
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[kk][i], fb[kk][j], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
-            if (more && !burst) issue_advance();
-        } else if (more && !burst && !(g.dbg & 1)) {            // (ablation without the products: the slab still has to be requested)
-            issue(jbuf);
+            if (more) issue_advance();
         }
         buf = buf + 1 == NS ? 0 : buf + 1;
     }
@@ -276,7 +270,6 @@ __global__ void __launch_bounds__(256 * KG, 2) gemm_g16_kernel(GArgs g) {
             }
         }
     }
-    if (g.dbg & 4) { if (acc[0][0][0] == 123.456f) g.C[0] = acc[1][1][3] + acc[0][1][2] + acc[1][0][1]; return; }
     auto store_rows = [&](int i, const f32x16 (&ai)[2]) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
@@ -407,10 +400,9 @@ int xgk_gemm_g16(hipStream_t st, bool transA, bool transB, int M, int N, int K, 
     // workgroups per CU, 256 with one) and every part keeps a reduction of >= 2560 -- 2688 x 1024 x 20000: 3 parts (158 us; 1 / 2 / 4
     // parts: 322 / 198 / 228) -- or, while the tiles alone leave CUs empty, of >= 1024 (1024 x 1536 x 5120, 96 tiles, four waves:
     // 87 / 65 / 55 / 51 / 52 us in 1 / 2 / 3 / 4 / 5 parts).
-    // splitk == -1: the product was launched beside a latency-bound chain (XGK_GEMM_BG).  diag XG_G16_BG=1: it then keeps to ONE
-    // workgroup per CU (32 KiB of LDS it does not use) and leaves the other half of every CU to the chain's launches
-    static const bool bg_on = xg_diag_env("XG_G16_BG") != nullptr;
-    const int extra_lds = (splitk == -1 && bg_on && c == 642) ? 32768 : 0;
+    // (splitk == -1: the product was launched beside a latency-bound chain, XGK_GEMM_BG.  Keeping it to ONE workgroup per CU there
+    //  was measured at the end of round 5 and is inside the noise: gone.)
+    constexpr int extra_lds = 0;
     if (splitk > 0) g.splitk = splitk;
     else if (!relu) {
         const long slots = (c >= 800 || extra_lds) ? 256 : 512;
@@ -419,7 +411,6 @@ int xgk_gemm_g16(hipStream_t st, bool transA, bool transB, int M, int N, int K, 
         if (sk > K / deep) sk = K / deep;
         g.splitk = sk < 1 ? 1 : (int)sk;
     }
-    { static const char* d = xg_diag_env("XG_G16_DBG"); if (d) g.dbg = atoi(d); }
     { static const char* d = xg_diag_env("XG_G16_SK"); if (d && !relu) g.splitk = atoi(d); }
     g.gm = xgk_group_rows(K / g.splitk / 2);          // (an operand panel is 128 x k_depth bf16 = half the bytes the rule was made for)
     switch (c) {

@@ -109,9 +109,6 @@ int xgk_relu_drop_bwd(hipStream_t st, float* dy, const float* y, int64_t n, XgDr
 // column reductions over rows of X (N,Cn) ld: out[c] += sum_r X[r][c]  (atomic accumulate; caller zeroes)
 int xgk_colsum(hipStream_t st, const float* X, int ld, int N, int Cn, float* out);
 // the same sums added into up to three accumulators (out2 / out3 may be null)
-// a plain fp32 product through hipBLASLt (xg_blaslt.hip): XG_OK, or 1 when the library has no kernel for it
-int xgk_blaslt_gemm(hipStream_t st, bool transA, bool transB, int M, int N, int K, const float* A, int lda, const float* B, int ldb,
-                    float* C, int ldc, const float* bias, bool relu, bool accumulate);
 int xgk_colsum3(hipStream_t st, const float* X, int ld, int N, int Cn, float* out, float* out2, float* out3);
 // out1[c] += sum_r X*Y ; (used for BN dgamma and a2w weight grad)
 int xgk_colsum_prod(hipStream_t st, const float* X, int ldx, const float* Y, int ldy, int N, int Cn, float* out);
@@ -180,10 +177,12 @@ struct SkSeg {
     // packed form of B (xg_pack.hip: 32 x 32 tiles in MFMA-fragment order, nck tiles per 32-column slice) or null: when
     // every segment of a launch has one, the launch takes the fast kernel (B operand global -> VGPR, no LDS)
     const float* Bp;                   // (bf16 tiles when the launch runs with gemm_mode 1: xgk_skinny's argument)
-    // optional row gather on A: row m of the operand is A + clamp(gather[m * gstride], 0, gather_max) * lda
+    // optional row gather on A: row m of the operand is A + clamp(gather[m], 0, gather_max) * lda
     // (embedding lookup folded into the product: caption_src/SAModel.py:105,198)
     const int64_t* gather;
-    int lda, K, nck, gstride, gather_max;
+    int lda, K, nck;
+    int a_bytes;                       // filled by xgk_skinny: extent of the A operand in bytes, ((rows - 1) lda + K) * 4 -- the fast kernel's buffer descriptor clamps there
+    int gather_max;
     int sflags;                        // filled by xgk_skinny: SKS_SCALED | SKS_WRITEBACK | SKS_EX
     // ---- cold
     const float* B; int ldb, b_ncontig;   // B (N,K) row-major ldb, or (K,N) when b_ncontig (LDS-staged kernel, fallbacks)
@@ -296,11 +295,6 @@ int xgk_attn_fwd(hipStream_t st, const float* p, const float* vproj, const float
 int xgk_attn_bwd(hipStream_t st, const float* daf, int lddaf, const float* p, const float* vproj, const float* V,
                  const float* w, const float* alpha, float* de, float* dp, int B, int K, int R, int A);
 // after the time loop: dvproj[b][k][a] = w_a sum_t de_t (1-th^2) ; dw[a] += sum de_t th ; dV[b][k][r] (+)= sum_t alpha_t daf_t
-// the same from x = ds2 (B, J = 4R) and M = V W_a2h^T (B, K, J): dalpha_k = x . M_k (xg_attn.hip: attn_bwd_split_m); 1 = shapes do not fit
-bool xgk_attn_bwd_m_ok(const float* x, int ldx, const float* p, const float* vproj, const float* M, int J, const float* w,
-                       const float* dp, int K, int A);
-int xgk_attn_bwd_m(hipStream_t st, const float* x, int ldx, const float* p, const float* vproj, const float* M, int J, const float* w,
-                   const float* alpha, float* de, float* dp, int B, int K, int A);
 int xgk_attn_bwd_post(hipStream_t st, const float* P /*(T,B,A)*/, const float* vproj, const float* w,
                       const float* DE /*(T,B,K)*/, float* dvproj, float* dw, int T, int B, int K, int A);
 // dV = sum_t alpha_t dAF_t (plain store) and dq / dw of the hoisted projection as ONE launch (T <= 32; otherwise the two passes)

@@ -44,15 +44,8 @@ struct Streams {
     int next = 0, next_mark = 0;
     bool forked = false, forked2 = false;
     int dh_split_step = 0, dh_mark = -1;      // heads_bwd -> decoder_bwd_core hand-off (see heads_bwd)
-    bool m_ready = false;                     // heads_bwd has enqueued M = V W_a2h^T into Ws::PRE[0] on the second side chain (ma_form)
     hipEvent_t grad_event = nullptr;          // XgRun.grad_event: recorded when every gradient but the encoder's is final
     hipEvent_t grad_event_head = nullptr;     // XgRun.grad_event_head: recorded when the logit.* gradients are final
-    // parameter-gradient work of the decoder backward that nothing downstream waits for, handed to the encoder backward, which
-    // enqueues it when its own latency-bound recurrence starts (decoder_bwd_core -> encoder_bwd)
-    std::function<int()> deferred;
-    // the vocabulary head's weight gradient (heads_bwd), enqueued by decoder_bwd_core at reverse-time step head_wgrad_step
-    std::function<int()> head_wgrad;
-    int head_wgrad_step = -1;
     Streams(hipStream_t m, const XgRun* run) : main(m), aux(m), aux2(m), a(aux_of(run)) {
         if (a) { aux = a->s; aux2 = a->s2; }
         if (run) { grad_event = static_cast<hipEvent_t>(run->grad_event); grad_event_head = static_cast<hipEvent_t>(run->grad_event_head); }
@@ -390,11 +383,6 @@ int encoder_fwd(hipStream_t st, const XgDims& d, const XgParams& p, const XgBnSt
     }
     if (hipMemsetAsync(w.zeroBR, 0, sizeof(float) * (size_t)B * R, (side ? ss->aux2 : st_main)) != hipSuccess) return XG_EHIP;   // (off the main chain)
     if (side) XG_TRY(ss->join2());
-    if (ss && ss->deferred) {                   // side work the caller wants under this latency-bound recurrence
-        std::function<int()> f = std::move(ss->deferred);
-        ss->deferred = nullptr;
-        XG_TRY(f());
-    }
     XgRun nodrop = run; nodrop.drop_p = 0.f;
     for (int i = 0; i < K; ++i) {                                                                  // sub_modules.py:132-148
         SkArgs sk{};
@@ -502,11 +490,6 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
         return a;
     };
     const bool fuse = R % 4 == 0;
-    if (ss.deferred) {                          // the decoder backward's leftover parameter gradients: under this recurrence
-        std::function<int()> f = std::move(ss.deferred);
-        ss.deferred = nullptr;
-        XG_TRY(f());
-    }
     for (int i = K - 1; i >= 0; --i) {                          // both modalities per launch
         if (!fuse || i == K - 1) XG_TRY(xgk_lstm_bwd2(st, enc_cell_bwd(0, i, curc, false), enc_cell_bwd(1, i, curc, false)));
         curc ^= 1;
@@ -518,8 +501,6 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
                 // (the product accumulates into dHs[i-1], which nothing reads afterwards: split-K across workgroups allowed)
                 if (fuse) {
                     sk.job[m] = job_lstm_bwd(enc_cell_bwd(m, i - 1, curc, true), w.dHs[m] + (size_t)(i - 1) * R, K * R); allow_split(sk, m, w);
-                    static const int enc_ks = xg_diag_env("XG_ENC_KS") ? atoi(xg_diag_env("XG_ENC_KS")) : 0;     // experiment: split cap of the encoder's backward launches
-                    sk.job[m].ksplit_cap = enc_ks;
                 }
                 else sk.job[m] = job_store(B, R, w.dHrec[m], R, false);
                 sk.job[m].nseg = 1;
@@ -662,7 +643,7 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         // xt as a matrix operand: the materialised rows, or embed.weight gathered by token
         auto xt_seg = [&](int which, const float* W) {
             SkSeg g = seg_nt(w, which, s.xt ? s.xt : p.embed_w, E, W, E, E);
-            if (!s.xt) { g.gather = s.tok; g.gstride = 1; g.gather_max = d.V - 1; }
+            if (!s.xt) { g.gather = s.tok; g.gather_max = d.V - 1; }
             return g;
         };
         // the attention rides in the second launch as two workgroups per video (SK_EPI_ATTN) when its shapes allow
@@ -672,20 +653,14 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         // throughput-bound across three streams, not bound by this chain); D is the simplest and the default.)
         static const bool no_fused = xg_diag_env("XG_NO_FUSED_ATTN") != nullptr;
         // (at hidden 1024 / 40 frames E wins instead: 8.51 vs 8.63 ms -- the stand-alone attention is then 24 us per step)
-        static const char xe_env = xg_diag_env("XG_XE_FORM") ? xg_diag_env("XG_XE_FORM")[0] : 0;          // experiment switch (B / D / E)
-        const char xe_form = xe_env ? xe_env : (R >= 1024 ? 'E' : 'D');
-        const bool fused_attn = (!s.pre1 || xe_form == 'E' || xe_form == 'G') && !no_fused && A <= 2048 && d.K <= 128 && ((uintptr_t)V % 8 == 0) &&
+        const char xe_form = R >= 1024 ? 'E' : 'D';
+        const bool fused_attn = (!s.pre1 || xe_form == 'E') && !no_fused && A <= 2048 && d.K <= 128 && ((uintptr_t)V % 8 == 0) &&
                                 ((uintptr_t)vproj % 16 == 0) && ((uintptr_t)p.a2w_w % 16 == 0);
         // S2' = h2 W_h2h2 + b rides in launch 1 (teacher forcing form B; the rollout form beyond 64 rows, where the three
         // launches are then 512 / 512 / 256 workgroups, one round each, instead of 256 / 768 / 256: 49.4 -> 46.5 us per step
         // at 128 rows) or in launch 2 (rollout form up to 64 rows: 37.1 us against 39.2 us in launch 1)
-        const bool s2_first = (s.pre1 != nullptr && xe_form == 'B') || (!s.pre1 && B > 64);
-        // rollout form: S1' = h1 W_h2h1 + xt W_i2h1 + b (everything of cell 1 that does not wait for the POS gate) rides in
-        // launch 1 as well, so that launch 2 -- the attention beside cell 1 -- keeps only cell 1's pos' product (K = R)
-        static const int s1_env = xg_diag_env("XG_S1_FIRST") ? atoi(xg_diag_env("XG_S1_FIRST")) : -1;
-        const bool s1_first = !s.pre1 && !s.sel && (s1_env >= 0 ? s1_env != 0 : false);
-        const bool s2_in_cell2 = s.pre1 != nullptr && (xe_form == 'D' || xe_form == 'G');     // (G, round 5: D with the attention as two workgroups per video inside launch 2)       // ... or stays a segment of cell 2 (measured for the
-                                                                            // rollout form at 128 rows too: 48.3 us)
+        const bool s2_first = !s.pre1 && B > 64;
+        const bool s2_in_cell2 = s.pre1 != nullptr && xe_form == 'D';       // ... or stays a segment of cell 2 (measured for the rollout form at 128 rows too: 48.3 us)
         SkArgs k1{}, k2{}, k3{};
         int n1 = 0, n2 = 0, n3 = 0;
         // the state may be updated IN PLACE (xg_step_fwd): cell 1 then runs in launch 2 beside products that still read the
@@ -696,14 +671,13 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         // dependent round trip)
         // Job order is dispatch order, and with two workgroups per CU resident at once a CU ends up with tile c of the first 256
         // and tile c of the next 256: the 256 S2' tiles (K = R) go FIRST so that every heavy p tile (K = 2R) is paired with a light
-        // one instead of with another p tile (round 4: 45.3 -> 44.5 us per step at 128 rows; XG_L1_ORDER=0: the old order)
-        static const int l1_order = xg_diag_env("XG_L1_ORDER") ? atoi(xg_diag_env("XG_L1_ORDER")) : 1;
+        // one instead of with another p tile (round 4: 45.3 -> 44.5 us per step at 128 rows)
         auto s2_job_early = [&](SkJob& j) {
             j = job_store(B, 4 * R, w.S2, 4 * R, false);
             j.cell_cols = 1; j.R = R; j.nseg = 1;
             j.seg[0] = seg_nt(w, PK_L2_H2H, s.h2, R, p.l2_h2h_w, R, R); j.bias[0] = p.l2_h2h_b;
         };
-        if (l1_order == 1 && s2_first) s2_job_early(k1.job[n1++]);
+        if (s2_first) s2_job_early(k1.job[n1++]);
         if (!s.pre1) {  // POS gate: pos' = dropout(relu(W_g xt + b)) * pos + pos                          :682
             SkJob& j = k1.job[n1++];
             j = job_store(B, R, s.gp, R, false);
@@ -736,15 +710,6 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
             j.nseg = 1;
             j.seg[0] = seg_nt(w, PK_L2_H2H, s.h2, R, p.l2_h2h_w, R, R); j.bias[0] = p.l2_h2h_b;
         };
-        if (s2_first && l1_order != 1) s2_job(k1.job[n1++]);
-        if (s1_first) {     // S1' (gate-major, cell tiling) -> w.S
-            SkJob& j = k1.job[n1++];
-            j = job_store(B, 4 * R, w.S, 4 * R, false);
-            j.cell_cols = 1; j.R = R;
-            j.nseg = 2;
-            j.seg[0] = seg_nt(w, PK_L1_H2H, s.h1, R, p.l1_h2h_w, R, R); j.bias[0] = p.l1_h2h_b;
-            j.seg[1] = xt_seg(PK_L1_I2H, p.l1_i2h_w); j.bias[1] = p.l1_i2h_b;
-        }
         if (fused_attn) {   // the attention's accumulators start from zero
             SkJob& j = k1.job[n1++];
             j = SkJob{};
@@ -753,32 +718,23 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         k1.njobs = n1;
         XG_TRY(xgk_skinny(st, k1, sk_mode(w)));
         // ---- launch 2: attention || rollout: cell 1 = h1 W_h2h + pos' W_a2h + xt W_i2h || S2'
-        // (XG_L2_ORDER=1 of the diag build: cell 1's tiles dispatched in front of the attention's workgroups)
-        static const int l2_order = xg_diag_env("XG_L2_ORDER") ? atoi(xg_diag_env("XG_L2_ORDER")) : 0;
         auto attn_job = [&](SkJob& j) {
             j = SkJob{};
             j.epi = SK_EPI_ATTN; j.M = B; j.R = R; j.attn_K = d.K; j.attn_A = A;
             j.attn_p = s.P; j.attn_q = vproj; j.attn_v = V; j.attn_w = p.a2w_w;
             j.attn_ex = s.alpha; j.attn_s = w.ATS; j.attn_c = w.AFU;
         };
-        if (fused_attn && l2_order == 0) attn_job(k2.job[n2++]);
+        if (fused_attn) attn_job(k2.job[n2++]);
         if (!s.pre1) {
             SkJob& j = k2.job[n2++];
             a.h_out = h1_new;
-            if (s1_first) { a.add = w.S; a.ldadd = 4 * R; }
             j = job_lstm(a);
-            if (s1_first) {
-                j.nseg = 1;
-                j.seg[0] = seg_nt(w, PK_L1_A2H, s.posg, R, p.l1_a2h_w, R, R); j.bias[0] = p.l1_a2h_b;
-            } else {
-                j.nseg = 3;
-                j.seg[0] = seg_nt(w, PK_L1_H2H, s.h1, R, p.l1_h2h_w, R, R); j.bias[0] = p.l1_h2h_b;
-                j.seg[1] = seg_nt(w, PK_L1_A2H, s.posg, R, p.l1_a2h_w, R, R); j.bias[1] = p.l1_a2h_b;
-                j.seg[2] = xt_seg(PK_L1_I2H, p.l1_i2h_w); j.bias[2] = p.l1_i2h_b;
-            }
+            j.nseg = 3;
+            j.seg[0] = seg_nt(w, PK_L1_H2H, s.h1, R, p.l1_h2h_w, R, R); j.bias[0] = p.l1_h2h_b;
+            j.seg[1] = seg_nt(w, PK_L1_A2H, s.posg, R, p.l1_a2h_w, R, R); j.bias[1] = p.l1_a2h_b;
+            j.seg[2] = xt_seg(PK_L1_I2H, p.l1_i2h_w); j.bias[2] = p.l1_i2h_b;
         }
         if (!s2_first && !s2_in_cell2) s2_job(k2.job[n2++]);
-        if (fused_attn && l2_order != 0) attn_job(k2.job[n2++]);
         k2.njobs = n2;
         if (n2 > 0) XG_TRY(xgk_skinny(st, k2, sk_mode(w)));
         if (!fused_attn) XG_TRY(xgk_attn_fwd(st, s.P, vproj, V, p.a2w_w, s.alpha, s.af, B, d.K, R, A, s.half_attn));
@@ -899,117 +855,12 @@ int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatc
     XG_TRY(init_and_vproj(ss, d, p, x.feat_mask, w));
     XG_TRY(zero_dsync(st, w));
     XG_TRY(ss.join());                                                                              // token-side products
-    static const int th_env = xg_diag_env("XG_FWD_TH") ? atoi(xg_diag_env("XG_FWD_TH")) : -1;      // diagnosis: where the early product starts
-    const int th = (ss.overlap() && T >= 4) ? (th_env > 0 && th_env < T ? th_env : T / 2) : 0;
+    const int th = (ss.overlap() && T >= 4) ? T / 2 : 0;          // the early product starts behind step T / 2 (split points swept in rounds 3-5: flat)
     // ... as a background product, with the stand-alone attention in its half-CU form beside it: the 128-VGPR attention
     // needs an EMPTY CU and waited for the whole persistent product (255 us: the chain simply stopped).  6.16 -> 6.10 ms.
-    static const int fwd_bg_env = xg_diag_env("XG_FWD_BG") ? atoi(xg_diag_env("XG_FWD_BG")) : 1;
-    const bool fwd_bg = fwd_bg_env && th > 0 && w.gm == 0;
+    const bool fwd_bg = th > 0 && w.gm == 0;
     *logit_rows_done = 0;
     if (run.prof_event0 && hipEventRecord(static_cast<hipEvent_t>(run.prof_event0), st) != hipSuccess) return XG_EHIP;
-    // ---- form F (round 4): cell 1 runs AHEAD.  Under teacher forcing cell 1 is a recurrence of its own -- h1(t) depends on
-    // h1(t-1) and the tokens only (sub_modules.py:683: its inputs xt and pos' are hoisted) -- and everything of a step that reads
-    // h1 alone (cell 1 itself, the h1 half of the attention query, the h1' and h2 segments of cell 2) can be computed before the
-    // step's own chain needs it.  Per step the chain keeps three launches, but each carries only what truly waits:
-    //   L1  p(t) += h2(t-1) W_h2a[:, R:]            (K = R; the h1 half and the bias were stored a step earlier) | zero the accumulators
-    //   L2  attention(t)  ||  cell 1(t+1)  ||  p(t+1) = h1(t) W_h2a[:, :R] + b  ||  S2(t) = h1(t) W_i2h2 + h2(t-1) W_h2h2 + biases
-    //   L3  cell 2(t) = (c / s) W_a2h2 + S2(t)      (K = R)
-    // instead of p (K = 2R) || cell 1, attention, cell 2 (K = 3R): the chain's launches shrink to a third of their reduction depth
-    // and the rest of the step's products ride beside the attention.  Same arithmetic per product (the sums of a cell's segments
-    // are formed in a different order: fp32 round-off only); parity suite green.  MEASURED AND NOT THE DEFAULT (XG_XE_FORM=F in
-    // the -DXG_DIAG build): 54.7 vs 50.5 us per step in situ, 6.00 vs 5.93 ms per iteration (hidden 1024 bf16: 7.85 either way) --
-    // a launch costs its fixed ~6 us plus its share of the step's 14 us of matrix time wherever that share sits, and the
-    // attention (VALU-bound: tanh) does not hide matrix time on the same SIMDs: moving work between the three launches does
-    // not shorten their sum.
-    static const char xe_env = xg_diag_env("XG_XE_FORM") ? xg_diag_env("XG_XE_FORM")[0] : 0;
-    const bool ahead = xe_env == 'F' && step_packed(w, d) && A <= 2048 && d.K <= 128 && ((uintptr_t)w.Venc % 8 == 0) &&
-                       ((uintptr_t)w.vproj % 16 == 0) && ((uintptr_t)p.a2w_w % 16 == 0);
-    if (ahead) {
-        const int K = d.K;
-        auto cell1 = [&](int t) {                    // cell 1 of step t: H1[t] -> H1[t + 1]
-            LstmFwdArgs a{};
-            a.add = w.PRE1 + (size_t)t * B * 4 * R; a.ldadd = 4 * R;
-            a.c_prev = w.C1 + t * BR; a.ldcp = R; a.h_prev = w.H1 + t * BR; a.ldhp = R; a.mask = x.seq_mask + t; a.ldm = T;
-            a.gates = w.G1 + (size_t)t * B * 4 * R; a.ldg = 4 * R; a.c_out = w.C1 + (t + 1) * BR; a.ldco = R;
-            a.h_out = w.H1 + (t + 1) * BR; a.ldho = R;
-            a.B = B; a.R = R; a.order = XG_ORDER_IFOG; a.mask_mode = XG_MASK_HOLD;
-            a.drop = xg_make_drop(&run, XG_SITE_L1, t);
-            SkJob j = job_lstm(a);
-            j.nseg = 1;
-            j.seg[0] = seg_nt(w, PK_L1_H2H, w.H1 + t * BR, R, p.l1_h2h_w, R, R); j.bias[0] = p.l1_h2h_b;
-            return j;
-        };
-        auto p_h1 = [&](int t) {                     // P[t] = H1[t] W_h2a[:, :R] + b   (the h1 half of step t's query)
-            SkJob j = job_store(B, A, w.P + (size_t)t * B * A, A, false);
-            j.nseg = 1;
-            j.seg[0] = seg_nt(w, PK_H2A1, w.H1 + t * BR, R, p.h2a_w, 2 * R, R);
-            j.bias[0] = p.h2a_b;
-            return j;
-        };
-        {   // ahead of the loop: cell 1(0) || the h1 half of p(0)
-            SkArgs k0{};
-            k0.njobs = 2; k0.job[0] = cell1(0); k0.job[1] = p_h1(0);
-            XG_TRY(xgk_skinny(st, k0, sk_mode(w)));
-        }
-        for (int t = 0; t < T; ++t) {
-            {   // L1
-                SkArgs k1{};
-                k1.njobs = 2;
-                k1.job[0] = job_store(B, A, w.P + (size_t)t * B * A, A, true);
-                k1.job[0].nseg = 1;
-                k1.job[0].seg[0] = seg_nt(w, PK_H2A2, w.H2 + t * BR, R, p.h2a_w + R, 2 * R, R);
-                k1.job[1] = SkJob{};
-                k1.job[1].epi = SK_EPI_ZERO; k1.job[1].M = 1; k1.job[1].N = B * R + ((B + 3) & ~3); k1.job[1].C = w.AFU;
-                XG_TRY(xgk_skinny(st, k1, sk_mode(w)));
-            }
-            {   // L2
-                SkArgs k2{};
-                int n2 = 0;
-                SkJob& ja = k2.job[n2++];
-                ja = SkJob{};
-                ja.epi = SK_EPI_ATTN; ja.M = B; ja.R = R; ja.attn_K = K; ja.attn_A = A;
-                ja.attn_p = w.P + (size_t)t * B * A; ja.attn_q = w.vproj; ja.attn_v = w.Venc; ja.attn_w = p.a2w_w;
-                ja.attn_ex = w.ALPHA + (size_t)t * B * K; ja.attn_s = w.ATS; ja.attn_c = w.AFU;
-                if (t + 1 < T) { k2.job[n2++] = cell1(t + 1); k2.job[n2++] = p_h1(t + 1); }
-                SkJob& js = k2.job[n2++];               // S2(t): everything of cell 2 that does not wait for the attention
-                js = job_store(B, 4 * R, w.S2, 4 * R, false);
-                js.cell_cols = 1; js.R = R; js.nseg = 2;
-                js.seg[0] = seg_nt(w, PK_L2_I2H, w.H1 + (t + 1) * BR, R, p.l2_i2h_w, R, R); js.bias[0] = p.l2_i2h_b;
-                js.seg[1] = seg_nt(w, PK_L2_H2H, w.H2 + t * BR, R, p.l2_h2h_w, R, R); js.bias[1] = p.l2_h2h_b;
-                k2.njobs = n2;
-                XG_TRY(xgk_skinny(st, k2, sk_mode(w)));
-            }
-            {   // L3
-                LstmFwdArgs c{};
-                c.add = w.S2; c.ldadd = 4 * R;
-                c.c_prev = w.C2 + t * BR; c.ldcp = R; c.h_prev = w.H2 + t * BR; c.ldhp = R; c.mask = x.seq_mask + t; c.ldm = T;
-                c.gates = w.G2 + (size_t)t * B * 4 * R; c.ldg = 4 * R; c.c_out = w.C2 + (t + 1) * BR; c.ldco = R;
-                c.h_out = w.H2 + (t + 1) * BR; c.ldho = R;
-                c.B = B; c.R = R; c.order = XG_ORDER_IFOG; c.mask_mode = XG_MASK_HOLD;
-                c.drop = xg_make_drop(&run, XG_SITE_L2, t);
-                SkArgs k3{};
-                k3.njobs = 1;
-                SkJob& j = k3.job[0];
-                j = job_lstm(c);
-                j.nseg = 1;
-                j.seg[0] = seg_nt(w, PK_L2_A2H, w.AFU, R, p.l2_a2h_w, R, R); j.bias[0] = p.l2_a2h_b;
-                SkSeg& g = j.seg[0];
-                g.row_scale = w.ATS; g.scaled_out = w.AF + t * BR; g.ld_out = R; g.ex = w.ALPHA + (size_t)t * B * K; g.ex_ld = K; g.ex_K = K;
-                XG_TRY(xgk_skinny(st, k3, sk_mode(w)));
-            }
-            if (th > 0 && t == th - 1) {
-                XG_TRY(ss.fork());
-                XG_TRY(cvt16(ss.aux, w, w.H2 + BR, (size_t)th * B * R));
-                XG_TRY(lin16(ss.aux, w.gm | (fwd_bg ? XGK_GEMM_BG : 0), th * B, d.V, R, w.H2 + BR, m16(w, w.H2 + BR), R, p.logit_w,
-                             w16(w, W16_LOGIT), p.logit_b, w.LOGITS, d.V));
-                *logit_rows_done = th * B;
-                if (early_loss)
-                    XG_TRY(xgk_xent_fwd(ss.aux, w.LOGITS, d.V, x.seq, x.seq_mask, nullptr, B, T, d.V, 1, w.LSE, w.sums, 0, th * B, false));
-            }
-        }
-        if (run.prof_event1 && hipEventRecord(static_cast<hipEvent_t>(run.prof_event1), st) != hipSuccess) return XG_EHIP;
-        return XG_OK;
-    }
     for (int t = 0; t < T; ++t) {
         StepIO s{};
         s.xt = w.Xe + (size_t)t * B * E; s.posg = w.POSG + t * BR; s.pre1 = w.PRE1 + (size_t)t * B * 4 * R;
@@ -1028,20 +879,6 @@ int decoder_fwd_xe(Streams& ss, const XgDims& d, const XgParams& p, const XgBatc
             *logit_rows_done = th * B;
             if (early_loss)
                 XG_TRY(xgk_xent_fwd(ss.aux, w.LOGITS, d.V, x.seq, x.seq_mask, nullptr, B, T, d.V, 1, w.LSE, w.sums, 0, th * B, false));
-        }
-        // (experiment, diag build: XG_FWD_TH2=<step> -- a SECOND background product for the steps [th, th2), so that fewer rows are left
-        //  for the product behind the loop)
-        static const int th2_env = xg_diag_env("XG_FWD_TH2") ? atoi(xg_diag_env("XG_FWD_TH2")) : 0;
-        if (th > 0 && th2_env > th && th2_env < T && t == th2_env - 1) {
-            const int n2 = (th2_env - th) * B;
-            const float* h2 = w.H2 + BR + (size_t)th * BR;
-            XG_TRY(ss.fork());
-            XG_TRY(cvt16(ss.aux, w, h2, (size_t)n2 * R));
-            XG_TRY(lin16(ss.aux, w.gm | (fwd_bg ? XGK_GEMM_BG : 0), n2, d.V, R, h2, m16(w, h2), R, p.logit_w, w16(w, W16_LOGIT), p.logit_b,
-                         w.LOGITS + (size_t)th * B * d.V, d.V));
-            *logit_rows_done = th2_env * B;
-            if (early_loss)
-                XG_TRY(xgk_xent_fwd(ss.aux, w.LOGITS, d.V, x.seq, x.seq_mask, nullptr, B, T, d.V, 1, w.LSE, w.sums, th * B, n2, false));
         }
     }
     if (run.prof_event1 && hipEventRecord(static_cast<hipEvent_t>(run.prof_event1), st) != hipSuccess) return XG_EHIP;
@@ -1082,10 +919,8 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     // The pointwise LSTM backward of step t-1 runs in the epilogue of the product that completes its dh.
     const bool fuse = R % 4 == 0;
     int cur = 0;
-    const bool ma = ss.m_ready && fuse;
-    if (ma && !w.zeroed) XG_TRY(ss.join2());     // M (heads_bwd, second auxiliary stream)
     if (w.zeroed) {
-        XG_TRY(ss.join2());                      // the zero block (zero_backward_block, second auxiliary stream) -- and M behind it
+        XG_TRY(ss.join2());                      // the zero block (zero_backward_block, second auxiliary stream)
     } else {
         for (int j = 0; j < 4; ++j) ZERO(w.dst[0][j], BR);
         ZERO(w.DAF, (size_t)T * BR);             // the dAF products accumulate (split-K across workgroups)
@@ -1157,9 +992,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         // tools/ubench/c1_sweep.sh: 6.08 -> 5.93 ms per iteration).
         // (round 5, lean kernel + the launcher's one-workgroup-per-CU split rule: a 4-way split -- 256 workgroups -- is the better
         //  cap again, 5.47-5.48 -> 5.44-5.45 ms; tools/ubench/caps_iter.sh)
-        static const int c1_ks = xg_diag_env("XG_C1_KS") ? atoi(xg_diag_env("XG_C1_KS")) : 4;
-        static const int c1_lowprio = xg_diag_env("XG_C1_LOWPRIO") ? atoi(xg_diag_env("XG_C1_LOWPRIO")) : 1;
-        j.ksplit_cap = c1_ks; j.low_prio = c1_lowprio;
+        j.ksplit_cap = 4; j.low_prio = 1;
         XG_TRY(xgk_skinny(s1, sk, sk_mode(w)));
         cur1 ^= 1;
         return XG_OK;
@@ -1169,8 +1002,7 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     // the reverse-time loop has already left are done BESIDE the loop on the auxiliary stream, behind the vocabulary
     // head's products: the loop alone leaves most of the chip idle, and whatever runs under it does not compete with
     // the encoder's backward afterwards.
-    static const int wg_bg = xg_diag_env("XG_WG_BG") ? atoi(xg_diag_env("XG_WG_BG")) : 0;   // experiment: weight gradients as background products
-    const int wgm = w.gm | ((wg_bg && ss.overlap()) ? XGK_GEMM_BG : 0);
+    const int wgm = w.gm;
     auto wgrads_chain2 = [=, &w](hipStream_t sq, int t0, int t1) -> int {
         const int rows = (t1 - t0) * B;
         if (rows <= 0) return XG_OK;
@@ -1203,66 +1035,24 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
         XG_TRY(nn16(sq, wgm, rows, E, 4 * R, ds1, m16(w, ds1), 4 * R, p.l1_i2h_w, w16(w, W16_L1_I2H), E, w.DXe + r0 * E, E, false));
         return XG_OK;
     };
-    static const int wg_chunks_env = xg_diag_env("XG_WG_CHUNKS") ? atoi(xg_diag_env("XG_WG_CHUNKS")) : 2;
-    // (fp32 products only: beside the bf16 GEMMs the loop loses more than the products gain, hidden-1024 iteration 8.50 -> 8.72 ms)
-    const int wg_chunks = (ss.overlap() && T >= 8 && w.gm == 0) ? (wg_chunks_env < 1 ? 1 : (wg_chunks_env > 4 ? 4 : wg_chunks_env)) : 1;
+    // (two ranges; fp32 products only: beside the bf16 GEMMs the loop loses more than the products gain, hidden-1024 iteration 8.50 -> 8.72 ms)
+    const int wg_chunks = (ss.overlap() && T >= 8 && w.gm == 0) ? 2 : 1;
     int wg_hi = T, wg_mark = -1;                 // steps [wg_hi, T) already have their weight gradients enqueued
     int c1_next = T - 1;                         // the next step chain 1 has to do
-    // (diagnosis, XG_LEAD_PROBE=1: how far ahead of the GPU is the enqueueing thread inside this loop?  One event per step on the
-    //  main stream; at the top of step t the host asks which steps' events have completed and prints the table at the end)
-    static const bool lead_probe = xg_diag_env("XG_LEAD_PROBE") != nullptr;
-    static hipEvent_t lead_ev[64];
-    static bool lead_init = false;
-    double lead_host_us[64]; int lead_done[64]; double lead_step_us[64];
-    if (lead_probe && !lead_init) { for (int i = 0; i < 64; ++i) (void)hipEventCreate(&lead_ev[i]); lead_init = true; }
-    auto now_us = []() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
-    const double lead_t0 = lead_probe ? now_us() : 0.0;
-    if (lead_probe && T <= 64) {                 // the PREVIOUS call's events: GPU time of each step (complete by now, or skipped)
-        static int lead_seen = 0;
-        if (++lead_seen % 8 == 1 && lead_seen > 1 && hipEventQuery(lead_ev[0]) == hipSuccess) {
-            fprintf(stderr, "[lead probe] GPU time between the step events of the previous call (us):");
-            for (int t = T - 2; t >= 0; --t) { float ms = 0.f; (void)hipEventElapsedTime(&ms, lead_ev[t + 1], lead_ev[t]); fprintf(stderr, " t=%d:%.1f", t, ms * 1e3f); }
-            fprintf(stderr, "\n");
-        }
-    }
     for (int t = T - 1; t >= 0; --t) {
-        if (lead_probe && T <= 64) {
-            lead_host_us[t] = now_us() - lead_t0;
-            int done = T;                          // the lowest step whose event has completed (T = none yet)
-            for (int u = T - 1; u > t; --u) { if (hipEventQuery(lead_ev[u]) == hipSuccess) done = u; else break; }
-            lead_done[t] = done;
-        }
         // dH of the early steps comes from the auxiliary stream; fused, step t-1's cell backward runs inside step t
         if (t == ss.dh_split_step - (fuse ? 0 : 1)) XG_TRY(ss.wait_mark(ss.dh_mark));
-        if (ss.head_wgrad && t <= ss.head_wgrad_step) { std::function<int()> f = std::move(ss.head_wgrad); ss.head_wgrad = nullptr; XG_TRY(f()); }
         float* dh2p = w.dst[cur ^ 1][2];
         float* ds2 = w.DS2 + (size_t)t * B * 4 * R;
         float* dp = w.DP + (size_t)t * B * A;
         float* daf = w.DAF + t * BR;
         if (!fuse || t == T - 1) XG_TRY(xgk_lstm_bwd(st, cell2_bwd(t, cur)));
-        if (ma) {
-            // two launches: the attention backward straight from ds2 (dalpha_k = ds2 . M_k), then dh2 = dp Wh2a[:, R:] + ds2 Wh (+ the
-            // held part + dH2OUT) with cell 2's backward at t-1 in the epilogue.  d(context) for dV: one product behind the loop.
-            XG_TRY(xgk_attn_bwd_m(st, ds2, 4 * R, w.P + (size_t)t * B * A, w.vproj, w.PRE[0], 4 * R, p.a2w_w, w.ALPHA + (size_t)t * B * K,
-                                  w.DE + (size_t)t * B * K, dp, B, K, A));
-            SkArgs sk{};
-            sk.njobs = 1;
-            if (t > 0) sk.job[0] = job_lstm_bwd(cell2_bwd(t - 1, cur ^ 1), dh2p, R);
-            else sk.job[0] = job_store(B, R, dh2p, R, true);
-            sk.job[0].nseg = 2;
-            sk.job[0].seg[0] = seg_nn(w, PKB_L2_H2H, ds2, 4 * R, p.l2_h2h_w, R, 4 * R);      // (available first: the other operand comes out of the launch in front)
-            sk.job[0].seg[1] = seg_nn(w, PKB_H2A2, dp, A, p.h2a_w + R, 2 * R, A);
-            allow_split(sk, 0, w);
-            XG_TRY(xgk_skinny(st, sk, sk_mode(w)));
-        } else {
         {   // s2 = h1' Wi + af Wa + h2 Wh : the two data gradients chain 2 needs now
             SkArgs sk{};
             sk.njobs = 2;
             sk.job[0] = job_store(B, R, daf, R, true);   sk.job[0].nseg = 1; sk.job[0].seg[0] = seg_nn(w, PKB_L2_A2H, ds2, 4 * R, p.l2_a2h_w, R, 4 * R);
             sk.job[1] = job_store(B, R, dh2p, R, true);  sk.job[1].nseg = 1; sk.job[1].seg[0] = seg_nn(w, PKB_L2_H2H, ds2, 4 * R, p.l2_h2h_w, R, 4 * R);
             allow_split(sk, 0, w); allow_split(sk, 1, w);
-            static const int a_ks = xg_diag_env("XG_A_KS") ? atoi(xg_diag_env("XG_A_KS")) : 0;      // experiment: split cap of launch A
-            sk.job[0].ksplit_cap = a_ks;
             XG_TRY(xgk_skinny(st, sk, sk_mode(w)));
         }
         XG_TRY(xgk_attn_bwd(st, daf, R, w.P + (size_t)t * B * A, w.vproj, w.Venc, p.a2w_w, w.ALPHA + (size_t)t * B * K,
@@ -1275,16 +1065,12 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
             sk.job[0].nseg = 1;
             sk.job[0].seg[0] = seg_nn(w, PKB_H2A2, dp, A, p.h2a_w + R, 2 * R, A);
             allow_split(sk, 0, w);
-            static const int b_ks = xg_diag_env("XG_B_KS") ? atoi(xg_diag_env("XG_B_KS")) : 0;      // experiment: split cap of launch B
-            sk.job[0].ksplit_cap = b_ks;
             XG_TRY(xgk_skinny(st, sk, sk_mode(w)));
         }
-        }
         cur ^= 1;
-        if (lead_probe && T <= 64) { (void)hipEventRecord(lead_ev[t], st); lead_step_us[t] = now_us() - lead_t0; }
         // chain 2 has finished step t: chain 1 may do it.  One event per c1_lag steps (an event record between two dependent
         // launches of the main chain costs it ~6 us; chain 1 has slack: its launch is shorter than chain 2's three)
-        static const int c1_lag = xg_diag_env("XG_C1_LAG") ? atoi(xg_diag_env("XG_C1_LAG")) : 7;
+        constexpr int c1_lag = 7;
         bool boundary = false;                // t == ceil(k T / chunks) for some k in 1 .. chunks - 1
         for (int k = 1; k < wg_chunks; ++k) boundary = boundary || t == (k * T + wg_chunks - 1) / wg_chunks;
         const int lag = c1_lag < 1 ? 1 : c1_lag;
@@ -1304,25 +1090,12 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
             wg_hi = t;
         }
     }
-    if (lead_probe && T <= 64) {
-        static int lead_calls = 0;
-        if (++lead_calls % 8 == 0) {
-            fprintf(stderr, "[lead probe] reverse-time loop, call %d: host time at the top of step t (us since the loop's start) | host time after the step's three launches | steps the GPU had completed\n", lead_calls);
-            for (int t = T - 1; t >= 0; --t)
-                fprintf(stderr, "[lead probe]   t=%2d  host %8.1f  %8.1f   GPU has finished step %s%d (host is %d steps ahead)\n", t, lead_host_us[t], lead_step_us[t],
-                        lead_done[t] == T ? ">" : "", lead_done[t] == T ? T - 1 : lead_done[t], (lead_done[t] == T ? T : lead_done[t]) - t - 1);
-        }
-    }
     const int cur2 = cur;
     XG_TRY(ss.fork());                        // chain 2 is complete: DS2, DP, DAF, DE
     hipStream_t sx = ss.aux;                  // parameter gradients that only need chain 2
     // ---- after the loop.  Main chain (the encoder backward waits for it): dVproj -> dV.  Everything else is a
     // parameter gradient and goes to the auxiliary stream, under the encoder's recurrent backward.
     // (dV first, as a plain store: accumulating on top of the product below it would read every element back)
-    if (ma) {                                 // d(context) of every step at once: DAF = DS2 W_a2h
-        XG_TRY(cvt16(st, w, w.DS2, (size_t)T * B * 4 * R));
-        XG_TRY(nn16(st, w.gm, T * B, R, 4 * R, w.DS2, m16(w, w.DS2), 4 * R, p.l2_a2h_w, nullptr, R, w.DAF, R, false));
-    }
     XG_TRY(xgk_attn_post_dV(st, w.P, w.vproj, p.a2w_w, w.DE, w.DVPROJ, g.a2w_w, w.ALPHA, w.DAF, R, (int64_t)BR, w.DV, T, B, K, A, R));
     XG_TRY(cvt16(st, w, w.DVPROJ, (size_t)N * A));
     XG_TRY(nn16(st, w.gm, N, R, A, w.DVPROJ, m16(w, w.DVPROJ), A, p.v2a_w, w16(w, W16_V2A), R, w.DV, R, true));
@@ -1364,30 +1137,12 @@ int decoder_bwd_core(Streams& ss, const XgDims& d, const XgParams& p, const XgPa
     if (ss.grad_event && hipEventRecord(ss.grad_event, sx) != hipSuccess) return XG_EHIP;
     return XG_OK;
     };
-    static const int defer_env = xg_diag_env("XG_DEFER_WG") ? atoi(xg_diag_env("XG_DEFER_WG")) : 0;
-    if (defer_env && ss.overlap()) { ss.deferred = tail; return XG_OK; }
     return tail();
 }
 
 // heads backward from dlogits (rows,V) in w.LOGITS and dcl (rows,C) in w.DCL -> DH2OUT, head param grads
 // Start of a full backward pass: clear the zero block beside whatever the main stream does first (the loss backward and
 // the first data-gradient product); decoder_bwd_core joins it.
-// The reverse-time loop in a TWO-launch form (round 5, XG_MA=1 of the diag build): the attention backward takes
-// dalpha_k = ds2 . M_k with M = V W_a2h^T (N x 4R, one product per backward, into the encoder's PRE[0] block, which nothing
-// reads after the encoder's forward recurrence) instead of d(context) . V_k, so the per-step product d(context) = ds2 W_a2h
-// leaves the chain -- it is formed for all steps at once behind the loop (dV needs it) -- and dh2 += ds2 W_h2h rides in the
-// step's remaining launch as a second segment.  Per step: attention backward -> one skinny launch, instead of skinny ->
-// attention backward -> skinny.  Parity suite green with it.  MEASURED AND NOT THE DEFAULT: 5.64-5.65 against 5.54-5.55 ms per
-// iteration.  The loop itself is only 60 us shorter (1285 vs 1344 us): the launch that disappears was 13 us of mostly real
-// work, and it comes back as +6 us in the attention backward (each of a video's two workgroups reads its 213 KB of M: 54 MB
-// per step) and +7 us in the remaining launch (K = 1536 -> 3584); the batched d(context) product (76 us) then sits on the main
-// chain in front of dV, and M (80 us) runs beside the head's products.
-bool ma_form(const XgDims& d, const XgParams& p, const Ws& w) {
-    static const bool on = xg_diag_env("XG_MA") != nullptr;
-    return on && d.R % 4 == 0 &&
-           xgk_attn_bwd_m_ok(w.DS2, 4 * d.R, w.P, w.vproj, w.PRE[0], 4 * d.R, p.a2w_w, w.DP, d.K, d.A);
-}
-
 int zero_backward_block(Streams& ss, Ws& w) {
     w.zeroed = false;
     if (!ss.overlap()) return XG_OK;
@@ -1408,18 +1163,10 @@ int heads_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams& g
     const int B = d.B, R = d.R, TB = d.T * B;
     const float* Hout = w.H2 + (size_t)B * R;
     XG_TRY(zero_backward_block(ss, w));       // (every caller continues with decoder_bwd_core, which joins it)
-    ss.m_ready = false;
-    if (ma_form(d, p, w)) {                   // M = V W_a2h^T for the attention backward of every step (see ma_form), beside the head's products
-        const int N = B * d.K;
-        if (!w.zeroed) XG_TRY(ss.fork2());    // (zero_backward_block forked the second side chain otherwise)
-        XG_TRY(lin16(ss.aux2, w.gm, N, 4 * R, R, w.Venc, m16(w, w.Venc), R, p.l2_a2h_w, nullptr, nullptr, w.PRE[0], 4 * R));
-        ss.m_ready = true;
-    }
     if (rows < TB) ZERO(w.DH2OUT + (size_t)rows * R, (size_t)(TB - rows) * R);
     // dH = dlogits * W: the reverse-time loop starts from the LAST step, so the rows of the late steps go first on the
     // main stream and the early steps' rows are produced on the auxiliary stream while the loop is already running.
-    static const int bth_env = xg_diag_env("XG_BWD_TH") ? atoi(xg_diag_env("XG_BWD_TH")) : -1;
-    const int th = (ss.overlap() && !have_cls && rows == TB && d.T >= 4) ? (bth_env > 0 && bth_env < d.T ? bth_env : d.T / 2) : 0;
+    const int th = (ss.overlap() && !have_cls && rows == TB && d.T >= 4) ? d.T / 2 : 0;
     const int r0 = th * B;
     ss.dh_split_step = th; ss.dh_mark = -1;
     unsigned short* dl16 = const_cast<unsigned short*>(m16(w, w.LOGITS));
@@ -1454,9 +1201,7 @@ int heads_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams& g
         }
         return XG_OK;
     };
-    static const int dwl_at = xg_diag_env("XG_DWL_AT") ? atoi(xg_diag_env("XG_DWL_AT")) : -1;   // experiment: enqueue it from inside the loop
-    if (dwl_at >= 0 && th > 0) { ss.head_wgrad = dwl; ss.head_wgrad_step = dwl_at < d.T ? dwl_at : d.T - 1; }
-    else XG_TRY(dwl());
+    XG_TRY(dwl());
     if (have_cls) {
         XG_TRY(gemm_tn_cs(st, w.gm, rows, d.C, d.H, w.DCL, d.C, w.HC, d.H, g.cls3_w, d.H, g.cls3_b));
         XG_TRY(gemm_nn(st, w.gm, rows, d.H, d.C, w.DCL, d.C, p.cls3_w, d.H, w.DHC, d.H, false));
@@ -1626,28 +1371,7 @@ extern "C" int xg_aux_create(void** aux) {
     a->magic = XG_AUX_MAGIC;
     for (int i = 0; i < XG_NEV; ++i) a->ev[i] = nullptr;
     bool ok = hipGetDevice(&a->device) == hipSuccess;
-    // (experiment, diag build: XG_AUX_CUMASK=n[,m] keeps the first side stream -- the background products -- on the first n CUs
-    //  of every XCD and the second -- the cell-1 chain and its products -- on the first m (default n): the main stream's launch
-    //  chains then find (32 - n) CUs per XCD that no background workgroup occupies.  Mask bit i = XCD i % 8, CU i / 8 of it:
-    //  tools/ubench/cumask_probe.hip)
-    int cu_n = 0, cu_m = 0;
-    if (const char* e = xg_diag_env("XG_AUX_CUMASK")) { cu_n = atoi(e); const char* c = strchr(e, ','); cu_m = c ? atoi(c + 1) : cu_n; }
-    // (experiment, diag build: XG_AUX_PRIO=1 creates the side streams at the LOWEST queue priority, so that the dispatcher serves
-    //  the caller's stream -- the launch chains -- first when both have workgroups pending)
-    static const bool low_prio = xg_diag_env("XG_AUX_PRIO") != nullptr;
-    auto masked = [](hipStream_t* st, int n) {
-        if (low_prio && (n <= 0 || n >= 32)) {
-            int least = 0, greatest = 0;
-            if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess) return false;
-            return hipStreamCreateWithPriority(st, hipStreamNonBlocking, least) == hipSuccess;
-        }
-        if (n <= 0 || n >= 32) return hipStreamCreateWithFlags(st, hipStreamNonBlocking) == hipSuccess;
-        uint32_t mask[8];
-        for (int w = 0; w < 8; ++w) mask[w] = 0;
-        for (int i = 0; i < 8 * n; ++i) mask[i >> 5] |= 1u << (i & 31);
-        return hipExtStreamCreateWithCUMask(st, 8, mask) == hipSuccess;
-    };
-    ok = ok && masked(&a->s, cu_n) && masked(&a->s2, cu_m);
+    ok = ok && hipStreamCreateWithFlags(&a->s, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&a->s2, hipStreamNonBlocking) == hipSuccess;
     // The ring / mark events only order launches of THIS device's streams against each other: kernels publish their results at
     // agent scope when they end, so the event's own system-scope fence (an L2 write-back + invalidate in front of whatever the
     // waiting stream runs next) buys nothing here and is switched off (round 6: 5.45 -> 5.40 ms per iteration, tools/r6/xe_ab.sh;
@@ -1910,15 +1634,8 @@ extern "C" int xg_xe_loss_fwd(void* stream, const XgDims* d, const XgParams* p, 
     Streams ss(st, run);
     int rows_done = 0;
     ZERO(w.sums, 2);                           // both halves of the cross-entropy add into it
-    static const int tok_late = xg_diag_env("XG_TOK_LATE") ? atoi(xg_diag_env("XG_TOK_LATE")) : 0;
-    if (tok_late && ss.overlap()) {
-        // the token-side products (nothing before the decoder loop waits for them) under the encoder's recurrence instead of
-        // beside its input-side products
-        ss.deferred = [&ss, d, p, x, run, &w]() -> int { XG_TRY(ss.fork()); return decoder_tokens_xe(ss.aux, *d, *p, *x, *run, w); };
-    } else {
-        XG_TRY(ss.fork());
-        XG_TRY(decoder_tokens_xe(ss.aux, *d, *p, *x, *run, w));
-    }
+    XG_TRY(ss.fork());
+    XG_TRY(decoder_tokens_xe(ss.aux, *d, *p, *x, *run, w));
     XG_TRY(encoder_fwd(st, *d, *p, bn, *x, *run, w, &ss));
     XG_TRY(decoder_fwd_xe(ss, *d, *p, *x, *run, w, &rows_done, true));
     XG_TRY(heads_fwd_logits(ss, *d, *p, *run, w, TB, rows_done));       // (joins the auxiliary stream)

@@ -717,7 +717,7 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 struct SkHeadBlk { int epi, M, N, R, nseg, ksplit, ntm, ntn, ntiles, hflags, ldc, nck_all; float* C; int* tickets; };
-struct SkSegHot { const float* A; const float* Bp; const int64_t* gather; int lda, K, nck, gstride, gather_max, sflags; };
+struct SkSegHot { const float* A; const float* Bp; const int64_t* gather; int lda, K, nck, a_bytes, gather_max, sflags; };
 struct SkEpiIn { const float* bias[3]; const float* add; const float* c_prev; const float* h_prev; const float* mask;
                  int ldadd, ldcp, ldhp, ldm, accumulate, relu, order, mask_mode; const float* gate_t; int ldt, ldy; float* gate_y; };
 struct SkEpiOut { float* gates; float* c_out; float* h_out; int ldg, ldco, ldho, cell_cols; XgDrop drop; int pad_; };
@@ -737,7 +737,7 @@ __device__ __forceinline__ void sk_hold(SkHeadBlk& h) {
                  "+s"(h.hflags), "+s"(h.ldc), "+s"(h.nck_all), "+s"(h.C), "+s"(h.tickets));
 }
 __device__ __forceinline__ void sk_hold(SkSegHot& g) {
-    asm volatile("" : "+s"(g.A), "+s"(g.Bp), "+s"(g.gather), "+s"(g.lda), "+s"(g.K), "+s"(g.nck), "+s"(g.gstride), "+s"(g.gather_max), "+s"(g.sflags));
+    asm volatile("" : "+s"(g.A), "+s"(g.Bp), "+s"(g.gather), "+s"(g.lda), "+s"(g.K), "+s"(g.nck), "+s"(g.a_bytes), "+s"(g.gather_max), "+s"(g.sflags));
 }
 __device__ __forceinline__ void sk_hold(SkEpiIn& e) {
     asm volatile("" : "+s"(e.bias[0]), "+s"(e.bias[1]), "+s"(e.bias[2]), "+s"(e.add), "+s"(e.c_prev), "+s"(e.h_prev), "+s"(e.mask));
@@ -766,8 +766,8 @@ __device__ __forceinline__ void sk_hold(SkEpiOut& e) {
 // of global_load / global_store), optional operands sit behind uniform branches instead of dummy-pointer selects, and the tile
 // decode uses shifts the launcher precomputed (power-of-two tile counts) instead of divisions.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t sk_rsrc(const void* p) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, 0x7FFFFFFF, 0x00020000);
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sk_rsrc(const void* p, int nbytes = 0x7FFFFFFF) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, nbytes, 0x00020000);
 }
 __device__ __forceinline__ f32x4 bld16(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0));
@@ -946,15 +946,14 @@ __device__ __forceinline__ void skf_epilogue(const SkJob& job, const SkHeadBlk& 
 // only the launches that need it pay for it.
 // (SCALE launches are single 256-tile cell-2 launches, one workgroup per CU: they get the 256-VGPR budget of two waves per
 // SIMD instead of spilling at 128.)
-// DEPTH: operands requested 1 or 2 chunks ahead of their MFMAs.  2 needs three B register sets and two A sets (~150 VGPRs), i.e.
-// two waves per SIMD: four-wave workgroups two per CU, or eight-wave workgroups one per CU (round 5; the round-3 attempt spilled
-// at the 128 registers of four waves per SIMD).
+// (Operands two chunks ahead of their MFMAs -- three B register sets, two A sets, two waves per SIMD -- were measured in rounds 3
+// and 5 and are gone: stand-alone step unchanged, iteration 1-3 % slower beside the background products, docs/EXPERIMENTS.md.)
 // SEL (round 6, rollout steps): the launch's SELECT job -- the POS gate -- first chooses the tokens of its tile's 32 rows from the
 // previous step's vocabulary statistics (one wave per row: xg_select.h), then gathers its embedding rows by them; the n-tile 0
 // workgroups also do the rows' bookkeeping.  Every n-tile of an m-tile repeats the choice (same data, same code: same tokens) --
 // 128 KB of L2 reads per workgroup instead of a launch of its own in front of the step.
-template <int NW, int PREC, bool SCALE, int DEPTH, bool SEL = false>
-__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu((SCALE || DEPTH == 2) ? 2 : 4, (SCALE || DEPTH == 2) ? 2 : 4)))
+template <int NW, int PREC, bool SCALE, bool SEL = false>
+__global__ void __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(SCALE ? 2 : 4, SCALE ? 2 : 4)))
 skf_kernel(SkArgs args) {
     XG_CHAIN_PRIO();
     SK_STAMP(0);
@@ -994,7 +993,7 @@ skf_kernel(SkArgs args) {
     }
     if ((int)blockIdx.x >= hd.ntiles) return;
     if (hd.hflags & SKH_LOW_PRIO) __builtin_amdgcn_s_setprio(0);
-    const int ntm = hd.ntm, ntn = hd.ntn, ks = hd.ksplit;      // (ksplit >= 1: xgk_skinny)
+    const int ntm = hd.ntm, ks = hd.ksplit;      // (ksplit >= 1: xgk_skinny)
     const bool cell_tiles = (hd.hflags & SKH_CELL_TILES) != 0;
     const int lg_ks = (hd.hflags >> SKH_LGKS_SHIFT) & 15;      // (the cross-workgroup split is a power of two)
     // A split launch's parts are whole ranges of block indices, part 0 first: the workgroups of the LAST part -- the ones that wait
@@ -1048,9 +1047,8 @@ skf_kernel(SkArgs args) {
     }
     if (gseg >= 0 && !chosen) {
         const int64_t* gp = job.seg[gseg].gather;
-        const unsigned gs8 = (unsigned)job.seg[gseg].gstride * 8u;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) gidx[i] = __float_as_int(ldf(reinterpret_cast<const float*>(gp), (unsigned)rowi[i] * gs8));
+        for (int i = 0; i < 4; ++i) gidx[i] = __float_as_int(ldf(reinterpret_cast<const float*>(gp), (unsigned)rowi[i] * 8u));
     }
     SK_STAMP(6);
 
@@ -1060,7 +1058,7 @@ skf_kernel(SkArgs args) {
 
     // (split-bf16: the plane registers leave no room for 19 prefetched values across the K loop at 128 VGPRs -- they would go
     //  to scratch, which costs more than it hides -- so that mode requests the cell operands behind the loop, under the reduction)
-    constexpr bool LATE_PRE = SPLIT3 && DEPTH == 1 && !SCALE;
+    constexpr bool LATE_PRE = SPLIT3 && !SCALE;
     EpiPre pre;
 #pragma unroll
     for (int i = 0; i < 16; ++i) pre.a[i] = 0.f;
@@ -1119,7 +1117,9 @@ skf_kernel(SkArgs args) {
         seg_start += nc;
         const bool have = c0 < c1;
         // operands through buffer descriptors: per-lane byte offsets fixed for the segment, the chunk is the scalar offset
-        const __amdgpu_buffer_rsrc_t rB = sk_rsrc(sg.Bp), rA = sk_rsrc(sg.A);
+        // (A: the operand's true extent -- the 16-byte pieces of a k tail that reach past the END of the operand's last row come back
+        //  as zeros from the descriptor's range check instead of being read; B: whole packed tiles)
+        const __amdgpu_buffer_rsrc_t rB = sk_rsrc(sg.Bp), rA = sk_rsrc(sg.A, sg.a_bytes);
         const unsigned lda4 = (unsigned)sg.lda * 4u;
         unsigned vA[4];
 #pragma unroll
@@ -1128,7 +1128,7 @@ skf_kernel(SkArgs args) {
             if (sg.gather) {
                 int t;
                 if (s == gseg) t = gidx[i];
-                else t = __float_as_int(ldf(reinterpret_cast<const float*>(sg.gather), (unsigned)row * ((unsigned)sg.gstride * 8u)));
+                else t = __float_as_int(ldf(reinterpret_cast<const float*>(sg.gather), (unsigned)row * 8u));
                 row = t < 0 ? 0 : (t > sg.gather_max ? sg.gather_max : t);
             }
             vA[i] = __umul24((unsigned)row, lda4) + (unsigned)lcol * 4u;       // (rows and byte pitches are below 2^24: checked by the launcher)
@@ -1144,11 +1144,9 @@ skf_kernel(SkArgs args) {
         }
         const bool wb_seg = SCALE && (sg.sflags & SKS_WRITEBACK);      // chunk c of the scaled rows is written back by n-tile c % ntn
         __amdgpu_buffer_rsrc_t rW = rA;
-        if (wb_seg) rW = sk_rsrc(job.seg[s].scaled_out);
+        if (wb_seg) rW = sk_rsrc(job.seg[s].scaled_out, sg.a_bytes);
         // Operands are requested one chunk ahead of their MFMAs: ping-pong B sets, one A set (reloaded right behind its LDS store).
-        // (Two chunks ahead was measured in round 3 and is not kept: it needs 10-12 registers beyond the 128 of four waves per
-        // SIMD and the step got slower, docs/EXPERIMENTS.md.)
-        f32x4 ra0[4], ra1[DEPTH == 2 ? 4 : 1], rb0[NPB], rb1[NPB], rb2[DEPTH == 2 ? NPB : 1];
+        f32x4 ra0[4], rb0[NPB], rb1[NPB];
         if (s == 0) SK_STAMP(1);
         const unsigned sB0 = (unsigned)(tn * nc) * (unsigned)TILEB;
         auto ldB = [&](int c, f32x4 (&b)[NPB]) {
@@ -1169,9 +1167,6 @@ skf_kernel(SkArgs args) {
         };
         if (have) {
             ldB(c0, rb0); ldAc(c0, ra0);
-            if constexpr (DEPTH == 2) {
-                if (c0 + 1 < c1) { ldB(c0 + 1, rb1); ldAc(c0 + 1, *reinterpret_cast<f32x4 (*)[4]>(ra1)); }
-            }
         }
         // ---- behind this segment's first operand request: the next segment's hot part, or -- behind the last one -- the
         // epilogue's output block (scalar-cache hits: the first round touched their lines' neighbours)
@@ -1197,7 +1192,7 @@ skf_kernel(SkArgs args) {
             else if (SPLIT3) st_chunk_split3(reinterpret_cast<unsigned short*>(As), lane, ra);
             else st_chunk(As, lane, ra);
             if (s == 0 && c == c0) SK_STAMP(2);
-            if (c + DEPTH < c1) { ldB(c + DEPTH, nxt); ldAc(c + DEPTH, ra); }
+            if (c + 1 < c1) { ldB(c + 1, nxt); ldAc(c + 1, ra); }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             __builtin_amdgcn_wave_barrier();
             if (SPLIT3) {
@@ -1242,21 +1237,9 @@ skf_kernel(SkArgs args) {
             __builtin_amdgcn_wave_barrier();
         };
         if (have) {
-            if constexpr (DEPTH == 2) {       // A sets alternate (period 2), B sets rotate (period 3)
-                auto& A1 = *reinterpret_cast<f32x4 (*)[4]>(ra1);
-                for (int c = c0; c < c1; c += 6) {
-                    chunk(c, ra0, rb0, rb2);
-                    if (c + 1 < c1) chunk(c + 1, A1, rb1, rb0);
-                    if (c + 2 < c1) chunk(c + 2, ra0, rb2, rb1);
-                    if (c + 3 < c1) chunk(c + 3, A1, rb0, rb2);
-                    if (c + 4 < c1) chunk(c + 4, ra0, rb1, rb0);
-                    if (c + 5 < c1) chunk(c + 5, A1, rb2, rb1);
-                }
-            } else {
-                for (int c = c0; c < c1; c += 2) {
-                    chunk(c, ra0, rb0, rb1);
-                    if (c + 1 < c1) chunk(c + 1, ra0, rb1, rb0);
-                }
+            for (int c = c0; c < c1; c += 2) {
+                chunk(c, ra0, rb0, rb1);
+                if (c + 1 < c1) chunk(c + 1, ra0, rb1, rb0);
             }
         }
         sg = sgn;
@@ -1319,7 +1302,6 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         // a narrower job's surplus workgroups find out that they are surplus only after their first round of descriptor loads
         // (~1 us) and hold a workgroup slot until then -- in front of a wider job they delayed its tiles by 1.5-3.4 us (in-kernel
         // stamps, profiles/r05_sk_trace_*.txt); behind it they delay nothing.
-        static const bool no_sort = xg_diag_env("XG_SK_NOSORT") != nullptr;
         auto job_tiles = [](const SkJob& jb) -> long {
             if (jb.epi == SK_EPI_ZERO || jb.epi == SK_EPI_COPY) return ((long)jb.M * jb.N + 4095) / 4096;
             if (jb.epi == SK_EPI_ATTN) return 2L * jb.M;
@@ -1328,7 +1310,7 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         };
         // (a SELECT job goes first whatever its width: its tiles carry the launch's longest prologue)
         auto before = [&](const SkJob& x, const SkJob& y) { return x.select != y.select ? x.select > y.select : job_tiles(x) > job_tiles(y); };
-        for (int i = 1; i < a.njobs && !no_sort; ++i)
+        for (int i = 1; i < a.njobs; ++i)
             for (int j = i; j > 0 && before(a.job[j], a.job[j - 1]); --j) { const SkJob t = a.job[j]; a.job[j] = a.job[j - 1]; a.job[j - 1] = t; }
     }
     bool vec = true, generic = false, packed = true, special = false;
@@ -1368,6 +1350,10 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         }
         tiles += ntm * ntn;
         max_tiles = ntm * ntn > max_tiles ? ntm * ntn : max_tiles;
+        {   // the fast kernel's epilogues address their operands as 32-bit byte offsets row * pitch * 4 + column
+            const int pitches[] = {jb.ldc, jb.ldadd, jb.ldcp, jb.ldhp, jb.ldg, jb.ldco, jb.ldho, jb.ldt, jb.ldy, jb.ldds, jb.lddci, jb.lddcp, jb.lddhh, jb.ldm};
+            for (int q : pitches) packed = packed && (double)jb.M * (q > 0 ? q : 0) * 4.0 < 4294967295.0;
+        }
         for (int s = 0; s < jb.nseg; ++s) {
             SkSeg& sg = jb.seg[s];
             if (!sg.A || !sg.B || sg.K <= 0) return XG_EINVAL;
@@ -1376,6 +1362,7 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
             // (the fast kernel's 32-bit / 24-bit address arithmetic: row index and byte pitch below 2^24, operands below 2 GB)
             packed = packed && jb.M < (1 << 24) && sg.lda < (1 << 22) && (!sg.gather || sg.gather_max < (1 << 24)) &&
                      (double)(sg.gather ? sg.gather_max + 1 : jb.M) * sg.lda * 4.0 < 2147483647.0;
+            if (packed) sg.a_bytes = (int)((((int64_t)(sg.gather ? sg.gather_max + 1 : jb.M) - 1) * sg.lda + sg.K) * 4);
             if (sg.row_scale && (!sg.Bp || sg.gather || (sg.scaled_out && (sg.ld_out != sg.lda || ((uintptr_t)sg.scaled_out % 16))))) return XG_EINVAL;
             if (sg.gather && !sg.Bp) return XG_EINVAL;        // the row gather exists on the packed path only
             vec = vec && ((uintptr_t)sg.A % 16 == 0) && (sg.lda % 4 == 0) && (sg.K % 4 == 0);
@@ -1409,9 +1396,8 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         // reduction.  (Round 4 filled 512 slots whenever it could; with the lean kernel of round 5 a part's fixed cost is
         // instruction issue and the ticket phase, not latency, and FEWER, longer parts win at hidden 512 -- encoder backward
         // and the reverse-time launches 4 / 4 / 8 -> 2 / 2 / 4 parts: 5.54-5.56 -> 5.50-5.51 ms, SCST 6.04 -> 6.00 -- while the
-        // 128-chunk reductions of hidden 1024 still want their two parts: tools/ubench/sktarget_iter.sh.)
-        static const int target = xg_diag_env("XG_SK_TARGET") ? atoi(xg_diag_env("XG_SK_TARGET")) : 256;     // diagnosis
-        static const int deep = xg_diag_env("XG_SK_DEEP_CHUNKS") ? atoi(xg_diag_env("XG_SK_DEEP_CHUNKS")) : 64;
+        // 128-chunk reductions of hidden 1024 still want their two parts.)
+        constexpr int target = 256, deep = 64;
         // (an LSTMB job's parts hand their tiles over through XGK_SKPART_TILES 8 KB slabs of scratch per job: SkJob.tickets)
         for (int j = 0; j < a.njobs && ok; ++j)
             if (a.job[j].epi == SK_EPI_LSTMB) {
@@ -1476,56 +1462,30 @@ int xgk_skinny(hipStream_t st, SkArgs& a, int gemm_mode) {
         // (bf16 tiles, hidden 1024: 4-wave workgroups throughout -- half the register footprint per workgroup is easier to place
         //  beside the bf16 GEMMs of the other streams: 8.20 -> 8.14 ms; at hidden 512 the rule above stands: fp32 6.08 vs 6.09,
         //  bf16 4.59 vs 4.66 ms)
-        static const int split_nw = xg_diag_env("XG_SK_SPLIT_NW") ? atoi(xg_diag_env("XG_SK_SPLIT_NW")) : 4;     // experiment: waves of a split launch's workgroups
-        const bool nw4_rule = (ks > 1 && (split_nw != 8 || tiles > 256)) || (force_nw ? force_nw == 4 : ((bf16 && max_k >= 1024) || tiles > 2 * 256));
+        // (split launches: four-wave workgroups)
+        const bool nw4_rule = ks > 1 || (force_nw ? force_nw == 4 : ((bf16 && max_k >= 1024) || tiles > 2 * 256));
         const dim3 grid((max_tiles + 7) & ~7, a.njobs);
         bool scaled = false;
         for (int j = 0; j < a.njobs; ++j)
             for (int q = 0; q < a.job[j].nseg; ++q) scaled = scaled || a.job[j].seg[q].row_scale != nullptr;
-        bool has_attn = false, has_zero = false, has_select = false;
-        for (int j = 0; j < a.njobs; ++j) {
-            has_attn = has_attn || a.job[j].epi == SK_EPI_ATTN; has_zero = has_zero || a.job[j].epi == SK_EPI_ZERO;
-            has_select = has_select || a.job[j].select != 0;
-        }
+        bool has_select = false;
+        for (int j = 0; j < a.njobs; ++j) has_select = has_select || a.job[j].select != 0;
         if (has_select) {            // the token choice in front of the gate tiles: exact-fp32 launches without a scaled operand
             if (bf16 || bf16x3 || scaled || ks > 1 || a.sel.ntiles < 1 || a.sel.ntiles > 16 * RSW_PER || a.sel.tw > 128 || !a.sel.part || a.sel.r.E % 4) return XG_EINVAL;
-            if (nw4_rule) hipLaunchKernelGGL((skf_kernel<4, 0, false, 1, true>), grid, dim3(256), 0, st, a);
-            else hipLaunchKernelGGL((skf_kernel<8, 0, false, 1, true>), grid, dim3(512), 0, st, a);
+            if (nw4_rule) hipLaunchKernelGGL((skf_kernel<4, 0, false, true>), grid, dim3(256), 0, st, a);
+            else hipLaunchKernelGGL((skf_kernel<8, 0, false, true>), grid, dim3(512), 0, st, a);
             XG_CHECK_LAUNCH();
             return XG_OK;
         }
-        static const bool dbg_nw4_scaled = xg_diag_env("XG_SK_NW4_SCALED") != nullptr, dbg_nw4_attn = xg_diag_env("XG_SK_NW4_ATTN") != nullptr,
-                          dbg_nw4_zero = xg_diag_env("XG_SK_NW4_ZERO") != nullptr;
-        const bool nw4 = nw4_rule || (dbg_nw4_scaled && scaled) || (dbg_nw4_attn && has_attn) || (dbg_nw4_zero && has_zero);
-        static const int dyn_lds = xg_diag_env("XG_SK_DYN_LDS") ? atoi(xg_diag_env("XG_SK_DYN_LDS")) : 0;      // diagnosis
-        // operands two chunks ahead (DEPTH 2, two waves per SIMD): XG_SK_DEEP bit 0 = launches of at most one tile per CU as
-        // eight-wave workgroups, bit 1 = launches of up to two tiles per CU as four-wave workgroups, bit 2 = the split launches
-        // (measured, round 5: stand-alone step unchanged at 39.6-41.0 us for every setting, iteration 5.62-5.75 against 5.56 ms --
-        //  half the occupancy co-schedules worse beside the background products; the variants exist in the diag build only)
-#ifdef XG_DIAG
-        static const int deep_env = xg_diag_env("XG_SK_DEEP") ? atoi(xg_diag_env("XG_SK_DEEP")) : 0;
-        const bool deep8 = (deep_env & 1) && !nw4_rule && !has_attn && tiles <= 256;
-        const bool deep4 = ((deep_env & 2) && !nw4_rule && !has_attn && tiles > 256 && tiles <= 512) || ((deep_env & 4) && ks > 1 && tiles <= 512);
-#else
-        constexpr bool deep8 = false, deep4 = false;
-#endif
-#define XG_SKF2(NW_, PREC_, D_) do { \
-            if (scaled) hipLaunchKernelGGL((skf_kernel<NW_, PREC_, true, D_>), grid, dim3(NW_ * 64), dyn_lds, st, a); \
-            else hipLaunchKernelGGL((skf_kernel<NW_, PREC_, false, D_>), grid, dim3(NW_ * 64), dyn_lds, st, a); } while (0)
-#ifdef XG_DIAG
-#define XG_SKF(PREC_) do { \
-            if (deep4) XG_SKF2(4, PREC_, 2); else if (deep8) XG_SKF2(8, PREC_, 2); else if (nw4) XG_SKF2(4, PREC_, 1); else XG_SKF2(8, PREC_, 1); } while (0)
-#else
-#define XG_SKF(PREC_) do { if (nw4) XG_SKF2(4, PREC_, 1); else XG_SKF2(8, PREC_, 1); } while (0)
-#endif
+        const bool nw4 = nw4_rule;
+#define XG_SKF2(NW_, PREC_) do { \
+            if (scaled) hipLaunchKernelGGL((skf_kernel<NW_, PREC_, true>), grid, dim3(NW_ * 64), 0, st, a); \
+            else hipLaunchKernelGGL((skf_kernel<NW_, PREC_, false>), grid, dim3(NW_ * 64), 0, st, a); } while (0)
+#define XG_SKF(PREC_) do { if (nw4) XG_SKF2(4, PREC_); else XG_SKF2(8, PREC_); } while (0)
         if (bf16) XG_SKF(1); else if (bf16x3 && planes) XG_SKF(3); else if (bf16x3) XG_SKF(2); else XG_SKF(0);
 #undef XG_SKF
 #undef XG_SKF2
         XG_CHECK_LAUNCH();
-#ifdef XG_DIAG
-        static const bool dbg_sync = xg_diag_env("XG_SYNC_LAUNCH") != nullptr;
-        if (dbg_sync) (void)hipStreamSynchronize(st);
-#endif
         return XG_OK;
     }
     for (int j = 0; j < a.njobs; ++j)

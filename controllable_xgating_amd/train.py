@@ -29,6 +29,27 @@ def shared_stream(kind):
     return st
 
 
+def dist_diagnosis():
+    """One line that explains a first multi-GPU failure (RCCL init, a hung collective, a missing device): what this process sees.
+    Printed by bench.py --gpus N and tests/test_gpu_dp2.py when the process group does not come up or the first collective fails."""
+    import os
+    env = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "HIP_VISIBLE_DEVICES",
+                                          "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES", "GPU_MAX_HW_QUEUES", "HSA_ENABLE_IPC_MODE_LEGACY",
+                                          "NCCL_MAX_NCHANNELS", "NCCL_DEBUG")}
+    try:
+        rccl = ".".join(str(v) for v in torch.cuda.nccl.version())
+    except Exception as e:                       # pragma: no cover
+        rccl = "unavailable (%r)" % (e,)
+    try:
+        ndev, cur = torch.cuda.device_count(), (torch.cuda.current_device() if torch.cuda.is_available() else None)
+        names = sorted({torch.cuda.get_device_name(i) for i in range(ndev)})
+    except Exception as e:                       # pragma: no cover
+        ndev, cur, names = -1, None, [repr(e)]
+    return "[xgate dist] rccl %s | torch %s hip %s | %d visible device(s) %s, current %s | %s" % (
+        rccl, torch.__version__, getattr(torch.version, "hip", None), ndev, names, cur,
+        " ".join("%s=%s" % (k, v) for k, v in env.items() if v is not None))
+
+
 class ClipAdam:
     """optimizer = optim.Adam(model.parameters(), lr, weight_decay) + clip_gradient(optimizer, clip):
     elementwise clamp of every gradient to +-grad_clip, then Adam with torch defaults

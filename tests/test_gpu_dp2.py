@@ -16,8 +16,16 @@ def _worker(rank, world, port, out_dir):
     import torch.distributed as dist
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
     torch.cuda.set_device(rank)
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
     from controllable_xgating_amd import train as tr
+    try:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+        probe = torch.ones(1, device="cuda:%d" % rank)
+        dist.all_reduce(probe)
+        torch.cuda.synchronize()
+        assert int(probe.item()) == world
+    except Exception:
+        print(tr.dist_diagnosis(), flush=True)          # the one line that explains a first two-GPU failure
+        raise
     from oracle import paramgen as pg
     from oracle import xgate_oracle as xo
     from tests.util import CFG, ZERO_GRAD_PARAMS, make_model

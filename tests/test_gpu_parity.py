@@ -195,27 +195,6 @@ def test_dataflow_step_kernel_equals_three_launch_step(rows):
     assert r.returncode == 0 and "us per step" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
 
 
-def test_two_launch_reverse_loop_switch_passes_the_gradient_tests():
-    """XG_MA=1 of the -DXG_DIAG library: the reverse-time loop with the attention backward fed from ds2 . (V W_a2h^T)
-    (xg_attn.hip: attn_bwd_split_m, xg_model.hip: ma_form) -- measured and not the default (docs/EXPERIMENTS.md), kept as a
-    switch: the oracle / golden gradient tests of the teacher-forced pass and of the replayed rollout must pass with it
-    (6 / 26 frames here; 40 frames: tests/test_gpu_fullsize.py runs under the same switch in the same way)."""
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    from controllable_xgating_amd import _native as nv
-    if os.environ.get("XG_MA"):
-        pytest.skip("already inside the switched run")
-    env = dict(os.environ, XG_MA="1", XG_LIBRARY=nv.LIB_DIAG_PATH)
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_parity.py"), "-q", "-x", "-m", "gpu", "-k",
-                        "test_xe_forward_backward_vs_oracle or test_xe_vs_reference_golden or test_scst_replay_vs_reference_golden or test_scst_iteration"],
-                       env=env, capture_output=True, text=True, timeout=1200, cwd=root)
-    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2500:] + r.stderr[-1500:]
-    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_fullsize.py"), "-q", "-x", "-m", "gpu", "-k", "config5"],
-                       env=env, capture_output=True, text=True, timeout=1200, cwd=root)
-    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-2500:] + r.stderr[-1500:]
-
-
 _GEMM_TD = r"""
 import sys, numpy as np, torch
 sys.path.insert(0, %r)

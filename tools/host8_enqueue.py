@@ -7,6 +7,11 @@ launches on four streams) while seven other launchers do the same on the same ho
 figure (bench.py: host_enqueue_ms_per_step, ~2 ms) the hosts's launch paths do not collide; the GPU-side times printed next to
 them are NOT scaling figures (one GPU is shared by all eight).
 
+Two passes: with the product library (the enqueue time then contains whatever the HIP runtime makes a launcher WAIT for when eight
+processes time-slice one GPU: the 43-76 ms maxima of round 5) and with the -DXG_NULL_LAUNCH build (every launch an empty kernel:
+the same call sequence with no GPU time behind it = the host's own cost; build it first:
+python -c "import __graft_entry__ as g; g.build_variant('null', ['-DXG_NULL_LAUNCH'])").
+
 usage: host8_enqueue.py [nproc (8)] [iterations (6)]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -59,29 +64,34 @@ def main():
     iters = int(sys.argv[2]) if len(sys.argv) > 2 else 6
     ctx = mp.get_context("spawn")
     out = {}
-    for world in (1, nproc):
-        d = tempfile.mkdtemp(prefix="h8_")
-        os.environ["H8_DIR"] = d
-        q = ctx.Queue()
-        ps = [ctx.Process(target=worker, args=(r, world, iters, q)) for r in range(world)]
-        for p in ps:
-            p.start()
-        ready = 0
-        while ready < world:
-            m = q.get(timeout=600)
-            ready += m[0] == "ready"
-        open(os.path.join(d, "go"), "w").close()
-        res = []
-        while len(res) < world:
-            m = q.get(timeout=600)
-            if m[0] == "done":
-                res.append(m[1:])
-        for p in ps:
-            p.join()
-        res.sort()
-        out["%d_process%s" % (world, "es" if world > 1 else "")] = [
-            {"rank": r[0], "host_enqueue_ms_per_step_median": round(r[1], 3), "min": round(r[2], 3), "max": round(r[3], 3),
-             "iteration_ms_shared_gpu": round(r[4], 3), "host_cores": r[5]} for r in res]
+    null_lib = os.path.join(ROOT, "controllable_xgating_amd", "lib", "libxgate_hip_null.so")
+    passes = [("product_library", None)] + ([("null_launch_library", null_lib)] if os.path.exists(null_lib) else [])
+    for label, lib in passes:
+      if lib:
+          os.environ["XG_LIBRARY"] = lib
+      for world in (1, nproc):
+          d = tempfile.mkdtemp(prefix="h8_")
+          os.environ["H8_DIR"] = d
+          q = ctx.Queue()
+          ps = [ctx.Process(target=worker, args=(r, world, iters, q)) for r in range(world)]
+          for p in ps:
+              p.start()
+          ready = 0
+          while ready < world:
+              m = q.get(timeout=600)
+              ready += m[0] == "ready"
+          open(os.path.join(d, "go"), "w").close()
+          res = []
+          while len(res) < world:
+              m = q.get(timeout=600)
+              if m[0] == "done":
+                  res.append(m[1:])
+          for p in ps:
+              p.join()
+          res.sort()
+          out.setdefault(label, {})["%d_process%s" % (world, "es" if world > 1 else "")] = [
+              {"rank": r[0], "host_enqueue_ms_per_step_median": round(r[1], 3), "min": round(r[2], 3), "max": round(r[3], 3),
+               "iteration_ms_shared_gpu": round(r[4], 3), "host_cores": r[5]} for r in res]
     print(json.dumps(out, indent=1))
 
 
