@@ -694,15 +694,29 @@ constexpr int V16_TW = 80, V16_NG = 5;
 #ifdef VP_TRACE
 // in-kernel phase stamps of the vocabulary product (tools/r6/vp_trace.py): entry, first slab staged, K loop done, tile in LDS, end
 __device__ long long vp_trace_buf[512 * 8];
-#define VP_STAMP(i) do { if (threadIdx.x == 0) vp_trace_buf[blockIdx.x * 8 + (i)] = wall_clock64(); } while (0)
+#define VP_STAMP(i) do { if (threadIdx.x == 0) { vp_trace_buf[blockIdx.x * 8 + (i)] = wall_clock64(); if ((i) == 1 || (i) == 2) vp_trace_buf[blockIdx.x * 8 + 4 + (i)] = clock64(); } } while (0)
 #else
 #define VP_STAMP(i) do {} while (0)
 #endif
+// Round 6 (in-kernel stamps, tools/r6/vp_trace.py: K loop 23.6 of 29.1 us = 83 % of the matrix rate the clock allows, tile -> LDS 1.2,
+// statistics + stores 2.7): (1) THREE LDS stages instead of two -- a slab is stored two slabs ahead of its products, so the fragments
+// of the NEXT block (also across the slab boundary) are requested under the current block's MFMAs and no wave starts a slab with an
+// exposed LDS round trip behind the barrier; (2) the epilogue stays in registers: a row's 80 logits sit in the 16 lanes of one DPP
+// row (5 per lane), so max / argmax / the two exponential sums are DPP reductions inside the row (xg_select.h helpers) -- no
+// 41 KB tile image in LDS, no barrier, and the stored rows leave as five 64-byte runs per row.
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) vocab_part16_kernel(VocabPartArgs a) {
     XG_CHAIN_PRIO();
     VP_STAMP(0);
-    constexpr int STAGE = (128 + V16_TW) * VT_LD;                   // floats per LDS stage
-    __shared__ __attribute__((aligned(16))) float smem[2 * STAGE];
+    // (16 rows beyond the 80 of the W slab: the threads whose third W piece lies past the slab store it there instead of under a branch --
+    //  a branch in the middle of a block cuts the scheduling region, and the seven LDS stores then sit in a cluster with their
+    //  s_waitcnt vmcnt in front of the block's MFMAs instead of between them: 39.6 cycles per MFMA instead of 32)
+    // Row stride 40 floats: a fragment read (row l15, this lane group's four k: ds_read_b128) is served 16 lanes at a time -- rows
+    // {0-3, 12-15} of lane group g with rows {4-11} of group g + 1 --, and at 36 (the 32 x 32 layout's stride) seven of those pairs
+    // share banks; at 40 the 16 lanes cover the 64 banks exactly once.
+    constexpr int V16_LD = 40;
+    constexpr int STAGE = (128 + V16_TW + 16) * V16_LD;              // floats per LDS stage
+    constexpr int NST = 3;
+    __shared__ __attribute__((aligned(16))) float smem[NST * STAGE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, l15 = lane & 15, g4 = (lane >> 4) << 2;
     const int n0 = blockIdx.x * V16_TW, ntiles = gridDim.x;
     const float* ap[4]; const float* wp[3];
@@ -716,9 +730,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         const int f = min(tid + 256 * i, V16_TW * 8 - 1);            // (pieces past the 80 x 32 slab repeat its last one: never stored)
         wp[i] = a.W + (size_t)min(n0 + (f >> 3), a.V - 1) * a.R + ((f & 7) << 2);
     }
-    const bool w2_on = tid + 512 < V16_TW * 8;
-    // two register sets of global loads (as gemm_w1_kernel): slab x travels in set x & 1, requested at the top of slab x - 2 and
-    // stored into LDS during the second block of slab x - 1 -- a slab is 2560 MFMA cycles, a loaded round trip is longer
+    // two register sets of global loads: slab x travels in set x & 1, requested at the top of slab x - 3 and stored into stage x % 3
+    // during the second block of slab x - 2 (1.5 slabs = ~2 us in flight; a slab is 2560 MFMA cycles)
     v_f32x4 ra[2][4], rw[2][3];
     v_f32x4 acc[2][V16_NG];
 #pragma unroll
@@ -736,41 +749,49 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int f = tid + 256 * i;
-            *reinterpret_cast<v_f32x4*>(As + (f >> 3) * VT_LD + ((f & 7) << 2)) = xa[i];
+            *reinterpret_cast<v_f32x4*>(As + (f >> 3) * V16_LD + ((f & 7) << 2)) = xa[i];
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int f = tid + 256 * i;
-            if (i < 2 || w2_on) *reinterpret_cast<v_f32x4*>(As + (128 + (f >> 3)) * VT_LD + ((f & 7) << 2)) = xw[i];
+            const int f = tid + 256 * i;                          // (f >= 640: rows 208 .. 223 of the stage, never read)
+            *reinterpret_cast<v_f32x4*>(As + (128 + (f >> 3)) * V16_LD + ((f & 7) << 2)) = xw[i];
         }
     };
+    // fragments of one 16-deep block: A rows wave * 32 + rb * 16 + l15, W rows gi * 16 + l15, this lane group's 4 k
+    v_f32x4 fa[2][2], fb[2][V16_NG];
+    auto read_frags = [&](const float* As, int kb, v_f32x4 (&xa)[2], v_f32x4 (&xb)[V16_NG]) {
+        const float* Bs = As + 128 * V16_LD;
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) xa[rb] = *reinterpret_cast<const v_f32x4*>(As + (wave * 32 + rb * 16 + l15) * V16_LD + kb * 16 + g4);
+#pragma unroll
+        for (int gi = 0; gi < V16_NG; ++gi) xb[gi] = *reinterpret_cast<const v_f32x4*>(Bs + (gi * 16 + l15) * V16_LD + kb * 16 + g4);
+    };
+    // ---- prologue: slabs 0 and 1 in LDS, slab 2 requested, the first block's fragments requested
     load_slab(0, ra[0], rw[0]);
     if (ns > 1) load_slab(1, ra[1], rw[1]);
     store_slab(smem, ra[0], rw[0]);
+    if (ns > 2) load_slab(2, ra[0], rw[0]);
+    if (ns > 1) store_slab(smem + STAGE, ra[1], rw[1]);
     __syncthreads();
+    read_frags(smem, 0, fa[0], fb[0]);
     VP_STAMP(1);
-    auto slab = [&](int s, auto set_tag, auto load_tag, auto store_tag) {
-        constexpr int SET = decltype(set_tag)::value;                // == s & 1
-        constexpr bool LOAD = decltype(load_tag)::value, STORE = decltype(store_tag)::value;      // slab s + 2 / s + 1 exist
-        const float* As = smem + SET * STAGE;
-        const float* Bs = As + 128 * VT_LD;
-        float* Ns = smem + (SET ^ 1) * STAGE;
-        v_f32x4 fa[2][2], fb[2][V16_NG];
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) fa[0][rb] = *reinterpret_cast<const v_f32x4*>(As + (wave * 32 + rb * 16 + l15) * VT_LD + g4);
-#pragma unroll
-        for (int gi = 0; gi < V16_NG; ++gi) fb[0][gi] = *reinterpret_cast<const v_f32x4*>(Bs + (gi * 16 + l15) * VT_LD + g4);
+    int st_cur = 0;                                                 // stage of the slab being multiplied (s % 3)
+    auto slab = [&](int s, auto set_tag, auto load_tag, auto store_tag, auto next_tag) {
+        constexpr int SET = decltype(set_tag)::value;                // == s & 1: the register set slab s + 2 sits in, and slab s + 3 does not
+        constexpr bool LOAD = decltype(load_tag)::value, STORE = decltype(store_tag)::value, NEXT = decltype(next_tag)::value;   // slabs s + 3 / s + 2 / s + 1 exist
+        const int st_nx = st_cur == NST - 1 ? 0 : st_cur + 1, st_st = st_cur == 0 ? NST - 1 : st_cur - 1;      // (s + 1) % 3, (s + 2) % 3
+        const float* As = smem + st_cur * STAGE;
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {                            // two 16-deep blocks per slab: 40 MFMAs each
-            if (LOAD && kb == 0) load_slab(s + 2, ra[SET], rw[SET]);
             if (kb == 0) {
-#pragma unroll
-                for (int rb = 0; rb < 2; ++rb) fa[1][rb] = *reinterpret_cast<const v_f32x4*>(As + (wave * 32 + rb * 16 + l15) * VT_LD + 16 + g4);
-#pragma unroll
-                for (int gi = 0; gi < V16_NG; ++gi) fb[1][gi] = *reinterpret_cast<const v_f32x4*>(Bs + (gi * 16 + l15) * VT_LD + 16 + g4);
+                if (LOAD) load_slab(s + 3, ra[SET ^ 1], rw[SET ^ 1]);
+                read_frags(As, 1, fa[1], fb[1]);
+            } else {
+                if (STORE) store_slab(smem + st_st * STAGE, ra[SET], rw[SET]);
+                if (NEXT) read_frags(smem + st_nx * STAGE, 0, fa[0], fb[0]);     // (stored two slabs ago, visible since the last barrier)
             }
-            if (STORE && kb == 1) store_slab(Ns, ra[SET ^ 1], rw[SET ^ 1]);
+            // (the NEXT reads overwrite fa[0] / fb[0]: block 0's MFMAs are program-ordered in front of them; kb == 1 multiplies set 1)
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk)
 #pragma unroll
@@ -779,73 +800,86 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     for (int gi = 0; gi < V16_NG; ++gi)
                         acc[rb][gi] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[kb][rb][kk], fb[kb][gi][kk], acc[rb][gi], 0, 0, 0);
             if (kb == 0) vt_interleave<40, 2 + V16_NG, LOAD ? 7 : 0>();
-            else vt_interleave<40, STORE ? 7 : 0, 0>();
+            else vt_interleave<40, (STORE ? 7 : 0) + (NEXT ? 2 + V16_NG : 0), 0>();
             __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        // workgroup barrier that orders LDS only: __syncthreads() also waits for every outstanding GLOBAL load (vmcnt(0)), i.e. for the
+        // slab requested at the top of this very slab -- the two register sets exist so that it does not have to be back yet
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        st_cur = st_nx;
     };
     {
         using T0 = std::integral_constant<int, 0>; using T1 = std::integral_constant<int, 1>;
         using Y = std::true_type; using N = std::false_type;
         int s = 0;
-        for (; s + 3 < ns; s += 2) { slab(s, T0{}, Y{}, Y{}); slab(s + 1, T1{}, Y{}, Y{}); }
-        if (s + 2 < ns) { slab(s, T0{}, Y{}, Y{}); slab(s + 1, T1{}, N{}, Y{}); slab(s + 2, T0{}, N{}, N{}); }
-        else if (s + 1 < ns) { slab(s, T0{}, N{}, Y{}); slab(s + 1, T1{}, N{}, N{}); }
-        else if (s < ns) slab(s, T0{}, N{}, N{});
+        for (; s + 4 < ns; s += 2) { slab(s, T0{}, Y{}, Y{}, Y{}); slab(s + 1, T1{}, Y{}, Y{}, Y{}); }
+        const int rem = ns - s;                                     // 1 .. 4, s even
+        if (rem == 4) { slab(s, T0{}, Y{}, Y{}, Y{}); slab(s + 1, T1{}, N{}, Y{}, Y{}); slab(s + 2, T0{}, N{}, N{}, Y{}); slab(s + 3, T1{}, N{}, N{}, N{}); }
+        else if (rem == 3) { slab(s, T0{}, N{}, Y{}, Y{}); slab(s + 1, T1{}, N{}, N{}, Y{}); slab(s + 2, T0{}, N{}, N{}, N{}); }
+        else if (rem == 2) { slab(s, T0{}, N{}, N{}, Y{}); slab(s + 1, T1{}, N{}, N{}, N{}); }
+        else slab(s, T0{}, N{}, N{}, N{});
     }
     VP_STAMP(2);
-    // epilogue through LDS as vocab_part_kernel: the tile as [128][81]; MFMA result layout: column 16 gi + l15, rows 4 (lane / 16) + r
-    constexpr int TL = V16_TW + 1;
-    float* tl = smem;
+    VP_STAMP(3);
+    // ---- epilogue in registers.  MFMA result layout: acc[rb][gi][r] = row wave * 32 + rb * 16 + g4 + r, column n0 + gi * 16 + l15:
+    // a row's 80 columns are the five values of each of the 16 lanes of one DPP row
+    float bv[V16_NG]; bool cok[V16_NG];
 #pragma unroll
     for (int gi = 0; gi < V16_NG; ++gi) {
         const int col = n0 + gi * 16 + l15;
-        const float bv = col < a.V ? a.bias[col] : 0.f;
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) tl[(wave * 32 + rb * 16 + g4 + r) * TL + gi * 16 + l15] = acc[rb][gi][r] + bv;
+        cok[gi] = col < a.V;
+        bv[gi] = cok[gi] ? a.bias[col] : 0.f;
     }
-    __syncthreads();
-    VP_STAMP(3);
-    constexpr int HW = V16_TW / 2;                                  // columns per (row, half-row) thread
-    const int row = tid >> 1, h = tid & 1, c0 = n0 + h * HW;
-    float x[HW];
-    float m = -INFINITY; int mc = 0x7fffffff;
+    const int sper = rs_per(ntiles), slot = rs_slot(blockIdx.x, sper);
+    // phase 1, branch-free (the eight rows' reductions interleave): x = logit in place of the accumulator, row statistics
+    float smx[8], se1[8], set_[8]; int smc[8];
 #pragma unroll
-    for (int j = 0; j < HW; ++j) {
-        x[j] = c0 + j < a.V ? tl[row * TL + h * HW + j] : -INFINITY;
-        if (x[j] > m) { m = x[j]; mc = c0 + j; }
-    }
-    {
-        const float om = __shfl_xor(m, 1, 64); const int oc = __shfl_xor(mc, 1, 64);
-        if (om > m || (om == m && oc < mc)) { m = om; mc = oc; }
-    }
-    float e1 = 0.f, et = 0.f;
+    for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
-    for (int j = 0; j < HW; ++j) {
-        const float d = x[j] - m;
-        const float e = __expf(d);
-        e1 += e;
-        et += a.inv_t == 1.0f ? e : __expf(d * a.inv_t);
-    }
-    e1 += __shfl_xor(e1, 1, 64); et += __shfl_xor(et, 1, 64);
-    if (row < a.B) {
-        if (h == 0) {
-            v_f32x4 pv = {m, e1, et, __int_as_float(mc)};
-            *reinterpret_cast<v_f32x4*>(a.part + ((size_t)row * rs_pitch(ntiles) + rs_slot(blockIdx.x, rs_per(ntiles))) * 4) = pv;
+        for (int r = 0; r < 4; ++r) {
+            float m = -INFINITY; int mc = 0x7fffffff;
+#pragma unroll
+            for (int gi = 0; gi < V16_NG; ++gi) {
+                const float x = cok[gi] ? acc[rb][gi][r] + bv[gi] : -INFINITY;
+                acc[rb][gi][r] = x;
+                const bool up = x > m;                                // (ascending columns: the first maximum stays)
+                mc = up ? n0 + gi * 16 + l15 : mc;
+                m = up ? x : m;
+            }
+            const float mx = rs_row_max(m);
+            mc = rs_row_min(m == mx ? mc : 0x7fffffff);
+            float e1 = 0.f, et = 0.f;
+#pragma unroll
+            for (int gi = 0; gi < V16_NG; ++gi) {
+                const float d = acc[rb][gi][r] - mx;                  // (-inf for columns past V: exp -> 0)
+                const float e = __expf(d);
+                e1 += e;
+                et += __expf(d * a.inv_t);
+            }
+            smx[rb * 4 + r] = mx; smc[rb * 4 + r] = mc; se1[rb * 4 + r] = rs_row_sum(e1); set_[rb * 4 + r] = rs_row_sum(et);
         }
-        if (row < a.wr_rows) {
-            float* dst = a.logits + (size_t)row * a.V + c0;
-            if ((a.V & 3) == 0 && c0 + HW <= a.V) {
+    }
+    // phase 2: the stores
 #pragma unroll
-                for (int j = 0; j < HW / 4; ++j) {
-                    v_f32x4 v = {x[4 * j], x[4 * j + 1], x[4 * j + 2], x[4 * j + 3]};
-                    *reinterpret_cast<v_f32x4*>(dst + 4 * j) = v;
-                }
-            } else {
+    for (int rb = 0; rb < 2; ++rb) {
 #pragma unroll
-                for (int j = 0; j < HW; ++j) if (c0 + j < a.V) dst[j] = x[j];
+        for (int r = 0; r < 4; ++r) {
+            const int row = wave * 32 + rb * 16 + g4 + r, q = rb * 4 + r;
+            if (row < a.B && l15 == 0) {
+                v_f32x4 pv = {smx[q], se1[q], set_[q], __int_as_float(smc[q])};
+                *reinterpret_cast<v_f32x4*>(a.part + ((size_t)row * (sper << 4) + slot) * 4) = pv;
+            }
+        }
+    }
+    if (wave * 32 < a.wr_rows) {                                    // (wave-uniform: the greedy half's waves store nothing)
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int row = wave * 32 + rb * 16 + g4 + r;
+                float* dst = a.logits + (size_t)row * a.V + n0 + l15;
+#pragma unroll
+                for (int gi = 0; gi < V16_NG; ++gi) if (row < a.wr_rows && cok[gi]) dst[gi * 16] = acc[rb][gi][r];
             }
         }
     }

@@ -20,7 +20,11 @@ torch.cuda.synchronize()
 n = 512 * 8
 buf = (C.c_longlong * n)()
 assert L.xg_debug_vp_trace(buf, n) == 0
-h = np.array(buf[:], dtype=np.int64).reshape(512, 8)[:250, :5].astype(np.float64)
+raw = np.array(buf[:], dtype=np.int64).reshape(512, 8)[:250]
+h = raw[:, :5].astype(np.float64)
+cyc = (raw[:, 6] - raw[:, 5]).astype(np.float64)            # shader clocks over the K loop (s_memtime)
+kl = (raw[:, 2] - raw[:, 1]) * 0.01
+print("K loop: %.0f shader clocks (mean) = %.1f per MFMA (1280 per wave; 32 = the matrix pipe's rate) at an effective %.2f GHz" % (cyc.mean(), cyc.mean() / 1280, cyc.mean() / kl.mean() / 1e3))
 t0 = h[:, 0].min()
 d = np.diff(h, axis=1) * 0.01
 print("vocab_part16_kernel, 250 workgroups (last launch of the rollout); us, mean / min / max over workgroups")
