@@ -350,18 +350,15 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
     opt = make_opt(None, vocab_size=cfg["V"], seq_length=cfg["L"], drop_prob_lm=drop, precision=precision,
                    rnn_size=cfg["R"], att_size=cfg["A"], input_encoding_size=cfg["E"], feat_size=cfg["F1"], feat_size2=cfg["F2"])
     model = SAModel(opt).to(dev)
-    if os.environ.get("XG_X3_TILES") is not None:       # diagnosis: split-bf16 over fp32 tiles (0: split in registers) instead of pre-split planes
-        model._packed_dtype_override = int(os.environ["XG_X3_TILES"])
     model.train()
     broadcast_parameters(model)
     x = synth_inputs(cfg["B"], cfg["K"], cfg["L"], cfg["V"], cfg["R"], cfg["F1"], cfg["F2"], cfg["C"], seed=rank, device=dev)
     # clamp + Adam start per parameter group as soon as its gradient is final (XG_NO_UPDATE_OVERLAP=1: after the backward)
     # --graph: the fixed-shape XE iteration replayed as ONE HIP graph (train.GraphedXEStep).  Not the default: the capture has to
     # be single-stream on this ROCm, which costs more GPU time (7.05 vs 6.10 ms) than the 2.4 ms of host work it removes
-    use_graph = (args.graph and not use_dist and workload in ("xe", "xe5") and args.path == "fused" and drop == 0.0
-                 and not os.environ.get("XG_BENCH_SLEEP_MS"))
+    use_graph = args.graph and not use_dist and workload in ("xe", "xe5") and args.path == "fused" and drop == 0.0
     optim = ClipAdam(model, lr=4e-4, grad_clip=0.1, overlap=os.environ.get("XG_NO_UPDATE_OVERLAP") is None,
-                     fused_zero=os.environ.get("XG_NO_FUSED_ZERO") is None, device_state=use_graph)
+                     fused_zero=True, device_state=use_graph)
     # data parallel: most of the gradient all-reduce runs under the CG encoder's backward (XG_NO_GRAD_OVERLAP=1: one
     # all-reduce after the backward)
     sync = None
@@ -375,19 +372,10 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
     rl_crit = RewardCriterion()
     reward_b = torch.randn(cfg["B"], 1, generator=torch.Generator().manual_seed(7)).to(dev)   # CIDEr stubbed (configs[2])
 
-    sleep_cycles_box = [int(float(os.environ.get("XG_BENCH_SLEEP_MS", "0")) * 2.4e6)]     # diagnosis (see `step` below)
-
     def step_scst():
-        if sleep_cycles_box[0]:
-            torch.cuda._sleep(sleep_cycles_box[0])
         optim.zero_grad()
-        if os.environ.get("XG_SCST_MODE") in (None, "batched"):      # no host sync anywhere in the iteration
-            gen, slp, greedy, n = scst_rollouts(model, x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], trim=False)
-            loss = rl_crit(slp, gen, reward_b, n=n[:1])
-        else:
-            gen, slp, greedy = scst_rollouts(model, x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"],
-                                             mode=os.environ.get("XG_SCST_MODE"))
-            loss = rl_crit(slp, gen, reward_b.expand(-1, gen.shape[1]))
+        gen, slp, greedy, n = scst_rollouts(model, x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], trim=False)     # no host sync anywhere in the iteration
+        loss = rl_crit(slp, gen, reward_b, n=n[:1])
         if sync is not None and state["overlap_comm"]:
             sync.arm()
         optim.arm()
@@ -396,15 +384,9 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
         optim.step()
         return loss
 
-    sleep_cycles = int(float(os.environ.get("XG_BENCH_SLEEP_MS", "0")) * 2.4e6)           # diagnosis: see below (torch.cuda._sleep counts shader clocks)
-
     def step():
         if workload == "scst":
             return step_scst()
-        if sleep_cycles:
-            # diagnosis only: a GPU-side spin at the head of the iteration lets the host run far ahead; if (time - spin) drops
-            # below the normal iteration time, the normal run has host-bound gaps
-            torch.cuda._sleep(sleep_cycles)
         optim.zero_grad()
         if args.path == "fused":
             loss = model.xe_loss(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"], x["seq"], x["seq_mask"])
@@ -587,7 +569,7 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
                                     "zero_grad + encoder fwd + 21 decoder steps + heads/loss + full backward")
                                    + (" + RCCL grad all-reduce" if world > 1 else "") + " + clip + Adam",
                    # (zero_grad is fused into the update: train.ClipAdam(fused_zero=True) leaves .grad at zero)
-                   "zero_grad": "fused into the update" if os.environ.get("XG_NO_FUSED_ZERO") is None else "memset",
+                   "zero_grad": "fused into the update",
                    "launch": "one HIP graph replay per iteration (train.GraphedXEStep)" if use_graph else "eager kernel launches",
                    "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
         "final_loss": round(final_loss, 5),
@@ -652,8 +634,6 @@ def step_group_by_arithmetic(args, ctx):
         opt = make_opt(None, vocab_size=cfg["V"], seq_length=cfg["L"], precision=precision, rnn_size=cfg["R"], att_size=cfg["A"],
                        input_encoding_size=cfg["E"], feat_size=cfg["F1"], feat_size2=cfg["F2"])
         model = SAModel(opt).to(ctx["dev"])
-        if os.environ.get("XG_X3_TILES") is not None:
-            model._packed_dtype_override = int(os.environ["XG_X3_TILES"])
         model.eval()
         out[precision] = round(measure_step_group(model, x) * 1e6, 2)
         del model

@@ -670,8 +670,6 @@ int xgk_gemm_bf16x(hipStream_t st, int planes, bool transA, bool transB, int M, 
         // 98 -> 63 us, dX 110 -> 74, PRE 104 -> 59, v2a(V) 94 -> 58 (tools/ubench/bs_skmax.sh)
         long sk = 512 / tiles;
         if (sk > nslab / 8) sk = nslab / 8;
-        static const char* skmax = xg_diag_env("XG_BS_SKMAX");      // diag: cap of the split (sweeps)
-        if (skmax && sk > atoi(skmax)) sk = atoi(skmax);
         if (sk >= 2) g.splitk = (int)sk;
     }
     // plain bf16 with a k-contiguous A (forward and data-gradient layouts): 256 x 128 tiles, 43 flop per operand byte instead

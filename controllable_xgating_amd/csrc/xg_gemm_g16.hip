@@ -391,8 +391,7 @@ int xgk_gemm_g16(hipStream_t st, bool transA, bool transB, int M, int N, int K, 
     const long tiles = (long)xg_cdiv(M, TM) * xg_cdiv(N, TN);
     static const char* cfg = xg_diag_env("XG_G16_CFG");     // diag build: 642 / 643 / 322 / 323 / 324 / 325 / 843 / 844
     const bool tn_layout = !akc && !bkc;
-    static const bool no8 = xg_diag_env("XG_G16_NO8") != nullptr;      // diag: without the eight-wave form
-    const int c = cfg ? atoi(cfg) : (tn_layout && tiles >= 1024 ? 323 : (tn_layout && tiles <= 256 && !no8 ? 844 : 642));
+    const int c = cfg ? atoi(cfg) : (tn_layout && tiles >= 1024 ? 323 : (tn_layout && tiles <= 256 ? 844 : 642));
     // Split of the reduction across workgroups (`splitk` <= 0: this kernel's own rule; the register-staged kernel's rule
     // filled 512 slots whenever the tiles did not).  A part's result is added with fp32 atomics behind a memset of C, and that
     // epilogue is expensive here: 5120 x 1024 x 1536 takes 34 us unsplit and 58-70 us in two parts, 5120 x 1024 x 4096 76 against
@@ -411,7 +410,6 @@ int xgk_gemm_g16(hipStream_t st, bool transA, bool transB, int M, int N, int K, 
         if (sk > K / deep) sk = K / deep;
         g.splitk = sk < 1 ? 1 : (int)sk;
     }
-    { static const char* d = xg_diag_env("XG_G16_SK"); if (d && !relu) g.splitk = atoi(d); }
     g.gm = xgk_group_rows(K / g.splitk / 2);          // (an operand panel is 128 x k_depth bf16 = half the bytes the rule was made for)
     switch (c) {
     case 323: return launch_g16_layout<32, 3>(st, g, akc, bkc);

@@ -651,10 +651,9 @@ int core_step(hipStream_t st, const XgDims& d, const XgParams& p, const XgRun& r
         // B: S2' in launch 1 + stand-alone attention, D: cell 2 keeps its h2 segment (K = 3R) + stand-alone attention,
         // E: the fused attention like the rollout form -- measure 6.77 / 6.73 / 6.74 ms per iteration (the iteration is
         // throughput-bound across three streams, not bound by this chain); D is the simplest and the default.)
-        static const bool no_fused = xg_diag_env("XG_NO_FUSED_ATTN") != nullptr;
         // (at hidden 1024 / 40 frames E wins instead: 8.51 vs 8.63 ms -- the stand-alone attention is then 24 us per step)
         const char xe_form = R >= 1024 ? 'E' : 'D';
-        const bool fused_attn = (!s.pre1 || xe_form == 'E') && !no_fused && A <= 2048 && d.K <= 128 && ((uintptr_t)V % 8 == 0) &&
+        const bool fused_attn = (!s.pre1 || xe_form == 'E') && A <= 2048 && d.K <= 128 && ((uintptr_t)V % 8 == 0) &&
                                 ((uintptr_t)vproj % 16 == 0) && ((uintptr_t)p.a2w_w % 16 == 0);
         // S2' = h2 W_h2h2 + b rides in launch 1 (teacher forcing form B; the rollout form beyond 64 rows, where the three
         // launches are then 512 / 512 / 256 workgroups, one round each, instead of 256 / 768 / 256: 49.4 -> 46.5 us per step

@@ -282,8 +282,7 @@ import os as _os
 _FORCE = _os.environ.get("XG_FORCE_DIST") == "1"      # run the collective even at world size 1 (single-GPU smoke of the path)
 
 
-import os as _os0
-_NO_EARLY_PACK = _os0.environ.get("XG_NO_EARLY_PACK") == "1"      # measurement switch (Python side; the library reads no environment)
+_NO_EARLY_PACK = False      # (tests flip it: the early-repack negative control)
 _SKIP_COLLECTIVE = False    # measurement switch (bench.py: exposed communication = iteration with - without the collective)
 
 

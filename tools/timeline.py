@@ -50,7 +50,7 @@ def main():
     qs = sorted({r["q"] for r in it}, key=lambda q: -sum(r["e"] - r["s"] for r in it if r["q"] == q))
     print("# NOTE: under rocprofv3 the enqueueing thread is slower than the GPU in places (a launch costs it ~10 us): idle gaps on the main\n"
           "# queue inside the loops -- the ~200-250 us one in the reverse-time loop in particular -- are host starvation that the\n"
-          "# un-profiled run does not have (docs/EXPERIMENTS.md round 5, XG_LEAD_PROBE: 63-65 us per step, no hole)")
+          "# un-profiled run does not have (docs/EXPERIMENTS.md round 5: per-step events, 63-65 us per step, no hole)")
     print("iteration span %.3f ms, %d kernels, queues %s" % ((t1 - t0) / 1e6, len(it), qs))
     for q in qs:
         iv = [(r["s"], r["e"]) for r in it if r["q"] == q]
