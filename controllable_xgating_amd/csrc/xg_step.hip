@@ -657,15 +657,15 @@ __device__ __forceinline__ void attn_part(const SkJob& job, int tile, float* sme
     // unnormalised context of this half: thread -> two adjacent columns
     for (int c = threadIdx.x * 2; c < R; c += NWV * 128) {
         float ax = 0.f, ay = 0.f;
-        // four rows per trip, written out: the four loads are requested first, then the four weights come out of LDS one by one
-        // (scalar reads, no b128), then the multiply-adds as plain v_fmac_f32, pinned.  Why: when the SLP vectorizer pairs the two
-        // accumulators (one ds_read_b128 for the four weights, four v_pk_fma_f32 with operand-select modifiers, one v_mov that
-        // moves the fourth weight into the first pair) the accumulated context shows run-to-run differences of single elements
-        // (~1e-4) -- but ONLY beside split-bf16 cell tiles in the same launch: the very same instruction sequence inside the
-        // fp32 and bf16 instantiations never does (round 5: loop ISA identical to the register numbers, -DSKF_ATTN_PKFMA with
-        // -fslp-vectorize fails 1-2 of 9 shapes per run, always bf16x3 at 128 rows; the pinned form passes with the vectorizer
-        // on, the plain form passes with it off).  No cause inside the instruction stream was found; the narrow remedy is this
-        // pinned form, the global -fno-slp-vectorize (__graft_entry__.FLAGS) is kept as the guard for every other float2 loop.
+        // four rows per trip, written out: the four loads are requested first, then the four weights come out of LDS, then the
+        // multiply-adds as plain v_fmac_f32, PINNED.  Why (docs/pkfma_hazard.md): left to the SLP vectorizer the two accumulators
+        // become one v_pk_fma_f32 per frame with the weight broadcast by operand select, and the form `op_sel:[0,1,0]` (the LOW
+        // lane takes the HIGH register of the weight pair) now and then loses its low-lane product in lanes 48-63 of the wave --
+        // one frame's term missing from up to 16 even context columns of one video -- but only while split-bf16 cell tiles share
+        // the CU (128-row launches; never beside fp32 / plain bf16 tiles, never in the stand-alone reproducer).  Round 6 bisection
+        // (diag_pkfma_bisect.inc): the same four FMAs as op_sel_hi:[1,0,1] only, as packed FMAs without operand select, or as
+        // these scalar ones never differ.  Guards: this pinned form, -fno-slp-vectorize (__graft_entry__.FLAGS), and
+        // tests/test_abi_cpu.py, which disassembles the product library and fails on any packed-fp32 `op_sel:`.
         const float* vp = Vb + (size_t)k0 * R + c;
         int r = 0;
         for (; r + 4 <= nrow; r += 4) {
@@ -674,11 +674,8 @@ __device__ __forceinline__ void attn_part(const SkJob& job, int tile, float* sme
             const float2 v2 = *reinterpret_cast<const float2*>(vp + (size_t)(r + 2) * R);
             const float2 v3 = *reinterpret_cast<const float2*>(vp + (size_t)(r + 3) * R);
             const float s0 = sx[r], s1 = sx[r + 1], s2 = sx[r + 2], s3 = sx[r + 3];
-#ifdef SKF_ATTN_PKFMA
-            ax += s0 * v0.x; ay += s0 * v0.y;
-            ax += s1 * v1.x; ay += s1 * v1.y;
-            ax += s2 * v2.x; ay += s2 * v2.y;
-            ax += s3 * v3.x; ay += s3 * v3.y;
+#if defined(SKF_PK_ASM)   // diagnosis builds: the packed forms of docs/pkfma_hazard.md
+#include "diag_pkfma_bisect.inc"
 #else
             // plain v_fmac_f32, pinned (the compiler pairs ax / ay into v_pk_fma_f32 with operand-select modifiers otherwise)
             asm volatile("v_fmac_f32 %0, %2, %3\n\tv_fmac_f32 %1, %2, %4" : "+v"(ax), "+v"(ay) : "v"(s0), "v"(v0.x), "v"(v0.y));

@@ -158,3 +158,19 @@ def test_struct_sizes_agree_between_header_binding_and_integration_stub(built, t
     assert L.xg_abi_check(hdr["XG_VERSION"], *sz) == 0
     assert L.xg_abi_check(hdr["XG_VERSION"], *sz[:4], 64) == -1
     assert L.xg_abi_check(hdr["XG_VERSION"] - 1, *sz) == -1
+
+
+def test_product_library_has_no_low_lane_operand_select_on_packed_fp32(built):
+    """docs/pkfma_hazard.md: `v_pk_fma_f32 ... op_sel:[0,1,0]` (the low lane takes the HIGH register of a pair) lost its low-lane
+    product in lanes 48-63 now and then beside split-bf16 tiles.  The attention context loop is pinned to v_fmac_f32 and the library is
+    built with -fno-slp-vectorize; this test reads the gfx950 code objects of the built product library back and fails on any
+    packed-fp32 instruction with an `op_sel:` modifier, wherever a later compiler or a new float2 loop puts one."""
+    import re
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import check_packed_opsel as chk
+    if not os.path.exists(chk.OBJDUMP):
+        pytest.skip("llvm-objdump not in this image")
+    objs = chk.code_objects(built)
+    assert len(objs) >= 8, "no gfx950 code objects found in %s" % built      # one per .hip translation unit
+    low = [(sym, ins) for sym, ins in chk.packed_opsel_sites(built) if re.search(r"\bop_sel:\[", ins)]
+    assert not low, "packed fp32 with low-lane operand select in the product library: %s" % low[:4]
