@@ -970,6 +970,11 @@ skf_kernel(SkArgs args) {
     RollSelectArgs sel;
     if constexpr (SEL) { sel = args.sel; sk_hold(sel); }       // (same round of scalar loads as the job's own blocks)
     sk_hold(hd); sk_hold(sg); sk_hold(ei);
+#ifdef SKF_PAD_SALU   // measurement build: what N more scalar instructions in every wave's prologue cost a launch
+#define SKF_STR2(x) #x
+#define SKF_STR(x) SKF_STR2(x)
+    asm volatile(".rept " SKF_STR(SKF_PAD_SALU) "\n\ts_mov_b32 %0, %0\n\t.endr" : "+s"(hd.nck_all));
+#endif
     int ef = (ei.bias[0] ? EF_B0 : 0) | (ei.bias[1] ? EF_B1 : 0) | (ei.bias[2] ? EF_B2 : 0) | (ei.add ? EF_ADD : 0) | (ei.mask ? EF_MASK : 0) |
                    (ei.accumulate ? EF_ACC : 0) | (ei.relu ? EF_RELU : 0) | (ei.order == XG_ORDER_IFOG ? EF_IFOG : 0) |
                    (ei.mask_mode == XG_MASK_HOLD ? EF_HOLD : 0);

@@ -3,6 +3,7 @@ the oracle on the same seeded inputs.  These sizes select kernel paths the small
 job, 128x128 GEMM tiles with split-K, the 2m = 128-row paired rollout).  About 10 s of CPU oracle per case."""
 import functools
 
+import os
 import numpy as np
 import pytest
 import torch
@@ -211,6 +212,7 @@ def test_config3_scst_b64_l30_replay_of_oracle_sampled_tokens():
     assert lens.min() < 5 and lens.max() > 20                     # ragged finishing steps
     P, lp_o, loss_o = _oracle_replay(d, Pn, xn, s_o, reward)
     model = make_model(d, P=Pn, train=True)
+    assert not os.environ.get("XG_NO_OVERLAP") and model._run(True, seed=0).aux, "this case must run with the overlap streams on"
     x = to_dev(xn)
     seq, slp = model.sample(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"],
                             {"sample_max": 0, "forced_tokens": s_o.cuda()})
@@ -239,6 +241,8 @@ def test_config3_scst_b64_l30_paired_rollout_vs_oracle():
     from controllable_xgating_amd import RewardCriterion
     d, Pn, xn, u, reward = _scst_case()
     model = make_model(d, P=Pn, train=True)
+    # the backward below runs over the side streams (the (T - 1)-step view of the T-step workspace, xg_rollout_bwd): say so
+    assert not os.environ.get("XG_NO_OVERLAP") and model._run(True, seed=0).aux, "this case must run with the overlap streams on"
     x = to_dev(xn)
     gen, slp, greedy, n = model.sample_pair(x["feats_rgb"], x["feats_opfl"], x["feat_mask"], x["pos_feats"],
                                             {"uniforms": torch.from_numpy(u).cuda()})
