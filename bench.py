@@ -567,12 +567,14 @@ def run_workload(args, workload, precision, steps, warmup, ctx, cpu_leg=True, pm
                    "timed_region": ("zero_grad + sampled + greedy rollouts (30 core steps, one 2m-row batch) + reward criterion + backward"
                                     if workload == "scst" else
                                     "zero_grad + encoder fwd + 21 decoder steps + heads/loss + full backward")
-                                   + (" + RCCL grad all-reduce" if world > 1 else "") + " + clip + Adam",
+                                   + ((" + gloo grad all-reduce" if os.environ.get("XG_FORCE_DIST") == "3" else " + RCCL grad all-reduce") if world > 1 else "") + " + clip + Adam",
                    # (zero_grad is fused into the update: train.ClipAdam(fused_zero=True) leaves .grad at zero)
                    "zero_grad": "fused into the update",
                    "launch": "one HIP graph replay per iteration (train.GraphedXEStep)" if use_graph else "eager kernel launches",
                    "gpu_max_hw_queues": os.environ.get("GPU_MAX_HW_QUEUES")},
         "final_loss": round(final_loss, 5),
+        **({"NOT_A_MEASUREMENT": "XG_FORCE_DIST=3: %d ranks time-slicing ONE GPU, all-reduce over gloo -- control-flow exercise only" % world}
+           if os.environ.get("XG_FORCE_DIST") == "3" else {}),
         "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": 8000.0, "unit": "GB/s",
                      "frac": round(achieved / 8000.0, 4), "traffic": traffic, "traffic_source": traffic_src,
                      "kernel": "decoder step launch group (xg_step_fwd: attention + POS gate + lstm_1 + lstm_2)",
@@ -675,7 +677,7 @@ def main():
         # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, RCCL over xGMI) -- never
         # silently run one GPU and call it N
         ndev = torch.cuda.device_count()
-        if ndev < args.gpus:
+        if ndev < args.gpus and os.environ.get("XG_FORCE_DIST") != "3":
             raise SystemExit("bench.py --gpus %d: only %d GPU(s) visible" % (args.gpus, ndev))
         import socket
         with socket.socket() as sk:
@@ -689,9 +691,15 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    # XG_FORCE_DIST=3: the N-rank control flow of this file on ONE GPU -- every rank on device 0, gloo instead of RCCL (which refuses
+    # two ranks on one device).  Exercises the sharding, the barriers, the max over ranks, the per-rank report and the collective's
+    # call sites where no multi-GPU box exists; its numbers mean nothing (time-sliced GPU, host-staged all-reduce) and say so.
+    one_gpu = os.environ.get("XG_FORCE_DIST") == "3"
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    use_dist = world > 1 or os.environ.get("XG_FORCE_DIST") in ("1", "2")    # XG_FORCE_DIST: exercise the RCCL path on one GPU
+    use_dist = world > 1 or os.environ.get("XG_FORCE_DIST") in ("1", "2")    # XG_FORCE_DIST=1|2: exercise the RCCL path on one GPU
     ctx = dict(world=world, rank=rank, dev=dev, use_dist=use_dist, rccl_log=None, cores=None, rccl_cap=None)
     if use_dist:
         ctx["cores"] = pin_host_thread(local, world)
@@ -703,7 +711,10 @@ def main():
         ctx["rccl_log"] = rccl_debug_setup(rank)
         from controllable_xgating_amd.train import dist_diagnosis
         try:
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            if one_gpu:
+                dist.init_process_group("gloo", rank=rank, world_size=world)
+            else:
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
             probe = torch.ones(1, device=dev)
             dist.all_reduce(probe)                  # the first collective brings the communicator up: fail HERE, with the one line that explains it
             torch.cuda.synchronize()

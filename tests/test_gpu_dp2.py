@@ -162,3 +162,26 @@ def test_two_rank_update_paths_agree(tmp_path):
         np.testing.assert_allclose(np.load(tmp_path / ("%s_v0.npy" % mode)), ref["v"], atol=1e-9 + 2e-3 * np.abs(ref["v"]).max(), err_msg=mode)
         disp = np.abs(np.load(tmp_path / ("%s_p0.npy" % mode)) - ref["p"])
         assert disp.max() <= 3.1 * 4e-4 and (disp > 4e-5).mean() <= 0.02, (mode, float(disp.max()))
+
+
+def test_bench_n_rank_control_flow_on_one_gpu_over_gloo(tmp_path):
+    """`bench.py --gpus 2` end to end where only one GPU exists (XG_FORCE_DIST=3: both ranks on device 0, gloo instead of RCCL): the
+    self-launch through torch.distributed.run, the shard per rank, barriers, max over ranks, schedule choice, per-rank report and
+    the ONE JSON line from rank 0.  The numbers are not measurements (the line says so); what is asserted is the contract's shape."""
+    import json, subprocess, sys
+    from tests.util import ROOT
+    env = dict(os.environ, XG_FORCE_DIST="3", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--no-cpu-baseline", "--no-pmc"],
+                       capture_output=True, text=True, timeout=600, env=env, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]                     # rank 0 alone prints, once
+    o = json.loads(lines[0])
+    assert o["n_gpus"] == 2 and o["steps"] == 2 and o["scaling"] == "weak" and "NOT_A_MEASUREMENT" in o
+    assert o["config"]["global_batch"] == 256 and o["config"]["parallelism"] == "dp2"
+    assert abs(o["value"] - 2 * 128 * 21 / (o["ms_per_step"] * 1e-3)) <= 1e-3 * o["value"]      # whole-job aggregate over both ranks
+    ranks = o["comm"]["per_rank"]
+    assert [p["rank"] for p in ranks] == [0, 1] and all(p["ms_per_step"] > 0 and p["ms_per_step_no_collective"] > 0 for p in ranks)
+    assert o["comm"]["gradient_bytes"] == 144489216 and o["comm"]["schedule"]["timed"] in ("overlapped_buckets", "one_collective_after_backward")
