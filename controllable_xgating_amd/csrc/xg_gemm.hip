@@ -195,6 +195,7 @@ struct GemmArgs {
     // weight-gradient layout only (A m-contiguous = dY^T): csum[q][m] += sum_k A(k, m) for up to three accumulators -- the bias
     // gradient(s) that belong to the same dY, formed from the A slabs the tn == 0 tiles stream anyway (no second pass over dY)
     float* csum[3];
+    int alone;    // XGK_GEMM_ALONE (xg_kernels.h)
 };
 
 // sum of this thread's A-slab registers (m-contiguous operand: 4 consecutive rows m per register, the same 4 for every register
@@ -1094,7 +1095,7 @@ int launch_td(hipStream_t st, const GemmArgs& a) {
     // chains, which are the critical path, and a product that keeps 16 wide loads per wave in flight lengthens every round trip of
     // the chain next to it.  XG_TD_ALL=1 (diag library) sends every eligible product here.
     static const int td_all = xg_diag_env("XG_TD_ALL") ? atoi(xg_diag_env("XG_TD_ALL")) : 0;
-    if (!td_all && !a.bg && tiles < 1024) return 1;
+    if (!td_all && !a.bg && !a.alone && tiles < 1024) return 1;
     static const int ks_env = xg_diag_env("XG_TD_KS") ? atoi(xg_diag_env("XG_TD_KS")) : 0;
     int ks = 1;
     if (tiles < 192) { ks = (int)(256 / tiles); if (ks > g.nrounds / 16) ks = g.nrounds / 16; if (ks < 1) ks = 1; }
@@ -1252,8 +1253,8 @@ int xgk_gemm_cs(hipStream_t st, int mode, bool transA, bool transB, int M, int N
     if (K < 0 || !A || !B || !C) return XG_EINVAL;
     const bool want_cs = cs1 != nullptr;
     if (want_cs && !transA) return XG_EINVAL;
-    const int bg = (mode & XGK_GEMM_BG) ? 1 : 0;
-    mode &= ~XGK_GEMM_BG;
+    const int bg = (mode & XGK_GEMM_BG) ? 1 : 0, alone = (mode & XGK_GEMM_ALONE) ? 1 : 0;
+    mode &= ~(XGK_GEMM_BG | XGK_GEMM_ALONE);
     // large products may run on the bf16 matrix cores (split-bf16 or plain bf16); skinny / tiny ones stay fp32
     // Split-bf16 (mode 3) keeps the weight-gradient layout (transA) in exact fp32 (round 5): alone the fp32 kernels are level or
     // ahead there (2048 x 512 x 2688: 60 against 65 us, dW_logit 504 against 530), and inside the iteration the 21 split-bf16
@@ -1268,7 +1269,7 @@ int xgk_gemm_cs(hipStream_t st, int mode, bool transA, bool transB, int M, int N
     if ((mode == 1 || mode == 3) && !x3_exact && M >= 256 && N >= 64 && K >= bf16_mink) {
         return xgk_gemm_bf16(st, mode, transA, transB, M, N, K, A, lda, B, ldb, C, ldc, bias, relu, accumulate, cs1, cs2, cs3);
     }
-    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1, 0, 1, bg, {nullptr, nullptr, nullptr}};
+    GemmArgs g{A, B, C, bias, M, N, K, lda, ldb, ldc, relu ? 1 : 0, accumulate ? 1 : 0, 1, 0, 1, bg, {nullptr, nullptr, nullptr}, alone};
     const bool akc = !transA;   // A (M,K) row-major -> k contiguous
     const bool bkc = transB;    // B (N,K) row-major -> k contiguous
     {   // offset-based loads: the largest byte offset inside either operand must fit 31 bits, and the m/n-contiguous
@@ -1292,7 +1293,7 @@ int xgk_gemm_cs(hipStream_t st, int mode, bool transA, bool transB, int M, int N
 int xgk_gemm_x(hipStream_t st, int mode, bool transA, bool transB, int M, int N, int K, const float* A, const unsigned short* A16,
                int lda, const float* B, const unsigned short* B16, int ldb, float* C, int ldc, const float* bias, bool relu,
                bool accumulate, float* cs1, float* cs2, float* cs3) {
-    if ((mode & ~XGK_GEMM_BG) == 1 && (A16 || B16) && M >= 256 && N >= 64 && K >= 256) {
+    if ((mode & ~(XGK_GEMM_BG | XGK_GEMM_ALONE)) == 1 && (A16 || B16) && M >= 256 && N >= 64 && K >= 256) {
         if (cs1 && !transA) return XG_EINVAL;
         return xgk_gemm_bf16x(st, 1 | (mode & XGK_GEMM_BG), transA, transB, M, N, K, A, A16, lda, B, B16, ldb, C, ldc, bias, relu, accumulate, cs1, cs2, cs3);
     }

@@ -17,7 +17,11 @@ static inline int xgk_group_rows(int k_depth) {
 }
 // `mode | XGK_GEMM_BG`: the product is launched on a side stream beside a latency-bound chain of small launches; the
 // persistent kernel then takes half of every CU instead of all of it (xg_gemm.hip: launch_pk)
-enum { XGK_GEMM_BG = 0x100 };
+enum { XGK_GEMM_BG = 0x100,
+       // `mode | XGK_GEMM_ALONE`: nothing latency-bound runs beside this product (the encoder's weight gradients at the tail of an
+       // iteration): the weight-gradient layout takes the operands-from-memory kernel (gemm_td_kernel), 18 % faster alone on the
+       // mid-size shapes and kept away from them elsewhere because it slows a launch chain on another stream (xg_gemm.hip: launch_td)
+       XGK_GEMM_ALONE = 0x200 };
 int xgk_gemm(hipStream_t st, int mode, bool transA, bool transB, int M, int N, int K, const float* A, int lda,
              const float* B, int ldb, float* C, int ldc, const float* bias, bool relu, bool accumulate);
 // the same product for the weight-gradient layout (transA) with the column sums of A = dY^T as a side output: cs[m] += sum_k A(k, m)

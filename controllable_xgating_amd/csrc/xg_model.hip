@@ -510,6 +510,8 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
         }
     }
     for (int m = 0; m < 2; ++m) XG_TRY(cvt16(st, w, w.dS[m], (size_t)N * 4 * R));      // read by three products each
+    static const bool no_tail_td = xg_diag_env("XG_NO_TAIL_TD") != nullptr;
+    const int gm_tail = w.gm | (no_tail_td ? 0 : XGK_GEMM_ALONE);
     XG_TRY(ss.fork2());                          // before modality 0's work is enqueued on the main stream
     for (int m = 0; m < 2; ++m) {
         // Hprev[b,k] = H[b,k-1], zero at k = 0 : one clean TN GEMM for dW_hh
@@ -518,8 +520,9 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
         if (K > 1)   // one strided 2-D copy covers all videos: rows = B, cols = (K-1)*R
             XG_TRY(xgk_copy2d(sx, w.Hprev[m] + R, K * R, w.Hs[m], K * R, B, (K - 1) * R, false));
         XG_TRY(cvt16(sx, w, w.Hprev[m], (size_t)N * R));
-        XG_TRY(tn16(sx, w.gm, N, 4 * R, R, w.dS[m], m16(w, w.dS[m]), 4 * R, w.Hprev[m], m16(w, w.Hprev[m]), R, g_whh[m], R, g_bih[m], g_bhh[m]));
-        XG_TRY(tn16(sx, w.gm, N, 4 * R, R, w.dS[m], m16(w, w.dS[m]), 4 * R, w.X[m], m16(w, w.X[m]), R, g_wih[m], R));
+        // (the recurrence is over: no launch chain runs beside these weight gradients -- XGK_GEMM_ALONE, xg_kernels.h)
+        XG_TRY(tn16(sx, gm_tail, N, 4 * R, R, w.dS[m], m16(w, w.dS[m]), 4 * R, w.Hprev[m], m16(w, w.Hprev[m]), R, g_whh[m], R, g_bih[m], g_bhh[m]));
+        XG_TRY(tn16(sx, gm_tail, N, 4 * R, R, w.dS[m], m16(w, w.dS[m]), 4 * R, w.X[m], m16(w, w.X[m]), R, g_wih[m], R));
         // the optical-flow modality's input-side backward runs beside the rgb one (second auxiliary stream, forked above)
         hipStream_t st_outer = st;
         hipStream_t st = (m == 1 && ss.overlap()) ? ss.aux2 : st_outer;
@@ -531,7 +534,7 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
                                  xg_make_drop(&run, m == 0 ? XG_SITE_EMB_RGB : XG_SITE_EMB_OPFL, 0), w.bn_s1[m], w.bn_s2[m]));
         XG_TRY(xgk_bn_bwd_apply(st, w.dX[m], w.Z[m], w.bn_mean[m], w.bn_var[m], bn_g[m], w.bn_s1[m], w.bn_s2[m], N, R,
                                 run.bn_eps, run.train != 0, g_bn_b[m], g_bn_g[m]));     // (+ the two parameter gradients)
-        XG_TRY(gemm_tn_cs(st, w.gm, N, R, F[m], w.dX[m], R, feats[m], F[m], g_emb_w[m], F[m], g_emb_b[m]));
+        XG_TRY(gemm_tn_cs(st, gm_tail, N, R, F[m], w.dX[m], R, feats[m], F[m], g_emb_w[m], F[m], g_emb_b[m]));
     }
     return ss.chain2_into_aux();              // the caller's join() of aux then covers the second side chain too
 }
