@@ -510,8 +510,7 @@ int encoder_bwd(Streams& ss, const XgDims& d, const XgParams& p, const XgParams&
         }
     }
     for (int m = 0; m < 2; ++m) XG_TRY(cvt16(st, w, w.dS[m], (size_t)N * 4 * R));      // read by three products each
-    static const bool no_tail_td = xg_diag_env("XG_NO_TAIL_TD") != nullptr;
-    const int gm_tail = w.gm | (no_tail_td ? 0 : XGK_GEMM_ALONE);
+    const int gm_tail = w.gm | XGK_GEMM_ALONE;
     XG_TRY(ss.fork2());                          // before modality 0's work is enqueued on the main stream
     for (int m = 0; m < 2; ++m) {
         // Hprev[b,k] = H[b,k-1], zero at k = 0 : one clean TN GEMM for dW_hh
